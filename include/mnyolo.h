@@ -1,0 +1,177 @@
+/* libmnyolo — C ABI of the MI355X-native MobileNet-YOLO hot path (gfx950 only).
+ *
+ * Drop-in boundary B2 of SURVEY §8(b).  The reference (eric612/Mobilenet-YOLO-Pytorch)
+ * owns no kernels: its hot path is stock torch.nn ops + torchvision.ops.nms.  Each entry
+ * point below therefore cites the reference CALL SITE whose arithmetic it replaces
+ * (paths relative to the reference repo root).
+ *
+ * Conventions
+ *  - Activations are channels-last (NHWC) fp32 unless stated otherwise.
+ *  - "View" arguments (x, in_scale, in_shift, in_act): the kernel reads
+ *        a = act(x * in_scale[c] + in_shift[c])      (in_scale == NULL -> a = act(x))
+ *    i.e. the BatchNorm-apply + activation of the PRODUCING layer is fused into the
+ *    consumer's load path; padding taps are 0 in the activated domain.
+ *  - `stats` (optional, may be NULL): per-channel partial sums of the raw output,
+ *    laid out [parts][2][C] (sum, sum of squares); `parts` is returned by the matching
+ *    *_stat_parts() query.  mny_bn_finalize() reduces them in fp64.
+ *  - Ownership: the caller allocates every buffer (inputs, outputs, workspaces).  The
+ *    library never allocates, frees or retains device pointers.
+ *  - All work is enqueued on `stream` (a hipStream_t passed as void*); no entry point
+ *    synchronises the device.
+ *  - Return value: 0 on success, a negative MNY_E* code otherwise; mny_last_error()
+ *    returns a thread-local message.  No C++ exception crosses this boundary.
+ *  - Re-entrant; deterministic (no floating-point atomics anywhere).
+ */
+#ifndef MNYOLO_H
+#define MNYOLO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MNY_OK 0
+#define MNY_EINVAL (-1)   /* bad argument (shape, alignment, null pointer) */
+#define MNY_EHIP (-2)     /* a HIP runtime call / kernel launch failed */
+#define MNY_EUNSUPPORTED (-3)
+
+/* activation codes (mobilenetv2.py:42 ReLU6, mbv2_yolo.py:24 LeakyReLU(0.1),
+ * mobilenetv3.py:14-23 hswish / ReLU) */
+#define MNY_ACT_NONE 0
+#define MNY_ACT_RELU6 1
+#define MNY_ACT_LEAKY 2
+#define MNY_ACT_RELU 3
+#define MNY_ACT_HSWISH 4
+
+int mny_version(void);
+const char* mny_last_error(void);
+/* max number of stat/partial rows any kernel will write (upper bound for workspace sizing) */
+int mny_max_parts(void);
+
+/* ---- stem: 3x3 stride-2 pad-1 conv 3->Cout on NCHW input, NHWC output -------------------
+ * replaces nn.Conv2d(3,32,3,2,1) at models/mobilenetv2.py:40 (used :113).               */
+int mny_stem_fwd(const float* x_nchw, const float* w /*[Cout,3,3,3]*/, float* y /*[N,H/2,W/2,Cout]*/,
+                 float* stats, int N, int H, int W, int Cout, void* stream);
+int mny_stem_stat_parts(int N, int H, int W, int Cout);
+/* dW = sum x * dy; `ws` holds [mny_stem_wgrad_parts()][Cout*27] floats */
+int mny_stem_wgrad(const float* x_nchw, const float* dy, float* dw, float* ws,
+                   int N, int H, int W, int Cout, void* stream);
+int mny_stem_wgrad_parts(int N, int H, int W, int Cout);
+
+/* ---- depthwise KxK (K=3|5), stride 1|2, pad K/2, no bias ---------------------------------
+ * replaces nn.Conv2d(C,C,3,s,1,groups=C) at models/mobilenetv2.py:65,79 and
+ * models/mbv2_yolo.py:22 (BasicConv depthwise); K=5 for models/mobilenetv3.py:54.        */
+int mny_dw_fwd(const float* x, const float* in_scale, const float* in_shift, int in_act,
+               const float* w /*[C,K,K]*/, float* y, float* stats,
+               int N, int H, int W, int C, int K, int stride, void* stream);
+int mny_dw_stat_parts(int N, int H, int W, int C, int K, int stride);
+/* dx[N,H,W,C] = (addend ? addend : 0) + conv_transpose(dy, w); H,W are the INPUT extents */
+int mny_dw_bwd_data(const float* dy, const float* w, const float* addend, float* dx,
+                    int N, int H, int W, int C, int K, int stride, void* stream);
+/* dw[C,K,K]; ws holds [mny_dw_wgrad_parts()][C*K*K] floats */
+int mny_dw_bwd_weight(const float* x, const float* in_scale, const float* in_shift, int in_act,
+                      const float* dy, float* dw, float* ws,
+                      int N, int H, int W, int C, int K, int stride, void* stream);
+int mny_dw_wgrad_parts(int N, int H, int W, int C, int K, int stride);
+
+/* ---- pointwise 1x1 conv == row-major GEMM on fp32 MFMA ----------------------------------
+ * y[M,Nc] = act_in(x)[M,K] * w[Nc,K]^T (+ bias) (+ addend)
+ * replaces nn.Conv2d(Cin,Cout,1) at models/mobilenetv2.py:48,69,75,83,
+ * models/mbv2_yolo.py:20 (BasicConv 1x1) and :82 (biased head conv).
+ * The same entry point computes the data gradient: dx[M,K] = dy[M,Nc] * wT[K,Nc]^T with
+ * wT = mny_transpose(w) and `addend` = the other gradient contribution (residual path). */
+int mny_pw_fwd(const float* x, const float* in_scale, const float* in_shift, int in_act,
+               const float* w, const float* bias, const float* addend, float* y, float* stats,
+               int64_t M, int K, int Nc, void* stream);
+int mny_pw_stat_parts(int64_t M, int K, int Nc);
+/* dw[Nc,K] = dy[M,Nc]^T * act_in(x)[M,K]; dbias[Nc] (optional) = column sums of dy.
+ * ws holds mny_pw_wgrad_ws_floats() floats. */
+int mny_pw_wgrad(const float* x, const float* in_scale, const float* in_shift, int in_act,
+                 const float* dy, float* dw, float* dbias, float* ws,
+                 int64_t M, int K, int Nc, void* stream);
+size_t mny_pw_wgrad_ws_floats(int64_t M, int K, int Nc);
+int mny_transpose(const float* src /*[R,Cc]*/, float* dst /*[Cc,R]*/, int R, int Cc, void* stream);
+
+/* ---- BatchNorm (training / eval), eps 1e-5, momentum 0.1 ---------------------------------
+ * replaces nn.BatchNorm2d at models/mobilenetv2.py:41,49,66,70,76,80,84 and
+ * models/mbv2_yolo.py:23.  Training: stats partials -> batch mean/var (biased for the
+ * normalisation, unbiased for running_var like torch) -> scale/shift consumed by views. */
+int mny_bn_finalize(const float* stats, int parts, int64_t count,
+                    const float* gamma, const float* beta, float eps, float momentum,
+                    float* running_mean, float* running_var,   /* updated in place; may be NULL */
+                    float* scale, float* shift, float* mean, float* invstd, int C, void* stream);
+int mny_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, float* scale, float* shift,
+                       int C, void* stream);
+/* backward, step 1: partial sums of dz = g * act'(scale*y+shift) and dz*yhat,
+ * yhat = (y-mean)*invstd  -> red[parts][2][C] */
+int mny_bn_bwd_reduce(const float* g, const float* y, const float* scale, const float* shift, int act,
+                      const float* mean, const float* invstd, float* red, int64_t M, int C, void* stream);
+int mny_bn_bwd_parts(int64_t M, int C);
+/* step 2: dgamma, dbeta and the per-channel coefficients of dy = ca*dz + cb*y + cc */
+int mny_bn_bwd_finalize(const float* red, int parts, int64_t count, const float* gamma,
+                        const float* mean, const float* invstd,
+                        float* dgamma, float* dbeta, float* coef /*[3][C]*/, int C, void* stream);
+/* step 3: dy = ca * g*act'(scale*y+shift) + cb*y + cc   (dy may alias g).
+ * coef == NULL: dy = g*act'(...) only (activation backward of a non-BN view). */
+int mny_bn_bwd_apply(const float* g, const float* y, const float* scale, const float* shift, int act,
+                     const float* coef, float* dy, int64_t M, int C, void* stream);
+
+/* ---- residual / upsample glue -----------------------------------------------------------
+ * out = view(a) + view(b) [+ nearest-2x-upsample(up)]   (all [N,H,W,C]; up is [N,H/2,W/2,C])
+ * replaces `x + self.conv(x)` (mobilenetv2.py:89), torch.add (mbv2_yolo.py:103,151) and
+ * nn.Upsample(scale_factor=2,'nearest') (mbv2_yolo.py:52).  b may be NULL (materialise a). */
+int mny_add_views(const float* a, const float* a_scale, const float* a_shift, int a_act,
+                  const float* b, const float* b_scale, const float* b_shift, int b_act,
+                  const float* up, float* out, int N, int H, int W, int C, void* stream);
+/* dst[N,H/2,W/2,C] = (accumulate ? dst : 0) + sum of the 2x2 children of src[N,H,W,C] */
+int mny_upsample_bwd(const float* src, float* dst, int accumulate, int N, int H, int W, int C, void* stream);
+/* dst = (accumulate ? dst : 0) + alpha[0] * src   (alpha: device scalar or NULL => 1) */
+int mny_axpy(const float* src, const float* alpha, float* dst, int accumulate, int64_t n, void* stream);
+
+/* ---- detection math ---------------------------------------------------------------------
+ * One head, channels-last [N,g,g,A*(5+C)] (channel = a*(5+C)+attr, yolo_loss.py:84).
+ * anchors_all: [n_anchors_all][2] already divided by img_size (yolo_loss.py:214);
+ * mask: the A indices of this head's anchors.
+ * targets: packed [T,5] = (label 1..C, cx, cy, w, h); t_off[N+1] = per-image offsets.  */
+typedef struct {
+    int N, g, A, C;            /* batch, grid, anchors of this head, classes */
+    int n_anchors_all;
+    float ignore_thresh, iou_thresh, iou_weighting;
+} mny_yolo_head;
+
+/* Training: replaces YOLOLoss.forward/get_target (models/yolo_loss.py:77-178,206-236),
+ * box_ciou (:257-293), class_loss (:425-434), weighted_mse_loss (:53-60) and their autograd
+ * graph.  out7 = (loss, recall, avg_iou, obj, no_obj, cls_score, count/N); dhead = dLoss/dhead.
+ * ws: mny_yolo_loss_ws_bytes() bytes. */
+int mny_yolo_loss(const float* head, const float* targets, const int32_t* t_off,
+                  const float* anchors_all, const int32_t* mask, const mny_yolo_head* hp,
+                  float* out7, float* dhead, void* ws, void* stream);
+size_t mny_yolo_loss_ws_bytes(const mny_yolo_head* hp, int total_targets);
+
+/* Eval: replaces YOLOLoss.get_pred_boxes (models/yolo_loss.py:180-204): decode every cell to
+ * (x1,y1,x2,y2,conf,cls_score,cls_idx), keep conf > val_conf, compact per image preserving
+ * (anchor,row,col) order.  rows: [N][A*g*g][7] capacity; counts[N]. */
+int mny_yolo_decode(const float* head, const float* anchors_all, const int32_t* mask,
+                    const mny_yolo_head* hp, float val_conf, float* rows, int32_t* counts, void* stream);
+
+/* Per-class NMS: replaces utils/box.py:11-31 + torchvision.ops.nms(boxes, score*conf, thr).
+ * rows: [total,7]; seg_off[S+1]: one segment per image.  out_idx: kept row indices (into rows),
+ * segment s occupies out_idx[seg_off[s] .. seg_off[s]+out_counts[s]), class-major then descending
+ * score (stable, ties by original order).  thr is a double and the float IoU is promoted before
+ * the strict `>` compare, like torchvision.  max_seg_rows: caller's upper bound on rows in any one
+ * segment (sizes the LDS sort buffer; 0 = use `total`).  A (segment,class) bucket larger than
+ * 8192 rows cannot be sorted in LDS: it keeps nothing and the int32 at ws+mny_nms_status_offset()
+ * receives the offending size (0 = ok).  ws: mny_nms_ws_bytes() bytes. */
+int mny_nms_per_class(const float* rows, const int32_t* seg_off, int S, int total, int max_seg_rows,
+                      int num_classes, double thr, int32_t* out_idx, int32_t* out_counts,
+                      void* ws, void* stream);
+size_t mny_nms_status_offset(int S, int total, int num_classes);
+size_t mny_nms_ws_bytes(int S, int total, int num_classes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MNYOLO_H */

@@ -1,0 +1,5 @@
+"""mobilenet-yolo-pytorch_amd — MI355X-native MobileNet-YOLO hot path.
+
+Import as `mobilenet_yolo_pytorch_amd` (the repo-root shim maps the hyphenated directory)."""
+from . import _lib  # noqa: F401
+from ._lib import MnyError  # noqa: F401

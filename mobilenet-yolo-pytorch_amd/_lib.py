@@ -1,0 +1,91 @@
+"""ctypes binding of libmnyolo.so (include/mnyolo.h).  The product has NO fallback: if the
+library is missing or a call fails, an exception is raised."""
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmnyolo.so")
+
+ACT_NONE, ACT_RELU6, ACT_LEAKY, ACT_RELU, ACT_HSWISH = 0, 1, 2, 3, 4
+
+
+class MnyError(RuntimeError):
+    pass
+
+
+class YoloHead(ctypes.Structure):
+    _fields_ = [("N", c_int), ("g", c_int), ("A", c_int), ("C", c_int), ("n_anchors_all", c_int),
+                ("ignore_thresh", c_float), ("iou_thresh", c_float), ("iou_weighting", c_float)]
+
+
+P = c_void_p
+_SIGS = {
+    # name: (restype, argtypes)
+    "mny_version": (c_int, []),
+    "mny_last_error": (c_char_p, []),
+    "mny_max_parts": (c_int, []),
+    "mny_stem_fwd": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "mny_stem_stat_parts": (c_int, [c_int, c_int, c_int, c_int]),
+    "mny_stem_wgrad": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
+    "mny_stem_wgrad_parts": (c_int, [c_int, c_int, c_int, c_int]),
+    "mny_dw_fwd": (c_int, [P, P, P, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "mny_dw_stat_parts": (c_int, [c_int] * 6),
+    "mny_dw_bwd_data": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "mny_dw_bwd_weight": (c_int, [P, P, P, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "mny_dw_wgrad_parts": (c_int, [c_int] * 6),
+    "mny_pw_fwd": (c_int, [P, P, P, c_int, P, P, P, P, P, c_int64, c_int, c_int, P]),
+    "mny_pw_stat_parts": (c_int, [c_int64, c_int, c_int]),
+    "mny_pw_wgrad": (c_int, [P, P, P, c_int, P, P, P, P, c_int64, c_int, c_int, P]),
+    "mny_pw_wgrad_ws_floats": (c_size_t, [c_int64, c_int, c_int]),
+    "mny_transpose": (c_int, [P, P, c_int, c_int, P]),
+    "mny_bn_finalize": (c_int, [P, c_int, c_int64, P, P, c_float, c_float, P, P, P, P, P, P, c_int, P]),
+    "mny_bn_eval_coeffs": (c_int, [P, P, P, P, c_float, P, P, c_int, P]),
+    "mny_bn_bwd_reduce": (c_int, [P, P, P, P, c_int, P, P, P, c_int64, c_int, P]),
+    "mny_bn_bwd_parts": (c_int, [c_int64, c_int]),
+    "mny_bn_bwd_finalize": (c_int, [P, c_int, c_int64, P, P, P, P, P, P, c_int, P]),
+    "mny_bn_bwd_apply": (c_int, [P, P, P, P, c_int, P, P, c_int64, c_int, P]),
+    "mny_add_views": (c_int, [P, P, P, c_int, P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, P]),
+    "mny_upsample_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "mny_axpy": (c_int, [P, P, P, c_int, c_int64, P]),
+    "mny_yolo_loss": (c_int, [P, P, P, P, P, ctypes.POINTER(YoloHead), P, P, P, P]),
+    "mny_yolo_loss_ws_bytes": (c_size_t, [ctypes.POINTER(YoloHead), c_int]),
+    "mny_yolo_decode": (c_int, [P, P, P, ctypes.POINTER(YoloHead), c_float, P, P, P]),
+    "mny_nms_per_class": (c_int, [P, P, c_int, c_int, c_int, c_int, c_double, P, P, P, P]),
+    "mny_nms_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "mny_nms_status_offset": (c_size_t, [c_int, c_int, c_int]),
+}
+EXPORTS = tuple(_SIGS)
+
+_lib = None
+
+
+def load():
+    """Load libmnyolo.so (raises MnyError when it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MnyError("libmnyolo.so not found at %s — run __graft_entry__.build() (hipcc, gfx950). "
+                           "There is no CPU fallback." % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point; raise MnyError with the library's message on failure."""
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise MnyError("%s failed (%d): %s" % (name, rc, lib.mny_last_error().decode()))
+
+
+def query(name, *args):
+    v = getattr(load(), name)(*args)
+    if isinstance(v, int) and v < 0:
+        raise MnyError("%s(%s) -> %d: %s" % (name, args, v, load().mny_last_error().decode()))
+    return v

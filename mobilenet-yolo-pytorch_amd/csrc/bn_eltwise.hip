@@ -1,0 +1,298 @@
+// BatchNorm (training + eval) split as "statistics in the producer's epilogue, apply in the consumer's
+// load path", plus the elementwise glue of the network (residual add, nearest-2x upsample, axpy).
+// All kernels are HBM-bound float4 streams in the shared channel-group thread layout; all reductions
+// are two-stage and deterministic (per-block partial rows, fp64 combine).
+//
+// replaces nn.BatchNorm2d (models/mobilenetv2.py:41-84, models/mbv2_yolo.py:23), ReLU6 / LeakyReLU
+// backward, `x + conv(x)` (mobilenetv2.py:89), torch.add (mbv2_yolo.py:103,151) and nn.Upsample (:52).
+#include "common.h"
+
+namespace mny {
+
+// ---- forward statistics -> scale/shift -----------------------------------------------------------
+// block = 32 channels x 8 slices of the partial rows
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int parts, double count,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float eps, float momentum, float* running_mean, float* running_var,
+                                                          float* scale, float* shift, float* mean_out, float* invstd_out, int C) {
+    __shared__ double red[2][8][32];
+    const int cl = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double s = 0.0, q = 0.0;
+    if (c < C)
+        for (int p = slice; p < parts; p += 8) {
+            s += (double)stats[((int64_t)p * 2 + 0) * C + c];
+            q += (double)stats[((int64_t)p * 2 + 1) * C + c];
+        }
+    red[0][slice][cl] = s;
+    red[1][slice][cl] = q;
+    __syncthreads();
+    if (slice == 0 && c < C) {
+        s = 0.0; q = 0.0;
+        for (int i = 0; i < 8; ++i) { s += red[0][i][cl]; q += red[1][i][cl]; }
+        const double mean = s / count;
+        double var = q / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[c] * invstd;
+        scale[c] = sc;
+        shift[c] = beta[c] - (float)mean * sc;
+        if (mean_out) mean_out[c] = (float)mean;
+        if (invstd_out) invstd_out[c] = invstd;
+        if (running_mean) {
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+    }
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm, const float* rv, float eps,
+                                      float* scale, float* shift, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] / sqrtf(rv[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - rm[c] * sc;
+}
+
+// ---- backward ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift, int act,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            float* __restrict__ red_out, int64_t M, int C, int cgb, int cg_total) {
+    __shared__ float4 red[256 * 2];
+    const int tid = threadIdx.x;
+    const int cgl = tid % cgb, pix = tid / cgb, ppb = blockDim.x / cgb;
+    const int cg = blockIdx.y * cgb + cgl;
+    const bool cvalid = cg < cg_total;
+    const int c = cg * 4;
+    float4 s1 = f4zero(), s2 = f4zero();
+    if (cvalid) {
+        const float4 sc = ld4(scale + c), sh = ld4(shift + c), mu = ld4(mean + c), is = ld4(invstd + c);
+        for (int64_t m = (int64_t)blockIdx.x * ppb + pix; m < M; m += (int64_t)gridDim.x * ppb) {
+            const float4 gv = ld4(g + m * C + c), yv = ld4(y + m * C + c);
+            float4 dz;
+            dz.x = gv.x * act_bwd(fmaf(yv.x, sc.x, sh.x), act);
+            dz.y = gv.y * act_bwd(fmaf(yv.y, sc.y, sh.y), act);
+            dz.z = gv.z * act_bwd(fmaf(yv.z, sc.z, sh.z), act);
+            dz.w = gv.w * act_bwd(fmaf(yv.w, sc.w, sh.w), act);
+            add4(s1, dz);
+            s2.x = fmaf(dz.x, (yv.x - mu.x) * is.x, s2.x);
+            s2.y = fmaf(dz.y, (yv.y - mu.y) * is.y, s2.y);
+            s2.z = fmaf(dz.z, (yv.z - mu.z) * is.z, s2.z);
+            s2.w = fmaf(dz.w, (yv.w - mu.w) * is.w, s2.w);
+        }
+    }
+    red[tid * 2] = s1;
+    red[tid * 2 + 1] = s2;
+    __syncthreads();
+    if (pix == 0 && cvalid) {
+        float4 a = f4zero(), b = f4zero();
+        for (int p = 0; p < ppb; ++p) { add4(a, red[(p * cgb + cgl) * 2]); add4(b, red[(p * cgb + cgl) * 2 + 1]); }
+        st4(red_out + (int64_t)blockIdx.x * 2 * C + c, a);
+        st4(red_out + (int64_t)blockIdx.x * 2 * C + C + c, b);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ red_in, int parts, double count,
+                                                              const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                              const float* __restrict__ invstd, float* dgamma, float* dbeta,
+                                                              float* coef, int C) {
+    __shared__ double red[2][8][32];
+    const int cl = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double s = 0.0, q = 0.0;
+    if (c < C)
+        for (int p = slice; p < parts; p += 8) {
+            s += (double)red_in[((int64_t)p * 2 + 0) * C + c];
+            q += (double)red_in[((int64_t)p * 2 + 1) * C + c];
+        }
+    red[0][slice][cl] = s;
+    red[1][slice][cl] = q;
+    __syncthreads();
+    if (slice == 0 && c < C) {
+        s = 0.0; q = 0.0;
+        for (int i = 0; i < 8; ++i) { s += red[0][i][cl]; q += red[1][i][cl]; }
+        dbeta[c] = (float)s;
+        dgamma[c] = (float)q;
+        // dy = a*(dz - s/M - yhat*q/M),  yhat = (y-mu)*invstd   ->   dy = ca*dz + cb*y + cc
+        const double a = (double)gamma[c] * (double)invstd[c];
+        const double b = -a * (double)invstd[c] * q / count;
+        coef[c] = (float)a;
+        coef[C + c] = (float)b;
+        coef[2 * C + c] = (float)(-a * s / count - b * (double)mean[c]);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift, int act,
+                                                           const float* __restrict__ coef, float* __restrict__ dy,
+                                                           int64_t M, int C, int cgb, int cg_total) {
+    const int cgl = threadIdx.x % cgb, pix = threadIdx.x / cgb, ppb = blockDim.x / cgb;
+    const int cg = blockIdx.y * cgb + cgl;
+    if (cg >= cg_total) return;
+    const int c = cg * 4;
+    const float4 sc = scale ? ld4(scale + c) : f4one(), sh = scale ? ld4(shift + c) : f4zero();
+    const float4 ca = coef ? ld4(coef + c) : f4one();
+    const float4 cb = coef ? ld4(coef + C + c) : f4zero();
+    const float4 cc = coef ? ld4(coef + 2 * C + c) : f4zero();
+    for (int64_t m = (int64_t)blockIdx.x * ppb + pix; m < M; m += (int64_t)gridDim.x * ppb) {
+        const float4 gv = ld4(g + m * C + c), yv = ld4(y + m * C + c);
+        float4 o;
+        o.x = fmaf(ca.x, gv.x * act_bwd(fmaf(yv.x, sc.x, sh.x), act), fmaf(cb.x, yv.x, cc.x));
+        o.y = fmaf(ca.y, gv.y * act_bwd(fmaf(yv.y, sc.y, sh.y), act), fmaf(cb.y, yv.y, cc.y));
+        o.z = fmaf(ca.z, gv.z * act_bwd(fmaf(yv.z, sc.z, sh.z), act), fmaf(cb.z, yv.z, cc.z));
+        o.w = fmaf(ca.w, gv.w * act_bwd(fmaf(yv.w, sc.w, sh.w), act), fmaf(cb.w, yv.w, cc.w));
+        st4(dy + m * C + c, o);
+    }
+}
+
+// ---- residual add / upsample ---------------------------------------------------------------------
+__global__ __launch_bounds__(256) void add_views_kernel(const float* __restrict__ a, const float* __restrict__ a_scale,
+                                                        const float* __restrict__ a_shift, int a_act,
+                                                        const float* __restrict__ b, const float* __restrict__ b_scale,
+                                                        const float* __restrict__ b_shift, int b_act,
+                                                        const float* __restrict__ up, float* __restrict__ out,
+                                                        int N, int H, int W, int C, int cgb, int cg_total) {
+    const int cgl = threadIdx.x % cgb, pix = threadIdx.x / cgb, ppb = blockDim.x / cgb;
+    const int cg = blockIdx.y * cgb + cgl;
+    if (cg >= cg_total) return;
+    const int c = cg * 4;
+    const float4 asc = a_scale ? ld4(a_scale + c) : f4one(), ash = a_scale ? ld4(a_shift + c) : f4zero();
+    const float4 bsc = b_scale ? ld4(b_scale + c) : f4one(), bsh = b_scale ? ld4(b_shift + c) : f4zero();
+    const int64_t M = (int64_t)N * H * W;
+    for (int64_t m = (int64_t)blockIdx.x * ppb + pix; m < M; m += (int64_t)gridDim.x * ppb) {
+        float4 o = xform4(ld4(a + m * C + c), asc, ash, a_act);
+        if (b) add4(o, xform4(ld4(b + m * C + c), bsc, bsh, b_act));
+        if (up) {
+            const int wi = (int)(m % W), hi = (int)((m / W) % H);
+            const int64_t n = m / ((int64_t)W * H);
+            add4(o, ld4(up + ((n * (H / 2) + hi / 2) * (W / 2) + wi / 2) * C + c));
+        }
+        st4(out + m * C + c, o);
+    }
+}
+
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ src, float* __restrict__ dst, int accumulate,
+                                                           int N, int H, int W, int C, int cgb, int cg_total) {
+    const int cgl = threadIdx.x % cgb, pix = threadIdx.x / cgb, ppb = blockDim.x / cgb;
+    const int cg = blockIdx.y * cgb + cgl;
+    if (cg >= cg_total) return;
+    const int c = cg * 4;
+    const int Hh = H / 2, Wh = W / 2;
+    const int64_t M = (int64_t)N * Hh * Wh;
+    for (int64_t m = (int64_t)blockIdx.x * ppb + pix; m < M; m += (int64_t)gridDim.x * ppb) {
+        const int wi = (int)(m % Wh), hi = (int)((m / Wh) % Hh);
+        const int64_t n = m / ((int64_t)Wh * Hh);
+        const float* s = src + ((n * H + 2 * hi) * W + 2 * wi) * C + c;
+        float4 o = accumulate ? ld4(dst + m * C + c) : f4zero();
+        add4(o, ld4(s)); add4(o, ld4(s + C));
+        add4(o, ld4(s + (int64_t)W * C)); add4(o, ld4(s + (int64_t)W * C + C));
+        st4(dst + m * C + c, o);
+    }
+}
+
+__global__ __launch_bounds__(256) void axpy_kernel(const float* __restrict__ src, const float* __restrict__ alpha,
+                                                   float* __restrict__ dst, int accumulate, int64_t n4, int64_t n) {
+    const float a = alpha ? alpha[0] : 1.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 v = ld4(src + i * 4);
+        float4 d = accumulate ? ld4(dst + i * 4) : f4zero();
+        d.x = fmaf(a, v.x, d.x); d.y = fmaf(a, v.y, d.y); d.z = fmaf(a, v.z, d.z); d.w = fmaf(a, v.w, d.w);
+        st4(dst + i * 4, d);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = n4 * 4 + threadIdx.x;
+        dst[i] = (accumulate ? dst[i] : 0.f) + a * src[i];
+    }
+}
+
+static inline dim3 rows_grid(int64_t M, const CgLayout& L, int cap) {
+    int64_t want = cdiv(M, L.ppb);
+    return dim3((unsigned)(want < cap ? want : cap), L.chunks);
+}
+
+}  // namespace mny
+
+using namespace mny;
+
+extern "C" int mny_bn_finalize(const float* stats, int parts, int64_t count, const float* gamma, const float* beta, float eps,
+                               float momentum, float* running_mean, float* running_var, float* scale, float* shift,
+                               float* mean, float* invstd, int C, void* stream) {
+    MNY_REQUIRE(stats && gamma && beta && scale && shift && parts > 0 && count > 0 && C > 0, "bn_finalize: bad arguments");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, stats, parts, (double)count,
+                       gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, invstd, C);
+    return check_launch("bn_finalize_kernel");
+}
+
+extern "C" int mny_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                                  float eps, float* scale, float* shift, int C, void* stream) {
+    MNY_REQUIRE(gamma && beta && running_mean && running_var && scale && shift && C > 0, "bn_eval_coeffs: bad arguments");
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta, running_mean,
+                       running_var, eps, scale, shift, C);
+    return check_launch("bn_eval_coeffs_kernel");
+}
+
+extern "C" int mny_bn_bwd_parts(int64_t M, int C) {
+    if (M <= 0 || C <= 0 || C % 4) return MNY_EINVAL;
+    CgLayout L = make_cg_layout(C);
+    return (int)rows_grid(M, L, 1024).x;
+}
+
+extern "C" int mny_bn_bwd_reduce(const float* g, const float* y, const float* scale, const float* shift, int act,
+                                 const float* mean, const float* invstd, float* red, int64_t M, int C, void* stream) {
+    MNY_REQUIRE(g && y && scale && shift && mean && invstd && red, "bn_bwd_reduce: null pointer");
+    MNY_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bn_bwd_reduce: bad shape M=%lld C=%d", (long long)M, C);
+    CgLayout L = make_cg_layout(C);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, rows_grid(M, L, 1024), dim3(L.threads), 0, (hipStream_t)stream, g, y, scale, shift, act,
+                       mean, invstd, red, M, C, L.cgb, L.cg_total);
+    return check_launch("bn_bwd_reduce_kernel");
+}
+
+extern "C" int mny_bn_bwd_finalize(const float* red, int parts, int64_t count, const float* gamma, const float* mean,
+                                   const float* invstd, float* dgamma, float* dbeta, float* coef, int C, void* stream) {
+    MNY_REQUIRE(red && gamma && mean && invstd && dgamma && dbeta && coef && parts > 0 && C > 0, "bn_bwd_finalize: bad arguments");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, red, parts, (double)count,
+                       gamma, mean, invstd, dgamma, dbeta, coef, C);
+    return check_launch("bn_bwd_finalize_kernel");
+}
+
+extern "C" int mny_bn_bwd_apply(const float* g, const float* y, const float* scale, const float* shift, int act, const float* coef,
+                                float* dy, int64_t M, int C, void* stream) {
+    MNY_REQUIRE(g && y && dy, "bn_bwd_apply: null pointer");
+    MNY_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bn_bwd_apply: bad shape");
+    CgLayout L = make_cg_layout(C);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, rows_grid(M, L, 8192), dim3(L.threads), 0, (hipStream_t)stream, g, y, scale, shift, act,
+                       coef, dy, M, C, L.cgb, L.cg_total);
+    return check_launch("bn_bwd_apply_kernel");
+}
+
+extern "C" int mny_add_views(const float* a, const float* a_scale, const float* a_shift, int a_act, const float* b,
+                             const float* b_scale, const float* b_shift, int b_act, const float* up, float* out, int N, int H,
+                             int W, int C, void* stream) {
+    MNY_REQUIRE(a && out, "add_views: null pointer");
+    MNY_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "add_views: bad shape");
+    MNY_REQUIRE(!up || (H % 2 == 0 && W % 2 == 0), "add_views: upsample operand needs even H,W");
+    CgLayout L = make_cg_layout(C);
+    hipLaunchKernelGGL(add_views_kernel, rows_grid((int64_t)N * H * W, L, 8192), dim3(L.threads), 0, (hipStream_t)stream, a, a_scale,
+                       a_shift, a_act, b, b_scale, b_shift, b_act, up, out, N, H, W, C, L.cgb, L.cg_total);
+    return check_launch("add_views_kernel");
+}
+
+extern "C" int mny_upsample_bwd(const float* src, float* dst, int accumulate, int N, int H, int W, int C, void* stream) {
+    MNY_REQUIRE(src && dst && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "upsample_bwd: bad arguments");
+    CgLayout L = make_cg_layout(C);
+    hipLaunchKernelGGL(upsample_bwd_kernel, rows_grid((int64_t)N * (H / 2) * (W / 2), L, 8192), dim3(L.threads), 0, (hipStream_t)stream,
+                       src, dst, accumulate, N, H, W, C, L.cgb, L.cg_total);
+    return check_launch("upsample_bwd_kernel");
+}
+
+extern "C" int mny_axpy(const float* src, const float* alpha, float* dst, int accumulate, int64_t n, void* stream) {
+    MNY_REQUIRE(src && dst && n > 0, "axpy: bad arguments");
+    const int64_t n4 = n / 4;
+    int64_t blocks = cdiv(n4 > 0 ? n4 : 1, 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, alpha, dst, accumulate, n4, n);
+    return check_launch("axpy_kernel");
+}

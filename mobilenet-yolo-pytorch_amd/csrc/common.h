@@ -1,0 +1,86 @@
+// Shared helpers for libmnyolo (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/mnyolo.h"
+
+namespace mny {
+
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+#define MNY_REQUIRE(cond, ...)                 \
+    do {                                       \
+        if (!(cond)) {                         \
+            mny::set_error(__VA_ARGS__);       \
+            return MNY_EINVAL;                 \
+        }                                      \
+    } while (0)
+
+constexpr int kWave = 64;        // CDNA wavefront
+constexpr int kMaxParts = 2048;  // upper bound on stat/partial rows (8 blocks x 256 CUs)
+
+__host__ __device__ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+__device__ __forceinline__ float act_fwd(float z, int act) {
+    switch (act) {
+        case MNY_ACT_RELU6: return fminf(fmaxf(z, 0.f), 6.f);
+        case MNY_ACT_LEAKY: return z > 0.f ? z : 0.1f * z;
+        case MNY_ACT_RELU: return fmaxf(z, 0.f);
+        case MNY_ACT_HSWISH: return z * fminf(fmaxf(z + 3.f, 0.f), 6.f) / 6.f;
+        default: return z;
+    }
+}
+// derivative of act at pre-activation z (matches torch's subgradient choices:
+// relu6/hardtanh: 1 on (0,6) exclusive; leaky_relu: slope for z<=0 ... torch uses x>0 ? 1 : slope)
+__device__ __forceinline__ float act_bwd(float z, int act) {
+    switch (act) {
+        case MNY_ACT_RELU6: return (z > 0.f && z < 6.f) ? 1.f : 0.f;
+        case MNY_ACT_LEAKY: return z > 0.f ? 1.f : 0.1f;
+        case MNY_ACT_RELU: return z > 0.f ? 1.f : 0.f;
+        case MNY_ACT_HSWISH: return z <= -3.f ? 0.f : (z >= 3.f ? 1.f : (2.f * z + 3.f) / 6.f);
+        default: return 1.f;
+    }
+}
+
+__device__ __forceinline__ float4 xform4(float4 v, float4 sc, float4 sh, int act) {
+    float4 r;
+    r.x = act_fwd(fmaf(v.x, sc.x, sh.x), act);
+    r.y = act_fwd(fmaf(v.y, sc.y, sh.y), act);
+    r.z = act_fwd(fmaf(v.z, sc.z, sh.z), act);
+    r.w = act_fwd(fmaf(v.w, sc.w, sh.w), act);
+    return r;
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 f4one() { return make_float4(1.f, 1.f, 1.f, 1.f); }
+__device__ __forceinline__ void fma4(float4& acc, float4 a, float4 b) {
+    acc.x = fmaf(a.x, b.x, acc.x); acc.y = fmaf(a.y, b.y, acc.y);
+    acc.z = fmaf(a.z, b.z, acc.z); acc.w = fmaf(a.w, b.w, acc.w);
+}
+__device__ __forceinline__ void add4(float4& acc, float4 a) { acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w; }
+
+// Channel-group thread layout shared by the NHWC stencil / elementwise kernels:
+// a thread owns 4 consecutive channels; `cgb` channel groups per block (<=256), `ppb` pixels per block.
+struct CgLayout {
+    int cg_total;   // C/4
+    int chunks;     // channel chunks (gridDim.y)
+    int cgb;        // channel groups per block
+    int ppb;        // pixels (or strips) per block
+    int threads;    // cgb*ppb
+};
+inline CgLayout make_cg_layout(int C) {
+    CgLayout L;
+    L.cg_total = C / 4;
+    L.chunks = (int)cdiv(L.cg_total, 256);
+    L.cgb = (int)cdiv(L.cg_total, L.chunks);
+    L.ppb = 256 / L.cgb; if (L.ppb < 1) L.ppb = 1;
+    L.threads = L.cgb * L.ppb;
+    return L;
+}
+
+}  // namespace mny

@@ -1,0 +1,280 @@
+// Depthwise KxK convolution (K = 3 | 5, stride 1 | 2), NHWC fp32 — forward, backward-data,
+// backward-weight.  HBM-bandwidth-bound (AI 0.9-2.2 FLOP/B): the design goal is
+// one coalesced pass over the input and one over the output.
+//
+// Thread = 4 consecutive channels (one float4) x one output column; it slides a KxK register
+// window down a strip of TH output rows, so every input row is loaded once per strip (K-S halo
+// rows re-read per strip come from L2).  Consecutive lanes cover consecutive channel groups and
+// then consecutive output columns: every wave-level load/store is a run of full 16-B vectors over
+// contiguous NHWC memory.  BatchNorm-apply + activation of the producer is fused into the load
+// (`view` arguments), the BN statistics of the output are fused into the epilogue as deterministic
+// per-block partial sums.
+//
+// replaces nn.Conv2d(groups=C) at models/mobilenetv2.py:65,79 and models/mbv2_yolo.py:22.
+#include "common.h"
+
+namespace mny {
+
+struct DwGeom {
+    int N, H, W, C, Ho, Wo;
+    int TH, nHS;        // strip height, strips per column
+    int64_t nstrips;    // N * Wo * nHS
+    int cg_total, cgb;  // channel groups total / per block
+};
+
+template <int KS>
+__device__ __forceinline__ void load_weights(const float* __restrict__ w, int c, bool flip, float4 (&wg)[KS * KS]) {
+    constexpr int KK = KS * KS;
+#pragma unroll
+    for (int t = 0; t < KK; ++t) {
+        int s = flip ? (KK - 1 - t) : t;
+        wg[t] = make_float4(w[(c + 0) * KK + s], w[(c + 1) * KK + s], w[(c + 2) * KK + s], w[(c + 3) * KK + s]);
+    }
+}
+
+// MODE 0: forward (y = conv(view(x)), optional stats)    [also backward-data for stride 1 with flip]
+// MODE 1: backward-weight (accumulate dy * view(x) per tap)
+template <int KS, int S, int MODE>
+__global__ __launch_bounds__(256) void dw_slide_kernel(
+    const float* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift, int in_act,
+    const float* __restrict__ w, int flip, const float* __restrict__ addend,
+    float* __restrict__ y,            // MODE 0: output; MODE 1: unused
+    const float* __restrict__ dy,     // MODE 1: output gradient
+    float* __restrict__ parts,        // MODE 0: stats [grid.x][2][C] (may be null); MODE 1: [grid.x][C*KK]
+    DwGeom g) {
+    constexpr int P = KS / 2;
+    constexpr int KK = KS * KS;
+    __shared__ float4 red[256 * 2];
+
+    const int tid = threadIdx.x;
+    const int cgl = tid % g.cgb;
+    const int pix = tid / g.cgb;
+    const int ppb = blockDim.x / g.cgb;
+    const int cg = blockIdx.y * g.cgb + cgl;
+    const bool cvalid = cg < g.cg_total;
+    const int c = cg * 4;
+
+    float4 wg[KK];
+    float4 sc = f4one(), sh = f4zero();
+    const bool has_xf = in_scale != nullptr;
+    if (cvalid) {
+        if (MODE == 0) load_weights<KS>(w, c, flip != 0, wg);
+        if (has_xf) { sc = ld4(in_scale + c); sh = ld4(in_shift + c); }
+    }
+    float4 acc_s1 = f4zero(), acc_s2 = f4zero();   // MODE 0 stats
+    float4 wacc[KK];                               // MODE 1 accumulators
+    if (MODE == 1) {
+#pragma unroll
+        for (int t = 0; t < KK; ++t) wacc[t] = f4zero();
+    }
+
+    if (cvalid) {
+        for (int64_t strip = (int64_t)blockIdx.x * ppb + pix; strip < g.nstrips; strip += (int64_t)gridDim.x * ppb) {
+            const int wo = (int)(strip % g.Wo);
+            const int hs = (int)((strip / g.Wo) % g.nHS);
+            const int n = (int)(strip / ((int64_t)g.Wo * g.nHS));
+            const int ho0 = hs * g.TH;
+            const int ho1 = min(ho0 + g.TH, g.Ho);
+            const float* xn = x + (int64_t)n * g.H * g.W * g.C + c;
+            float4 win[KS][KS];
+            auto load_row = [&](int r, int hi) {
+#pragma unroll
+                for (int q = 0; q < KS; ++q) {
+                    const int wi = wo * S - P + q;
+                    float4 v = f4zero();
+                    if (hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) {
+                        v = ld4(xn + ((int64_t)hi * g.W + wi) * g.C);
+                        if (has_xf || in_act != MNY_ACT_NONE) v = xform4(v, sc, sh, in_act);
+                    }
+                    win[r][q] = v;
+                }
+            };
+#pragma unroll
+            for (int r = 0; r < KS - S; ++r) load_row(r + S, ho0 * S - P + r);   // pre-shifted; first iter shifts down
+            for (int ho = ho0; ho < ho1; ++ho) {
+#pragma unroll
+                for (int r = 0; r < KS - S; ++r)
+#pragma unroll
+                    for (int q = 0; q < KS; ++q) win[r][q] = win[r + S][q];
+#pragma unroll
+                for (int r = KS - S; r < KS; ++r) load_row(r, ho * S - P + r);
+                const int64_t o = (((int64_t)n * g.Ho + ho) * g.Wo + wo) * g.C + c;
+                if (MODE == 0) {
+                    float4 out = addend ? ld4(addend + o) : f4zero();
+#pragma unroll
+                    for (int r = 0; r < KS; ++r)
+#pragma unroll
+                        for (int q = 0; q < KS; ++q) fma4(out, win[r][q], wg[r * KS + q]);
+                    st4(y + o, out);
+                    add4(acc_s1, out);
+                    fma4(acc_s2, out, out);
+                } else {
+                    const float4 d = ld4(dy + o);
+#pragma unroll
+                    for (int r = 0; r < KS; ++r)
+#pragma unroll
+                        for (int q = 0; q < KS; ++q) fma4(wacc[r * KS + q], win[r][q], d);
+                }
+            }
+        }
+    }
+
+    if (parts == nullptr) return;
+    // deterministic block reduction over the `ppb` pixel slots, fixed order
+    if (MODE == 0) {
+        red[tid * 2 + 0] = acc_s1;
+        red[tid * 2 + 1] = acc_s2;
+        __syncthreads();
+        if (pix == 0 && cvalid) {
+            float4 a = f4zero(), b = f4zero();
+            for (int p = 0; p < ppb; ++p) { add4(a, red[(p * g.cgb + cgl) * 2]); add4(b, red[(p * g.cgb + cgl) * 2 + 1]); }
+            float* dst = parts + (int64_t)blockIdx.x * 2 * g.C;
+            st4(dst + c, a);
+            st4(dst + g.C + c, b);
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < KK; ++t) {
+            __syncthreads();
+            red[tid] = wacc[t];
+            __syncthreads();
+            if (pix == 0 && cvalid) {
+                float4 a = f4zero();
+                for (int p = 0; p < ppb; ++p) add4(a, red[p * g.cgb + cgl]);
+                float* dst = parts + (int64_t)blockIdx.x * g.C * KK;
+                dst[(c + 0) * KK + t] = a.x; dst[(c + 1) * KK + t] = a.y;
+                dst[(c + 2) * KK + t] = a.z; dst[(c + 3) * KK + t] = a.w;
+            }
+        }
+    }
+}
+
+// stride-2 backward-data as a gather over the (at most ceil(K/2)^2) contributing taps
+template <int KS>
+__global__ __launch_bounds__(256) void dw_bwd_data_s2_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                             const float* __restrict__ addend, float* __restrict__ dx,
+                                                             int N, int H, int W, int C, int Ho, int Wo, int cgb, int cg_total) {
+    constexpr int P = KS / 2;
+    constexpr int KK = KS * KS;
+    const int cgl = threadIdx.x % cgb, pix = threadIdx.x / cgb, ppb = blockDim.x / cgb;
+    const int cg = blockIdx.y * cgb + cgl;
+    if (cg >= cg_total) return;
+    const int c = cg * 4;
+    float4 wg[KK];
+    load_weights<KS>(w, c, false, wg);
+    const int64_t npix = (int64_t)N * H * W;
+    for (int64_t p = (int64_t)blockIdx.x * ppb + pix; p < npix; p += (int64_t)gridDim.x * ppb) {
+        const int wi = (int)(p % W);
+        const int hi = (int)((p / W) % H);
+        const int n = (int)(p / ((int64_t)W * H));
+        float4 out = addend ? ld4(addend + p * C + c) : f4zero();
+#pragma unroll
+        for (int kh = 0; kh < KS; ++kh) {
+            const int th = hi + P - kh;
+            if (th < 0 || (th & 1)) continue;
+            const int ho = th >> 1;
+            if (ho >= Ho) continue;
+#pragma unroll
+            for (int kw = 0; kw < KS; ++kw) {
+                const int tw = wi + P - kw;
+                if (tw < 0 || (tw & 1)) continue;
+                const int wo = tw >> 1;
+                if (wo >= Wo) continue;
+                fma4(out, ld4(dy + (((int64_t)n * Ho + ho) * Wo + wo) * C + c), wg[kh * KS + kw]);
+            }
+        }
+        st4(dx + p * C + c, out);
+    }
+}
+
+// sum partial rows [parts][n] -> out[n] in a fixed order
+__global__ void reduce_rows_kernel(const float* __restrict__ parts, int nparts, int n, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int p = 0; p < nparts; ++p) s += (double)parts[(int64_t)p * n + i];
+    out[i] = (float)s;
+}
+
+static int dw_geom(DwGeom& g, CgLayout& L, int& gx, int N, int H, int W, int C, int K, int stride) {
+    MNY_REQUIRE(K == 3 || K == 5, "dw: kernel size %d unsupported (3 or 5)", K);
+    MNY_REQUIRE(stride == 1 || stride == 2, "dw: stride %d unsupported", stride);
+    MNY_REQUIRE(C % 4 == 0 && C > 0, "dw: C=%d must be a positive multiple of 4", C);
+    MNY_REQUIRE(N > 0 && H > 0 && W > 0, "dw: empty tensor");
+    const int P = K / 2;
+    g.N = N; g.H = H; g.W = W; g.C = C;
+    g.Ho = (H + 2 * P - K) / stride + 1;
+    g.Wo = (W + 2 * P - K) / stride + 1;
+    const int ns = (int)cdiv(g.Ho, 8);
+    g.TH = (int)cdiv(g.Ho, ns);
+    g.nHS = (int)cdiv(g.Ho, g.TH);
+    g.nstrips = (int64_t)N * g.Wo * g.nHS;
+    L = make_cg_layout(C);
+    g.cg_total = L.cg_total; g.cgb = L.cgb;
+    int64_t want = cdiv(g.nstrips, L.ppb);
+    gx = (int)(want < kMaxParts ? want : kMaxParts);
+    return MNY_OK;
+}
+
+template <int MODE>
+static int dw_launch(const float* x, const float* sc, const float* sh, int act, const float* w, int flip,
+                     const float* addend, float* y, const float* dy, float* parts,
+                     int N, int H, int W, int C, int K, int stride, hipStream_t st) {
+    DwGeom g; CgLayout L; int gx;
+    int rc = dw_geom(g, L, gx, N, H, W, C, K, stride);
+    if (rc) return rc;
+    dim3 grid(gx, L.chunks), block(L.threads);
+#define MNY_DW(KS_, S_) hipLaunchKernelGGL((dw_slide_kernel<KS_, S_, MODE>), grid, block, 0, st, x, sc, sh, act, w, flip, addend, y, dy, parts, g)
+    if (K == 3 && stride == 1) MNY_DW(3, 1);
+    else if (K == 3 && stride == 2) MNY_DW(3, 2);
+    else if (K == 5 && stride == 1) MNY_DW(5, 1);
+    else MNY_DW(5, 2);
+#undef MNY_DW
+    return check_launch("dw_slide_kernel");
+}
+
+}  // namespace mny
+
+using namespace mny;
+
+extern "C" int mny_dw_stat_parts(int N, int H, int W, int C, int K, int stride) {
+    DwGeom g; CgLayout L; int gx;
+    if (dw_geom(g, L, gx, N, H, W, C, K, stride)) return MNY_EINVAL;
+    return gx;
+}
+extern "C" int mny_dw_wgrad_parts(int N, int H, int W, int C, int K, int stride) {
+    return mny_dw_stat_parts(N, H, W, C, K, stride);
+}
+
+extern "C" int mny_dw_fwd(const float* x, const float* in_scale, const float* in_shift, int in_act, const float* w,
+                          float* y, float* stats, int N, int H, int W, int C, int K, int stride, void* stream) {
+    MNY_REQUIRE(x && w && y, "dw_fwd: null pointer");
+    return dw_launch<0>(x, in_scale, in_shift, in_act, w, 0, nullptr, y, nullptr, stats, N, H, W, C, K, stride, (hipStream_t)stream);
+}
+
+extern "C" int mny_dw_bwd_data(const float* dy, const float* w, const float* addend, float* dx,
+                               int N, int H, int W, int C, int K, int stride, void* stream) {
+    MNY_REQUIRE(dy && w && dx, "dw_bwd_data: null pointer");
+    if (stride == 1)   // transposed conv == correlation with the flipped filter
+        return dw_launch<0>(dy, nullptr, nullptr, MNY_ACT_NONE, w, 1, addend, dx, nullptr, nullptr, N, H, W, C, K, 1, (hipStream_t)stream);
+    MNY_REQUIRE(stride == 2 && (K == 3 || K == 5) && C % 4 == 0, "dw_bwd_data: unsupported K=%d stride=%d C=%d", K, stride, C);
+    const int P = K / 2;
+    const int Ho = (H + 2 * P - K) / 2 + 1, Wo = (W + 2 * P - K) / 2 + 1;
+    CgLayout L = make_cg_layout(C);
+    int64_t want = cdiv((int64_t)N * H * W, L.ppb);
+    dim3 grid((unsigned)(want < 8192 ? want : 8192), L.chunks), block(L.threads);
+    if (K == 3) hipLaunchKernelGGL((dw_bwd_data_s2_kernel<3>), grid, block, 0, (hipStream_t)stream, dy, w, addend, dx, N, H, W, C, Ho, Wo, L.cgb, L.cg_total);
+    else hipLaunchKernelGGL((dw_bwd_data_s2_kernel<5>), grid, block, 0, (hipStream_t)stream, dy, w, addend, dx, N, H, W, C, Ho, Wo, L.cgb, L.cg_total);
+    return check_launch("dw_bwd_data_s2_kernel");
+}
+
+extern "C" int mny_dw_bwd_weight(const float* x, const float* in_scale, const float* in_shift, int in_act, const float* dy,
+                                 float* dw, float* ws, int N, int H, int W, int C, int K, int stride, void* stream) {
+    MNY_REQUIRE(x && dy && dw && ws, "dw_bwd_weight: null pointer");
+    int rc = dw_launch<1>(x, in_scale, in_shift, in_act, nullptr, 0, nullptr, nullptr, dy, ws, N, H, W, C, K, stride, (hipStream_t)stream);
+    if (rc) return rc;
+    const int parts = mny_dw_wgrad_parts(N, H, W, C, K, stride);
+    const int n = C * K * K;
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, parts, n, dw);
+    return check_launch("reduce_rows_kernel");
+}

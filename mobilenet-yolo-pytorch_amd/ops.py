@@ -1,0 +1,203 @@
+"""Thin torch-tensor wrappers over the C ABI (include/mnyolo.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every arithmetic op is a HIP kernel
+of libmnyolo.so.  All tensors are fp32, contiguous, on a CUDA(=HIP) device; activations are NHWC.
+A `view` is the tuple (tensor, scale|None, shift|None, act) — see mnyolo.h "View arguments".
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ACT_NONE, YoloHead, call, query
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def _p(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.dtype in (torch.float32, torch.int32) and t.is_contiguous(), \
+        "libmnyolo needs contiguous fp32/int32 device tensors (got %s %s)" % (t.device, t.dtype)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _st():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _new(*shape, like=None, dtype=torch.float32):
+    return torch.empty(shape, device=like.device, dtype=dtype)
+
+
+# ---- stem -------------------------------------------------------------------------------------------
+def stem_fwd(x_nchw, w, want_stats=True):
+    N, _, H, W = x_nchw.shape
+    Co = w.shape[0]
+    y = _new(N, (H + 1) // 2, (W + 1) // 2, Co, like=x_nchw)
+    parts = query("mny_stem_stat_parts", N, H, W, Co)
+    stats = _new(parts, 2, Co, like=x_nchw) if want_stats else None
+    call("mny_stem_fwd", _p(x_nchw), _p(w), _p(y), _p(stats), N, H, W, Co, _st())
+    return y, stats
+
+
+def stem_wgrad(x_nchw, dy):
+    N, _, H, W = x_nchw.shape
+    Co = dy.shape[3]
+    parts = query("mny_stem_wgrad_parts", N, H, W, Co)
+    ws = _new(parts, Co * 27, like=dy)
+    dw = _new(Co, 3, 3, 3, like=dy)
+    call("mny_stem_wgrad", _p(x_nchw), _p(dy), _p(dw), _p(ws), N, H, W, Co, _st())
+    return dw
+
+
+# ---- depthwise --------------------------------------------------------------------------------------
+def dw_fwd(view, w, stride, want_stats=True):
+    x, sc, sh, act = view
+    N, H, W, C = x.shape
+    K = w.shape[-1]
+    Ho, Wo = (H + 2 * (K // 2) - K) // stride + 1, (W + 2 * (K // 2) - K) // stride + 1
+    y = _new(N, Ho, Wo, C, like=x)
+    stats = _new(query("mny_dw_stat_parts", N, H, W, C, K, stride), 2, C, like=x) if want_stats else None
+    call("mny_dw_fwd", _p(x), _p(sc), _p(sh), act, _p(w), _p(y), _p(stats), N, H, W, C, K, stride, _st())
+    return y, stats
+
+
+def dw_bwd_data(dy, w, in_hw, stride, addend=None, out=None):
+    N, _, _, C = dy.shape
+    H, W = in_hw
+    K = w.shape[-1]
+    dx = out if out is not None else _new(N, H, W, C, like=dy)
+    call("mny_dw_bwd_data", _p(dy), _p(w), _p(addend), _p(dx), N, H, W, C, K, stride, _st())
+    return dx
+
+
+def dw_bwd_weight(view, dy, K, stride):
+    x, sc, sh, act = view
+    N, H, W, C = x.shape
+    ws = _new(query("mny_dw_wgrad_parts", N, H, W, C, K, stride), C * K * K, like=x)
+    dw = _new(C, 1, K, K, like=x)
+    call("mny_dw_bwd_weight", _p(x), _p(sc), _p(sh), act, _p(dy), _p(dw), _p(ws), N, H, W, C, K, stride, _st())
+    return dw
+
+
+# ---- pointwise --------------------------------------------------------------------------------------
+def pw_fwd(view, w2d, bias=None, addend=None, want_stats=True, out=None):
+    x, sc, sh, act = view
+    K = x.shape[-1]
+    M = x.numel() // K
+    Nc = w2d.shape[0]
+    y = out if out is not None else _new(*x.shape[:-1], Nc, like=x)
+    stats = _new(query("mny_pw_stat_parts", M, K, Nc), 2, Nc, like=x) if want_stats else None
+    call("mny_pw_fwd", _p(x), _p(sc), _p(sh), act, _p(w2d), _p(bias), _p(addend), _p(y), _p(stats), M, K, Nc, _st())
+    return y, stats
+
+
+def pw_wgrad(view, dy, want_dbias=False):
+    x, sc, sh, act = view
+    K = x.shape[-1]
+    M = x.numel() // K
+    Nc = dy.shape[-1]
+    ws = _new(query("mny_pw_wgrad_ws_floats", M, K, Nc), like=x)
+    dw = _new(Nc, K, like=x)
+    db = _new(Nc, like=x) if want_dbias else None
+    call("mny_pw_wgrad", _p(x), _p(sc), _p(sh), act, _p(dy), _p(dw), _p(db), _p(ws), M, K, Nc, _st())
+    return dw, db
+
+
+def transpose(w2d):
+    R, C = w2d.shape
+    out = _new(C, R, like=w2d)
+    call("mny_transpose", _p(w2d), _p(out), R, C, _st())
+    return out
+
+
+# ---- batch norm -------------------------------------------------------------------------------------
+def bn_finalize(stats, count, gamma, beta, running_mean=None, running_var=None):
+    C = gamma.numel()
+    scale, shift, mean, invstd = (_new(C, like=gamma) for _ in range(4))
+    call("mny_bn_finalize", _p(stats), stats.shape[0], count, _p(gamma), _p(beta), BN_EPS, BN_MOMENTUM,
+         _p(running_mean), _p(running_var), _p(scale), _p(shift), _p(mean), _p(invstd), C, _st())
+    return scale, shift, mean, invstd
+
+
+def bn_eval_coeffs(gamma, beta, rm, rv):
+    C = gamma.numel()
+    scale, shift = _new(C, like=gamma), _new(C, like=gamma)
+    call("mny_bn_eval_coeffs", _p(gamma), _p(beta), _p(rm), _p(rv), BN_EPS, _p(scale), _p(shift), C, _st())
+    return scale, shift
+
+
+def bn_backward(g, y, scale, shift, act, gamma, mean, invstd, out=None):
+    """-> (dy, dgamma, dbeta) for z = scale*y+shift, a = act(z), given g = dL/da."""
+    C = y.shape[-1]
+    M = y.numel() // C
+    parts = query("mny_bn_bwd_parts", M, C)
+    red = _new(parts, 2, C, like=y)
+    call("mny_bn_bwd_reduce", _p(g), _p(y), _p(scale), _p(shift), act, _p(mean), _p(invstd), _p(red), M, C, _st())
+    dgamma, dbeta, coef = _new(C, like=y), _new(C, like=y), _new(3, C, like=y)
+    call("mny_bn_bwd_finalize", _p(red), parts, M, _p(gamma), _p(mean), _p(invstd), _p(dgamma), _p(dbeta), _p(coef), C, _st())
+    dy = out if out is not None else torch.empty_like(y)
+    call("mny_bn_bwd_apply", _p(g), _p(y), _p(scale), _p(shift), act, _p(coef), _p(dy), M, C, _st())
+    return dy, dgamma, dbeta
+
+
+# ---- glue -------------------------------------------------------------------------------------------
+def add_views(a, b=None, up=None, out=None):
+    x = a[0]
+    N, H, W, C = x.shape
+    o = out if out is not None else torch.empty_like(x)
+    bt, bsc, bsh, bact = b if b is not None else (None, None, None, ACT_NONE)
+    call("mny_add_views", _p(a[0]), _p(a[1]), _p(a[2]), a[3], _p(bt), _p(bsc), _p(bsh), bact, _p(up), _p(o), N, H, W, C, _st())
+    return o
+
+
+def upsample_bwd(src, dst=None, accumulate=False):
+    N, H, W, C = src.shape
+    d = dst if dst is not None else _new(N, H // 2, W // 2, C, like=src)
+    call("mny_upsample_bwd", _p(src), _p(d), int(accumulate), N, H, W, C, _st())
+    return d
+
+
+def axpy(src, dst, alpha=None, accumulate=False):
+    call("mny_axpy", _p(src), _p(alpha), _p(dst), int(accumulate), src.numel(), _st())
+    return dst
+
+
+# ---- detection --------------------------------------------------------------------------------------
+def make_head(N, g, A, C, n_anchors_all, ignore_thresh, iou_thresh, iou_weighting):
+    return YoloHead(N, g, A, C, n_anchors_all, ignore_thresh, iou_thresh, iou_weighting)
+
+
+def yolo_loss(head, targets, t_off, anchors_all, mask, hp):
+    """head [N,g,g,A*(5+C)] -> (out7 [7] device tensor, dhead)."""
+    ws = torch.empty(query("mny_yolo_loss_ws_bytes", ctypes.byref(hp), 0), device=head.device, dtype=torch.uint8)
+    out7 = _new(7, like=head)
+    dhead = torch.empty_like(head)
+    call("mny_yolo_loss", _p(head), _p(targets), _p(t_off), _p(anchors_all), _p(mask), ctypes.byref(hp),
+         _p(out7), _p(dhead), ctypes.c_void_p(ws.data_ptr()), _st())
+    return out7, dhead
+
+
+def yolo_decode(head, anchors_all, mask, hp, val_conf):
+    cells = hp.A * hp.g * hp.g
+    rows = _new(hp.N, cells, 7, like=head)
+    counts = _new(hp.N, like=head, dtype=torch.int32)
+    call("mny_yolo_decode", _p(head), _p(anchors_all), _p(mask), ctypes.byref(hp), float(val_conf), _p(rows), _p(counts), _st())
+    return rows, counts
+
+
+def nms_per_class(rows, seg_off, num_classes, thr=0.45, max_seg_rows=0):
+    """rows [total,7], seg_off int32 [S+1] (device) -> (out_idx int32 [total], out_counts int32 [S], status)."""
+    total = rows.shape[0]
+    S = seg_off.numel() - 1
+    nbytes = query("mny_nms_ws_bytes", S, total, num_classes)
+    ws = torch.empty(nbytes, device=rows.device, dtype=torch.uint8)
+    out_idx = torch.empty(max(total, 1), device=rows.device, dtype=torch.int32)
+    out_counts = torch.empty(S, device=rows.device, dtype=torch.int32)
+    call("mny_nms_per_class", _p(rows), _p(seg_off), S, total, int(max_seg_rows), num_classes, float(thr), _p(out_idx), _p(out_counts),
+         ctypes.c_void_p(ws.data_ptr()), _st())
+    off = query("mny_nms_status_offset", S, total, num_classes)
+    status = ws[off:off + 4].view(torch.int32)
+    return out_idx, out_counts, status

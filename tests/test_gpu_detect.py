@@ -1,0 +1,163 @@
+"""Detection math on the GPU (loss fwd+bwd, decode+compaction, per-class NMS) through the C ABI,
+against the oracle and the fixtures captured from the real reference."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nms_ref, procedural, yolo_ref
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available()
+    from mobilenet_yolo_pytorch_amd import ops as o
+    return o
+
+
+def _pack(targets):
+    off = np.zeros(len(targets) + 1, np.int32)
+    off[1:] = np.cumsum([len(t) for t in targets])
+    allt = torch.cat([t.reshape(-1, 5) for t in targets]) if off[-1] else torch.zeros(0, 5)
+    if allt.shape[0] == 0:
+        allt = torch.zeros(1, 5)
+    return allt.float().contiguous().cuda(), torch.from_numpy(off).cuda()
+
+
+def _head_args(ops, spec, N, g, img=352):
+    anchors = torch.tensor([(aw / img, ah / img) for aw, ah in spec.anchors], dtype=torch.float32).cuda()
+    mask = torch.tensor(spec.mask, dtype=torch.int32).cuda()
+    hp = ops.make_head(N, g, len(spec.mask), spec.num_classes, len(spec.anchors), spec.ignore_thresh,
+                       spec.iou_thresh, spec.iou_weighting)
+    return anchors, mask, hp
+
+
+def _run_loss(ops, head_nchw, targets, spec, img=352):
+    N, _, g, _ = head_nchw.shape
+    anchors, mask, hp = _head_args(ops, spec, N, g, img)
+    tg, off = _pack(targets)
+    h = head_nchw.permute(0, 2, 3, 1).contiguous().cuda()
+    out7, dhead = ops.yolo_loss(h, tg, off, anchors, mask, hp)
+    return out7.cpu().double().numpy(), dhead.cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def test_loss_matches_reference_fixture(ops):
+    """fp32 tolerance: loss/metrics 2e-5 relative, dL/dhead 1e-4 relative + 1e-8 absolute
+    (GPU expf/atanf differ from the CPU libm by a few ulp)."""
+    z = np.load(os.path.join(G, "loss_decode.npz"))
+    specs = yolo_ref.specs_from_config(procedural.VOC_CONFIG)
+    tg = list(torch.split(torch.from_numpy(z["t_all"]), z["t_counts"].tolist()))
+    for hi in range(2):
+        out7, dhead = _run_loss(ops, torch.from_numpy(z["head%d" % hi]), tg, specs[hi])
+        np.testing.assert_allclose(out7, z["tuple%d" % hi], rtol=2e-5, atol=1e-6)
+        np.testing.assert_allclose(dhead.numpy(), z["grad%d" % hi], rtol=1e-4, atol=1e-8)
+
+
+@pytest.mark.parametrize("N,g,seed", [(8, 11, 0), (16, 22, 1), (3, 4, 2), (2, 13, 3)])
+def test_loss_matches_oracle_random(ops, N, g, seed):
+    specs = yolo_ref.specs_from_config(procedural.VOC_CONFIG)
+    hi = seed % 2
+    gen = torch.Generator().manual_seed(seed)
+    head = torch.randn(N, 75, g, g, generator=gen) * 0.7
+    tg = procedural.targets(N, seed=seed + 10, empty_every=3, boxes_per_image=1 + seed)
+    hr = head.clone().requires_grad_(True)
+    ref = yolo_ref.loss_forward(hr, tg, specs[hi], [352, 352])
+    ref[0].backward()
+    out7, dhead = _run_loss(ops, head, tg, specs[hi])
+    np.testing.assert_allclose(out7, np.array([float(v) for v in ref]), rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(dhead.numpy(), hr.grad.numpy(), rtol=1e-4, atol=1e-8)
+
+
+def test_loss_all_images_empty(ops):
+    specs = yolo_ref.specs_from_config(procedural.VOC_CONFIG)
+    head = torch.randn(2, 75, 11, 11)
+    tg = [torch.zeros(0, 5), torch.zeros(0, 5)]
+    hr = head.clone().requires_grad_(True)
+    ref = yolo_ref.loss_forward(hr, tg, specs[0], [352, 352])
+    ref[0].backward()
+    out7, dhead = _run_loss(ops, head, tg, specs[0])
+    np.testing.assert_allclose(out7, np.array([float(v) for v in ref]), rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(dhead.numpy(), hr.grad.numpy(), rtol=1e-4, atol=1e-9)
+
+
+def test_decode_matches_reference_fixture(ops):
+    """box coordinates within 1e-4 (north star); counts and order exact away from the threshold."""
+    z = np.load(os.path.join(G, "loss_decode.npz"))
+    specs = yolo_ref.specs_from_config(procedural.VOC_CONFIG)
+    for hi, g in enumerate((11, 22)):
+        head = torch.from_numpy(z["head%d" % hi])
+        anchors, mask, hp = _head_args(ops, specs[hi], 4, g)
+        h = head.permute(0, 2, 3, 1).contiguous().cuda()
+        for vc in (1, 3, 5):
+            rows, counts = ops.yolo_decode(h, anchors, mask, hp, vc / 10)
+            counts = counts.cpu().tolist()
+            assert counts == z["dec%d_%d_counts" % (hi, vc)].tolist()
+            got = torch.cat([rows[b, :counts[b]] for b in range(4)]).cpu().numpy()
+            ref = z["dec%d_%d_rows" % (hi, vc)]
+            np.testing.assert_allclose(got[:, :6], ref[:, :6], rtol=0, atol=1e-4)
+            assert np.array_equal(got[:, 6], ref[:, 6])
+
+
+def _rand_rows(n, C, seed, quant=False):
+    r = np.random.RandomState(seed)
+    xy = r.rand(n, 2).astype(np.float32)
+    wh = (0.02 + 0.28 * r.rand(n, 2)).astype(np.float32)
+    conf = r.rand(n, 1).astype(np.float32)
+    sc = r.rand(n, 1).astype(np.float32)
+    if quant:                                   # many exact score ties
+        conf = np.round(conf, 1) + 0.05
+        sc = np.ones_like(sc)
+    cls = r.randint(0, C, size=(n, 1)).astype(np.float32)
+    return torch.from_numpy(np.concatenate((xy - wh / 2, xy + wh / 2, conf, sc, cls), 1).astype(np.float32))
+
+
+@pytest.mark.parametrize("sizes,C,quant", [([50, 0, 300, 7], 20, False), ([1815] * 6, 20, False), ([400, 33], 7, True),
+                                            ([0, 0], 20, False), ([20000], 20, False)])
+def test_nms_indices_bit_exact(ops, sizes, C, quant):
+    """Same rows into both implementations -> identical kept indices, order included (Q13)."""
+    segs = [_rand_rows(n, C, seed=11 + i, quant=quant) for i, n in enumerate(sizes)]
+    rows = torch.cat(segs) if sum(sizes) else torch.zeros(0, 7)
+    off = np.zeros(len(sizes) + 1, np.int32)
+    off[1:] = np.cumsum(sizes)
+    dev_rows = rows.cuda() if rows.shape[0] else torch.zeros(1, 7).cuda()[:0]
+    out_idx, out_counts, status = ops.nms_per_class(dev_rows, torch.from_numpy(off).cuda(), C, 0.45, max_seg_rows=max(sizes))
+    assert int(status.cpu()) == 0
+    out_idx, out_counts = out_idx.cpu().numpy(), out_counts.cpu().numpy()
+    for s, seg in enumerate(segs):
+        _, ref_idx = nms_ref.nms_rows(seg, C, 0.45)
+        got = out_idx[off[s]:off[s] + out_counts[s]] - off[s]
+        assert out_counts[s] == len(ref_idx)
+        assert np.array_equal(got, ref_idx.numpy())
+
+
+def test_nms_reference_driver_fixture(ops):
+    z = np.load(os.path.join(G, "loss_decode.npz"))
+    zn = np.load(os.path.join(G, "nms_driver.npz"))
+    per_img = []
+    for b in range(4):
+        parts = []
+        for hi in range(2):
+            cnt = z["dec%d_3_counts" % hi]
+            o = int(cnt[:b].sum())
+            parts.append(torch.from_numpy(z["dec%d_3_rows" % hi][o:o + cnt[b]]))
+        per_img.append(torch.cat(parts))                       # utils/box.py:17
+    sizes = [len(p) for p in per_img]
+    off = np.zeros(5, np.int32)
+    off[1:] = np.cumsum(sizes)
+    rows = torch.cat(per_img)
+    out_idx, out_counts, status = ops.nms_per_class(rows.cuda(), torch.from_numpy(off).cuda(), 20, 0.45, max_seg_rows=max(sizes))
+    assert int(status.cpu()) == 0
+    assert out_counts.cpu().tolist() == zn["counts"].tolist()
+    kept = torch.cat([rows[out_idx.cpu()[off[s]:off[s] + out_counts[s].item()].long()] for s in range(4)])
+    assert np.array_equal(kept.numpy(), zn["rows"])
+
+
+def test_nms_bucket_overflow_is_reported(ops):
+    rows = _rand_rows(9000, 1, seed=5)
+    off = torch.tensor([0, 9000], dtype=torch.int32).cuda()
+    _, counts, status = ops.nms_per_class(rows.cuda(), off, 1, 0.45)
+    assert int(status.cpu()) == 9000 and int(counts.cpu()[0]) == 0

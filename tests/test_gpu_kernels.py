@@ -1,0 +1,195 @@
+"""Per-kernel parity on a real MI355X: every HIP kernel, called through the C ABI, against a plain
+torch-CPU fp32 reference of the same op (floating-point kernels; tolerance stated per test)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+ACTS = {0: lambda z: z, 1: lambda z: torch.clamp(z, 0, 6), 2: lambda z: F.leaky_relu(z, 0.1)}
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from mobilenet_yolo_pytorch_amd import ops as o
+    return o
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def nchw(t):
+    return t.cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def check(a, b, rtol=1e-4, atol=1e-5, what=""):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    assert (err <= tol).all(), "%s: max err %.3e (tol %.3e at worst), max|ref| %.3e" % (
+        what, err.max().item(), tol.flatten()[err.argmax()].item(), b.abs().max().item())
+
+
+def view_ref(x, sc, sh, act):
+    z = x if sc is None else x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    return ACTS[act](z)
+
+
+def stats_ref(y):
+    return y.double().sum((0, 2, 3)), (y.double() ** 2).sum((0, 2, 3))
+
+
+def stats_got(st):
+    return st[:, 0].double().sum(0).cpu(), st[:, 1].double().sum(0).cpu()
+
+
+@pytest.mark.parametrize("N,H,W,C,K,s,act", [
+    (2, 11, 11, 32, 3, 1, 1), (3, 22, 22, 96, 3, 2, 1), (2, 13, 9, 144, 3, 1, 2), (1, 44, 44, 192, 3, 2, 0),
+    (2, 11, 11, 960, 3, 1, 1), (2, 16, 16, 72, 5, 2, 1), (1, 9, 12, 120, 5, 1, 2), (5, 7, 7, 1280, 3, 1, 1)])
+def test_dw_forward_backward(ops, N, H, W, C, K, s, act):
+    x = rnd(N, C, H, W, seed=1)
+    w = rnd(C, 1, K, K, seed=2, scale=0.4)
+    sc, sh = 1 + 0.2 * rnd(C, seed=3), 0.3 * rnd(C, seed=4)
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    a = view_ref(xr, sc, sh, act)
+    a.retain_grad()
+    y = F.conv2d(a, wr, None, s, K // 2, 1, C)
+    dy = rnd(*y.shape, seed=5)
+    y.backward(dy)
+    got, st = ops.dw_fwd((nhwc(x), sc.cuda(), sh.cuda(), act), w.cuda().contiguous(), s)
+    check(nchw(got), y, 1e-4, 1e-5, "dw fwd")
+    s1, s2 = stats_got(st)
+    r1, r2 = stats_ref(y)
+    check(s1, r1, 1e-4, 1e-3, "dw stats sum")
+    check(s2, r2, 1e-4, 1e-3, "dw stats sumsq")
+    # backward-data gives the gradient wrt the *activated* input a
+    dx = ops.dw_bwd_data(nhwc(dy), w.cuda().contiguous(), (H, W), s)
+    check(nchw(dx), a.grad, 1e-4, 1e-5, "dw bwd data")
+    add = rnd(N, C, H, W, seed=6)
+    dx2 = ops.dw_bwd_data(nhwc(dy), w.cuda().contiguous(), (H, W), s, addend=nhwc(add))
+    check(nchw(dx2), a.grad + add, 1e-4, 1e-5, "dw bwd data + addend")
+    dw = ops.dw_bwd_weight((nhwc(x), sc.cuda(), sh.cuda(), act), nhwc(dy), K, s)
+    check(dw, wr.grad, 2e-4, 1e-4, "dw bwd weight")
+
+
+@pytest.mark.parametrize("M,K,Nc,act,bias", [
+    (300, 32, 16, 0, False), (1000, 16, 96, 1, False), (777, 24, 144, 1, False), (513, 144, 24, 2, False),
+    (2 * 11 * 11, 1280, 512, 1, False), (1024, 512, 512, 2, False), (4 * 121, 1024, 75, 2, True),
+    (130, 96, 576, 0, False), (257, 960, 160, 1, False), (64, 320, 1280, 0, False), (100, 512, 1024, 2, False)])
+def test_pw_forward_wgrad_dgrad(ops, M, K, Nc, act, bias):
+    x = rnd(M, K, seed=1)
+    w = rnd(Nc, K, seed=2, scale=K ** -0.5)
+    b = rnd(Nc, seed=7) if bias else None
+    sc, sh = 1 + 0.2 * rnd(K, seed=3), 0.3 * rnd(K, seed=4)
+    a = ACTS[act](x * sc + sh)
+    y = a @ w.t() + (b if bias else 0)
+    xs = x.view(1, 1, M, K).cuda()
+    got, st = ops.pw_fwd((xs, sc.cuda(), sh.cuda(), act), w.cuda(), bias=b.cuda() if bias else None, want_stats=not bias)
+    check(got.view(M, Nc), y, 2e-4, 2e-5, "pw fwd")
+    if not bias:
+        s1, s2 = stats_got(st)
+        check(s1, y.double().sum(0), 1e-4, 2e-3, "pw stats sum")
+        check(s2, (y.double() ** 2).sum(0), 1e-4, 2e-3, "pw stats sumsq")
+    # no-transform path + addend
+    add = rnd(M, Nc, seed=8)
+    got2, _ = ops.pw_fwd((xs, None, None, 0), w.cuda(), addend=add.view(1, 1, M, Nc).cuda(), want_stats=False)
+    check(got2.view(M, Nc), x @ w.t() + add, 2e-4, 2e-5, "pw fwd plain+addend")
+    # weight gradient: dW = dY^T a ; bias gradient = column sums
+    dy = rnd(M, Nc, seed=9)
+    dw, db = ops.pw_wgrad((xs, sc.cuda(), sh.cuda(), act), dy.view(1, 1, M, Nc).cuda(), want_dbias=True)
+    check(dw, dy.t() @ a, 2e-4, 2e-4, "pw wgrad")
+    check(db, dy.sum(0), 1e-4, 1e-4, "pw dbias")
+    # data gradient through the same NT kernel with the transposed weight
+    wt = ops.transpose(w.cuda())
+    check(wt, w.t(), 0, 0, "transpose")
+    dx, _ = ops.pw_fwd((dy.view(1, 1, M, Nc).cuda(), None, None, 0), wt, want_stats=False)
+    check(dx.view(M, K), dy @ w, 2e-4, 2e-5, "pw dgrad")
+
+
+def test_pw_mfma_layout_asymmetric(ops):
+    # A = I against an asymmetric B catches transposed / permuted fragment layouts
+    K = 64
+    x = torch.eye(K)
+    w = torch.arange(96 * K, dtype=torch.float32).view(96, K) / 100
+    got, _ = ops.pw_fwd((x.view(1, 1, K, K).cuda(), None, None, 0), w.cuda(), want_stats=False)
+    check(got.view(K, 96), w.t(), 0, 1e-6, "identity x asymmetric")
+
+
+@pytest.mark.parametrize("N,H,W,C,act", [(4, 11, 11, 32, 1), (2, 22, 22, 96, 2), (3, 8, 8, 144, 0), (2, 5, 5, 1280, 1)])
+def test_bn_train_forward_backward(ops, N, H, W, C, act):
+    y = rnd(N, C, H, W, seed=1) * (1 + rnd(1, C, 1, 1, seed=2).abs()) + rnd(1, C, 1, 1, seed=3)
+    gamma, beta = 1 + 0.3 * rnd(C, seed=4), 0.2 * rnd(C, seed=5)
+    rm, rv = 0.1 * rnd(C, seed=6), 1 + 0.1 * rnd(C, seed=7).abs()
+    yr = y.clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    z = F.batch_norm(yr, rm_ref, rv_ref, gr, br, True, 0.1, 1e-5)
+    a = ACTS[act](z)
+    g = rnd(*a.shape, seed=8)
+    a.backward(g)
+    # forward: stats through the dw kernel's epilogue path are tested elsewhere; here feed exact partials
+    yd = nhwc(y)
+    M = N * H * W
+    st = torch.stack((yd.view(M, C).sum(0), (yd.view(M, C) ** 2).sum(0))).view(1, 2, C).contiguous()
+    rmd, rvd = rm.cuda(), rv.cuda()
+    scale, shift, mean, invstd = ops.bn_finalize(st, M, gamma.cuda(), beta.cuda(), rmd, rvd)
+    zz = nchw(yd * scale + shift)
+    check(zz, z, 1e-4, 1e-5, "bn apply")
+    check(rmd, rm_ref, 1e-5, 1e-6, "running_mean")
+    check(rvd, rv_ref, 1e-5, 1e-6, "running_var")
+    dy, dgamma, dbeta = ops.bn_backward(nhwc(g), yd, scale, shift, act, gamma.cuda(), mean, invstd)
+    check(nchw(dy), yr.grad, 2e-4, 2e-5, "bn dy")
+    check(dgamma, gr.grad, 2e-4, 2e-4, "bn dgamma")
+    check(dbeta, br.grad, 2e-4, 2e-4, "bn dbeta")
+    sc2, sh2 = ops.bn_eval_coeffs(gamma.cuda(), beta.cuda(), rm.cuda(), rv.cuda())
+    ze = F.batch_norm(y, rm, rv, gamma, beta, False, 0.1, 1e-5)
+    check(nchw(yd * sc2 + sh2), ze, 1e-4, 1e-5, "bn eval coeffs")
+
+
+@pytest.mark.parametrize("N,H,W,Co", [(2, 32, 32, 32), (3, 22, 18, 16), (1, 352, 352, 32)])
+def test_stem(ops, N, H, W, Co):
+    x = rnd(N, 3, H, W, seed=1)
+    w = rnd(Co, 3, 3, 3, seed=2, scale=0.3)
+    wr = w.clone().requires_grad_(True)
+    y = F.conv2d(x, wr, None, 2, 1)
+    dy = rnd(*y.shape, seed=3)
+    y.backward(dy)
+    got, st = ops.stem_fwd(x.cuda(), w.cuda())
+    check(nchw(got), y, 1e-4, 1e-5, "stem fwd")
+    s1, s2 = stats_got(st)
+    r1, r2 = stats_ref(y)
+    check(s1, r1, 1e-4, 1e-2, "stem stats")
+    check(s2, r2, 1e-4, 1e-2, "stem stats sq")
+    dw = ops.stem_wgrad(x.cuda(), nhwc(dy))
+    check(dw, wr.grad, 2e-4, 2e-3, "stem wgrad")
+
+
+def test_glue(ops):
+    N, H, W, C = 2, 8, 6, 96
+    a, b = rnd(N, C, H, W, seed=1), rnd(N, C, H, W, seed=2)
+    up = rnd(N, C, H // 2, W // 2, seed=3)
+    sc, sh = 1 + 0.2 * rnd(C, seed=4), 0.3 * rnd(C, seed=5)
+    ref = a + view_ref(b, sc, sh, 2) + F.interpolate(up, scale_factor=2, mode="nearest")
+    got = ops.add_views((nhwc(a), None, None, 0), (nhwc(b), sc.cuda(), sh.cuda(), 2), up=nhwc(up))
+    check(nchw(got), ref, 1e-5, 1e-6, "add_views")
+    g = rnd(N, C, H, W, seed=6)
+    ur = up.clone().requires_grad_(True)
+    F.interpolate(ur, scale_factor=2, mode="nearest").backward(g)
+    check(nchw(ops.upsample_bwd(nhwc(g))), ur.grad, 1e-5, 1e-6, "upsample bwd")
+    d = nhwc(up).clone()
+    ops.upsample_bwd(nhwc(g), d, accumulate=True)
+    check(nchw(d), ur.grad + up, 1e-5, 1e-6, "upsample bwd acc")
+    v = rnd(1003, seed=7)
+    alpha = torch.tensor([0.5]).cuda()
+    dst = torch.ones(1003).cuda()
+    ops.axpy(v.cuda(), dst, alpha, accumulate=True)
+    check(dst, 1 + 0.5 * v, 1e-6, 1e-6, "axpy")
