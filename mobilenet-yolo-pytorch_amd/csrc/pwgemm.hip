@@ -56,6 +56,7 @@ __global__ __launch_bounds__(256) void pw_gemm_nt_kernel(GemmArgs p) {
     const int n0 = blockIdx.y * BN;
     const bool has_xf = p.in_scale != nullptr;
     const bool do_xf = has_xf || p.in_act != MNY_ACT_NONE;
+    const bool kvec = (p.K & 3) == 0;   // rows 16-B aligned -> float4 loads; else scalar tail-safe loads
 
     for (int k = tid; k < Kpad; k += 256) {
         sScale[k] = (has_xf && k < p.K) ? p.in_scale[k] : 1.f;
@@ -95,8 +96,13 @@ __global__ __launch_bounds__(256) void pw_gemm_nt_kernel(GemmArgs p) {
                 const int k = k0 + kq * 4;
                 float4 v = f4zero();
                 if (m < p.M && k < p.K) {
-                    v = ld4(p.A + m * p.K + k);
-                    if (do_xf) v = xform4(v, ld4(sScale + k), ld4(sShift + k), p.in_act);
+                    const float* src = p.A + m * p.K + k;
+                    if (kvec) v = ld4(src);
+                    else { v.x = src[0]; if (k + 1 < p.K) v.y = src[1]; if (k + 2 < p.K) v.z = src[2]; if (k + 3 < p.K) v.w = src[3]; }
+                    if (do_xf) {
+                        v = xform4(v, ld4(sScale + k), ld4(sShift + k), p.in_act);
+                        if (!kvec) { if (k + 1 >= p.K) v.y = 0.f; if (k + 2 >= p.K) v.z = 0.f; if (k + 3 >= p.K) v.w = 0.f; }
+                    }
                 }
                 ra[i] = v;
             }
@@ -108,7 +114,11 @@ __global__ __launch_bounds__(256) void pw_gemm_nt_kernel(GemmArgs p) {
                     const int row = idx / (BK / 4), kq = idx % (BK / 4);
                     const int n = n0 + row;
                     const int k = k0 + kq * 4;
-                    if (n < p.N && k < p.K) v = ld4(p.B + (int64_t)n * p.K + k);
+                    if (n < p.N && k < p.K) {
+                        const float* src = p.B + (int64_t)n * p.K + k;
+                        if (kvec) v = ld4(src);
+                        else { v.x = src[0]; if (k + 1 < p.K) v.y = src[1]; if (k + 2 < p.K) v.z = src[2]; if (k + 3 < p.K) v.w = src[3]; }
+                    }
                 }
                 rb[i] = v;
             }
@@ -393,7 +403,6 @@ extern "C" int mny_pw_fwd(const float* x, const float* in_scale, const float* in
                           void* stream) {
     MNY_REQUIRE(x && w && y, "pw_fwd: null pointer");
     MNY_REQUIRE(M > 0 && K > 0 && Nc > 0, "pw_fwd: empty problem");
-    MNY_REQUIRE(K % 4 == 0, "pw_fwd: K=%d must be a multiple of 4", K);
     MNY_REQUIRE(!(stats && bias), "pw_fwd: stats and bias are mutually exclusive");
     NtPlan pl = nt_plan(M, K, Nc);
     MNY_REQUIRE(pl.lds <= 64 * 1024, "pw_fwd: K=%d too large for the LDS scale cache", K);
