@@ -153,23 +153,30 @@ size_t mny_yolo_loss_ws_bytes(const mny_yolo_head* hp, int total_targets);
 
 /* Eval: replaces YOLOLoss.get_pred_boxes (models/yolo_loss.py:180-204): decode every cell to
  * (x1,y1,x2,y2,conf,cls_score,cls_idx), keep conf > val_conf, compact per image preserving
- * (anchor,row,col) order.  rows: [N][A*g*g][7] capacity; counts[N]. */
+ * (anchor,row,col) order.  Image n writes rows[n*row_stride + base + i]; base = base_counts[n]
+ * (NULL -> 0) so a second head can append behind the first (utils/box.py:17 `cat`);
+ * counts[n] = base + kept.  row_stride >= A*g*g (+ what earlier heads may have written). */
 int mny_yolo_decode(const float* head, const float* anchors_all, const int32_t* mask,
-                    const mny_yolo_head* hp, float val_conf, float* rows, int32_t* counts, void* stream);
+                    const mny_yolo_head* hp, float val_conf, float* rows, int row_stride,
+                    const int32_t* base_counts, int32_t* counts, void* stream);
 
 /* Per-class NMS: replaces utils/box.py:11-31 + torchvision.ops.nms(boxes, score*conf, thr).
- * rows: [total,7]; seg_off[S+1]: one segment per image.  out_idx: kept row indices (into rows),
- * segment s occupies out_idx[seg_off[s] .. seg_off[s]+out_counts[s]), class-major then descending
- * score (stable, ties by original order).  thr is a double and the float IoU is promoted before
- * the strict `>` compare, like torchvision.  max_seg_rows: caller's upper bound on rows in any one
- * segment (sizes the LDS sort buffer; 0 = use `total`).  A (segment,class) bucket larger than
- * 8192 rows cannot be sorted in LDS: it keeps nothing and the int32 at ws+mny_nms_status_offset()
- * receives the offending size (0 = ok).  ws: mny_nms_ws_bytes() bytes. */
-int mny_nms_per_class(const float* rows, const int32_t* seg_off, int S, int total, int max_seg_rows,
-                      int num_classes, double thr, int32_t* out_idx, int32_t* out_counts,
-                      void* ws, void* stream);
-size_t mny_nms_status_offset(int S, int total, int num_classes);
-size_t mny_nms_ws_bytes(int S, int total, int num_classes);
+ * rows: [capacity,7]; segment s (one image) = rows[seg_begin[s] .. seg_begin[s]+seg_count[s]).
+ * out_idx: kept row indices (into rows); segment s occupies out_idx[seg_begin[s] ..
+ * +out_counts[s]), class-major then descending score (stable, ties by original order).
+ * out_rows (optional): the kept rows gathered densely, segment after segment.
+ * thr is a double and the float IoU is promoted before the strict `>` compare, like torchvision.
+ * max_seg_rows: caller's upper bound on rows in any one segment (sizes the LDS sort buffer;
+ * 0 = use `capacity`).  A (segment,class) bucket larger than 8192 rows cannot be sorted in LDS:
+ * it keeps nothing and the int32 at ws+mny_nms_status_offset() receives the offending size (0 = ok).
+ * The int32[S+1] exclusive prefix of out_counts is left at ws+mny_nms_prefix_offset().
+ * ws: mny_nms_ws_bytes() bytes. */
+int mny_nms_per_class(const float* rows, const int32_t* seg_begin, const int32_t* seg_count, int S,
+                      int capacity, int max_seg_rows, int num_classes, double thr,
+                      int32_t* out_idx, int32_t* out_counts, float* out_rows, void* ws, void* stream);
+size_t mny_nms_ws_bytes(int S, int capacity, int num_classes);
+size_t mny_nms_status_offset(int S, int capacity, int num_classes);
+size_t mny_nms_prefix_offset(int S, int capacity, int num_classes);
 
 #ifdef __cplusplus
 }

@@ -50,10 +50,11 @@ _SIGS = {
     "mny_axpy": (c_int, [P, P, P, c_int, c_int64, P]),
     "mny_yolo_loss": (c_int, [P, P, P, P, P, ctypes.POINTER(YoloHead), P, P, P, P]),
     "mny_yolo_loss_ws_bytes": (c_size_t, [ctypes.POINTER(YoloHead), c_int]),
-    "mny_yolo_decode": (c_int, [P, P, P, ctypes.POINTER(YoloHead), c_float, P, P, P]),
-    "mny_nms_per_class": (c_int, [P, P, c_int, c_int, c_int, c_int, c_double, P, P, P, P]),
+    "mny_yolo_decode": (c_int, [P, P, P, ctypes.POINTER(YoloHead), c_float, P, c_int, P, P, P]),
+    "mny_nms_per_class": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_double, P, P, P, P, P]),
     "mny_nms_ws_bytes": (c_size_t, [c_int, c_int, c_int]),
     "mny_nms_status_offset": (c_size_t, [c_int, c_int, c_int]),
+    "mny_nms_prefix_offset": (c_size_t, [c_int, c_int, c_int]),
 }
 EXPORTS = tuple(_SIGS)
 

@@ -323,13 +323,14 @@ static size_t loss_ws_layout(const mny_yolo_head* hp, char* base, LossWs* ws) {
 // ---- decode + ordered compaction: one block per image ----------------------------------------------
 __global__ __launch_bounds__(256) void yolo_decode_kernel(const float* __restrict__ head, const float* __restrict__ anchors,
                                                           const int32_t* __restrict__ mask, mny_yolo_head hp, float val_conf,
-                                                          float* __restrict__ rows, int32_t* __restrict__ counts) {
+                                                          float* __restrict__ rows, int row_stride,
+                                                          const int32_t* __restrict__ base_counts, int32_t* __restrict__ counts) {
     __shared__ int wsum[4];
     __shared__ int base_s;
     const int n = blockIdx.x, g = hp.g, A = hp.A, T = 5 + hp.C;
     const int cells = A * g * g;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) base_s = 0;
+    if (threadIdx.x == 0) base_s = base_counts ? base_counts[n] : 0;
     __syncthreads();
     for (int c0 = 0; c0 < cells; c0 += 256) {
         const int cell = c0 + threadIdx.x;       // (a, gy, gx) order: yolo_loss.py:201-203
@@ -358,7 +359,7 @@ __global__ __launch_bounds__(256) void yolo_decode_kernel(const float* __restric
         for (int w = 0; w < wave; ++w) woff += wsum[w];
         const int base = base_s;
         if (keep) {
-            float* dst = rows + ((int64_t)n * cells + base + woff + before) * 7;
+            float* dst = rows + ((int64_t)n * row_stride + base + woff + before) * 7;
             for (int k = 0; k < 7; ++k) dst[k] = r[k];
         }
         __syncthreads();
@@ -379,8 +380,8 @@ __device__ __forceinline__ uint32_t desc_key(float s) {       // larger score ->
 
 // grid (S, C).  Fills the bucket in original row order (stable), sorts by (score desc, position asc),
 // greedy suppression with block-parallel IoU passes, writes kept row indices to tmp[bucket_base + r].
-__global__ __launch_bounds__(256) void nms_bucket_kernel(const float* __restrict__ rows, const int32_t* __restrict__ seg_off,
-                                                         int num_classes, double thr, int cap, int32_t* __restrict__ tmp,
+__global__ __launch_bounds__(256) void nms_bucket_kernel(const float* __restrict__ rows, const int32_t* __restrict__ seg_begin,
+                                                         const int32_t* __restrict__ seg_count, int num_classes, double thr, int cap, int32_t* __restrict__ tmp,
                                                          int32_t* __restrict__ bucket_base, int32_t* __restrict__ kept_count,
                                                          int32_t* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) unsigned char nms_smem[];
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(256) void nms_bucket_kernel(const float* __restrict
     __shared__ int32_t s_wsum[2][4];
     __shared__ int32_t s_n, s_lower, s_next, s_kept;
     const int s = blockIdx.x, c = blockIdx.y;
-    const int r0 = seg_off[s], r1 = seg_off[s + 1];
+    const int r0 = seg_begin[s], r1 = r0 + seg_count[s];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float cf = (float)c;
     if (threadIdx.x == 0) { s_n = 0; s_lower = 0; }
@@ -487,18 +488,56 @@ __global__ __launch_bounds__(256) void nms_bucket_kernel(const float* __restrict
 }
 
 // grid S: concatenate the kept lists of a segment in class order
-__global__ __launch_bounds__(256) void nms_compact_kernel(const int32_t* __restrict__ seg_off, int num_classes,
+__global__ __launch_bounds__(256) void nms_compact_kernel(const int32_t* __restrict__ seg_begin, int num_classes,
                                                           const int32_t* __restrict__ tmp, const int32_t* __restrict__ bucket_base,
                                                           const int32_t* __restrict__ kept_count, int32_t* __restrict__ out_idx,
                                                           int32_t* __restrict__ out_counts) {
     const int s = blockIdx.x;
-    int off = seg_off[s];
+    const int begin = seg_begin[s];
+    int off = begin;
     for (int c = 0; c < num_classes; ++c) {
         const int k = kept_count[s * num_classes + c], b = bucket_base[s * num_classes + c];
         for (int i = threadIdx.x; i < k; i += 256) out_idx[off + i] = tmp[b + i];
         off += k;
     }
-    if (threadIdx.x == 0) out_counts[s] = off - seg_off[s];
+    if (threadIdx.x == 0) out_counts[s] = off - begin;
+}
+
+// single block: exclusive scan of out_counts -> out_prefix[S+1]
+__global__ __launch_bounds__(256) void nms_scan_kernel(const int32_t* __restrict__ counts, int S, int32_t* __restrict__ prefix) {
+    __shared__ int32_t tot[256];
+    __shared__ int32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < S; b0 += 256) {
+        const int i = b0 + threadIdx.x;
+        const int v = i < S ? counts[i] : 0;
+        tot[threadIdx.x] = v;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {
+            const int t = threadIdx.x >= d ? tot[threadIdx.x - d] : 0;
+            __syncthreads();
+            tot[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < S) prefix[i] = carry + tot[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 255) carry += tot[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) prefix[S] = carry;
+}
+
+// grid S: gather the kept rows densely, segment after segment
+__global__ __launch_bounds__(256) void nms_gather_kernel(const float* __restrict__ rows, const int32_t* __restrict__ seg_begin,
+                                                         const int32_t* __restrict__ out_idx, const int32_t* __restrict__ out_counts,
+                                                         const int32_t* __restrict__ prefix, float* __restrict__ out_rows) {
+    const int s = blockIdx.x;
+    const int k = out_counts[s], b = seg_begin[s], o = prefix[s];
+    for (int i = threadIdx.x; i < k * 7; i += 256) {
+        const int r = i / 7, f = i % 7;
+        out_rows[(int64_t)(o + r) * 7 + f] = rows[(int64_t)out_idx[b + r] * 7 + f];
+    }
 }
 
 }  // namespace mny
@@ -527,10 +566,13 @@ extern "C" int mny_yolo_loss(const float* head, const float* targets, const int3
 }
 
 extern "C" int mny_yolo_decode(const float* head, const float* anchors_all, const int32_t* mask, const mny_yolo_head* hp,
-                               float val_conf, float* rows, int32_t* counts, void* stream) {
+                               float val_conf, float* rows, int row_stride, const int32_t* base_counts, int32_t* counts,
+                               void* stream) {
     MNY_REQUIRE(head && anchors_all && mask && hp && rows && counts, "yolo_decode: null pointer");
     MNY_REQUIRE(hp->N > 0 && hp->g > 0 && hp->A > 0 && hp->C > 0, "yolo_decode: bad head spec");
-    hipLaunchKernelGGL(yolo_decode_kernel, dim3(hp->N), dim3(256), 0, (hipStream_t)stream, head, anchors_all, mask, *hp, val_conf, rows, counts);
+    MNY_REQUIRE(row_stride >= hp->A * hp->g * hp->g, "yolo_decode: row_stride %d smaller than the %d cells of one image", row_stride, hp->A * hp->g * hp->g);
+    hipLaunchKernelGGL(yolo_decode_kernel, dim3(hp->N), dim3(256), 0, (hipStream_t)stream, head, anchors_all, mask, *hp, val_conf, rows,
+                       row_stride, base_counts, counts);
     return check_launch("yolo_decode_kernel");
 }
 
@@ -540,27 +582,33 @@ static int nms_cap_for(int total) {
     return cap;
 }
 
-extern "C" size_t mny_nms_ws_bytes(int S, int total, int num_classes) {
-    if (S <= 0 || total < 0 || num_classes <= 0) return 0;
-    // tmp[total] + bucket_base[S*C] + kept_count[S*C] + status
-    return align256((size_t)(total > 0 ? total : 1) * 4) + 2 * align256((size_t)S * num_classes * 4) + 256;
+extern "C" size_t mny_nms_ws_bytes(int S, int capacity, int num_classes) {
+    if (S <= 0 || capacity < 0 || num_classes <= 0) return 0;
+    // tmp[capacity] + bucket_base[S*C] + kept_count[S*C] + prefix[S+1] + status
+    return align256((size_t)(capacity > 0 ? capacity : 1) * 4) + 2 * align256((size_t)S * num_classes * 4) + align256((size_t)(S + 1) * 4) + 256;
 }
 
-extern "C" size_t mny_nms_status_offset(int S, int total, int num_classes) {
-    return align256((size_t)(total > 0 ? total : 1) * 4) + 2 * align256((size_t)S * num_classes * 4);
+extern "C" size_t mny_nms_status_offset(int S, int capacity, int num_classes) {
+    return align256((size_t)(capacity > 0 ? capacity : 1) * 4) + 2 * align256((size_t)S * num_classes * 4) + align256((size_t)(S + 1) * 4);
 }
 
-extern "C" int mny_nms_per_class(const float* rows, const int32_t* seg_off, int S, int total, int max_seg_rows, int num_classes,
-                                 double thr, int32_t* out_idx, int32_t* out_counts, void* wsp, void* stream) {
-    MNY_REQUIRE(seg_off && out_idx && out_counts && wsp, "nms: null pointer");
-    MNY_REQUIRE(S > 0 && total >= 0 && num_classes > 0, "nms: bad sizes");
+extern "C" size_t mny_nms_prefix_offset(int S, int capacity, int num_classes) {
+    return align256((size_t)(capacity > 0 ? capacity : 1) * 4) + 2 * align256((size_t)S * num_classes * 4);
+}
+
+extern "C" int mny_nms_per_class(const float* rows, const int32_t* seg_begin, const int32_t* seg_count, int S, int capacity,
+                                 int max_seg_rows, int num_classes, double thr, int32_t* out_idx, int32_t* out_counts,
+                                 float* out_rows, void* wsp, void* stream) {
+    MNY_REQUIRE(seg_begin && seg_count && out_idx && out_counts && wsp, "nms: null pointer");
+    MNY_REQUIRE(S > 0 && capacity >= 0 && num_classes > 0, "nms: bad sizes");
     char* base = (char*)wsp;
     int32_t* tmp = (int32_t*)base;
-    int32_t* bucket_base = (int32_t*)(base + align256((size_t)(total > 0 ? total : 1) * 4));
+    int32_t* bucket_base = (int32_t*)(base + align256((size_t)(capacity > 0 ? capacity : 1) * 4));
     int32_t* kept = (int32_t*)((char*)bucket_base + align256((size_t)S * num_classes * 4));
-    int32_t* status = (int32_t*)((char*)kept + align256((size_t)S * num_classes * 4));   // max bucket size that did NOT fit (0 = ok)
+    int32_t* prefix = (int32_t*)((char*)kept + align256((size_t)S * num_classes * 4));
+    int32_t* status = (int32_t*)((char*)prefix + align256((size_t)(S + 1) * 4));   // largest bucket that did NOT fit (0 = ok)
     hipStream_t st = (hipStream_t)stream;
-    const int cap = nms_cap_for(max_seg_rows > 0 && max_seg_rows < total ? max_seg_rows : total);
+    const int cap = nms_cap_for(max_seg_rows > 0 && max_seg_rows < capacity ? max_seg_rows : capacity);
     const size_t lds = (size_t)cap * (8 + 4 + 1);
     static bool attr_set = false;
     if (!attr_set) {
@@ -568,9 +616,12 @@ extern "C" int mny_nms_per_class(const float* rows, const int32_t* seg_off, int 
         if (e != hipSuccess) { set_error("nms: hipFuncSetAttribute: %s", hipGetErrorString(e)); return MNY_EHIP; }
         attr_set = true;
     }
-    hipMemsetAsync(status, 0, 4, st);
-    hipLaunchKernelGGL(nms_bucket_kernel, dim3(S, num_classes), dim3(256), lds, st, rows, seg_off, num_classes, thr, cap, tmp,
+    if (hipMemsetAsync(status, 0, 4, st) != hipSuccess) { set_error("nms: memset failed"); return MNY_EHIP; }
+    hipLaunchKernelGGL(nms_bucket_kernel, dim3(S, num_classes), dim3(256), lds, st, rows, seg_begin, seg_count, num_classes, thr, cap, tmp,
                        bucket_base, kept, status);
-    hipLaunchKernelGGL(nms_compact_kernel, dim3(S), dim3(256), 0, st, seg_off, num_classes, tmp, bucket_base, kept, out_idx, out_counts);
+    hipLaunchKernelGGL(nms_compact_kernel, dim3(S), dim3(256), 0, st, seg_begin, num_classes, tmp, bucket_base, kept, out_idx, out_counts);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(256), 0, st, out_counts, S, prefix);
+    if (out_rows)
+        hipLaunchKernelGGL(nms_gather_kernel, dim3(S), dim3(256), 0, st, rows, seg_begin, out_idx, out_counts, prefix, out_rows);
     return check_launch("nms kernels");
 }

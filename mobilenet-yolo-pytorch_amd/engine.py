@@ -1,0 +1,414 @@
+"""Static execution plans for the MobileNet-YOLO graph: one flat list of C-ABI calls for the forward
+pass, one for the backward pass, built once per (batch, height, width, mode) and replayed every step.
+
+All device buffers (raw conv outputs, BN coefficients, gradients, workspaces) are allocated when the
+plan is built and stay resident — at bs=256/352x352 that is ~60 GB of the 288 GB HBM — so a step does
+no allocation, no host<->device synchronisation and no Python work besides walking the call list
+(which is also what makes the whole step hipGraph-capturable).
+
+Backward dataflow (per conv+BN+act unit, given G = dL/d(activated output)):
+    bn_bwd_reduce(G, Y) -> bn_bwd_finalize -> dgamma, dbeta, coef ; bn_bwd_apply -> dY
+    wgrad(view(input), dY) -> dW        dgrad(dY, W) (+ addend) -> G of the input
+Residual adds alias G to both operands; a second contribution to a value is fused into the producing
+kernel's `addend` epilogue, so no separate accumulation pass exists.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ACT_NONE, MnyError, YoloHead
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+_vp = ctypes.c_void_p
+
+
+def _ptr(t):
+    return _vp(t.data_ptr()) if t is not None else None
+
+
+class CallList:
+    """A replayable sequence of C-ABI calls."""
+
+    def __init__(self):
+        self.calls = []
+        self.keep = []           # tensors referenced by raw pointers
+        self.marks = {}          # name -> call index (for DP bucket events)
+
+    def add(self, name, *args):
+        fn = getattr(_lib.load(), name)
+        conv = []
+        for a in args:
+            if isinstance(a, torch.Tensor):
+                assert a.is_contiguous() and a.is_cuda, name
+                self.keep.append(a)
+                conv.append(_vp(a.data_ptr()))
+            else:
+                conv.append(a)
+        self.calls.append((fn, tuple(conv), name))
+
+    def run(self, begin=0, end=None):
+        lib = _lib.load()
+        for fn, args, name in self.calls[begin:end]:
+            rc = fn(*args)
+            if rc != 0:
+                raise MnyError("%s failed (%d): %s" % (name, rc, lib.mny_last_error().decode()))
+
+
+class _Unit:
+    """Resident state of one conv+BN+act unit."""
+    __slots__ = ("Y", "coef4", "scale", "shift", "mean", "invstd", "act", "C", "M", "shape")
+
+
+class NetPlan:
+    def __init__(self, net, N, H, W, training):
+        self.net, self.N, self.H, self.W, self.training = net, N, H, W, training
+        dev = net.device
+        self.dev = dev
+        assert H % 32 == 0 and W % 32 == 0, "input height/width must be multiples of 32 (got %dx%d)" % (H, W)
+        g = net.graph
+        self.stream = _vp(0)
+        self.x_ptr = _vp(0)
+        self.fwd = CallList()
+        self.units = {}          # value id -> _Unit
+        self.reals = {}          # value id -> tensor
+        f32 = dict(device=dev, dtype=torch.float32)
+        max_parts = _lib.query("mny_max_parts")
+        maxC = max(v.C for v in g.values)
+        self.stats_ws = torch.empty(max_parts * 2 * maxC, **f32)
+        P = net.param_tensors
+        self.param_ptrs = [(t, t.data_ptr()) for t in net.all_state_tensors()]
+
+        def shape(v):
+            return (N, H // v.down, W // v.down, v.C)
+
+        def view(v):
+            if v.kind == "unit":
+                u = self.units[v.id]
+                return (u.Y, u.scale, u.shift, v.act)
+            return (self.reals[v.id], None, None, ACT_NONE)
+
+        self._view = view
+        self._shape = shape
+        for nd in g.nodes:
+            o = nd.out
+            shp = shape(o)
+            M = shp[0] * shp[1] * shp[2]
+            if nd.op in ("stem", "dw", "pw"):
+                u = _Unit()
+                u.Y = torch.empty(shp, **f32)
+                u.coef4 = torch.empty(4, o.C, **f32)
+                u.scale, u.shift, u.mean, u.invstd = u.coef4[0], u.coef4[1], u.coef4[2], u.coef4[3]
+                u.act, u.C, u.M, u.shape = o.act, o.C, M, shp
+                self.units[o.id] = u
+                w = P[nd.conv + ".weight"]
+                stats = self.stats_ws if training else None
+                if nd.op == "stem":
+                    parts = _lib.query("mny_stem_stat_parts", N, H, W, o.C)
+                    self.fwd.add("mny_stem_fwd", self.x_ptr, w, u.Y, stats, N, H, W, o.C, self.stream)
+                elif nd.op == "dw":
+                    i = nd.ins[0]
+                    ish = shape(i)
+                    xv = view(i)
+                    parts = _lib.query("mny_dw_stat_parts", N, ish[1], ish[2], o.C, nd.k, nd.stride)
+                    self.fwd.add("mny_dw_fwd", xv[0], xv[1], xv[2], xv[3], w, u.Y, stats, N, ish[1], ish[2], o.C, nd.k, nd.stride, self.stream)
+                else:
+                    i = nd.ins[0]
+                    xv = view(i)
+                    parts = _lib.query("mny_pw_stat_parts", M, i.C, o.C)
+                    self.fwd.add("mny_pw_fwd", xv[0], xv[1], xv[2], xv[3], w, None, None, u.Y, stats, M, i.C, o.C, self.stream)
+                gam, bet = P[nd.bn + ".weight"], P[nd.bn + ".bias"]
+                rm, rv = P[nd.bn + ".running_mean"], P[nd.bn + ".running_var"]
+                if training:
+                    self.fwd.add("mny_bn_finalize", self.stats_ws, parts, M, gam, bet, BN_EPS, BN_MOMENTUM, rm, rv,
+                                 u.scale, u.shift, u.mean, u.invstd, o.C, self.stream)
+                else:
+                    self.fwd.add("mny_bn_eval_coeffs", gam, bet, rm, rv, BN_EPS, u.scale, u.shift, o.C, self.stream)
+            elif nd.op == "pwb":
+                i = nd.ins[0]
+                xv = view(i)
+                t = torch.empty(shp, **f32)
+                self.reals[o.id] = t
+                self.fwd.add("mny_pw_fwd", xv[0], xv[1], xv[2], xv[3], P[nd.conv + ".weight"], P[nd.conv + ".bias"], None, t, None,
+                             M, i.C, o.C, self.stream)
+            elif nd.op == "add":
+                a = view(nd.ins[0])
+                has_b, has_up = nd.k & 1, nd.k & 2
+                b = view(nd.ins[1]) if has_b else (None, None, None, ACT_NONE)
+                up = self.reals[nd.ins[-1].id] if has_up else None
+                if has_up:
+                    assert nd.ins[-1].kind == "real"
+                t = torch.empty(shp, **f32)
+                self.reals[o.id] = t
+                self.fwd.add("mny_add_views", a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], up, t, shp[0], shp[1], shp[2], shp[3], self.stream)
+            else:
+                raise AssertionError(nd.op)
+
+        self.heads = [self.reals[o.id] for o in g.outputs]
+        self._build_detection()
+        if training:
+            self._build_backward()
+
+    # ------------------------------------------------------------------------------------------
+    def _build_detection(self):
+        net, dev, N = self.net, self.dev, self.N
+        f32 = dict(device=dev, dtype=torch.float32)
+        self.hp, self.anchors, self.masks = [], [], []
+        img = [self.H, self.W]                                  # mbv2_yolo.py:139-140 (Q8: [H,W] against (w,h) anchors)
+        for hi, hs in enumerate(net.yolo_losses):
+            g = self.heads[hi].shape[1]
+            assert self.heads[hi].shape[1] == self.heads[hi].shape[2], "square grids only (yolo_loss.py:71)"
+            hs.img_size = img
+            anchors = torch.tensor([(aw / img[0], ah / img[1]) for aw, ah in hs.anchors], dtype=torch.float32).to(dev)
+            self.anchors.append(anchors)
+            self.masks.append(torch.tensor(hs.mask, dtype=torch.int32).to(dev))
+            self.hp.append(YoloHead(N, g, len(hs.mask), hs.num_classes, len(hs.anchors), hs.ignore_threshold, hs.iou_thresh, hs.iou_weighting))
+        if self.training:
+            self.out14 = torch.zeros(2, 7, **f32)
+            self.dheads = [torch.empty_like(h) for h in self.heads]
+            self.t_ptr, self.off_ptr = _vp(0), _vp(0)
+            self.loss_ws = []
+            for hi in range(2):
+                nbytes = _lib.query("mny_yolo_loss_ws_bytes", ctypes.byref(self.hp[hi]), 0)
+                ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+                self.loss_ws.append(ws)
+                self.fwd.add("mny_yolo_loss", self.heads[hi], self.t_ptr, self.off_ptr, self.anchors[hi], self.masks[hi],
+                             ctypes.byref(self.hp[hi]), self.out14[hi], self.dheads[hi], ws, self.stream)
+            self.t_dev = torch.zeros(max(4 * N, 64), 5, **f32)
+            self.off_dev = torch.zeros(N + 1, device=dev, dtype=torch.int32)
+        else:
+            C = net.num_classes
+            self.cells = [hp.A * hp.g * hp.g for hp in self.hp]
+            self.cap = sum(self.cells)
+            self.rows = torch.zeros(N, self.cap, 7, **f32)
+            self.cnt0 = torch.zeros(N, device=dev, dtype=torch.int32)
+            self.cnt1 = torch.zeros(N, device=dev, dtype=torch.int32)
+            self.seg_begin = (torch.arange(N, dtype=torch.int32) * self.cap).to(dev)
+            self.out_idx = torch.zeros(N * self.cap, device=dev, dtype=torch.int32)
+            self.out_counts = torch.zeros(N, device=dev, dtype=torch.int32)
+            self.out_rows = torch.zeros(N * self.cap, 7, **f32)
+            self.nms_ws = torch.empty(_lib.query("mny_nms_ws_bytes", N, N * self.cap, C), device=dev, dtype=torch.uint8)
+            self.val_conf = [ctypes.c_float(0.1), ctypes.c_float(0.1)]
+            self.det = CallList()
+            self.det.add("mny_yolo_decode", self.heads[0], self.anchors[0], self.masks[0], ctypes.byref(self.hp[0]), self.val_conf[0],
+                         self.rows, self.cap, None, self.cnt0, self.stream)
+            self.det.add("mny_yolo_decode", self.heads[1], self.anchors[1], self.masks[1], ctypes.byref(self.hp[1]), self.val_conf[1],
+                         self.rows, self.cap, self.cnt0, self.cnt1, self.stream)
+            self.det.add("mny_nms_per_class", self.rows, self.seg_begin, self.cnt1, N, N * self.cap, self.cap, C, ctypes.c_double(0.45),
+                         self.out_idx, self.out_counts, self.out_rows, self.nms_ws, self.stream)
+            so = _lib.query("mny_nms_status_offset", N, N * self.cap, C)
+            self.nms_status = self.nms_ws[so:so + 4].view(torch.int32)
+
+    # ------------------------------------------------------------------------------------------
+    def _build_backward(self):
+        net, g, N = self.net, self.net.graph, self.N
+        dev = self.dev
+        f32 = dict(device=dev, dtype=torch.float32)
+        P = net.param_tensors
+        bwd = self.bwd = CallList()
+        view, shape = self._view, self._shape
+
+        # which nodes lie on a path to a loss
+        needed = set()
+        stack = [o for o in g.outputs]
+        while stack:
+            v = stack.pop()
+            if v.node is None or v.id in needed:
+                continue
+            needed.add(v.id)
+            stack.extend(v.node.ins)
+        order = [nd for nd in reversed(g.nodes) if nd.out.id in needed]
+
+        # flat gradient arena in backward production order (heads first -> DP buckets complete early)
+        self.grad_params = []
+        off = 0
+        slots = {}
+        for nd in order:
+            names = []
+            if nd.conv:
+                names.append(nd.conv + ".weight")
+                if nd.bias:
+                    names.append(nd.conv + ".bias")
+            if nd.bn:
+                names += [nd.bn + ".weight", nd.bn + ".bias"]
+            for nm in names:
+                n = P[nm].numel()
+                slots[nm] = (off, n)
+                self.grad_params.append(nm)
+                off += (n + 3) // 4 * 4
+        self.gflat = torch.zeros(off, **f32)
+        self.gviews = {nm: self.gflat[o:o + n].view(P[nm].shape) for nm, (o, n) in slots.items()}
+        self.grad_slots = slots
+
+        def gv(nm):
+            return self.gviews[nm]
+
+        # workspaces shared by all layers (single stream => sequential use)
+        ws_floats = 1
+        max_parts = _lib.query("mny_max_parts")
+        for nd in order:
+            o = nd.out
+            shp = shape(o)
+            M = shp[0] * shp[1] * shp[2]
+            if nd.op in ("pw", "pwb"):
+                ws_floats = max(ws_floats, _lib.query("mny_pw_wgrad_ws_floats", M, nd.ins[0].C, o.C))
+            elif nd.op == "dw":
+                ws_floats = max(ws_floats, max_parts * o.C * nd.k * nd.k)
+            elif nd.op == "stem":
+                ws_floats = max(ws_floats, max_parts * o.C * 27)
+        self.ws = torch.empty(ws_floats, **f32)
+        maxC = max(v.C for v in g.values)
+        self.red_ws = torch.empty(1024 * 2 * maxC, **f32)
+        self.coef_ws = torch.empty(3 * maxC, **f32)
+        self.g_scale = torch.ones(2, **f32)           # upstream dL/dloss_i, written by backward()
+        self.wT = {}
+
+        class GS:
+            __slots__ = ("buf", "shared")
+
+            def __init__(self):
+                self.buf, self.shared = None, False
+        gs = {v.id: GS() for v in g.values}
+        self.grad_bufs = []
+
+        def alloc(v):
+            t = torch.empty(shape(v), **f32)
+            self.grad_bufs.append(t)
+            return t
+
+        def contribute_alias(v, buf):
+            s = gs[v.id]
+            if s.buf is None:
+                s.buf, s.shared = buf, True
+                return
+            if s.shared:
+                nb = alloc(v)
+                bwd.add("mny_axpy", s.buf, None, nb, 0, nb.numel(), self.stream)
+                s.buf, s.shared = nb, False
+            bwd.add("mny_axpy", buf, None, s.buf, 1, s.buf.numel(), self.stream)
+
+        def contribute_kernel(v, emit):
+            """emit(out, addend) appends the producing call."""
+            s = gs[v.id]
+            if s.buf is None:
+                s.buf, s.shared = alloc(v), False
+                emit(s.buf, None)
+            elif not s.shared:
+                emit(s.buf, s.buf)
+            else:
+                nb = alloc(v)
+                emit(nb, s.buf)
+                s.buf, s.shared = nb, False
+
+        for hi, o in enumerate(g.outputs):
+            gs[o.id].buf = self.dheads[hi]
+            bwd.add("mny_axpy", self.dheads[hi], self.g_scale[hi:hi + 1], self.dheads[hi], 0, self.dheads[hi].numel(), self.stream)
+
+        for nd in order:
+            o = nd.out
+            shp = shape(o)
+            M = shp[0] * shp[1] * shp[2]
+            s = gs[o.id]
+            assert s.buf is not None, "no gradient reached %s" % o.name
+            G = s.buf
+            if nd.op == "add":
+                has_b, has_up = nd.k & 1, nd.k & 2
+                contribute_alias(nd.ins[0], G)
+                if has_b:
+                    contribute_alias(nd.ins[1], G)
+                if has_up:
+                    upv = nd.ins[-1]
+                    us = gs[upv.id]
+                    if us.buf is None:
+                        us.buf, us.shared = alloc(upv), False
+                        bwd.add("mny_upsample_bwd", G, us.buf, 0, shp[0], shp[1], shp[2], shp[3], self.stream)
+                    else:
+                        if us.shared:
+                            nb = alloc(upv)
+                            bwd.add("mny_axpy", us.buf, None, nb, 0, nb.numel(), self.stream)
+                            us.buf, us.shared = nb, False
+                        bwd.add("mny_upsample_bwd", G, us.buf, 1, shp[0], shp[1], shp[2], shp[3], self.stream)
+                bwd.marks[o.name] = len(bwd.calls)
+                continue
+            if nd.op == "pwb":
+                dY = G
+            else:
+                u = self.units[o.id]
+                parts = _lib.query("mny_bn_bwd_parts", M, o.C)
+                gam = P[nd.bn + ".weight"]
+                dY = G if not s.shared else alloc(o)
+                bwd.add("mny_bn_bwd_reduce", G, u.Y, u.scale, u.shift, o.act, u.mean, u.invstd, self.red_ws, M, o.C, self.stream)
+                bwd.add("mny_bn_bwd_finalize", self.red_ws, parts, M, gam, u.mean, u.invstd, gv(nd.bn + ".weight"), gv(nd.bn + ".bias"),
+                        self.coef_ws, o.C, self.stream)
+                bwd.add("mny_bn_bwd_apply", G, u.Y, u.scale, u.shift, o.act, self.coef_ws, dY, M, o.C, self.stream)
+            w = P[nd.conv + ".weight"]
+            if nd.op == "stem":
+                bwd.add("mny_stem_wgrad", self.x_ptr, dY, gv(nd.conv + ".weight"), self.ws, N, self.H, self.W, o.C, self.stream)
+            elif nd.op == "dw":
+                i = nd.ins[0]
+                ish = shape(i)
+                xv = view(i)
+                bwd.add("mny_dw_bwd_weight", xv[0], xv[1], xv[2], xv[3], dY, gv(nd.conv + ".weight"), self.ws, N, ish[1], ish[2], o.C,
+                        nd.k, nd.stride, self.stream)
+                contribute_kernel(i, lambda out, addend, dY=dY, w=w, ish=ish, nd=nd, C=o.C: bwd.add(
+                    "mny_dw_bwd_data", dY, w, addend, out, N, ish[1], ish[2], C, nd.k, nd.stride, self.stream))
+            else:   # pw / pwb
+                i = nd.ins[0]
+                xv = view(i)
+                db = gv(nd.conv + ".bias") if nd.bias else None
+                bwd.add("mny_pw_wgrad", xv[0], xv[1], xv[2], xv[3], dY, gv(nd.conv + ".weight"), db, self.ws, M, i.C, o.C, self.stream)
+                wT = torch.empty(i.C, o.C, **f32)
+                self.wT[nd.conv] = wT
+                bwd.add("mny_transpose", w, wT, o.C, i.C, self.stream)
+                contribute_kernel(i, lambda out, addend, dY=dY, wT=wT, M=M, K=o.C, Nc=i.C: bwd.add(
+                    "mny_pw_fwd", dY, None, None, ACT_NONE, wT, None, addend, out, None, M, K, Nc, self.stream))
+            bwd.marks[o.name] = len(bwd.calls)
+
+    # ------------------------------------------------------------------------------------------
+    def stale(self):
+        return any(t.data_ptr() != p for t, p in self.param_ptrs)
+
+    def _bind(self, x):
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and tuple(x.shape) == (self.N, 3, self.H, self.W)
+        self.x_ptr.value = x.data_ptr()
+        self.stream.value = torch.cuda.current_stream(self.dev).cuda_stream
+
+    def set_targets(self, targets):
+        """targets: list (len N) of [n_i,5] float tensors (label,cx,cy,w,h), CPU or device."""
+        assert len(targets) == self.N, "need one target tensor per image"
+        counts = [int(t.shape[0]) for t in targets]
+        total = sum(counts)
+        if total > self.t_dev.shape[0]:
+            self.t_dev = torch.zeros(2 * total, 5, device=self.dev, dtype=torch.float32)
+        acc, offs = 0, [0]
+        for c in counts:
+            acc += c
+            offs.append(acc)
+        off = torch.tensor(offs, dtype=torch.int32)
+        if total:
+            packed = torch.cat([t.reshape(-1, 5) for t in targets if t.shape[0]]).to(torch.float32)
+            self.t_dev[:total].copy_(packed, non_blocking=True)
+        self.off_dev.copy_(off, non_blocking=True)
+        self.t_ptr.value = self.t_dev.data_ptr()
+        self.off_ptr.value = self.off_dev.data_ptr()
+
+    def forward_train(self, x, targets):
+        self._bind(x)
+        self.set_targets(targets)
+        self.fwd.run()
+        self.saved_x = x
+        return self.out14
+
+    def backward(self, g_losses):
+        self.stream.value = torch.cuda.current_stream(self.dev).cuda_stream
+        self.x_ptr.value = self.saved_x.data_ptr()
+        self.g_scale.copy_(g_losses.reshape(2).to(self.g_scale.dtype))
+        self.bwd.run()
+
+    def forward_eval(self, x, val_conf):
+        self._bind(x)
+        self.fwd.run()
+        for i in range(2):
+            self.val_conf[i].value = val_conf[i]
+        self.det.run()

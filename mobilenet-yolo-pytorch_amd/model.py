@@ -1,0 +1,203 @@
+"""Drop-in `yolo` module: same constructor config, forward contract and `state_dict` keys as the
+reference's models/mbv2_yolo.py:105-173, executed entirely by libmnyolo (HIP) through static plans.
+
+    model = yolo(config).cuda()
+    outputs = model(images, targets)          # training: ((loss, recall, avg_iou, obj, no_obj, cls, count), (...))
+    sum(o[0] for o in outputs).backward()     # fills p.grad for the 202 trainable tensors
+    detections = model.eval()(images)         # list (len N) of [k_i,7] tensors after per-class NMS
+
+There is no CPU fallback: calling the module with CPU tensors, or without the built library, raises.
+The nn.Conv2d / nn.BatchNorm2d children are parameter holders only (their own forward is never used),
+which is what keeps checkpoints written by the reference's train.py:175-226 loadable.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .arch import mbv2_yolo_graph
+from .engine import NetPlan
+
+
+class Holder(nn.Module):
+    """Plain container; children are registered under the reference's names / indices."""
+
+    def forward(self, *a, **k):
+        raise RuntimeError("parameter holder: use the top-level yolo module")
+
+
+class HeadState:
+    """Python-side state of one detection head — the attributes train.py / inference.py touch on
+    `model.yolo_losses[i]` (val_conf r/w: train.py:149-150,417-418; img_size: mbv2_yolo.py:139-140)."""
+
+    def __init__(self, anchors, mask, num_classes, img_size, ignore_threshold, iou_thresh, val_conf=0.1, iou_weighting=0.01):
+        self.anchors = [tuple(a) for a in anchors]
+        self.mask = list(mask)
+        self.num_mask = len(mask)
+        self.num_anchors = len(anchors)
+        self.num_classes = num_classes
+        self.bbox_attrs = 5 + num_classes
+        self.img_size = img_size
+        self.ignore_threshold = ignore_threshold
+        self.iou_thresh = iou_thresh
+        self.val_conf = val_conf
+        self.iou_weighting = iou_weighting
+
+
+class _TrainStep(torch.autograd.Function):
+    """One autograd node for the whole network + both losses.  Parameter gradients are written
+    straight into the model's flat gradient arena (and exposed as `p.grad` views) instead of being
+    returned through autograd, so no per-parameter AccumulateGrad work happens."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, model, plan, targets):
+        out14 = plan.forward_train(x, targets)
+        res = out14.clone()
+        ctx.model, ctx.plan = model, plan
+        losses, metrics = res[:, 0].contiguous(), res[:, 1:].contiguous()
+        ctx.mark_non_differentiable(metrics)
+        return losses, metrics
+
+    @staticmethod
+    def backward(ctx, g_losses, _g_metrics):
+        ctx.model._run_backward(ctx.plan, g_losses.contiguous())
+        return None, None, None, None, None
+
+
+class yolo(nn.Module):
+    def __init__(self, config, sync_metrics=False):
+        super().__init__()
+        y = config["yolo"]
+        self.num_classes = y["num_classes"]
+        self.num_anchors = y["num_anchors"]
+        self.seg_num_classes = config["seg"]["num_classes"] if "seg" in config else None
+        self.sync_metrics = sync_metrics          # True: metrics as python floats like the reference (forces a device sync)
+        self.graph = mbv2_yolo_graph(self.num_classes, self.num_anchors, self.seg_num_classes)
+        self._build_modules()
+        self.yolo_losses = [HeadState(y["anchors"], y["mask"][i], self.num_classes, [config["img_w"], config["img_h"]],
+                                      y["ignore_thresh"][i], y["iou_thresh"], iou_weighting=config["iou_weighting"])
+                            for i in range(2)]                                   # plain list: not in state_dict (mbv2_yolo.py:132)
+        self.img_size = [config["img_w"], config["img_h"]]
+        self._plans = {}
+        self._anchor = None
+        self.grad_hook = None                      # DP: called as hook(plan) after gradients are complete
+
+    def __getstate__(self):           # torch.save(model) (train.py:431): plans hold raw device pointers
+        d = self.__dict__.copy()
+        d["_plans"], d["_anchor"], d["grad_hook"] = {}, None, None
+        return d
+
+    # ---- parameters ---------------------------------------------------------------------------
+    def _build_modules(self):
+        for path, kind, a in self.graph.modules:
+            parts = path.split(".")
+            m = self
+            for p in parts[:-1]:
+                if p not in m._modules:
+                    m.add_module(p, Holder())
+                m = m._modules[p]
+            if kind == "conv":
+                cin, cout, k, stride, groups, bias = a
+                mod = nn.Conv2d(cin, cout, k, stride, k // 2, groups=groups, bias=bias)
+                if path.startswith("backbone."):                              # mobilenetv2.py:146-152
+                    mod.weight.data.normal_(0, math.sqrt(2.0 / (k * k * cout)))
+                elif not bias:                                                 # BasicConv: mbv2_yolo.py:32-36
+                    nn.init.kaiming_normal_(mod.weight, mode="fan_out")
+                # biased head convs keep nn.Conv2d's default init (mbv2_yolo.py:82)
+            else:
+                mod = nn.BatchNorm2d(a[0])                                     # weight 1, bias 0 (both inits)
+            m.add_module(parts[-1], mod)
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def all_state_tensors(self):
+        return [t for t in self.state_dict(keep_vars=True).values()]
+
+    @property
+    def param_tensors(self):
+        return {k: (v.data if isinstance(v, nn.Parameter) else v) for k, v in self.state_dict(keep_vars=True).items()}
+
+    # ---- plans --------------------------------------------------------------------------------
+    def _plan(self, N, H, W, training):
+        key = (N, H, W, training)
+        p = self._plans.get(key)
+        if p is None or p.stale():
+            if not torch.cuda.is_available() or self.device.type != "cuda":
+                raise _lib.MnyError("yolo runs only on an MI355X (HIP) device: move the module and inputs to cuda; "
+                                    "there is no CPU fallback")
+            _lib.load()
+            p = NetPlan(self, N, H, W, training)
+            self._plans[key] = p
+            if len(self._plans) > 8:                                            # multi-scale training: bound resident plans
+                self._plans.pop(next(iter(self._plans)))
+        return p
+
+    def _check_input(self, x):
+        if not isinstance(x, torch.Tensor) or not x.is_cuda:
+            raise _lib.MnyError("input must be a CUDA(HIP) tensor — the HIP path has no CPU fallback")
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError("expected images [N,3,H,W], got %s" % (tuple(x.shape),))
+        return x.contiguous().float()
+
+    # ---- forward ------------------------------------------------------------------------------
+    def forward(self, x, targets=None, seg_maps=None):
+        x = self._check_input(x)
+        N, _, H, W = x.shape
+        for hs in self.yolo_losses:
+            hs.img_size = [H, W]                                                # mbv2_yolo.py:139-140
+        if targets is None:
+            return self._forward_eval(x)
+        plan = self._plan(N, H, W, True)
+        if self._anchor is None or self._anchor.device != x.device:
+            self._anchor = torch.zeros((), device=x.device, requires_grad=True)
+        if self.training:
+            nbt = [b for k, b in self.named_buffers() if k.endswith("num_batches_tracked")]
+            torch._foreach_add_(nbt, 1)
+        losses, metrics = _TrainStep.apply(x, self._anchor, self, plan, targets)
+        out = []
+        if self.sync_metrics:
+            m = metrics.tolist()
+        for i in range(2):
+            if self.sync_metrics:     # reference types: python floats, no_obj a tensor (yolo_loss.py:170-178)
+                r = (losses[i], m[i][0], m[i][1], m[i][2], metrics[i, 3], m[i][4], m[i][5])
+            else:
+                r = (losses[i],) + tuple(metrics[i, j] for j in range(6))
+            out.append(r)
+        return tuple(out)
+
+    def _run_backward(self, plan, g_losses):
+        P = dict(self.named_parameters())
+        # gradient accumulation (backward twice without zero_grad(set_to_none=True)): keep the old arena
+        first = P[plan.grad_params[0]]
+        prev = None
+        if first.grad is not None and first.grad.data_ptr() == plan.gviews[plan.grad_params[0]].data_ptr():
+            prev = plan.gflat.clone()
+        plan.backward(g_losses)
+        if prev is not None:
+            plan.gflat.add_(prev)
+        for nm in plan.grad_params:
+            p = P[nm]
+            gview = plan.gviews[nm]
+            if p.grad is None:
+                p.grad = gview
+            elif p.grad.data_ptr() != gview.data_ptr():
+                p.grad.add_(gview)                                              # foreign .grad tensor: accumulate into it
+        if self.grad_hook is not None:
+            self.grad_hook(plan)
+
+    def _forward_eval(self, x):
+        N, _, H, W = x.shape
+        if self.training:
+            raise RuntimeError("call model.eval() before inference (the reference's eval path uses running statistics)")
+        plan = self._plan(N, H, W, False)
+        with torch.no_grad():
+            plan.forward_eval(x, [float(h.val_conf) for h in self.yolo_losses])
+            counts = plan.out_counts.tolist()                                   # the one host sync of the eval path
+            if int(plan.nms_status.item()) != 0:
+                raise _lib.MnyError("NMS: a class bucket of %d boxes exceeds the 8192-box LDS limit" % int(plan.nms_status.item()))
+            total = sum(counts)
+            dets = plan.out_rows[:total].clone()
+        return list(torch.split(dets, counts))                                  # list of [k_i,7] (mbv2_yolo.py:159-166)

@@ -180,24 +180,31 @@ def yolo_loss(head, targets, t_off, anchors_all, mask, hp):
     return out7, dhead
 
 
-def yolo_decode(head, anchors_all, mask, hp, val_conf):
+def yolo_decode(head, anchors_all, mask, hp, val_conf, rows=None, row_stride=None, base_counts=None):
     cells = hp.A * hp.g * hp.g
-    rows = _new(hp.N, cells, 7, like=head)
+    row_stride = row_stride or cells
+    if rows is None:
+        rows = _new(hp.N, row_stride, 7, like=head)
     counts = _new(hp.N, like=head, dtype=torch.int32)
-    call("mny_yolo_decode", _p(head), _p(anchors_all), _p(mask), ctypes.byref(hp), float(val_conf), _p(rows), _p(counts), _st())
+    call("mny_yolo_decode", _p(head), _p(anchors_all), _p(mask), ctypes.byref(hp), float(val_conf), _p(rows), int(row_stride),
+         _p(base_counts), _p(counts), _st())
     return rows, counts
 
 
-def nms_per_class(rows, seg_off, num_classes, thr=0.45, max_seg_rows=0):
-    """rows [total,7], seg_off int32 [S+1] (device) -> (out_idx int32 [total], out_counts int32 [S], status)."""
-    total = rows.shape[0]
-    S = seg_off.numel() - 1
-    nbytes = query("mny_nms_ws_bytes", S, total, num_classes)
-    ws = torch.empty(nbytes, device=rows.device, dtype=torch.uint8)
-    out_idx = torch.empty(max(total, 1), device=rows.device, dtype=torch.int32)
-    out_counts = torch.empty(S, device=rows.device, dtype=torch.int32)
-    call("mny_nms_per_class", _p(rows), _p(seg_off), S, total, int(max_seg_rows), num_classes, float(thr), _p(out_idx), _p(out_counts),
-         ctypes.c_void_p(ws.data_ptr()), _st())
-    off = query("mny_nms_status_offset", S, total, num_classes)
-    status = ws[off:off + 4].view(torch.int32)
-    return out_idx, out_counts, status
+def nms_per_class(rows, seg_begin, seg_count, num_classes, thr=0.45, max_seg_rows=0, gather=True):
+    """rows [capacity,7]; seg_begin/seg_count int32 [S] (device).
+    -> (out_idx int32 [capacity], out_counts int32 [S], out_rows [capacity,7]|None, prefix int32 [S+1], status int32 [1])"""
+    capacity = rows.shape[0]
+    S = seg_begin.numel()
+    nbytes = query("mny_nms_ws_bytes", S, capacity, num_classes)
+    ws = torch.empty(nbytes, device=seg_begin.device, dtype=torch.uint8)
+    out_idx = torch.empty(max(capacity, 1), device=seg_begin.device, dtype=torch.int32)
+    out_counts = torch.empty(S, device=seg_begin.device, dtype=torch.int32)
+    out_rows = torch.empty(max(capacity, 1), 7, device=seg_begin.device) if gather else None
+    call("mny_nms_per_class", _p(rows) if capacity else None, _p(seg_begin), _p(seg_count), S, capacity, int(max_seg_rows), num_classes,
+         float(thr), _p(out_idx), _p(out_counts), _p(out_rows), ctypes.c_void_p(ws.data_ptr()), _st())
+    so = query("mny_nms_status_offset", S, capacity, num_classes)
+    po = query("mny_nms_prefix_offset", S, capacity, num_classes)
+    status = ws[so:so + 4].view(torch.int32)
+    prefix = ws[po:po + 4 * (S + 1)].view(torch.int32)
+    return out_idx, out_counts, out_rows, prefix, status

@@ -95,6 +95,12 @@ def test_decode_matches_reference_fixture(ops):
         for vc in (1, 3, 5):
             rows, counts = ops.yolo_decode(h, anchors, mask, hp, vc / 10)
             counts = counts.cpu().tolist()
+            # second head appended behind the first inside wider per-image slots
+            wide, c2 = ops.yolo_decode(h, anchors, mask, hp, vc / 10, row_stride=2 * rows.shape[1] + 3)
+            wide, c3 = ops.yolo_decode(h, anchors, mask, hp, vc / 10, rows=wide, row_stride=2 * rows.shape[1] + 3, base_counts=c2)
+            assert c3.cpu().tolist() == [2 * c for c in counts]
+            for b in range(4):
+                assert torch.equal(wide[b, counts[b]:2 * counts[b]], rows[b, :counts[b]])
             assert counts == z["dec%d_%d_counts" % (hi, vc)].tolist()
             got = torch.cat([rows[b, :counts[b]] for b in range(4)]).cpu().numpy()
             ref = z["dec%d_%d_rows" % (hi, vc)]
@@ -124,14 +130,17 @@ def test_nms_indices_bit_exact(ops, sizes, C, quant):
     off = np.zeros(len(sizes) + 1, np.int32)
     off[1:] = np.cumsum(sizes)
     dev_rows = rows.cuda() if rows.shape[0] else torch.zeros(1, 7).cuda()[:0]
-    out_idx, out_counts, status = ops.nms_per_class(dev_rows, torch.from_numpy(off).cuda(), C, 0.45, max_seg_rows=max(sizes))
+    beg, cnt = torch.from_numpy(off[:-1].copy()).cuda(), torch.tensor(sizes, dtype=torch.int32).cuda()
+    out_idx, out_counts, out_rows, prefix, status = ops.nms_per_class(dev_rows, beg, cnt, C, 0.45, max_seg_rows=max(sizes))
     assert int(status.cpu()) == 0
-    out_idx, out_counts = out_idx.cpu().numpy(), out_counts.cpu().numpy()
+    out_idx, out_counts, prefix = out_idx.cpu().numpy(), out_counts.cpu().numpy(), prefix.cpu().numpy()
+    assert np.array_equal(prefix, np.concatenate(([0], np.cumsum(out_counts))))
     for s, seg in enumerate(segs):
-        _, ref_idx = nms_ref.nms_rows(seg, C, 0.45)
+        ref_rows, ref_idx = nms_ref.nms_rows(seg, C, 0.45)
         got = out_idx[off[s]:off[s] + out_counts[s]] - off[s]
         assert out_counts[s] == len(ref_idx)
         assert np.array_equal(got, ref_idx.numpy())
+        assert np.array_equal(out_rows[prefix[s]:prefix[s + 1]].cpu().numpy(), ref_rows.numpy())
 
 
 def test_nms_reference_driver_fixture(ops):
@@ -149,15 +158,15 @@ def test_nms_reference_driver_fixture(ops):
     off = np.zeros(5, np.int32)
     off[1:] = np.cumsum(sizes)
     rows = torch.cat(per_img)
-    out_idx, out_counts, status = ops.nms_per_class(rows.cuda(), torch.from_numpy(off).cuda(), 20, 0.45, max_seg_rows=max(sizes))
+    beg, cnt = torch.from_numpy(off[:-1].copy()).cuda(), torch.tensor(sizes, dtype=torch.int32).cuda()
+    out_idx, out_counts, out_rows, prefix, status = ops.nms_per_class(rows.cuda(), beg, cnt, 20, 0.45, max_seg_rows=max(sizes))
     assert int(status.cpu()) == 0
     assert out_counts.cpu().tolist() == zn["counts"].tolist()
-    kept = torch.cat([rows[out_idx.cpu()[off[s]:off[s] + out_counts[s].item()].long()] for s in range(4)])
-    assert np.array_equal(kept.numpy(), zn["rows"])
+    assert np.array_equal(out_rows[:int(prefix[-1])].cpu().numpy(), zn["rows"])
 
 
 def test_nms_bucket_overflow_is_reported(ops):
     rows = _rand_rows(9000, 1, seed=5)
-    off = torch.tensor([0, 9000], dtype=torch.int32).cuda()
-    _, counts, status = ops.nms_per_class(rows.cuda(), off, 1, 0.45)
+    beg, cnt = torch.tensor([0], dtype=torch.int32).cuda(), torch.tensor([9000], dtype=torch.int32).cuda()
+    _, counts, _, _, status = ops.nms_per_class(rows.cuda(), beg, cnt, 1, 0.45)
     assert int(status.cpu()) == 9000 and int(counts.cpu()[0]) == 0

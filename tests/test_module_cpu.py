@@ -1,0 +1,70 @@
+"""CPU: host-side logic of the drop-in module — state_dict contract, pickling, loud failure without a GPU."""
+import io
+import json
+import os
+
+import pytest
+import torch
+
+from oracle import net_ref, procedural
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _mk(cfg=None):
+    from mobilenet_yolo_pytorch_amd import yolo
+    torch.manual_seed(0)
+    return yolo(cfg or procedural.VOC_CONFIG)
+
+
+def test_state_dict_matches_reference_manifest():
+    for name in ("voc", "bdd100k"):
+        man = json.load(open(os.path.join(G, "state_keys_%s.json" % name)))
+        sd = _mk(man["config"]).state_dict()
+        assert [[k, list(v.shape)] for k, v in sd.items()] == man["keys"]
+        assert sum(p.numel() for p in _mk(man["config"]).parameters()) == man["num_params"]
+
+
+def test_checkpoint_roundtrip_with_oracle_model():
+    ref = procedural.fill_state_dict_(net_ref.RefYolo(procedural.VOC_CONFIG))
+    m = _mk()
+    missing, unexpected = m.load_state_dict(ref.state_dict(), strict=True)
+    assert not missing and not unexpected
+    for k, v in ref.state_dict().items():
+        assert torch.equal(m.state_dict()[k], v)
+
+
+def test_init_statistics_follow_reference():
+    m = _mk()
+    sd = m.state_dict()
+    w = sd["backbone.features.1.conv.3.weight"]                   # 1x1 32->16: std = sqrt(2/(1*1*16))
+    assert abs(w.std().item() - (2 / 16) ** 0.5) < 0.05
+    w = sd["conv_for_S32.conv.weight"]                            # kaiming fan_out: std = sqrt(2/512)
+    assert abs(w.std().item() - (2 / 512) ** 0.5) < 0.01
+    assert torch.all(sd["conv_for_S32.bn.weight"] == 1) and torch.all(sd["conv_for_S32.bn.bias"] == 0)
+    assert sd["yolo_headS32.3.bias"].abs().max() <= 1 / 1024 ** 0.5 + 1e-6   # nn.Conv2d default
+
+
+def test_whole_module_pickles():
+    m = _mk()
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    m2 = torch.load(buf, weights_only=False)
+    assert list(m2.state_dict().keys()) == list(m.state_dict().keys())
+    assert m2.yolo_losses[0].val_conf == 0.1
+
+
+def test_attributes_the_callers_touch():
+    m = _mk()
+    m.yolo_losses[0].val_conf = 0.3
+    m.yolo_losses[1].val_conf = 0.3
+    assert m.num_classes == 20 and len(m.yolo_losses) == 2
+    assert not any("yolo_losses" in k for k in m.state_dict())
+
+
+def test_cpu_call_fails_loudly():
+    from mobilenet_yolo_pytorch_amd import MnyError
+    m = _mk().eval()
+    with pytest.raises(MnyError, match="no CPU fallback"):
+        m(torch.zeros(1, 3, 96, 96))
