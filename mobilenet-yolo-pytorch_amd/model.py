@@ -26,6 +26,15 @@ class Holder(nn.Module):
     def forward(self, *a, **k):
         raise RuntimeError("parameter holder: use the top-level yolo module")
 
+    def __getitem__(self, i):          # index like the reference's nn.Sequential children
+        return self._modules[str(i)]
+
+    def __len__(self):
+        return len(self._modules)
+
+    def __iter__(self):
+        return iter(self._modules.values())
+
 
 class HeadState:
     """Python-side state of one detection head — the attributes train.py / inference.py touch on
