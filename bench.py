@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py — MobileNetV2-YOLO 352x352 fwd+bwd @ bs256 per GPU (BASELINE.json configs[1] / [2]).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = zero_grad -> forward(images, targets) (network + both on-device YOLO losses) -> backward, on a
+fixed synthetic batch resident in HBM.  With N>1 every rank runs its own 256-image shard
+(weak scaling) and the fp32 gradient arena is averaged with RCCL all-reduce buckets launched from inside
+the backward pass.  Rank 0 prints ONE JSON line.
+
+Extra objects on the line:
+  roofline     — the dominant kernel of the step (by measured time), bracketed by HIP events on the
+                 launch stream during the timed region; achieved = algorithmic FLOPs (or bytes) of those
+                 launches / their summed duration.
+  cpu_baseline — the oracle's torch-CPU port of the reference (oracle/net_ref.py), same synthetic
+                 distribution, bounded sample, timed on this host's cores (rank 0, N=1 only).
+  nms          — BASELINE config 5: 100k boxes x 20 classes per-class NMS, GPU boxes/s and the
+                 single-thread C restatement of torchvision's CPU kernel beside it.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
+BATCH = 256
+SIZE = 352
+
+MFMA_KERNELS = {"mny_pw_fwd", "mny_pw_wgrad"}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=BATCH, help="images per GPU (the metric is quoted at 256)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-nms", action="store_true")
+    ap.add_argument("--breakdown", action="store_true", help="print a per-entry-point time table to stderr")
+    return ap.parse_args()
+
+
+def make_batch(batch, rank, device):
+    from mobilenet_yolo_pytorch_amd import synthetic
+    x = synthetic.images(batch, SIZE, SIZE, seed=rank).to(device)
+    tg = synthetic.targets(batch, seed=1 + rank, empty_every=16)
+    return x, tg
+
+
+def cpu_baseline():
+    """Reference semantics on the host CPU: oracle/net_ref.py (stock torch ops + restated loss), bs=16."""
+    from oracle import net_ref, procedural
+    torch.manual_seed(0)
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    m = net_ref.RefYolo(procedural.VOC_CONFIG).train()
+    bs = 16
+    x = procedural.images(bs, SIZE, SIZE, seed=0)
+    tg = procedural.targets(bs, seed=1, empty_every=16)
+
+    def step():
+        for p in m.parameters():
+            p.grad = None
+        r = m(x, tg)
+        (r[0][0] + r[1][0]).backward()
+    step()
+    t0 = time.perf_counter()
+    n = 0
+    while n < 2 or (time.perf_counter() - t0 < 12 and n < 6):
+        step()
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(bs * n / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d fwd+bwd steps at bs=%d, 352x352, oracle/net_ref.py (torch CPU fp32)" % (n, bs)}
+
+
+def nms_bench(device):
+    """BASELINE config 5: one image-segment of 100,000 rows, 20 classes."""
+    import numpy as np
+    from mobilenet_yolo_pytorch_amd import ops
+    from oracle import nms_ref
+    r = np.random.RandomState(2)
+    n, C = 100000, 20
+    ctr = r.rand(n, 2).astype(np.float32)
+    wh = (0.02 + 0.28 * r.rand(n, 2)).astype(np.float32)
+    rows = np.concatenate((ctr - wh / 2, ctr + wh / 2, r.rand(n, 2).astype(np.float32), r.randint(0, C, (n, 1)).astype(np.float32)), 1)
+    rows_t = torch.from_numpy(rows.astype(np.float32))
+    dev_rows = rows_t.to(device)
+    beg = torch.zeros(1, dtype=torch.int32, device=device)
+    cnt = torch.full((1,), n, dtype=torch.int32, device=device)
+    out = ops.nms_per_class(dev_rows, beg, cnt, C)
+    torch.cuda.synchronize()
+    assert int(out[4].item()) == 0
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = ops.nms_per_class(dev_rows, beg, cnt, C)
+    torch.cuda.synchronize()
+    gpu_dt = (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter()
+    _, ref_idx = nms_ref.nms_rows(rows_t, C, 0.45)
+    cpu_dt = time.perf_counter() - t0
+    kept = int(out[1].item())
+    same = kept == len(ref_idx) and torch.equal(out[0][:kept].cpu().long(), ref_idx)
+    return {"workload": "per-class NMS, 100000 boxes x 20 classes, thr 0.45", "boxes_per_s": round(n / gpu_dt, 1),
+            "ms": round(gpu_dt * 1e3, 3), "kept": kept, "matches_cpu_indices": bool(same),
+            "cpu_boxes_per_s": round(n / cpu_dt, 1), "cpu_kind": "port (oracle/nms_ref.c, 1 thread)"}
+
+
+def roofline_from(events, calls_by_list):
+    """Aggregate HIP-event durations per entry point; pick the dominant one."""
+    agg = {}
+    for which, evs in events.items():
+        calls = calls_by_list[which]
+        for idx, name, a, b in evs:
+            ms = a.elapsed_time(b)
+            meta = calls[idx][3] or {}
+            d = agg.setdefault(name, {"ms": 0.0, "n": 0, "flops": 0, "bytes": 0})
+            d["ms"] += ms
+            d["n"] += 1
+            d["flops"] += meta.get("flops", 0)
+            d["bytes"] += meta.get("bytes", 0)
+    return agg
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    from mobilenet_yolo_pytorch_amd import synthetic, yolo
+    torch.manual_seed(0)                      # identical init on every rank
+    model = yolo(synthetic.VOC_CONFIG).to(device).train()
+    reducer = None
+    if world > 1:
+        from mobilenet_yolo_pytorch_amd.dp import attach_data_parallel
+        reducer = attach_data_parallel(model)
+    x, tg = make_batch(a.batch, rank, device)
+
+    def step():
+        for p in model.parameters():
+            p.grad = None                     # optimizer.zero_grad(set_to_none=True), train.py:254
+        out = model(x, tg)                    # train.py:260
+        (out[0][0] + out[1][0]).backward()    # train.py:276,282
+        return out
+
+    for _ in range(max(a.warmup, 1)):
+        out = step()
+    torch.cuda.synchronize()
+    plan = model._plans[(a.batch, SIZE, SIZE, True)]
+
+    # timed region: K steps, barrier + sync on both sides; the dominant kernels are bracketed by HIP events
+    plan.enable_timing(only=None if a.breakdown else MFMA_KERNELS)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    if reducer is not None:
+        reducer.wait()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    timing = plan.disable_timing()
+    loss = float(out[0][0]) + float(out[1][0])
+
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        agg = roofline_from({"fwd": timing["fwd"], "bwd": timing["bwd"]}, {"fwd": plan.fwd.calls, "bwd": plan.bwd.calls})
+        if a.breakdown:
+            tot = sum(d["ms"] for d in agg.values()) / a.steps
+            for name, d in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+                ms = d["ms"] / a.steps
+                print("%-22s %8.3f ms/step  %5.1f%%  n=%3d  %7.1f TF/s  %7.1f GB/s" % (
+                    name, ms, 100 * ms / tot, d["n"] // a.steps, d["flops"] / d["ms"] / 1e9 if d["ms"] else 0,
+                    d["bytes"] / d["ms"] / 1e6 if d["ms"] else 0), file=sys.stderr)
+            print("sum of bracketed kernels %.3f ms/step; wall %.3f ms/step" % (tot, dt / a.steps * 1e3), file=sys.stderr)
+        dom = max((n for n in agg if n in MFMA_KERNELS), key=lambda n: agg[n]["ms"])
+        d = agg[dom]
+        achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        roof = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                "launches_per_step": d["n"] // a.steps, "ms_per_step": round(d["ms"] / a.steps, 3),
+                "algorithmic_gflop_per_step": round(d["flops"] / a.steps / 1e9, 2),
+                "algorithmic_hbm_gbs": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1)}
+        res = {
+            "metric": "images/sec MobileNetV2-YOLO 352x352 fwd+bwd @ bs256", "value": round(world * a.batch * a.steps / dt, 2),
+            "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "MobileNetV2-YOLO 352x352 bs=%d/GPU fwd+loss+bwd fp32 (BASELINE configs[%d])" % (a.batch, 1 if world == 1 else 2),
+                       "global_batch": world * a.batch, "parallelism": "dp%d" % world,
+                       "timed_region": "zero_grad + forward(net + 2 on-device YOLO losses) + backward; random-init weights",
+                       "loss": round(loss, 5)},
+            "roofline": roof,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        if world == 1 and not a.no_nms:
+            res["nms"] = nms_bench(device)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

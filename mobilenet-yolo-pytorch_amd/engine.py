@@ -36,7 +36,7 @@ class CallList:
         self.keep = []           # tensors referenced by raw pointers
         self.marks = {}          # name -> call index (for DP bucket events)
 
-    def add(self, name, *args):
+    def add(self, name, *args, meta=None):
         fn = getattr(_lib.load(), name)
         conv = []
         for a in args:
@@ -46,14 +46,34 @@ class CallList:
                 conv.append(_vp(a.data_ptr()))
             else:
                 conv.append(a)
-        self.calls.append((fn, tuple(conv), name))
+        self.calls.append((fn, tuple(conv), name, meta))   # meta: algorithmic {flops, bytes} of the call
 
     def run(self, begin=0, end=None):
         lib = _lib.load()
-        for fn, args, name in self.calls[begin:end]:
+        for fn, args, name, _ in self.calls[begin:end]:
             rc = fn(*args)
             if rc != 0:
                 raise MnyError("%s failed (%d): %s" % (name, rc, lib.mny_last_error().decode()))
+
+    def run_timed(self, events, only=None, begin=0, end=None):
+        """Like run(), bracketing each call (or only the entry points named in `only`) with HIP events
+        recorded on torch's current stream — the stream the kernels are launched on.
+        Appends (call index, name, start, end) to `events`."""
+        lib = _lib.load()
+        end = len(self.calls) if end is None else end
+        for idx in range(begin, end):
+            fn, args, name, _ = self.calls[idx]
+            timed = only is None or name in only
+            if timed:
+                a = torch.cuda.Event(enable_timing=True)
+                b = torch.cuda.Event(enable_timing=True)
+                a.record()
+            rc = fn(*args)
+            if rc != 0:
+                raise MnyError("%s failed (%d): %s" % (name, rc, lib.mny_last_error().decode()))
+            if timed:
+                b.record()
+                events.append((idx, name, a, b))
 
 
 class _Unit:
@@ -70,6 +90,8 @@ class NetPlan:
         g = net.graph
         self.stream = _vp(0)
         self.x_ptr = _vp(0)
+        self.timing = None
+        self.reducer = None
         self.fwd = CallList()
         self.units = {}          # value id -> _Unit
         self.reals = {}          # value id -> tensor
@@ -106,18 +128,21 @@ class NetPlan:
                 stats = self.stats_ws if training else None
                 if nd.op == "stem":
                     parts = _lib.query("mny_stem_stat_parts", N, H, W, o.C)
-                    self.fwd.add("mny_stem_fwd", self.x_ptr, w, u.Y, stats, N, H, W, o.C, self.stream)
+                    self.fwd.add("mny_stem_fwd", self.x_ptr, w, u.Y, stats, N, H, W, o.C, self.stream,
+                                 meta=dict(flops=2 * M * o.C * 27, bytes=4 * (N * 3 * H * W + M * o.C)))
                 elif nd.op == "dw":
                     i = nd.ins[0]
                     ish = shape(i)
                     xv = view(i)
                     parts = _lib.query("mny_dw_stat_parts", N, ish[1], ish[2], o.C, nd.k, nd.stride)
-                    self.fwd.add("mny_dw_fwd", xv[0], xv[1], xv[2], xv[3], w, u.Y, stats, N, ish[1], ish[2], o.C, nd.k, nd.stride, self.stream)
+                    self.fwd.add("mny_dw_fwd", xv[0], xv[1], xv[2], xv[3], w, u.Y, stats, N, ish[1], ish[2], o.C, nd.k, nd.stride, self.stream,
+                                 meta=dict(flops=2 * M * o.C * nd.k * nd.k, bytes=4 * (N * ish[1] * ish[2] * o.C + M * o.C + o.C * nd.k * nd.k)))
                 else:
                     i = nd.ins[0]
                     xv = view(i)
                     parts = _lib.query("mny_pw_stat_parts", M, i.C, o.C)
-                    self.fwd.add("mny_pw_fwd", xv[0], xv[1], xv[2], xv[3], w, None, None, u.Y, stats, M, i.C, o.C, self.stream)
+                    self.fwd.add("mny_pw_fwd", xv[0], xv[1], xv[2], xv[3], w, None, None, u.Y, stats, M, i.C, o.C, self.stream,
+                                 meta=dict(flops=2 * M * i.C * o.C, bytes=4 * (M * i.C + M * o.C + i.C * o.C)))
                 gam, bet = P[nd.bn + ".weight"], P[nd.bn + ".bias"]
                 rm, rv = P[nd.bn + ".running_mean"], P[nd.bn + ".running_var"]
                 if training:
@@ -131,7 +156,7 @@ class NetPlan:
                 t = torch.empty(shp, **f32)
                 self.reals[o.id] = t
                 self.fwd.add("mny_pw_fwd", xv[0], xv[1], xv[2], xv[3], P[nd.conv + ".weight"], P[nd.conv + ".bias"], None, t, None,
-                             M, i.C, o.C, self.stream)
+                             M, i.C, o.C, self.stream, meta=dict(flops=2 * M * i.C * o.C, bytes=4 * (M * i.C + M * o.C + i.C * o.C)))
             elif nd.op == "add":
                 a = view(nd.ins[0])
                 has_b, has_up = nd.k & 1, nd.k & 2
@@ -349,20 +374,24 @@ class NetPlan:
                 i = nd.ins[0]
                 ish = shape(i)
                 xv = view(i)
+                dwb = 4 * (N * ish[1] * ish[2] * o.C + M * o.C)
                 bwd.add("mny_dw_bwd_weight", xv[0], xv[1], xv[2], xv[3], dY, gv(nd.conv + ".weight"), self.ws, N, ish[1], ish[2], o.C,
-                        nd.k, nd.stride, self.stream)
-                contribute_kernel(i, lambda out, addend, dY=dY, w=w, ish=ish, nd=nd, C=o.C: bwd.add(
-                    "mny_dw_bwd_data", dY, w, addend, out, N, ish[1], ish[2], C, nd.k, nd.stride, self.stream))
+                        nd.k, nd.stride, self.stream, meta=dict(flops=2 * M * o.C * nd.k * nd.k, bytes=dwb))
+                contribute_kernel(i, lambda out, addend, dY=dY, w=w, ish=ish, nd=nd, C=o.C, M=M, dwb=dwb: bwd.add(
+                    "mny_dw_bwd_data", dY, w, addend, out, N, ish[1], ish[2], C, nd.k, nd.stride, self.stream,
+                    meta=dict(flops=2 * M * C * nd.k * nd.k, bytes=dwb)))
             else:   # pw / pwb
                 i = nd.ins[0]
                 xv = view(i)
                 db = gv(nd.conv + ".bias") if nd.bias else None
-                bwd.add("mny_pw_wgrad", xv[0], xv[1], xv[2], xv[3], dY, gv(nd.conv + ".weight"), db, self.ws, M, i.C, o.C, self.stream)
+                bwd.add("mny_pw_wgrad", xv[0], xv[1], xv[2], xv[3], dY, gv(nd.conv + ".weight"), db, self.ws, M, i.C, o.C, self.stream,
+                        meta=dict(flops=2 * M * i.C * o.C, bytes=4 * (M * i.C + M * o.C + i.C * o.C)))
                 wT = torch.empty(i.C, o.C, **f32)
                 self.wT[nd.conv] = wT
                 bwd.add("mny_transpose", w, wT, o.C, i.C, self.stream)
                 contribute_kernel(i, lambda out, addend, dY=dY, wT=wT, M=M, K=o.C, Nc=i.C: bwd.add(
-                    "mny_pw_fwd", dY, None, None, ACT_NONE, wT, None, addend, out, None, M, K, Nc, self.stream))
+                    "mny_pw_fwd", dY, None, None, ACT_NONE, wT, None, addend, out, None, M, K, Nc, self.stream,
+                    meta=dict(flops=2 * M * K * Nc, bytes=4 * (M * K + M * Nc + K * Nc))))
             bwd.marks[o.name] = len(bwd.calls)
 
     # ------------------------------------------------------------------------------------------
@@ -396,7 +425,10 @@ class NetPlan:
     def forward_train(self, x, targets):
         self._bind(x)
         self.set_targets(targets)
-        self.fwd.run()
+        if self.timing is not None:
+            self.fwd.run_timed(self.timing["fwd"], self.timing["only"])
+        else:
+            self.fwd.run()
         self.saved_x = x
         return self.out14
 
@@ -404,7 +436,24 @@ class NetPlan:
         self.stream.value = torch.cuda.current_stream(self.dev).cuda_stream
         self.x_ptr.value = self.saved_x.data_ptr()
         self.g_scale.copy_(g_losses.reshape(2).to(self.g_scale.dtype))
-        self.bwd.run()
+        if self.reducer is not None:
+            self.reducer.run_backward()             # segmented replay + bucketed RCCL all-reduce (dp.py)
+        else:
+            self.run_bwd_segment(0, None)
+
+    def run_bwd_segment(self, begin, end):
+        if self.timing is not None:
+            self.bwd.run_timed(self.timing["bwd"], self.timing["only"], begin, end)
+        else:
+            self.bwd.run(begin, end)
+
+    def enable_timing(self, only=None):
+        """Bracket calls with HIP events (bench.py roofline leg); disable with disable_timing()."""
+        self.timing = {"fwd": [], "bwd": [], "only": set(only) if only else None}
+
+    def disable_timing(self):
+        t, self.timing = self.timing, None
+        return t
 
     def forward_eval(self, x, val_conf):
         self._bind(x)

@@ -95,6 +95,7 @@ class yolo(nn.Module):
     def __getstate__(self):           # torch.save(model) (train.py:431): plans hold raw device pointers
         d = self.__dict__.copy()
         d["_plans"], d["_anchor"], d["grad_hook"] = {}, None, None
+        d.pop("dp_reducer", None)
         return d
 
     # ---- parameters ---------------------------------------------------------------------------
@@ -184,6 +185,8 @@ class yolo(nn.Module):
         prev = None
         if first.grad is not None and first.grad.data_ptr() == plan.gviews[plan.grad_params[0]].data_ptr():
             prev = plan.gflat.clone()
+        red = getattr(self, "dp_reducer", None)
+        plan.reducer = red.for_plan(plan) if red is not None else None
         plan.backward(g_losses)
         if prev is not None:
             plan.gflat.add_(prev)
