@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-nms", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="print a per-entry-point time table to stderr")
+    ap.add_argument("--detail", default="", help="comma list of entry points: print their per-call table to stderr")
     return ap.parse_args()
 
 
@@ -57,14 +58,34 @@ def make_batch(batch, rank, device):
     return x, tg
 
 
-def cpu_baseline():
-    """Reference semantics on the host CPU: oracle/net_ref.py (stock torch ops + restated loss), bs=16."""
+def usable_cores():
+    """Cores this process may actually use: affinity mask, capped by a cgroup CPU quota if one is set."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except (OSError, ValueError, IndexError):
+            pass
+    return n
+
+
+def cpu_baseline(budget_s=20.0):
+    """Reference semantics on the host CPU: oracle/net_ref.py (stock torch ops + restated loss).
+    Bounded sample: bs=8 fwd+bwd steps for ~budget_s seconds (at least one timed step)."""
     from oracle import net_ref, procedural
     torch.manual_seed(0)
-    ncores = os.cpu_count() or 1
+    ncores = min(usable_cores(), 32)          # torch's conv kernels stop scaling (and thrash) far below 256 threads
     torch.set_num_threads(ncores)
     m = net_ref.RefYolo(procedural.VOC_CONFIG).train()
-    bs = 16
+    bs = 8
     x = procedural.images(bs, SIZE, SIZE, seed=0)
     tg = procedural.targets(bs, seed=1, empty_every=16)
 
@@ -73,15 +94,18 @@ def cpu_baseline():
             p.grad = None
         r = m(x, tg)
         (r[0][0] + r[1][0]).backward()
-    step()
+    t0 = time.perf_counter()
+    step()                                     # warm-up (allocator, mkldnn primitive cache)
+    warm = time.perf_counter() - t0
     t0 = time.perf_counter()
     n = 0
-    while n < 2 or (time.perf_counter() - t0 < 12 and n < 6):
+    while n < 1 or (time.perf_counter() - t0 + warm < budget_s and n < 8):
         step()
         n += 1
     dt = time.perf_counter() - t0
-    return {"value": round(bs * n / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d fwd+bwd steps at bs=%d, 352x352, oracle/net_ref.py (torch CPU fp32)" % (n, bs)}
+    return {"value": round(bs * n / dt, 3), "unit": "images/s", "cores": ncores, "kind": "port",
+            "sample": "%d fwd+bwd steps at bs=%d, 352x352, oracle/net_ref.py (torch CPU fp32, %d threads of %d visible cores)" % (
+                n, bs, ncores, os.cpu_count() or 0)}
 
 
 def nms_bench(device):
@@ -200,6 +224,18 @@ def main():
                     name, ms, 100 * ms / tot, d["n"] // a.steps, d["flops"] / d["ms"] / 1e9 if d["ms"] else 0,
                     d["bytes"] / d["ms"] / 1e6 if d["ms"] else 0), file=sys.stderr)
             print("sum of bracketed kernels %.3f ms/step; wall %.3f ms/step" % (tot, dt / a.steps * 1e3), file=sys.stderr)
+            want = set(a.detail.split(",")) if a.detail else set()
+            per = {}
+            for which in ("fwd", "bwd"):
+                calls = plan.fwd.calls if which == "fwd" else plan.bwd.calls
+                for idx, name, e0, e1 in timing[which]:
+                    if name in want:
+                        k = (which, idx)
+                        per.setdefault(k, [name, calls[idx][3] or {}, 0.0])[2] += e0.elapsed_time(e1)
+            for (which, idx), (name, meta, ms) in sorted(per.items(), key=lambda kv: -kv[1][2]):
+                ms /= a.steps
+                print("%s %-18s %-28s %8.3f ms  %7.1f TF/s %7.1f GB/s" % (which, name, meta.get("shape", ""), ms,
+                      meta.get("flops", 0) / ms / 1e9 if ms else 0, meta.get("bytes", 0) / ms / 1e6 if ms else 0), file=sys.stderr)
         dom = max((n for n in agg if n in MFMA_KERNELS), key=lambda n: agg[n]["ms"])
         d = agg[dom]
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12

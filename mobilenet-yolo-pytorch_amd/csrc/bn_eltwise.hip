@@ -11,16 +11,16 @@ namespace mny {
 
 // ---- forward statistics -> scale/shift -----------------------------------------------------------
 // block = 32 channels x 8 slices of the partial rows
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int parts, double count,
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ stats, int parts, double count,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float eps, float momentum, float* running_mean, float* running_var,
                                                           float* scale, float* shift, float* mean_out, float* invstd_out, int C) {
-    __shared__ double red[2][8][32];
+    __shared__ double red[2][32][32];
     const int cl = threadIdx.x & 31, slice = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     double s = 0.0, q = 0.0;
     if (c < C)
-        for (int p = slice; p < parts; p += 8) {
+        for (int p = slice; p < parts; p += 32) {
             s += (double)stats[((int64_t)p * 2 + 0) * C + c];
             q += (double)stats[((int64_t)p * 2 + 1) * C + c];
         }
@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     __syncthreads();
     if (slice == 0 && c < C) {
         s = 0.0; q = 0.0;
-        for (int i = 0; i < 8; ++i) { s += red[0][i][cl]; q += red[1][i][cl]; }
+        for (int i = 0; i < 32; ++i) { s += red[0][i][cl]; q += red[1][i][cl]; }
         const double mean = s / count;
         double var = q / count - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -95,16 +95,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ red_in, int parts, double count,
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ red_in, int parts, double count,
                                                               const float* __restrict__ gamma, const float* __restrict__ mean,
                                                               const float* __restrict__ invstd, float* dgamma, float* dbeta,
                                                               float* coef, int C) {
-    __shared__ double red[2][8][32];
+    __shared__ double red[2][32][32];
     const int cl = threadIdx.x & 31, slice = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     double s = 0.0, q = 0.0;
     if (c < C)
-        for (int p = slice; p < parts; p += 8) {
+        for (int p = slice; p < parts; p += 32) {
             s += (double)red_in[((int64_t)p * 2 + 0) * C + c];
             q += (double)red_in[((int64_t)p * 2 + 1) * C + c];
         }
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
     __syncthreads();
     if (slice == 0 && c < C) {
         s = 0.0; q = 0.0;
-        for (int i = 0; i < 8; ++i) { s += red[0][i][cl]; q += red[1][i][cl]; }
+        for (int i = 0; i < 32; ++i) { s += red[0][i][cl]; q += red[1][i][cl]; }
         dbeta[c] = (float)s;
         dgamma[c] = (float)q;
         // dy = a*(dz - s/M - yhat*q/M),  yhat = (y-mu)*invstd   ->   dy = ca*dz + cb*y + cc
@@ -221,7 +221,7 @@ extern "C" int mny_bn_finalize(const float* stats, int parts, int64_t count, con
                                float momentum, float* running_mean, float* running_var, float* scale, float* shift,
                                float* mean, float* invstd, int C, void* stream) {
     MNY_REQUIRE(stats && gamma && beta && scale && shift && parts > 0 && count > 0 && C > 0, "bn_finalize: bad arguments");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, stats, parts, (double)count,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, stats, parts, (double)count,
                        gamma, beta, eps, momentum, running_mean, running_var, scale, shift, mean, invstd, C);
     return check_launch("bn_finalize_kernel");
 }
@@ -253,7 +253,7 @@ extern "C" int mny_bn_bwd_reduce(const float* g, const float* y, const float* sc
 extern "C" int mny_bn_bwd_finalize(const float* red, int parts, int64_t count, const float* gamma, const float* mean,
                                    const float* invstd, float* dgamma, float* dbeta, float* coef, int C, void* stream) {
     MNY_REQUIRE(red && gamma && mean && invstd && dgamma && dbeta && coef && parts > 0 && C > 0, "bn_bwd_finalize: bad arguments");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, red, parts, (double)count,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, red, parts, (double)count,
                        gamma, mean, invstd, dgamma, dbeta, coef, C);
     return check_launch("bn_bwd_finalize_kernel");
 }

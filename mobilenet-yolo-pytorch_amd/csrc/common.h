@@ -20,7 +20,7 @@ int check_launch(const char* what);
     } while (0)
 
 constexpr int kWave = 64;        // CDNA wavefront
-constexpr int kMaxParts = 2048;  // upper bound on stat/partial rows (8 blocks x 256 CUs)
+constexpr int kMaxParts = 1024;  // upper bound on stat/partial rows (4 blocks x 256 CUs)
 
 __host__ __device__ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
@@ -82,5 +82,10 @@ inline CgLayout make_cg_layout(int C) {
     L.threads = L.cgb * L.ppb;
     return L;
 }
+
+
+// partial rows [parts][n] -> out[n]: 32 outputs x 8 part-slices per block, fp64 combine, fixed order
+__global__ void reduce_parts_f64_kernel(const float* __restrict__ parts, int nparts, int n, float* __restrict__ out);
+int launch_reduce_parts(const float* parts, int nparts, int n, float* out, hipStream_t st);
 
 }  // namespace mny

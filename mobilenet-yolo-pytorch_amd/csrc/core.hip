@@ -22,6 +22,29 @@ int check_launch(const char* what) {
     }
     return MNY_OK;
 }
+__global__ __launch_bounds__(256) void reduce_parts_f64_kernel(const float* __restrict__ parts, int nparts, int n, float* __restrict__ out) {
+    __shared__ double red[8][32];
+    const int ol = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + ol;
+    double s0 = 0.0, s1 = 0.0;
+    if (i < n) {
+        int p = slice;
+        for (; p + 8 < nparts; p += 16) { s0 += (double)parts[(int64_t)p * n + i]; s1 += (double)parts[(int64_t)(p + 8) * n + i]; }
+        if (p < nparts) s0 += (double)parts[(int64_t)p * n + i];
+    }
+    red[slice][ol] = s0 + s1;
+    __syncthreads();
+    if (slice == 0 && i < n) {
+        double s = 0.0;
+        for (int k = 0; k < 8; ++k) s += red[k][ol];
+        out[i] = (float)s;
+    }
+}
+
+int launch_reduce_parts(const float* parts, int nparts, int n, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(reduce_parts_f64_kernel, dim3((n + 31) / 32), dim3(256), 0, st, parts, nparts, n, out);
+    return check_launch("reduce_parts_f64_kernel");
+}
 }  // namespace mny
 
 extern "C" int mny_version(void) { return 100; }

@@ -187,15 +187,6 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2_kernel(const float* __rest
     }
 }
 
-// sum partial rows [parts][n] -> out[n] in a fixed order
-__global__ void reduce_rows_kernel(const float* __restrict__ parts, int nparts, int n, float* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double s = 0.0;
-    for (int p = 0; p < nparts; ++p) s += (double)parts[(int64_t)p * n + i];
-    out[i] = (float)s;
-}
-
 static int dw_geom(DwGeom& g, CgLayout& L, int& gx, int N, int H, int W, int C, int K, int stride) {
     MNY_REQUIRE(K == 3 || K == 5, "dw: kernel size %d unsupported (3 or 5)", K);
     MNY_REQUIRE(stride == 1 || stride == 2, "dw: stride %d unsupported", stride);
@@ -274,7 +265,5 @@ extern "C" int mny_dw_bwd_weight(const float* x, const float* in_scale, const fl
     int rc = dw_launch<1>(x, in_scale, in_shift, in_act, nullptr, 0, nullptr, nullptr, dy, ws, N, H, W, C, K, stride, (hipStream_t)stream);
     if (rc) return rc;
     const int parts = mny_dw_wgrad_parts(N, H, W, C, K, stride);
-    const int n = C * K * K;
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, parts, n, dw);
-    return check_launch("reduce_rows_kernel");
+    return launch_reduce_parts(ws, parts, C * K * K, dw, (hipStream_t)stream);
 }

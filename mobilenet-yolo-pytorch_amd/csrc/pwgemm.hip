@@ -232,7 +232,17 @@ static NtPlan nt_plan(int64_t M, int K, int N) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// weight gradient: dW[N][K] = sum_m dY[m][n] * act_in(X)[m][k]
+// weight gradient: dW[N][K] = sum_m dY[m][n] * act_in(X)[m][k]      (reduction over M, output tiny)
+//
+// Both operands are M-major, which is exactly the MFMA operand layout (lane = channel, k = row).
+// A block owns a BI x BJ tile of dW for a slice of M; it streams 16/32-row chunks of dY and X through a
+// double-buffered LDS stage (coalesced float4 loads along the channel axis, BN-apply + activation applied
+// to X on the way in) and feeds v_mfma_f32_32x32x2_f32 from conflict-free ds_read_b32 (lanes = consecutive
+// channels).  Two decompositions:
+//   MODE 0 (fat dW):  2x2 waves, each TIxTJ tiles of 32x32 -> BI = 64*TI, BJ = 64*TJ, chunk = 16 rows.
+//   MODE 1 (thin dW): all 4 waves own the SAME TIxTJ tiles (BI = 32*TI, BJ = 32*TJ = whole dW) and split the
+//                     32-row chunk four ways; a fixed-order LDS reduction combines them at the end.
+// Partials [split][N][K] are then summed in a fixed order by reduce_parts_kernel (deterministic).
 // ------------------------------------------------------------------------------------------------
 struct WgradArgs {
     const float* X; const float* in_scale; const float* in_shift; int in_act;
@@ -241,29 +251,37 @@ struct WgradArgs {
     int64_t rows_per_block;
 };
 
-template <int TI, int TJ>
+template <int MODE, int TI, int TJ>
 __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgradArgs p) {
-    __shared__ float red[3][16][64];
+    constexpr int KC = MODE == 0 ? 16 : 32;
+    constexpr int BI = (MODE == 0 ? 64 : 32) * TI;
+    constexpr int BJ = (MODE == 0 ? 64 : 32) * TJ;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sA = smem;                      // [2][KC][BI]  dY
+    float* sB = smem + 2 * KC * BI;        // [2][KC][BJ]  act(X)
+    float* sScale = sB + 2 * KC * BJ;      // [BJ]
+    float* sShift = sScale + BJ;
+
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, kk = lane >> 5;
-    const int co0 = blockIdx.x * 32 * TI;
-    const int ci0 = blockIdx.y * 32 * TJ;
+    const int co0 = blockIdx.x * BI, ci0 = blockIdx.y * BJ;
     const int64_t m_begin = (int64_t)blockIdx.z * p.rows_per_block;
     const int64_t m_end = min(m_begin + p.rows_per_block, p.M);
     const bool has_xf = p.in_scale != nullptr;
     const bool do_xf = has_xf || p.in_act != MNY_ACT_NONE;
+    const bool vecA = (p.N & 3) == 0, vecB = (p.K & 3) == 0;
 
-    float sc[TJ], sh[TJ];
-    bool ciok[TJ], cook[TI];
-#pragma unroll
-    for (int j = 0; j < TJ; ++j) {
-        const int ci = ci0 + j * 32 + li;
-        ciok[j] = ci < p.K;
-        sc[j] = (has_xf && ciok[j]) ? p.in_scale[ci] : 1.f;
-        sh[j] = (has_xf && ciok[j]) ? p.in_shift[ci] : 0.f;
+    for (int j = tid; j < BJ; j += 256) {
+        const int ci = ci0 + j;
+        sScale[j] = (has_xf && ci < p.K) ? p.in_scale[ci] : 1.f;
+        sShift[j] = (has_xf && ci < p.K) ? p.in_shift[ci] : 0.f;
     }
-#pragma unroll
-    for (int i = 0; i < TI; ++i) cook[i] = (co0 + i * 32 + li) < p.N;
+    __syncthreads();
+
+    const int ioff = MODE == 0 ? (wave >> 1) * 32 * TI : 0;
+    const int joff = MODE == 0 ? (wave & 1) * 32 * TJ : 0;
+    const int krow0 = MODE == 0 ? 0 : wave * (KC / 4);
+    constexpr int KROWS = MODE == 0 ? KC : KC / 4;
 
     f32x16 acc[TI][TJ];
 #pragma unroll
@@ -273,80 +291,178 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgradArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // the 4 waves of a block interleave row pairs so the block streams contiguous 8-row chunks
-    constexpr int UN = 4;
-    for (int64_t mb = m_begin + wave * 2; mb < m_end; mb += 8 * UN) {
-        float a[UN][TI], b[UN][TJ];
+    constexpr int A_F4 = KC * BI / 4, B_F4 = KC * BJ / 4;
+    constexpr int A_PER = (A_F4 + 255) / 256, B_PER = (B_F4 + 255) / 256;
+    float4 ra[A_PER], rb[B_PER];
+
+    auto gload = [&](int64_t m0) {
 #pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int64_t m = mb + u * 8 + kk;
-            const bool mok = m < m_end;
-#pragma unroll
-            for (int i = 0; i < TI; ++i) a[u][i] = (mok && cook[i]) ? p.dY[m * p.N + co0 + i * 32 + li] : 0.f;
-#pragma unroll
-            for (int j = 0; j < TJ; ++j) {
-                float v = 0.f;
-                if (mok && ciok[j]) {
-                    v = p.X[m * p.K + ci0 + j * 32 + li];
-                    if (do_xf) v = act_fwd(fmaf(v, sc[j], sh[j]), p.in_act);
+        for (int i = 0; i < A_PER; ++i) {
+            const int idx = tid + i * 256;
+            float4 v = f4zero();
+            if (idx < A_F4) {
+                const int row = idx / (BI / 4), c = (idx % (BI / 4)) * 4;
+                const int64_t m = m0 + row;
+                const int co = co0 + c;
+                if (m < m_end && co < p.N) {
+                    const float* src = p.dY + m * p.N + co;
+                    if (vecA) v = ld4(src);
+                    else { v.x = src[0]; if (co + 1 < p.N) v.y = src[1]; if (co + 2 < p.N) v.z = src[2]; if (co + 3 < p.N) v.w = src[3]; }
                 }
-                b[u][j] = v;
             }
+            ra[i] = v;
         }
 #pragma unroll
-        for (int u = 0; u < UN; ++u)
+        for (int i = 0; i < B_PER; ++i) {
+            const int idx = tid + i * 256;
+            float4 v = f4zero();
+            if (idx < B_F4) {
+                const int row = idx / (BJ / 4), c = (idx % (BJ / 4)) * 4;
+                const int64_t m = m0 + row;
+                const int ci = ci0 + c;
+                if (m < m_end && ci < p.K) {
+                    const float* src = p.X + m * p.K + ci;
+                    if (vecB) v = ld4(src);
+                    else { v.x = src[0]; if (ci + 1 < p.K) v.y = src[1]; if (ci + 2 < p.K) v.z = src[2]; if (ci + 3 < p.K) v.w = src[3]; }
+                    if (do_xf) {
+                        v = xform4(v, ld4(sScale + c), ld4(sShift + c), p.in_act);
+                        if (!vecB) { if (ci + 1 >= p.K) v.y = 0.f; if (ci + 2 >= p.K) v.z = 0.f; if (ci + 3 >= p.K) v.w = 0.f; }
+                    }
+                }
+            }
+            rb[i] = v;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_PER; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < A_F4) st4(sA + buf * KC * BI + idx * 4, ra[i]);       // [row][c] is exactly idx*4
+        }
+#pragma unroll
+        for (int i = 0; i < B_PER; ++i) {
+            const int idx = tid + i * 256;
+            if (idx < B_F4) st4(sB + buf * KC * BJ + idx * 4, rb[i]);
+        }
+    };
+
+    const int64_t nchunks = (m_end - m_begin + KC - 1) / KC;
+    if (nchunks > 0) {
+        gload(m_begin);
+        lstore(0);
+    }
+    __syncthreads();
+    for (int64_t ch = 0; ch < nchunks; ++ch) {
+        const int buf = (int)(ch & 1);
+        if (ch + 1 < nchunks) gload(m_begin + (ch + 1) * KC);
+        const float* a_base = sA + buf * KC * BI + (krow0 + kk) * BI + ioff + li;
+        const float* b_base = sB + buf * KC * BJ + (krow0 + kk) * BJ + joff + li;
+#pragma unroll
+        for (int kp = 0; kp < KROWS / 2; ++kp) {
+            float af[TI], bf[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) af[i] = a_base[kp * 2 * BI + i * 32];
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) bf[j] = b_base[kp * 2 * BJ + j * 32];
 #pragma unroll
             for (int i = 0; i < TI; ++i)
 #pragma unroll
                 for (int j = 0; j < TJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i], b[u][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (ch + 1 < nchunks) lstore(buf ^ 1);
+        __syncthreads();
     }
 
-    // cross-wave reduction (fixed order 0+1+2+3), one 32x32 tile at a time
     float* dst = p.partial + (int64_t)blockIdx.z * p.N * p.K;
+    if (MODE == 0) {
 #pragma unroll
-    for (int i = 0; i < TI; ++i)
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < TJ; ++j) {
-            __syncthreads();
-            if (wave > 0) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[i][j][r];
-            }
-            __syncthreads();
-            if (wave == 0) {
-                const int ci = ci0 + j * 32 + li;
+            for (int j = 0; j < TJ; ++j) {
+                const int ci = ci0 + joff + j * 32 + li;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float v = ((acc[i][j][r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane];
-                    const int co = co0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-                    if (co < p.N && ci < p.K) dst[(int64_t)co * p.K + ci] = v;
+                    const int co = co0 + ioff + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                    if (co < p.N && ci < p.K) dst[(int64_t)co * p.K + ci] = acc[i][j][r];
                 }
             }
-        }
+    } else {
+        float* red = smem;                 // [3][16][64] (12 KB <= staging area)
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                __syncthreads();
+                if (wave > 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[((wave - 1) * 16 + r) * 64 + lane] = acc[i][j][r];
+                }
+                __syncthreads();
+                if (wave == 0) {
+                    const int ci = ci0 + j * 32 + li;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = ((acc[i][j][r] + red[(0 * 16 + r) * 64 + lane]) + red[(1 * 16 + r) * 64 + lane]) + red[(2 * 16 + r) * 64 + lane];
+                        const int co = co0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                        if (co < p.N && ci < p.K) dst[(int64_t)co * p.K + ci] = v;
+                    }
+                }
+            }
+    }
 }
 
-struct WgPlan { int TI, TJ, gx, gy, splits; int64_t rows_per_block; };
+struct WgPlan { int mode, TI, TJ, gx, gy, splits; int64_t rows_per_block; size_t lds; };
 
-static int pick_tile(int n32) { return n32 >= 3 ? 4 : (n32 == 2 ? 2 : 1); }
+static int pick_block(int c) {      // 64 or 128: minimise the padded extent, ties -> 128
+    const int p64 = (int)cdiv(c, 64) * 64, p128 = (int)cdiv(c, 128) * 128;
+    return p128 <= p64 ? 128 : 64;
+}
 
 static WgPlan wg_plan(int64_t M, int K, int N) {
     WgPlan pl;
     const int nco = (int)cdiv(N, 32), nci = (int)cdiv(K, 32);
-    pl.TI = pick_tile(nco);
-    pl.TJ = pick_tile(nci);
-    if (pl.TI == 4 && pl.TJ == 4) { if (nco >= nci) pl.TJ = 2; else pl.TI = 2; }   // <= 8 accumulator tiles
-    pl.gx = (int)cdiv(nco, pl.TI);
-    pl.gy = (int)cdiv(nci, pl.TJ);
-    int64_t splits = 2048 / ((int64_t)pl.gx * pl.gy);
+    int BI, BJ, KC;
+    if (nco * nci <= 6) {
+        pl.mode = 1; pl.TI = nco; pl.TJ = nci; BI = 32 * nco; BJ = 32 * nci; KC = 32;
+        pl.gx = pl.gy = 1;
+    } else {
+        pl.mode = 0; BI = pick_block(N); BJ = pick_block(K); KC = 16;
+        pl.TI = BI / 64; pl.TJ = BJ / 64;
+        pl.gx = (int)cdiv(N, BI); pl.gy = (int)cdiv(K, BJ);
+    }
+    int64_t splits = 1536 / ((int64_t)pl.gx * pl.gy);
     if (splits < 1) splits = 1;
-    int64_t max_splits = cdiv(M, 64);
+    const int64_t max_splits = cdiv(M, 4 * KC);
     if (splits > max_splits) splits = max_splits;
-    if (splits > 1024) splits = 1024;
-    int64_t rpb = cdiv(cdiv(M, splits), 8) * 8;
+    if (splits > 768) splits = 768;
+    const int64_t rpb = cdiv(cdiv(M, splits), KC) * KC;
     pl.rows_per_block = rpb;
     pl.splits = (int)cdiv(M, rpb);
+    size_t stage = (size_t)2 * KC * (BI + BJ) * sizeof(float);
+    if (stage < 3 * 16 * 64 * sizeof(float)) stage = 3 * 16 * 64 * sizeof(float);
+    pl.lds = stage + 2 * BJ * sizeof(float);
     return pl;
+}
+
+// partial rows [parts][n] -> out[n]: 32 outputs x 8 part-slices per block, fp64, fixed order
+__global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restrict__ parts, int nparts, int64_t n, float* __restrict__ out) {
+    __shared__ double red[8][32];
+    const int ol = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    const int64_t i = (int64_t)blockIdx.x * 32 + ol;
+    double s0 = 0.0, s1 = 0.0;
+    if (i < n) {
+        int pidx = slice;
+        for (; pidx + 8 < nparts; pidx += 16) { s0 += (double)parts[(int64_t)pidx * n + i]; s1 += (double)parts[(int64_t)(pidx + 8) * n + i]; }
+        if (pidx < nparts) s0 += (double)parts[(int64_t)pidx * n + i];
+    }
+    red[slice][ol] = s0 + s1;
+    __syncthreads();
+    if (slice == 0 && i < n) {
+        double s = 0.0;
+        for (int k = 0; k < 8; ++k) s += red[k][ol];
+        out[i] = (float)s;
+    }
 }
 
 // column sums of a [M][C] matrix -> partial rows; used for the head convs' bias gradient
@@ -363,14 +479,6 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ y
     red[slot][threadIdx.x & 63] = s;
     __syncthreads();
     if (slot == 0 && c < C) parts[(int64_t)blockIdx.x * C + c] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
-}
-
-__global__ void reduce_rows_f32_kernel(const float* __restrict__ parts, int nparts, int64_t n, float* __restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float s = 0.f;
-    for (int p = 0; p < nparts; ++p) s += parts[(int64_t)p * n + i];
-    out[i] = s;
 }
 
 __global__ void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int Cc) {
@@ -432,27 +540,29 @@ extern "C" int mny_pw_wgrad(const float* x, const float* in_scale, const float* 
     WgradArgs a{x, in_scale, in_shift, in_act, dy, ws, M, K, Nc, pl.rows_per_block};
     dim3 grid(pl.gx, pl.gy, pl.splits), block(256);
     hipStream_t st = (hipStream_t)stream;
-#define MNY_WG(I, J) hipLaunchKernelGGL((pw_wgrad_kernel<I, J>), grid, block, 0, st, a)
-    const int key = pl.TI * 10 + pl.TJ;
+#define MNY_WG(MD, I, J) hipLaunchKernelGGL((pw_wgrad_kernel<MD, I, J>), grid, block, pl.lds, st, a)
+    const int key = pl.mode * 100 + pl.TI * 10 + pl.TJ;
     switch (key) {
-        case 11: MNY_WG(1, 1); break; case 12: MNY_WG(1, 2); break; case 14: MNY_WG(1, 4); break;
-        case 21: MNY_WG(2, 1); break; case 22: MNY_WG(2, 2); break; case 24: MNY_WG(2, 4); break;
-        case 41: MNY_WG(4, 1); break; case 42: MNY_WG(4, 2); break;
-        default: set_error("pw_wgrad: no kernel for tile %dx%d", pl.TI, pl.TJ); return MNY_EUNSUPPORTED;
+        case 11: MNY_WG(0, 1, 1); break; case 12: MNY_WG(0, 1, 2); break; case 21: MNY_WG(0, 2, 1); break; case 22: MNY_WG(0, 2, 2); break;
+        case 111: MNY_WG(1, 1, 1); break; case 112: MNY_WG(1, 1, 2); break; case 113: MNY_WG(1, 1, 3); break; case 114: MNY_WG(1, 1, 4); break;
+        case 115: MNY_WG(1, 1, 5); break; case 116: MNY_WG(1, 1, 6); break; case 121: MNY_WG(1, 2, 1); break; case 122: MNY_WG(1, 2, 2); break;
+        case 123: MNY_WG(1, 2, 3); break; case 131: MNY_WG(1, 3, 1); break; case 132: MNY_WG(1, 3, 2); break; case 141: MNY_WG(1, 4, 1); break;
+        case 151: MNY_WG(1, 5, 1); break; case 161: MNY_WG(1, 6, 1); break;
+        default: set_error("pw_wgrad: no kernel for mode %d tile %dx%d", pl.mode, pl.TI, pl.TJ); return MNY_EUNSUPPORTED;
     }
 #undef MNY_WG
     int rc = check_launch("pw_wgrad_kernel");
     if (rc) return rc;
     const int64_t n = (int64_t)Nc * K;
-    hipLaunchKernelGGL(reduce_rows_f32_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, ws, pl.splits, n, dw);
-    rc = check_launch("reduce_rows_f32_kernel");
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(n, 32)), dim3(256), 0, st, ws, pl.splits, n, dw);
+    rc = check_launch("reduce_parts_kernel");
     if (rc) return rc;
     if (dbias) {
         const int parts = colsum_parts(M);
         float* cs = ws + (size_t)pl.splits * Nc * K;
         const int64_t rpb = cdiv(M, parts);
         hipLaunchKernelGGL(colsum_kernel, dim3(parts, (unsigned)cdiv(Nc, 64)), dim3(256), 0, st, dy, cs, M, Nc, rpb);
-        hipLaunchKernelGGL(reduce_rows_f32_kernel, dim3((unsigned)cdiv(Nc, 256)), dim3(256), 0, st, cs, parts, (int64_t)Nc, dbias);
+        hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(Nc, 32)), dim3(256), 0, st, cs, parts, (int64_t)Nc, dbias);
         rc = check_launch("colsum");
     }
     return rc;

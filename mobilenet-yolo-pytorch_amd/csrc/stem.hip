@@ -97,14 +97,6 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
     }
 }
 
-__global__ void stem_reduce_kernel(const float* __restrict__ parts, int nparts, int n, float* __restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double s = 0.0;
-    for (int p = 0; p < nparts; ++p) s += (double)parts[(int64_t)p * n + i];
-    out[i] = (float)s;
-}
-
 static int stem_geom(StemGeom& g, int& gx, int N, int H, int W, int Cout) {
     MNY_REQUIRE(N > 0 && H > 0 && W > 0, "stem: empty tensor");
     MNY_REQUIRE(Cout % 4 == 0 && Cout >= 4 && Cout <= 256, "stem: Cout=%d must be a multiple of 4 in [4,256]", Cout);
@@ -145,7 +137,5 @@ extern "C" int mny_stem_wgrad(const float* x_nchw, const float* dy, float* dw, f
     hipLaunchKernelGGL((stem_kernel<1>), dim3(gx), dim3(g.cgb * g.ppb), 0, (hipStream_t)stream, x_nchw, nullptr, nullptr, dy, ws, g);
     rc = check_launch("stem_kernel<wgrad>");
     if (rc) return rc;
-    const int n = Cout * 27;
-    hipLaunchKernelGGL(stem_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, ws, gx, n, dw);
-    return check_launch("stem_reduce_kernel");
+    return launch_reduce_parts(ws, gx, Cout * 27, dw, (hipStream_t)stream);
 }

@@ -136,13 +136,14 @@ class NetPlan:
                     xv = view(i)
                     parts = _lib.query("mny_dw_stat_parts", N, ish[1], ish[2], o.C, nd.k, nd.stride)
                     self.fwd.add("mny_dw_fwd", xv[0], xv[1], xv[2], xv[3], w, u.Y, stats, N, ish[1], ish[2], o.C, nd.k, nd.stride, self.stream,
-                                 meta=dict(flops=2 * M * o.C * nd.k * nd.k, bytes=4 * (N * ish[1] * ish[2] * o.C + M * o.C + o.C * nd.k * nd.k)))
+                                 meta=dict(flops=2 * M * o.C * nd.k * nd.k, bytes=4 * (N * ish[1] * ish[2] * o.C + M * o.C + o.C * nd.k * nd.k),
+                                           shape="C%d H%d s%d" % (o.C, ish[1], nd.stride)))
                 else:
                     i = nd.ins[0]
                     xv = view(i)
                     parts = _lib.query("mny_pw_stat_parts", M, i.C, o.C)
                     self.fwd.add("mny_pw_fwd", xv[0], xv[1], xv[2], xv[3], w, None, None, u.Y, stats, M, i.C, o.C, self.stream,
-                                 meta=dict(flops=2 * M * i.C * o.C, bytes=4 * (M * i.C + M * o.C + i.C * o.C)))
+                                 meta=dict(flops=2 * M * i.C * o.C, bytes=4 * (M * i.C + M * o.C + i.C * o.C), shape="M%d K%d N%d" % (M, i.C, o.C)))
                 gam, bet = P[nd.bn + ".weight"], P[nd.bn + ".bias"]
                 rm, rv = P[nd.bn + ".running_mean"], P[nd.bn + ".running_var"]
                 if training:
@@ -156,7 +157,7 @@ class NetPlan:
                 t = torch.empty(shp, **f32)
                 self.reals[o.id] = t
                 self.fwd.add("mny_pw_fwd", xv[0], xv[1], xv[2], xv[3], P[nd.conv + ".weight"], P[nd.conv + ".bias"], None, t, None,
-                             M, i.C, o.C, self.stream, meta=dict(flops=2 * M * i.C * o.C, bytes=4 * (M * i.C + M * o.C + i.C * o.C)))
+                             M, i.C, o.C, self.stream, meta=dict(flops=2 * M * i.C * o.C, bytes=4 * (M * i.C + M * o.C + i.C * o.C), shape="M%d K%d N%d" % (M, i.C, o.C)))
             elif nd.op == "add":
                 a = view(nd.ins[0])
                 has_b, has_up = nd.k & 1, nd.k & 2
@@ -376,22 +377,22 @@ class NetPlan:
                 xv = view(i)
                 dwb = 4 * (N * ish[1] * ish[2] * o.C + M * o.C)
                 bwd.add("mny_dw_bwd_weight", xv[0], xv[1], xv[2], xv[3], dY, gv(nd.conv + ".weight"), self.ws, N, ish[1], ish[2], o.C,
-                        nd.k, nd.stride, self.stream, meta=dict(flops=2 * M * o.C * nd.k * nd.k, bytes=dwb))
+                        nd.k, nd.stride, self.stream, meta=dict(flops=2 * M * o.C * nd.k * nd.k, bytes=dwb, shape="C%d H%d s%d" % (o.C, ish[1], nd.stride)))
                 contribute_kernel(i, lambda out, addend, dY=dY, w=w, ish=ish, nd=nd, C=o.C, M=M, dwb=dwb: bwd.add(
                     "mny_dw_bwd_data", dY, w, addend, out, N, ish[1], ish[2], C, nd.k, nd.stride, self.stream,
-                    meta=dict(flops=2 * M * C * nd.k * nd.k, bytes=dwb)))
+                    meta=dict(flops=2 * M * C * nd.k * nd.k, bytes=dwb, shape="C%d H%d s%d" % (C, ish[1], nd.stride))))
             else:   # pw / pwb
                 i = nd.ins[0]
                 xv = view(i)
                 db = gv(nd.conv + ".bias") if nd.bias else None
                 bwd.add("mny_pw_wgrad", xv[0], xv[1], xv[2], xv[3], dY, gv(nd.conv + ".weight"), db, self.ws, M, i.C, o.C, self.stream,
-                        meta=dict(flops=2 * M * i.C * o.C, bytes=4 * (M * i.C + M * o.C + i.C * o.C)))
+                        meta=dict(flops=2 * M * i.C * o.C, bytes=4 * (M * i.C + M * o.C + i.C * o.C), shape="M%d K%d N%d" % (M, i.C, o.C)))
                 wT = torch.empty(i.C, o.C, **f32)
                 self.wT[nd.conv] = wT
                 bwd.add("mny_transpose", w, wT, o.C, i.C, self.stream)
                 contribute_kernel(i, lambda out, addend, dY=dY, wT=wT, M=M, K=o.C, Nc=i.C: bwd.add(
                     "mny_pw_fwd", dY, None, None, ACT_NONE, wT, None, addend, out, None, M, K, Nc, self.stream,
-                    meta=dict(flops=2 * M * K * Nc, bytes=4 * (M * K + M * Nc + K * Nc))))
+                    meta=dict(flops=2 * M * K * Nc, bytes=4 * (M * K + M * Nc + K * Nc), shape="dgrad M%d K%d N%d" % (M, K, Nc))))
             bwd.marks[o.name] = len(bwd.calls)
 
     # ------------------------------------------------------------------------------------------
