@@ -24,25 +24,20 @@ constexpr int kMaxParts = 1024;  // upper bound on stat/partial rows (4 blocks x
 
 __host__ __device__ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Branch-free activations.  relu6 / leaky(0.1) / relu / identity are all  min(max(z, slope*z), hi)  with
+// (slope, hi) = (0,6) / (0.1,inf) / (0,inf) / (1,inf); `act` is wave-uniform, so slope/hi live in SGPRs and the
+// per-element cost is v_mul + v_max + v_min (a per-element switch made the HBM-bound stencils VALU-bound).
+__device__ __forceinline__ float act_slope(int act) { return act == MNY_ACT_NONE ? 1.f : (act == MNY_ACT_LEAKY ? 0.1f : 0.f); }
+__device__ __forceinline__ float act_hi(int act) { return act == MNY_ACT_RELU6 ? 6.f : INFINITY; }
 __device__ __forceinline__ float act_fwd(float z, int act) {
-    switch (act) {
-        case MNY_ACT_RELU6: return fminf(fmaxf(z, 0.f), 6.f);
-        case MNY_ACT_LEAKY: return z > 0.f ? z : 0.1f * z;
-        case MNY_ACT_RELU: return fmaxf(z, 0.f);
-        case MNY_ACT_HSWISH: return z * fminf(fmaxf(z + 3.f, 0.f), 6.f) / 6.f;
-        default: return z;
-    }
+    if (act == MNY_ACT_HSWISH) return z * fminf(fmaxf(z + 3.f, 0.f), 6.f) / 6.f;
+    return fminf(fmaxf(z, act_slope(act) * z), act_hi(act));
 }
-// derivative of act at pre-activation z (matches torch's subgradient choices:
-// relu6/hardtanh: 1 on (0,6) exclusive; leaky_relu: slope for z<=0 ... torch uses x>0 ? 1 : slope)
+// derivative at pre-activation z (torch's subgradient choices: relu6 = hardtanh: 1 on the open interval (0,6);
+// leaky_relu: z > 0 ? 1 : slope)
 __device__ __forceinline__ float act_bwd(float z, int act) {
-    switch (act) {
-        case MNY_ACT_RELU6: return (z > 0.f && z < 6.f) ? 1.f : 0.f;
-        case MNY_ACT_LEAKY: return z > 0.f ? 1.f : 0.1f;
-        case MNY_ACT_RELU: return z > 0.f ? 1.f : 0.f;
-        case MNY_ACT_HSWISH: return z <= -3.f ? 0.f : (z >= 3.f ? 1.f : (2.f * z + 3.f) / 6.f);
-        default: return 1.f;
-    }
+    if (act == MNY_ACT_HSWISH) return z <= -3.f ? 0.f : (z >= 3.f ? 1.f : (2.f * z + 3.f) / 6.f);
+    return (z > 0.f ? 1.f : act_slope(act)) * (z < act_hi(act) ? 1.f : 0.f);
 }
 
 __device__ __forceinline__ float4 xform4(float4 v, float4 sc, float4 sh, int act) {

@@ -21,6 +21,8 @@
 //
 // replaces nn.Conv2d(Cin,Cout,1) at models/mobilenetv2.py:48,69,75,83 and models/mbv2_yolo.py:20,82
 // and their autograd backward (convolution_backward = 57.5 % of the reference's CPU step).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace mny {
@@ -28,8 +30,6 @@ namespace mny {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128;
-constexpr int BK = 16;
-constexpr int LDP = BK + 4;   // LDS row pitch (floats)
 
 struct GemmArgs {
     const float* A; const float* in_scale; const float* in_shift; int in_act;
@@ -38,9 +38,10 @@ struct GemmArgs {
     int m_tiles; int tiles_per_block;
 };
 
-template <int TN>
+template <int TN, int BK>
 __global__ __launch_bounds__(256) void pw_gemm_nt_kernel(GemmArgs p) {
     constexpr int BN = 32 * TN;
+    constexpr int LDP = BK + 4;   // LDS row pitch (floats): 20 / 36 -> conflict-free ds_read_b128 fragments
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                           // [2][BM][LDP]
     float* Bs = smem + 2 * BM * LDP;            // [2][BN][LDP]
@@ -58,11 +59,13 @@ __global__ __launch_bounds__(256) void pw_gemm_nt_kernel(GemmArgs p) {
     const bool do_xf = has_xf || p.in_act != MNY_ACT_NONE;
     const bool kvec = (p.K & 3) == 0;   // rows 16-B aligned -> float4 loads; else scalar tail-safe loads
 
-    for (int k = tid; k < Kpad; k += 256) {
-        sScale[k] = (has_xf && k < p.K) ? p.in_scale[k] : 1.f;
-        sShift[k] = (has_xf && k < p.K) ? p.in_shift[k] : 0.f;
+    if (do_xf) {                                  // (the host sizes the LDS without this area when !do_xf)
+        for (int k = tid; k < Kpad; k += 256) {
+            sScale[k] = (has_xf && k < p.K) ? p.in_scale[k] : 1.f;
+            sShift[k] = (has_xf && k < p.K) ? p.in_shift[k] : 0.f;
+        }
+        __syncthreads();
     }
-    __syncthreads();
 
     // staging assignment: A tile = BM*BK/4 = 512 float4 -> 2 per thread; B tile = BN*BK/4 -> TN/2 per thread
     constexpr int A_PER = BM * BK / 4 / 256;
@@ -210,9 +213,290 @@ __global__ __launch_bounds__(256) void pw_gemm_nt_kernel(GemmArgs p) {
     }
 }
 
-struct NtPlan { int TN; int n_tiles; int m_tiles; int gx; int tiles_per_block; size_t lds; };
+// ------------------------------------------------------------------------------------------------
+// NT GEMM v2: LDS-DMA pipeline.
+//
+// The register-staged kernel above exposes HBM/L2 latency: one k-tile of prefetch, two waves per SIMD and
+// one M-tile per block leave each wave idle ~60 % of the time.  v2 fixes the structure, CDNA4-style:
+//   * global_load_lds_dwordx4 (LDS-DMA) copies tiles HBM -> LDS without touching VGPRs, so a 3-stage ring
+//     keeps two k-tiles in flight behind the one being multiplied (counted `s_waitcnt vmcnt(N)` + raw
+//     `s_barrier`: the DMA queue is never drained inside the loop);
+//   * with no staging registers the kernel fits 3 workgroups per CU (48 KB LDS, <=168 VGPR+AGPR);
+//   * each block is persistent over a run of consecutive M-tiles and walks one flat (tile, k-tile) sequence,
+//     so the next tile's loads are already in flight during the epilogue stores;
+//   * BN-apply + activation of the producer is applied when the A fragment is READ from LDS (3 VALU per
+//     element, hidden under 64-cycle MFMAs) because a DMA cannot transform;
+//   * the LDS image is lane-linear per DMA instruction (hardware rule), so bank conflicts are removed by
+//     XOR-swizzling the 16-B chunk index on the SOURCE address and on the fragment read (chunk ^ (row>>2)&3);
+//   * block id -> (m-run, n-tile) puts the n-tiles that share an A panel on the same XCD (bid % 8).
+// Requirements: K % 4 == 0 (16-B aligned rows); anything else takes the register-staged kernel.
+// Out-of-range rows are clamped to a valid row (their outputs are never stored); k-chunks past K re-read the
+// row start and are annihilated by zeroed B fragments (and zero scale/shift).
+// ------------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-static NtPlan nt_plan(int64_t M, int K, int N) {
+__device__ const float4 mny_zero16 = {0.f, 0.f, 0.f, 0.f};   // DMA source for B chunks past K
+
+struct Gemm2Args {
+    const float* A; const float* in_scale; const float* in_shift; int in_act;
+    const float* B; const float* bias; const float* addend; float* C; float* stats;
+    int64_t M; int K; int N;
+    int m_tiles, tiles_per_block, gx, n_tiles;
+};
+
+// XF: 0 = A used as is, 1 = scale/shift + min(max(z, slope*z), hi) activation, 2 = scale/shift + hswish
+template <int TN, int XF>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void pw_gemm_nt_dma_kernel(Gemm2Args p) {
+    constexpr int BN = 32 * TN, BKD = 16, S = 3;
+    constexpr int A_ST = BM * BKD, B_ST = BN * BKD, STAGE = A_ST + B_ST;     // floats
+    constexpr int NA = BM / 16, NB = BN / 16, NL = NA + NB;                   // 1-KiB DMA instructions per stage
+    constexpr int LPW = (NL + 3) / 4;                                         // per wave (surplus ones duplicate the last)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* sScale = smem + S * STAGE;
+
+    // block -> (m-run x, n-tile y): the n_tiles blocks of one m-run are consecutive within one XCD
+    const int bid = blockIdx.x, xcd = bid & 7, local = bid >> 3;
+    const int y = local % p.n_tiles, x = (local / p.n_tiles) * 8 + xcd;
+    if (x >= p.gx) return;
+    const int n0 = y * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lrow = lane & 31, khalf = lane >> 5;
+    const int swz = (lrow >> 2) & 3;
+    const int nk = (p.K + BKD - 1) / BKD;
+    const int Kpad = nk * BKD;
+    float* sShift = sScale + Kpad;
+    const float slope = act_slope(p.in_act), hi = act_hi(p.in_act);
+    if (XF != 0) {
+        const bool has_xf = p.in_scale != nullptr;
+        for (int k = tid; k < Kpad; k += 256) {
+            sScale[k] = (k < p.K) ? (has_xf ? p.in_scale[k] : 1.f) : 0.f;
+            sShift[k] = (k < p.K && has_xf) ? p.in_shift[k] : 0.f;
+        }
+    }
+    const int mt_begin = x * p.tiles_per_block;
+    const int mt_end = min(mt_begin + p.tiles_per_block, p.m_tiles);
+    const int total = (mt_end - mt_begin) * nk;
+
+    // per-lane constants of this wave's LPW DMA instructions: instruction j covers tile rows 16j..16j+15, 4 lanes per row
+    const int drow = lane >> 2, dpos = lane & 3;
+    int d_row[LPW], d_k[LPW], d_lds[LPW];
+    bool d_isA[LPW];
+    const float* d_bptr[LPW];
+#pragma unroll
+    for (int i = 0; i < LPW; ++i) {
+        int j = wv + 4 * i;
+        if (j >= NL) j = NL - 1;
+        d_isA[i] = j < NA;
+        const int row = (d_isA[i] ? j : j - NA) * 16 + drow;
+        d_row[i] = row;
+        d_k[i] = (dpos ^ ((row >> 2) & 3)) * 4;                  // swizzled source chunk
+        d_lds[i] = d_isA[i] ? j * 256 : A_ST + (j - NA) * 256;
+        int n = n0 + row;
+        if (n >= p.N) n = p.N - 1;
+        d_bptr[i] = p.B + (int64_t)n * p.K + d_k[i];
+    }
+    const float* zero_src = reinterpret_cast<const float*>(&mny_zero16);
+    const bool ragged_k = (p.K % BKD) != 0;
+
+    auto issue = [&](int mt, int kt, int slot) {
+        float* stage = smem + slot * STAGE;
+        const bool tail = ragged_k && kt == nk - 1;
+#pragma unroll
+        for (int i = 0; i < LPW; ++i) {
+            const float* src;
+            if (d_isA[i]) {
+                int m = mt * BM + d_row[i];
+                if (m >= (int)p.M) m = (int)p.M - 1;
+                int k = kt * BKD + d_k[i];
+                if (tail && k >= p.K) k = 0;                      // finite filler, annihilated by zero B / zero scale
+                src = p.A + (int64_t)m * p.K + k;
+            } else {
+                src = d_bptr[i] + kt * BKD;
+                if (tail && kt * BKD + d_k[i] >= p.K) src = zero_src;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(stage + d_lds[i]), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float s1[TN], s2[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t) { s1[t] = 0.f; s2[t] = 0.f; }
+
+    auto compute = [&](int kt, int slot) {
+        const float* stA = smem + slot * STAGE;
+        const float* stB = stA + A_ST;
+        const float* a_row = stA + (wv * 32 + lrow) * BKD;
+#pragma unroll
+        for (int kc = 0; kc < BKD / 8; ++kc) {
+            const int chunk = kc * 2 + khalf;
+            float4 af = ld4(a_row + ((chunk ^ swz) << 2));
+            float4 bf[TN];
+#pragma unroll
+            for (int u = 0; u < TN; ++u) bf[u] = ld4(stB + (u * 32 + lrow) * BKD + ((chunk ^ swz) << 2));
+            if (XF != 0) {
+                const int kbase = kt * BKD + chunk * 4;
+                const float4 sc = ld4(sScale + kbase), sh = ld4(sShift + kbase);
+                float z0 = fmaf(af.x, sc.x, sh.x), z1 = fmaf(af.y, sc.y, sh.y), z2 = fmaf(af.z, sc.z, sh.z), z3 = fmaf(af.w, sc.w, sh.w);
+                if (XF == 1) {
+                    af.x = fminf(fmaxf(z0, slope * z0), hi); af.y = fminf(fmaxf(z1, slope * z1), hi);
+                    af.z = fminf(fmaxf(z2, slope * z2), hi); af.w = fminf(fmaxf(z3, slope * z3), hi);
+                } else {
+                    af.x = z0 * fminf(fmaxf(z0 + 3.f, 0.f), 6.f) / 6.f; af.y = z1 * fminf(fmaxf(z1 + 3.f, 0.f), 6.f) / 6.f;
+                    af.z = z2 * fminf(fmaxf(z2 + 3.f, 0.f), 6.f) / 6.f; af.w = z3 * fminf(fmaxf(z3 + 3.f, 0.f), 6.f) / 6.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < TN; ++u) {
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf[u].x, acc[u], 0, 0, 0);
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf[u].y, acc[u], 0, 0, 0);
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf[u].z, acc[u], 0, 0, 0);
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf[u].w, acc[u], 0, 0, 0);
+            }
+        }
+    };
+
+    auto epilogue = [&](int mt) {
+        const int64_t m0 = (int64_t)mt * BM;
+#pragma unroll
+        for (int u = 0; u < TN; ++u) {
+            const int col = n0 + u * 32 + lrow;
+            const bool cok = col < p.N;
+            const float bv = (p.bias && cok) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = m0 + wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                float v = acc[u][r] + bv;
+                if (cok && row < p.M) {
+                    if (p.addend) v += p.addend[row * p.N + col];
+                    p.C[row * p.N + col] = v;
+                    s1[u] += v;
+                    s2[u] = fmaf(v, v, s2[u]);
+                }
+                acc[u][r] = 0.f;
+            }
+        }
+    };
+
+    // flat (tile, k-tile) walk; stage t lives in ring slot t % 3, two stages stay in flight behind the consumer
+    int i_mt = mt_begin, i_kt = 0, i_slot = 0;           // next stage to issue
+    auto issue_next = [&]() {
+        issue(i_mt, i_kt, i_slot);
+        if (++i_kt == nk) { i_kt = 0; ++i_mt; }
+        if (++i_slot == S) i_slot = 0;
+    };
+    int c_mt = mt_begin, c_kt = 0, c_slot = 0;           // stage being consumed
+    auto consume = [&]() {
+        compute(c_kt, c_slot);
+        if (++c_kt == nk) { epilogue(c_mt); c_kt = 0; ++c_mt; }
+        if (++c_slot == S) c_slot = 0;
+    };
+
+    const int pre = total < S - 1 ? total : S - 1;
+    for (int t = 0; t < pre; ++t) issue_next();
+    const int steady = total - pre;                      // steps that still have a stage to issue
+    for (int t = 0; t < steady; ++t) {
+        wait_vmcnt<LPW*(S - 2)>();                       // my share of the oldest stage has landed
+        __builtin_amdgcn_s_barrier();                    // ... for every wave; the slot refilled below is fully consumed
+        issue_next();
+        consume();
+    }
+    for (int t = 0; t < pre; ++t) {                      // drain
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        consume();
+    }
+
+    if (p.stats) {
+        wait_vmcnt<0>();
+        __syncthreads();
+        float* red = smem;   // [4][BN][2]
+#pragma unroll
+        for (int u = 0; u < TN; ++u) {
+            const float a = s1[u] + __shfl_xor(s1[u], 32);
+            const float b = s2[u] + __shfl_xor(s2[u], 32);
+            if (khalf == 0) {
+                red[(wv * BN + u * 32 + lrow) * 2 + 0] = a;
+                red[(wv * BN + u * 32 + lrow) * 2 + 1] = b;
+            }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.N) {
+            float a = 0.f, b = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { a += red[(w * BN + tid) * 2]; b += red[(w * BN + tid) * 2 + 1]; }
+            p.stats[(int64_t)x * 2 * p.N + n0 + tid] = a;
+            p.stats[(int64_t)x * 2 * p.N + p.N + n0 + tid] = b;
+        }
+    }
+}
+
+typedef void (*Nt2Kernel)(Gemm2Args);
+static Nt2Kernel nt2_kernel(int TN, int XF) {
+#define MNY_K(T) (XF == 0 ? (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 0> : XF == 1 ? (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 1> : (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 2>)
+    switch (TN) { case 1: return MNY_K(1); case 2: return MNY_K(2); case 3: return MNY_K(3); default: return MNY_K(4); }
+#undef MNY_K
+}
+
+struct Nt2Plan { int TN, n_tiles, m_tiles, gx, tiles_per_block, grid; size_t lds; };
+
+static size_t nt2_lds(int TN, int K, bool xf) {
+    const int Kpad = (int)cdiv(K, 16) * 16;
+    size_t ring = (size_t)3 * (BM * 16 + 32 * TN * 16) * sizeof(float);
+    size_t red = (size_t)4 * 32 * TN * 2 * sizeof(float);
+    return (ring > red ? ring : red) + (xf ? 2 * Kpad * sizeof(float) : 0);
+}
+
+// resident workgroups per CU for (TN, XF) at a given dynamic-LDS size (queried once per combination)
+static int nt2_blocks_per_cu(int TN, int XF, size_t lds) {
+    static int cache[5][3][4];      // [TN][XF][lds bucket of 16 KB up to 64 KB]
+    int bucket = (int)((lds + 16383) / 16384) - 1;
+    if (bucket < 0) bucket = 0;
+    if (bucket > 3) bucket = 3;
+    int& c = cache[TN][XF][bucket];
+    if (c == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)nt2_kernel(TN, XF), 256, (size_t)(bucket + 1) * 16384) != hipSuccess || nb < 1) nb = 1;
+        if (nb > 4) nb = 4;
+        c = nb;
+    }
+    return c;
+}
+
+static Nt2Plan nt2_plan(int64_t M, int K, int N, bool xf) {
+    Nt2Plan pl;
+    int best = 1, best_pad = 1 << 30;
+    for (int tn = 4; tn >= 1; --tn) {
+        int pad = (int)cdiv(N, 32 * tn) * 32 * tn;
+        if (pad < best_pad) { best_pad = pad; best = tn; }
+    }
+    // grid depends only on (M,K,N): occupancy is taken for the transform variant so stat_parts() and fwd agree
+    const int blocks_per_cu = nt2_blocks_per_cu(best, 1, nt2_lds(best, K, true));
+    pl.TN = best;
+    pl.n_tiles = (int)cdiv(N, 32 * best);
+    pl.m_tiles = (int)cdiv(M, BM);
+    int want = 256 * blocks_per_cu / pl.n_tiles;      // one full wave of resident workgroups
+    if (want < 8) want = 8;
+    if (want > kMaxParts) want = kMaxParts;
+    int gx = pl.m_tiles < want ? pl.m_tiles : want;
+    pl.tiles_per_block = (int)cdiv(pl.m_tiles, gx);
+    pl.gx = (int)cdiv(pl.m_tiles, pl.tiles_per_block);
+    pl.grid = (int)cdiv(pl.gx, 8) * 8 * pl.n_tiles;
+    pl.lds = nt2_lds(best, K, xf);
+    return pl;
+}
+
+struct NtPlan { int TN; int BK; int n_tiles; int m_tiles; int gx; int tiles_per_block; size_t lds; };
+
+static NtPlan nt_plan(int64_t M, int K, int N, bool xf = true) {
     NtPlan pl;
     int best = 1; int best_pad = 1 << 30;
     for (int tn = 4; tn >= 1; --tn) {   // minimise padded N; ties -> wider tile (fewer re-reads of A)
@@ -226,8 +510,13 @@ static NtPlan nt_plan(int64_t M, int K, int N) {
     int gx = pl.m_tiles < max_gx ? pl.m_tiles : max_gx;
     pl.tiles_per_block = (int)cdiv(pl.m_tiles, gx);
     pl.gx = (int)cdiv(pl.m_tiles, pl.tiles_per_block);
-    const int Kpad = (int)cdiv(K, BK) * BK;
-    pl.lds = (size_t)(2 * BM * LDP + 2 * 32 * best * LDP + 2 * Kpad) * sizeof(float);
+    // deep K: BK = 32 halves the barriers per FLOP — as long as two blocks still fit the CU's 160 KB of LDS
+    auto lds_for = [&](int bk) {
+        const int Kpad = (int)cdiv(K, bk) * bk;
+        return (size_t)(2 * BM * (bk + 4) + 2 * 32 * best * (bk + 4) + (xf ? 2 * Kpad : 0)) * sizeof(float);
+    };
+    pl.BK = (K >= 64 && K % 32 == 0 && lds_for(32) <= 80 * 1024) ? 32 : 16;
+    pl.lds = lds_for(pl.BK);
     return pl;
 }
 
@@ -503,6 +792,7 @@ using namespace mny;
 
 extern "C" int mny_pw_stat_parts(int64_t M, int K, int Nc) {
     if (M <= 0 || K <= 0 || Nc <= 0) return MNY_EINVAL;
+    if ((K & 3) == 0 && getenv("MNY_GEMM_V1") == nullptr) return nt2_plan(M, K, Nc, true).gx;
     return nt_plan(M, K, Nc).gx;
 }
 
@@ -512,17 +802,40 @@ extern "C" int mny_pw_fwd(const float* x, const float* in_scale, const float* in
     MNY_REQUIRE(x && w && y, "pw_fwd: null pointer");
     MNY_REQUIRE(M > 0 && K > 0 && Nc > 0, "pw_fwd: empty problem");
     MNY_REQUIRE(!(stats && bias), "pw_fwd: stats and bias are mutually exclusive");
-    NtPlan pl = nt_plan(M, K, Nc);
-    MNY_REQUIRE(pl.lds <= 64 * 1024, "pw_fwd: K=%d too large for the LDS scale cache", K);
+    hipStream_t st = (hipStream_t)stream;
+    const bool xf = in_scale != nullptr || in_act != MNY_ACT_NONE;
+    static const bool force_v1 = getenv("MNY_GEMM_V1") != nullptr;   // A/B switch for profiling
+    if ((K & 3) == 0 && !force_v1) {                // LDS-DMA pipeline (v2)
+        Nt2Plan p2 = nt2_plan(M, K, Nc, xf);
+        MNY_REQUIRE(p2.lds <= 64 * 1024, "pw_fwd: K=%d too large for the LDS scale cache", K);
+        Gemm2Args g{x, in_scale, in_shift, in_act, w, bias, addend, y, stats, M, K, Nc, p2.m_tiles, p2.tiles_per_block, p2.gx, p2.n_tiles};
+        dim3 grid2(p2.grid), block2(256);
+        const int XF = !xf ? 0 : (in_act == MNY_ACT_HSWISH ? 2 : 1);
+        hipLaunchKernelGGL(nt2_kernel(p2.TN, XF), grid2, block2, p2.lds, st, g);
+        return check_launch("pw_gemm_nt_dma_kernel");
+    }
+    NtPlan pl = nt_plan(M, K, Nc, xf);
+    MNY_REQUIRE(pl.lds <= 160 * 1024, "pw_fwd: K=%d too large for the LDS scale cache", K);
     GemmArgs a{x, in_scale, in_shift, in_act, w, bias, addend, y, stats, M, K, Nc, pl.m_tiles, pl.tiles_per_block};
     dim3 grid(pl.gx, pl.n_tiles), block(256);
-    hipStream_t st = (hipStream_t)stream;
-    switch (pl.TN) {
-        case 1: hipLaunchKernelGGL((pw_gemm_nt_kernel<1>), grid, block, pl.lds, st, a); break;
-        case 2: hipLaunchKernelGGL((pw_gemm_nt_kernel<2>), grid, block, pl.lds, st, a); break;
-        case 3: hipLaunchKernelGGL((pw_gemm_nt_kernel<3>), grid, block, pl.lds, st, a); break;
-        default: hipLaunchKernelGGL((pw_gemm_nt_kernel<4>), grid, block, pl.lds, st, a); break;
+    static bool attr_done = false;
+    if (!attr_done) {                             // > 64 KB of dynamic LDS needs an explicit opt-in per kernel
+        const void* ks[] = {(const void*)pw_gemm_nt_kernel<1, 16>, (const void*)pw_gemm_nt_kernel<2, 16>, (const void*)pw_gemm_nt_kernel<3, 16>,
+                            (const void*)pw_gemm_nt_kernel<4, 16>, (const void*)pw_gemm_nt_kernel<1, 32>, (const void*)pw_gemm_nt_kernel<2, 32>,
+                            (const void*)pw_gemm_nt_kernel<3, 32>, (const void*)pw_gemm_nt_kernel<4, 32>};
+        for (const void* k : ks)
+            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                set_error("pw_fwd: hipFuncSetAttribute failed"); return MNY_EHIP;
+            }
+        attr_done = true;
     }
+#define MNY_NT(T, B) hipLaunchKernelGGL((pw_gemm_nt_kernel<T, B>), grid, block, pl.lds, st, a)
+    switch (pl.TN * 100 + pl.BK) {
+        case 116: MNY_NT(1, 16); break; case 216: MNY_NT(2, 16); break; case 316: MNY_NT(3, 16); break; case 416: MNY_NT(4, 16); break;
+        case 132: MNY_NT(1, 32); break; case 232: MNY_NT(2, 32); break; case 332: MNY_NT(3, 32); break; default: MNY_NT(4, 32); break;
+    }
+#undef MNY_NT
+
     return check_launch("pw_gemm_nt_kernel");
 }
 
