@@ -701,7 +701,182 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgradArgs p) {
     }
 }
 
-struct WgPlan { int mode, TI, TJ, gx, gy, splits; int64_t rows_per_block; size_t lds; };
+// ------------------------------------------------------------------------------------------------
+// weight gradient v2: the same decomposition fed by LDS-DMA (3-stage ring of 16-row chunks, counted
+// vmcnt, raw barriers).  The chunk image [row][channel] is linear, i.e. exactly the lane-linear order a
+// DMA instruction writes, and fragments are read along the channel axis (conflict-free ds_read_b32), so no
+// swizzle is needed.  Rows past the block's M-slice take dY from a 16-B zero buffer (product = 0 * finite),
+// X rows are clamped to a valid row; BN-apply + activation is applied to X when its fragment is read.
+// Requires N % 4 == 0 and K % 4 == 0 (16-B aligned rows) and a non-hswish view.
+// ------------------------------------------------------------------------------------------------
+template <int MODE, int TI, int TJ>
+__global__ __launch_bounds__(256) void pw_wgrad_dma_kernel(WgradArgs p) {
+    constexpr int KC = 16, S = 3;
+    constexpr int BI = (MODE == 0 ? 64 : 32) * TI;
+    constexpr int BJ = (MODE == 0 ? 64 : 32) * TJ;
+    constexpr int A_ST = KC * BI, B_ST = KC * BJ, STAGE = A_ST + B_ST;      // floats
+    constexpr int NA = A_ST / 256, NB = B_ST / 256, NL = NA + NB;           // 1-KiB DMA instructions per stage
+    constexpr int LPW = (NL + 3) / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, kk = lane >> 5;
+    const int co0 = blockIdx.x * BI, ci0 = blockIdx.y * BJ;
+    const int64_t m_begin = (int64_t)blockIdx.z * p.rows_per_block;
+    const int64_t m_end = min(m_begin + p.rows_per_block, p.M);
+    const bool has_xf = p.in_scale != nullptr;
+    const float slope = act_slope(p.in_act), hi = act_hi(p.in_act);
+
+    const int ioff = MODE == 0 ? (wave >> 1) * 32 * TI : 0;
+    const int joff = MODE == 0 ? (wave & 1) * 32 * TJ : 0;
+    const int krow0 = MODE == 0 ? 0 : wave * (KC / 4);
+    constexpr int KROWS = MODE == 0 ? KC : KC / 4;
+
+    float sc[TJ], sh[TJ];
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        const int ci = ci0 + joff + j * 32 + li;
+        sc[j] = (has_xf && ci < p.K) ? p.in_scale[ci] : 1.f;
+        sh[j] = (has_xf && ci < p.K) ? p.in_shift[ci] : 0.f;
+    }
+
+    // per-lane constants of this wave's DMA instructions
+    const float* zero_src = reinterpret_cast<const float*>(&mny_zero16);
+    int d_row[LPW], d_lds[LPW];
+    bool d_isA[LPW], d_ok[LPW];
+    int64_t d_off[LPW];
+#pragma unroll
+    for (int i = 0; i < LPW; ++i) {
+        int j = wave + 4 * i;
+        if (j >= NL) j = NL - 1;
+        d_isA[i] = j < NA;
+        const int q = (d_isA[i] ? j : j - NA) * 64 + lane;          // float4 index inside the tile
+        const int W4 = (d_isA[i] ? BI : BJ) / 4;
+        d_row[i] = q / W4;
+        const int c = (q % W4) * 4;
+        d_lds[i] = d_isA[i] ? j * 256 : A_ST + (j - NA) * 256;
+        if (d_isA[i]) { d_ok[i] = co0 + c < p.N; d_off[i] = co0 + c; }
+        else { d_ok[i] = ci0 + c < p.K; d_off[i] = ci0 + c; }
+    }
+
+    auto issue = [&](int64_t m0, int slot) {
+        float* stage = smem + slot * STAGE;
+#pragma unroll
+        for (int i = 0; i < LPW; ++i) {
+            const int64_t m = m0 + d_row[i];
+            const float* src;
+            if (d_isA[i]) src = (d_ok[i] && m < m_end) ? p.dY + m * p.N + d_off[i] : zero_src;
+            else src = d_ok[i] ? p.X + (m < m_end ? m : m_end - 1) * p.K + d_off[i] : zero_src;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(stage + d_lds[i]), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto compute = [&](int slot) {
+        const float* a_base = smem + slot * STAGE + (krow0 + kk) * BI + ioff + li;
+        const float* b_base = smem + slot * STAGE + A_ST + (krow0 + kk) * BJ + joff + li;
+#pragma unroll
+        for (int kp = 0; kp < KROWS / 2; ++kp) {
+            float af[TI], bf[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) af[i] = a_base[kp * 2 * BI + i * 32];
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const float z = fmaf(b_base[kp * 2 * BJ + j * 32], sc[j], sh[j]);
+                bf[j] = fminf(fmaxf(z, slope * z), hi);
+            }
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    const int total = (int)((m_end - m_begin + KC - 1) / KC);
+    int i_t = 0, i_slot = 0, c_slot = 0;
+    auto issue_next = [&]() {
+        issue(m_begin + (int64_t)i_t * KC, i_slot);
+        ++i_t;
+        if (++i_slot == S) i_slot = 0;
+    };
+    const int pre = total < S - 1 ? total : S - 1;
+    for (int t = 0; t < pre; ++t) issue_next();
+    const int steady = total - pre;
+    for (int t = 0; t < steady; ++t) {
+        wait_vmcnt<LPW*(S - 2)>();
+        __builtin_amdgcn_s_barrier();
+        issue_next();
+        compute(c_slot);
+        if (++c_slot == S) c_slot = 0;
+    }
+    for (int t = 0; t < pre; ++t) {
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        compute(c_slot);
+        if (++c_slot == S) c_slot = 0;
+    }
+
+    float* dst = p.partial + (int64_t)blockIdx.z * p.N * p.K;
+    if (MODE == 0) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const int ci = ci0 + joff + j * 32 + li;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + ioff + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                    if (co < p.N && ci < p.K) dst[(int64_t)co * p.K + ci] = acc[i][j][r];
+                }
+            }
+    } else {
+        float* red = smem;                 // [3][16][64] (12 KB <= ring)
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                __syncthreads();
+                if (wave > 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[((wave - 1) * 16 + r) * 64 + lane] = acc[i][j][r];
+                }
+                __syncthreads();
+                if (wave == 0) {
+                    const int ci = ci0 + j * 32 + li;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = ((acc[i][j][r] + red[(0 * 16 + r) * 64 + lane]) + red[(1 * 16 + r) * 64 + lane]) + red[(2 * 16 + r) * 64 + lane];
+                        const int co = co0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                        if (co < p.N && ci < p.K) dst[(int64_t)co * p.K + ci] = v;
+                    }
+                }
+            }
+    }
+}
+
+typedef void (*WgKernel)(WgradArgs);
+static WgKernel wg_dma_kernel(int mode, int TI, int TJ) {
+    switch (mode * 100 + TI * 10 + TJ) {
+#define MNY_W(MD, I, J) case MD * 100 + I * 10 + J: return (WgKernel)pw_wgrad_dma_kernel<MD, I, J>;
+        MNY_W(0, 1, 1) MNY_W(0, 1, 2) MNY_W(0, 2, 1) MNY_W(0, 2, 2)
+        MNY_W(1, 1, 1) MNY_W(1, 1, 2) MNY_W(1, 1, 3) MNY_W(1, 1, 4) MNY_W(1, 1, 5) MNY_W(1, 1, 6) MNY_W(1, 2, 1) MNY_W(1, 2, 2) MNY_W(1, 2, 3)
+        MNY_W(1, 3, 1) MNY_W(1, 3, 2) MNY_W(1, 4, 1) MNY_W(1, 5, 1) MNY_W(1, 6, 1)
+#undef MNY_W
+        default: return nullptr;
+    }
+}
+
+struct WgPlan { int mode, TI, TJ, gx, gy, splits; int64_t rows_per_block; size_t lds, lds_dma; };
 
 static int pick_block(int c) {      // 64 or 128: minimise the padded extent, ties -> 128
     const int p64 = (int)cdiv(c, 64) * 64, p128 = (int)cdiv(c, 128) * 128;
@@ -731,6 +906,8 @@ static WgPlan wg_plan(int64_t M, int K, int N) {
     size_t stage = (size_t)2 * KC * (BI + BJ) * sizeof(float);
     if (stage < 3 * 16 * 64 * sizeof(float)) stage = 3 * 16 * 64 * sizeof(float);
     pl.lds = stage + 2 * BJ * sizeof(float);
+    pl.lds_dma = (size_t)3 * 16 * (BI + BJ) * sizeof(float);
+    if (pl.lds_dma < 3 * 16 * 64 * sizeof(float)) pl.lds_dma = 3 * 16 * 64 * sizeof(float);
     return pl;
 }
 
@@ -853,9 +1030,13 @@ extern "C" int mny_pw_wgrad(const float* x, const float* in_scale, const float* 
     WgradArgs a{x, in_scale, in_shift, in_act, dy, ws, M, K, Nc, pl.rows_per_block};
     dim3 grid(pl.gx, pl.gy, pl.splits), block(256);
     hipStream_t st = (hipStream_t)stream;
+    static const bool force_v1 = getenv("MNY_WGRAD_V1") != nullptr;
+    WgKernel dk = ((Nc & 3) == 0 && (K & 3) == 0 && in_act != MNY_ACT_HSWISH && !force_v1) ? wg_dma_kernel(pl.mode, pl.TI, pl.TJ) : nullptr;
+    const int key = dk ? -1 : pl.mode * 100 + pl.TI * 10 + pl.TJ;
+    if (dk) hipLaunchKernelGGL(dk, grid, block, pl.lds_dma, st, a);
 #define MNY_WG(MD, I, J) hipLaunchKernelGGL((pw_wgrad_kernel<MD, I, J>), grid, block, pl.lds, st, a)
-    const int key = pl.mode * 100 + pl.TI * 10 + pl.TJ;
     switch (key) {
+        case -1: break;
         case 11: MNY_WG(0, 1, 1); break; case 12: MNY_WG(0, 1, 2); break; case 21: MNY_WG(0, 2, 1); break; case 22: MNY_WG(0, 2, 2); break;
         case 111: MNY_WG(1, 1, 1); break; case 112: MNY_WG(1, 1, 2); break; case 113: MNY_WG(1, 1, 3); break; case 114: MNY_WG(1, 1, 4); break;
         case 115: MNY_WG(1, 1, 5); break; case 116: MNY_WG(1, 1, 6); break; case 121: MNY_WG(1, 2, 1); break; case 122: MNY_WG(1, 2, 2); break;
