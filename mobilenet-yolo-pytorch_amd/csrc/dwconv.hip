@@ -34,7 +34,9 @@ __device__ __forceinline__ void load_weights(const float* __restrict__ w, int c,
 
 // MODE 0: forward (y = conv(view(x)), optional stats)    [also backward-data for stride 1 with flip]
 // MODE 1: backward-weight (accumulate dy * view(x) per tap)
-template <int KS, int S, int MODE>
+// XF: 0 = input used as is, 1 = scale/shift + min(max(z, slope*z), hi), 2 = scale/shift + hswish (compile-time: the
+// inner loop must stay free of control flow)
+template <int KS, int S, int MODE, int XF>
 __global__ __launch_bounds__(256) void dw_slide_kernel(
     const float* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift, int in_act,
     const float* __restrict__ w, int flip, const float* __restrict__ addend,
@@ -77,27 +79,45 @@ __global__ __launch_bounds__(256) void dw_slide_kernel(
             const int ho1 = min(ho0 + g.TH, g.Ho);
             const float* xn = x + (int64_t)n * g.H * g.W * g.C + c;
             float4 win[KS][KS];
-            auto load_row = [&](int r, int hi) {
+            const float slope = act_slope(in_act), hi_clip = act_hi(in_act);
+            auto tap_ok = [&](int hi, int q) { const int wi = wo * S - P + q; return hi >= 0 && hi < g.H && wi >= 0 && wi < g.W; };
+            // loads are UNCONDITIONAL (address clamped into the image) so the inner loop has no control flow and all
+            // loads of a row are in flight together; out-of-image taps are zeroed by a select afterwards
+            auto tap_ld = [&](int hi, int q) {
+                const int wi = min(max(wo * S - P + q, 0), g.W - 1);
+                const int hc = min(max(hi, 0), g.H - 1);
+                return ld4(xn + ((int64_t)hc * g.W + wi) * g.C);
+            };
+            auto tap_fin = [&](float4 v, int hi, int q) {       // padding taps are 0 in the ACTIVATED domain
+                if (XF != 0) {
+                    float z[4] = {fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w)};
 #pragma unroll
-                for (int q = 0; q < KS; ++q) {
-                    const int wi = wo * S - P + q;
-                    float4 v = f4zero();
-                    if (hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) {
-                        v = ld4(xn + ((int64_t)hi * g.W + wi) * g.C);
-                        if (has_xf || in_act != MNY_ACT_NONE) v = xform4(v, sc, sh, in_act);
-                    }
-                    win[r][q] = v;
+                    for (int e = 0; e < 4; ++e)
+                        z[e] = XF == 1 ? fminf(fmaxf(z[e], slope * z[e]), hi_clip) : z[e] * fminf(fmaxf(z[e] + 3.f, 0.f), 6.f) / 6.f;
+                    v = make_float4(z[0], z[1], z[2], z[3]);
                 }
+                return tap_ok(hi, q) ? v : f4zero();
             };
 #pragma unroll
-            for (int r = 0; r < KS - S; ++r) load_row(r + S, ho0 * S - P + r);   // pre-shifted; first iter shifts down
+            for (int r = 0; r < KS - S; ++r)                     // pre-shifted; the first iteration shifts them down
+#pragma unroll
+                for (int q = 0; q < KS; ++q) win[r + S][q] = tap_fin(tap_ld(ho0 * S - P + r, q), ho0 * S - P + r, q);
             for (int ho = ho0; ho < ho1; ++ho) {
+                float4 cur[S][KS];
+#pragma unroll
+                for (int r = 0; r < S; ++r)
+#pragma unroll
+                    for (int q = 0; q < KS; ++q) cur[r][q] = tap_ld(ho * S - P + (KS - S) + r, q);
+                float4 d = f4zero();
+                if (MODE == 1) d = ld4(dy + (((int64_t)n * g.Ho + ho) * g.Wo + wo) * g.C + c);
 #pragma unroll
                 for (int r = 0; r < KS - S; ++r)
 #pragma unroll
                     for (int q = 0; q < KS; ++q) win[r][q] = win[r + S][q];
 #pragma unroll
-                for (int r = KS - S; r < KS; ++r) load_row(r, ho * S - P + r);
+                for (int r = 0; r < S; ++r)
+#pragma unroll
+                    for (int q = 0; q < KS; ++q) win[KS - S + r][q] = tap_fin(cur[r][q], ho * S - P + (KS - S) + r, q);
                 const int64_t o = (((int64_t)n * g.Ho + ho) * g.Wo + wo) * g.C + c;
                 if (MODE == 0) {
                     float4 out = addend ? ld4(addend + o) : f4zero();
@@ -109,7 +129,6 @@ __global__ __launch_bounds__(256) void dw_slide_kernel(
                     add4(acc_s1, out);
                     fma4(acc_s2, out, out);
                 } else {
-                    const float4 d = ld4(dy + o);
 #pragma unroll
                     for (int r = 0; r < KS; ++r)
 #pragma unroll
@@ -215,7 +234,10 @@ static int dw_launch(const float* x, const float* sc, const float* sh, int act, 
     int rc = dw_geom(g, L, gx, N, H, W, C, K, stride);
     if (rc) return rc;
     dim3 grid(gx, L.chunks), block(L.threads);
-#define MNY_DW(KS_, S_) hipLaunchKernelGGL((dw_slide_kernel<KS_, S_, MODE>), grid, block, 0, st, x, sc, sh, act, w, flip, addend, y, dy, parts, g)
+    const int xf = (sc == nullptr && act == MNY_ACT_NONE) ? 0 : (act == MNY_ACT_HSWISH ? 2 : 1);
+#define MNY_DW(KS_, S_) do { if (xf == 0) hipLaunchKernelGGL((dw_slide_kernel<KS_, S_, MODE, 0>), grid, block, 0, st, x, sc, sh, act, w, flip, addend, y, dy, parts, g); \
+        else if (xf == 1) hipLaunchKernelGGL((dw_slide_kernel<KS_, S_, MODE, 1>), grid, block, 0, st, x, sc, sh, act, w, flip, addend, y, dy, parts, g); \
+        else hipLaunchKernelGGL((dw_slide_kernel<KS_, S_, MODE, 2>), grid, block, 0, st, x, sc, sh, act, w, flip, addend, y, dy, parts, g); } while (0)
     if (K == 3 && stride == 1) MNY_DW(3, 1);
     else if (K == 3 && stride == 2) MNY_DW(3, 2);
     else if (K == 5 && stride == 1) MNY_DW(5, 1);
