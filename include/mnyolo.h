@@ -44,6 +44,7 @@ extern "C" {
 #define MNY_ACT_LEAKY 2
 #define MNY_ACT_RELU 3
 #define MNY_ACT_HSWISH 4
+#define MNY_ACT_HSIGMOID 5   /* relu6(z+3)/6, mobilenetv3.py:20-23; only as the gate operand of mny_mul_views */
 
 int mny_version(void);
 const char* mny_last_error(void);
@@ -126,6 +127,19 @@ int mny_bn_bwd_apply(const float* g, const float* y, const float* scale, const f
 int mny_add_views(const float* a, const float* a_scale, const float* a_shift, int a_act,
                   const float* b, const float* b_scale, const float* b_shift, int b_act,
                   const float* up, float* out, int N, int H, int W, int C, void* stream);
+/* out = view(a) * view(b): the per-pixel "SE" gate of models/mobilenetv3.py:40-41 (x * hsigmoid(bn(conv(..)))).
+ * backward of one operand: dst = (addend ? addend : 0) + g * view(other). */
+int mny_mul_views(const float* a, const float* a_scale, const float* a_shift, int a_act,
+                  const float* b, const float* b_scale, const float* b_shift, int b_act,
+                  float* out, int64_t M, int C, void* stream);
+int mny_mul_views_bwd(const float* g, const float* o, const float* o_scale, const float* o_shift, int o_act,
+                      const float* addend, float* dst, int64_t M, int C, void* stream);
+/* PartAdd(a, upsample2x(up)) of models/mbv3_yolo.py:85-96,135 for Ca <= Cb:
+ * out[..., :Ca] = view(a) + up2x[..., :Ca];  out[..., Ca:] = up2x[..., Ca:].   out/up2x have Cb channels. */
+int mny_partadd_up(const float* a, const float* a_scale, const float* a_shift, int a_act, const float* up,
+                   float* out, int N, int H, int W, int Ca, int Cb, void* stream);
+/* dst[M,Ca] = (accumulate ? dst : 0) + src[M,Cb][:, :Ca]   (gradient of the PartAdd's first operand) */
+int mny_slice_channels(const float* src, float* dst, int accumulate, int64_t M, int Ca, int Cb, void* stream);
 /* dst[N,H/2,W/2,C] = (accumulate ? dst : 0) + sum of the 2x2 children of src[N,H,W,C] */
 int mny_upsample_bwd(const float* src, float* dst, int accumulate, int N, int H, int W, int C, void* stream);
 /* dst = (accumulate ? dst : 0) + alpha[0] * src   (alpha: device scalar or NULL => 1) */

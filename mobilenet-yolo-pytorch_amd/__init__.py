@@ -4,3 +4,4 @@ Import as `mobilenet_yolo_pytorch_amd` (the repo-root shim maps the hyphenated d
 from . import _lib  # noqa: F401
 from ._lib import MnyError  # noqa: F401
 from .model import yolo, HeadState  # noqa: F401
+from . import mbv3  # noqa: F401

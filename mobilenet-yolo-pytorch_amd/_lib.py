@@ -7,7 +7,7 @@ from ctypes import c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmnyolo.so")
 
-ACT_NONE, ACT_RELU6, ACT_LEAKY, ACT_RELU, ACT_HSWISH = 0, 1, 2, 3, 4
+ACT_NONE, ACT_RELU6, ACT_LEAKY, ACT_RELU, ACT_HSWISH, ACT_HSIGMOID = 0, 1, 2, 3, 4, 5
 
 
 class MnyError(RuntimeError):
@@ -46,6 +46,10 @@ _SIGS = {
     "mny_bn_bwd_finalize": (c_int, [P, c_int, c_int64, P, P, P, P, P, P, c_int, P]),
     "mny_bn_bwd_apply": (c_int, [P, P, P, P, c_int, P, P, c_int64, c_int, P]),
     "mny_add_views": (c_int, [P, P, P, c_int, P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, P]),
+    "mny_mul_views": (c_int, [P, P, P, c_int, P, P, P, c_int, P, c_int64, c_int, P]),
+    "mny_mul_views_bwd": (c_int, [P, P, P, P, c_int, P, P, c_int64, c_int, P]),
+    "mny_partadd_up": (c_int, [P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "mny_slice_channels": (c_int, [P, P, c_int, c_int64, c_int, c_int, P]),
     "mny_upsample_bwd": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "mny_axpy": (c_int, [P, P, P, c_int, c_int64, P]),
     "mny_yolo_loss": (c_int, [P, P, P, P, P, ctypes.POINTER(YoloHead), P, P, P, P]),

@@ -208,6 +208,104 @@ __global__ __launch_bounds__(256) void axpy_kernel(const float* __restrict__ src
     }
 }
 
+
+// ---- scalar-channel variants (C not a multiple of 4: the 10-channel SE bottleneck of MobileNetV3) ---------
+__global__ __launch_bounds__(256) void bn_bwd_reduce_c1_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                                               const float* __restrict__ scale, const float* __restrict__ shift, int act,
+                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                               float* __restrict__ red_out, int64_t M, int C, int cb) {
+    __shared__ float red[256 * 2];
+    const int tid = threadIdx.x;
+    const int cl = tid % cb, pix = tid / cb, ppb = blockDim.x / cb;
+    const int c = blockIdx.y * cb + cl;
+    float s1 = 0.f, s2 = 0.f;
+    if (c < C) {
+        const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+        for (int64_t m = (int64_t)blockIdx.x * ppb + pix; m < M; m += (int64_t)gridDim.x * ppb) {
+            const float yv = y[m * C + c];
+            const float dz = g[m * C + c] * act_bwd(fmaf(yv, sc, sh), act);
+            s1 += dz;
+            s2 = fmaf(dz, (yv - mu) * is, s2);
+        }
+    }
+    red[tid * 2] = s1; red[tid * 2 + 1] = s2;
+    __syncthreads();
+    if (pix == 0 && c < C) {
+        float a = 0.f, b = 0.f;
+        for (int p = 0; p < ppb; ++p) { a += red[(p * cb + cl) * 2]; b += red[(p * cb + cl) * 2 + 1]; }
+        red_out[(int64_t)blockIdx.x * 2 * C + c] = a;
+        red_out[(int64_t)blockIdx.x * 2 * C + C + c] = b;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_c1_kernel(const float* __restrict__ g, const float* __restrict__ y,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift, int act,
+                                                              const float* __restrict__ coef, float* __restrict__ dy, int64_t total, int C) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        const float sc = scale ? scale[c] : 1.f, sh = scale ? shift[c] : 0.f;
+        const float ca = coef ? coef[c] : 1.f, cb = coef ? coef[C + c] : 0.f, cc = coef ? coef[2 * C + c] : 0.f;
+        const float yv = y[e];
+        dy[e] = fmaf(ca, g[e] * act_bwd(fmaf(yv, sc, sh), act), fmaf(cb, yv, cc));
+    }
+}
+
+// ---- per-pixel gate (MobileNetV3 "SE") and PartAdd --------------------------------------------------------
+__global__ __launch_bounds__(256) void mul_views_kernel(const float* __restrict__ a, const float* __restrict__ a_scale,
+                                                        const float* __restrict__ a_shift, int a_act,
+                                                        const float* __restrict__ b, const float* __restrict__ b_scale,
+                                                        const float* __restrict__ b_shift, int b_act,
+                                                        const float* __restrict__ addend, float* __restrict__ out,
+                                                        int64_t M, int C, int cgb, int cg_total, int bwd) {
+    const int cgl = threadIdx.x % cgb, pix = threadIdx.x / cgb, ppb = blockDim.x / cgb;
+    const int cg = blockIdx.y * cgb + cgl;
+    if (cg >= cg_total) return;
+    const int c = cg * 4;
+    const float4 asc = a_scale ? ld4(a_scale + c) : f4one(), ash = a_scale ? ld4(a_shift + c) : f4zero();
+    const float4 bsc = b_scale ? ld4(b_scale + c) : f4one(), bsh = b_scale ? ld4(b_shift + c) : f4zero();
+    for (int64_t m = (int64_t)blockIdx.x * ppb + pix; m < M; m += (int64_t)gridDim.x * ppb) {
+        // forward: a and b are both views; backward (bwd=1): a is the raw upstream gradient, b the other operand's view
+        const float4 x = bwd ? ld4(a + m * C + c) : xform4(ld4(a + m * C + c), asc, ash, a_act);
+        const float4 w = xform4(ld4(b + m * C + c), bsc, bsh, b_act);
+        float4 o = addend ? ld4(addend + m * C + c) : f4zero();
+        fma4(o, x, w);
+        st4(out + m * C + c, o);
+    }
+}
+
+__global__ __launch_bounds__(256) void partadd_up_kernel(const float* __restrict__ a, const float* __restrict__ a_scale,
+                                                         const float* __restrict__ a_shift, int a_act,
+                                                         const float* __restrict__ up, float* __restrict__ out,
+                                                         int N, int H, int W, int Ca, int Cb, int cgb, int cg_total) {
+    const int cgl = threadIdx.x % cgb, pix = threadIdx.x / cgb, ppb = blockDim.x / cgb;
+    const int cg = blockIdx.y * cgb + cgl;
+    if (cg >= cg_total) return;
+    const int c = cg * 4;
+    const bool in_a = c < Ca;
+    const float4 asc = (a_scale && in_a) ? ld4(a_scale + c) : f4one(), ash = (a_scale && in_a) ? ld4(a_shift + c) : f4zero();
+    const int64_t M = (int64_t)N * H * W;
+    for (int64_t m = (int64_t)blockIdx.x * ppb + pix; m < M; m += (int64_t)gridDim.x * ppb) {
+        const int wi = (int)(m % W), hi = (int)((m / W) % H);
+        const int64_t n = m / ((int64_t)W * H);
+        float4 o = ld4(up + ((n * (H / 2) + hi / 2) * (W / 2) + wi / 2) * Cb + c);
+        if (in_a) add4(o, xform4(ld4(a + m * Ca + c), asc, ash, a_act));
+        st4(out + m * Cb + c, o);
+    }
+}
+
+__global__ __launch_bounds__(256) void slice_channels_kernel(const float* __restrict__ src, float* __restrict__ dst, int accumulate,
+                                                             int64_t M, int Ca, int Cb, int cgb, int cg_total) {
+    const int cgl = threadIdx.x % cgb, pix = threadIdx.x / cgb, ppb = blockDim.x / cgb;
+    const int cg = blockIdx.y * cgb + cgl;
+    if (cg >= cg_total) return;
+    const int c = cg * 4;
+    for (int64_t m = (int64_t)blockIdx.x * ppb + pix; m < M; m += (int64_t)gridDim.x * ppb) {
+        float4 o = accumulate ? ld4(dst + m * Ca + c) : f4zero();
+        add4(o, ld4(src + m * Cb + c));
+        st4(dst + m * Ca + c, o);
+    }
+}
+
 static inline dim3 rows_grid(int64_t M, const CgLayout& L, int cap) {
     int64_t want = cdiv(M, L.ppb);
     return dim3((unsigned)(want < cap ? want : cap), L.chunks);
@@ -234,8 +332,17 @@ extern "C" int mny_bn_eval_coeffs(const float* gamma, const float* beta, const f
     return check_launch("bn_eval_coeffs_kernel");
 }
 
+static void c1_layout(int64_t M, int C, int& cb, int& chunks, int& gx) {
+    chunks = (int)cdiv(C, 256);
+    cb = (int)cdiv(C, chunks);
+    const int ppb = 256 / cb > 0 ? 256 / cb : 1;
+    int64_t want = cdiv(M, ppb);
+    gx = (int)(want < 1024 ? want : 1024);
+}
+
 extern "C" int mny_bn_bwd_parts(int64_t M, int C) {
-    if (M <= 0 || C <= 0 || C % 4) return MNY_EINVAL;
+    if (M <= 0 || C <= 0) return MNY_EINVAL;
+    if (C % 4) { int cb, ch, gx; c1_layout(M, C, cb, ch, gx); return gx; }
     CgLayout L = make_cg_layout(C);
     return (int)rows_grid(M, L, 1024).x;
 }
@@ -243,7 +350,13 @@ extern "C" int mny_bn_bwd_parts(int64_t M, int C) {
 extern "C" int mny_bn_bwd_reduce(const float* g, const float* y, const float* scale, const float* shift, int act,
                                  const float* mean, const float* invstd, float* red, int64_t M, int C, void* stream) {
     MNY_REQUIRE(g && y && scale && shift && mean && invstd && red, "bn_bwd_reduce: null pointer");
-    MNY_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bn_bwd_reduce: bad shape M=%lld C=%d", (long long)M, C);
+    MNY_REQUIRE(M > 0 && C > 0, "bn_bwd_reduce: bad shape M=%lld C=%d", (long long)M, C);
+    if (C % 4) {
+        int cb, ch, gx; c1_layout(M, C, cb, ch, gx);
+        const int ppb = 256 / cb > 0 ? 256 / cb : 1;
+        hipLaunchKernelGGL(bn_bwd_reduce_c1_kernel, dim3(gx, ch), dim3(cb * ppb), 0, (hipStream_t)stream, g, y, scale, shift, act, mean, invstd, red, M, C, cb);
+        return check_launch("bn_bwd_reduce_c1_kernel");
+    }
     CgLayout L = make_cg_layout(C);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, rows_grid(M, L, 1024), dim3(L.threads), 0, (hipStream_t)stream, g, y, scale, shift, act,
                        mean, invstd, red, M, C, L.cgb, L.cg_total);
@@ -261,7 +374,12 @@ extern "C" int mny_bn_bwd_finalize(const float* red, int parts, int64_t count, c
 extern "C" int mny_bn_bwd_apply(const float* g, const float* y, const float* scale, const float* shift, int act, const float* coef,
                                 float* dy, int64_t M, int C, void* stream) {
     MNY_REQUIRE(g && y && dy, "bn_bwd_apply: null pointer");
-    MNY_REQUIRE(M > 0 && C > 0 && C % 4 == 0, "bn_bwd_apply: bad shape");
+    MNY_REQUIRE(M > 0 && C > 0, "bn_bwd_apply: bad shape");
+    if (C % 4) {
+        int64_t blocks = cdiv(M * C, 256); if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(bn_bwd_apply_c1_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, y, scale, shift, act, coef, dy, M * C, C);
+        return check_launch("bn_bwd_apply_c1_kernel");
+    }
     CgLayout L = make_cg_layout(C);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, rows_grid(M, L, 8192), dim3(L.threads), 0, (hipStream_t)stream, g, y, scale, shift, act,
                        coef, dy, M, C, L.cgb, L.cg_total);
@@ -295,4 +413,40 @@ extern "C" int mny_axpy(const float* src, const float* alpha, float* dst, int ac
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, alpha, dst, accumulate, n4, n);
     return check_launch("axpy_kernel");
+}
+
+extern "C" int mny_mul_views(const float* a, const float* a_scale, const float* a_shift, int a_act, const float* b,
+                             const float* b_scale, const float* b_shift, int b_act, float* out, int64_t M, int C, void* stream) {
+    MNY_REQUIRE(a && b && out && M > 0 && C > 0 && C % 4 == 0, "mul_views: bad arguments");
+    CgLayout L = make_cg_layout(C);
+    hipLaunchKernelGGL(mul_views_kernel, rows_grid(M, L, 8192), dim3(L.threads), 0, (hipStream_t)stream, a, a_scale, a_shift, a_act, b, b_scale,
+                       b_shift, b_act, nullptr, out, M, C, L.cgb, L.cg_total, 0);
+    return check_launch("mul_views_kernel");
+}
+
+extern "C" int mny_mul_views_bwd(const float* g, const float* o, const float* o_scale, const float* o_shift, int o_act,
+                                 const float* addend, float* dst, int64_t M, int C, void* stream) {
+    MNY_REQUIRE(g && o && dst && M > 0 && C > 0 && C % 4 == 0, "mul_views_bwd: bad arguments");
+    CgLayout L = make_cg_layout(C);
+    hipLaunchKernelGGL(mul_views_kernel, rows_grid(M, L, 8192), dim3(L.threads), 0, (hipStream_t)stream, g, nullptr, nullptr, MNY_ACT_NONE, o,
+                       o_scale, o_shift, o_act, addend, dst, M, C, L.cgb, L.cg_total, 1);
+    return check_launch("mul_views_kernel(bwd)");
+}
+
+extern "C" int mny_partadd_up(const float* a, const float* a_scale, const float* a_shift, int a_act, const float* up, float* out,
+                              int N, int H, int W, int Ca, int Cb, void* stream) {
+    MNY_REQUIRE(a && up && out && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "partadd_up: bad arguments");
+    MNY_REQUIRE(Ca > 0 && Ca <= Cb && Ca % 4 == 0 && Cb % 4 == 0, "partadd_up: need Ca <= Cb, both multiples of 4");
+    CgLayout L = make_cg_layout(Cb);
+    hipLaunchKernelGGL(partadd_up_kernel, rows_grid((int64_t)N * H * W, L, 8192), dim3(L.threads), 0, (hipStream_t)stream, a, a_scale, a_shift,
+                       a_act, up, out, N, H, W, Ca, Cb, L.cgb, L.cg_total);
+    return check_launch("partadd_up_kernel");
+}
+
+extern "C" int mny_slice_channels(const float* src, float* dst, int accumulate, int64_t M, int Ca, int Cb, void* stream) {
+    MNY_REQUIRE(src && dst && M > 0 && Ca > 0 && Ca <= Cb && Ca % 4 == 0 && Cb % 4 == 0, "slice_channels: bad arguments");
+    CgLayout L = make_cg_layout(Ca);
+    hipLaunchKernelGGL(slice_channels_kernel, rows_grid(M, L, 8192), dim3(L.threads), 0, (hipStream_t)stream, src, dst, accumulate, M, Ca, Cb,
+                       L.cgb, L.cg_total);
+    return check_launch("slice_channels_kernel");
 }

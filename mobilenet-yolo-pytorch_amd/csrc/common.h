@@ -30,13 +30,17 @@ __host__ __device__ inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 
 __device__ __forceinline__ float act_slope(int act) { return act == MNY_ACT_NONE ? 1.f : (act == MNY_ACT_LEAKY ? 0.1f : 0.f); }
 __device__ __forceinline__ float act_hi(int act) { return act == MNY_ACT_RELU6 ? 6.f : INFINITY; }
 __device__ __forceinline__ float act_fwd(float z, int act) {
-    if (act == MNY_ACT_HSWISH) return z * fminf(fmaxf(z + 3.f, 0.f), 6.f) / 6.f;
+    if (act >= MNY_ACT_HSWISH) {
+        const float h = fminf(fmaxf(z + 3.f, 0.f), 6.f) / 6.f;
+        return act == MNY_ACT_HSWISH ? z * h : h;
+    }
     return fminf(fmaxf(z, act_slope(act) * z), act_hi(act));
 }
 // derivative at pre-activation z (torch's subgradient choices: relu6 = hardtanh: 1 on the open interval (0,6);
 // leaky_relu: z > 0 ? 1 : slope)
 __device__ __forceinline__ float act_bwd(float z, int act) {
     if (act == MNY_ACT_HSWISH) return z <= -3.f ? 0.f : (z >= 3.f ? 1.f : (2.f * z + 3.f) / 6.f);
+    if (act == MNY_ACT_HSIGMOID) return (z > -3.f && z < 3.f) ? (1.f / 6.f) : 0.f;
     return (z > 0.f ? 1.f : act_slope(act)) * (z < act_hi(act) ? 1.f : 0.f);
 }
 

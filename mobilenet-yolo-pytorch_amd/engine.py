@@ -168,6 +168,17 @@ class NetPlan:
                 t = torch.empty(shp, **f32)
                 self.reals[o.id] = t
                 self.fwd.add("mny_add_views", a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], up, t, shp[0], shp[1], shp[2], shp[3], self.stream)
+            elif nd.op == "mul":
+                a, b = view(nd.ins[0]), view(nd.ins[1])
+                t = torch.empty(shp, **f32)
+                self.reals[o.id] = t
+                self.fwd.add("mny_mul_views", a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], t, M, o.C, self.stream)
+            elif nd.op == "partadd":
+                a = view(nd.ins[0])
+                up = self.reals[nd.ins[1].id]
+                t = torch.empty(shp, **f32)
+                self.reals[o.id] = t
+                self.fwd.add("mny_partadd_up", a[0], a[1], a[2], a[3], up, t, shp[0], shp[1], shp[2], nd.ins[0].C, o.C, self.stream)
             else:
                 raise AssertionError(nd.op)
 
@@ -259,6 +270,8 @@ class NetPlan:
             if nd.bn:
                 names += [nd.bn + ".weight", nd.bn + ".bias"]
             for nm in names:
+                if nm in slots:
+                    continue                     # module applied twice (mbv3_yolo.py:133-134): one slot, two contributions
                 n = P[nm].numel()
                 slots[nm] = (off, n)
                 self.grad_params.append(nm)
@@ -267,8 +280,23 @@ class NetPlan:
         self.gviews = {nm: self.gflat[o:o + n].view(P[nm].shape) for nm, (o, n) in slots.items()}
         self.grad_slots = slots
 
+        written = set()
+        self.shared_tmp = []
+
         def gv(nm):
-            return self.gviews[nm]
+            """Destination of a parameter gradient.  The first contribution writes the arena slot; a later one (shared
+            module) writes a scratch tensor that `flush_shared()` adds into the slot right after the producing call."""
+            if nm not in written:
+                written.add(nm)
+                return self.gviews[nm]
+            tmp = torch.empty_like(self.gviews[nm])
+            self.shared_tmp.append((tmp, self.gviews[nm]))
+            return tmp
+
+        def flush_shared():
+            while self.shared_tmp:
+                tmp, dst = self.shared_tmp.pop()
+                bwd.add("mny_axpy", tmp, None, dst, 1, tmp.numel(), self.stream)
 
         # workspaces shared by all layers (single stream => sequential use)
         ws_floats = 1
@@ -357,6 +385,32 @@ class NetPlan:
                         bwd.add("mny_upsample_bwd", G, us.buf, 1, shp[0], shp[1], shp[2], shp[3], self.stream)
                 bwd.marks[o.name] = len(bwd.calls)
                 continue
+            if nd.op == "mul":
+                va, vb = view(nd.ins[0]), view(nd.ins[1])
+                contribute_kernel(nd.ins[0], lambda out, addend, G=G, vb=vb, M=M, C=o.C: bwd.add(
+                    "mny_mul_views_bwd", G, vb[0], vb[1], vb[2], vb[3], addend, out, M, C, self.stream))
+                contribute_kernel(nd.ins[1], lambda out, addend, G=G, va=va, M=M, C=o.C: bwd.add(
+                    "mny_mul_views_bwd", G, va[0], va[1], va[2], va[3], addend, out, M, C, self.stream))
+                bwd.marks[o.name] = len(bwd.calls)
+                continue
+            if nd.op == "partadd":
+                av, upv = nd.ins[0], nd.ins[1]
+                for tgt, emit in ((av, lambda dst, acc, G=G, M=M, Ca=av.C, Cb=o.C: bwd.add(
+                                        "mny_slice_channels", G, dst, acc, M, Ca, Cb, self.stream)),
+                                  (upv, lambda dst, acc, G=G, shp=shp: bwd.add(
+                                        "mny_upsample_bwd", G, dst, acc, shp[0], shp[1], shp[2], shp[3], self.stream))):
+                    ts = gs[tgt.id]
+                    if ts.buf is None:
+                        ts.buf, ts.shared = alloc(tgt), False
+                        emit(ts.buf, 0)
+                    else:
+                        if ts.shared:
+                            nb = alloc(tgt)
+                            bwd.add("mny_axpy", ts.buf, None, nb, 0, nb.numel(), self.stream)
+                            ts.buf, ts.shared = nb, False
+                        emit(ts.buf, 1)
+                bwd.marks[o.name] = len(bwd.calls)
+                continue
             if nd.op == "pwb":
                 dY = G
             else:
@@ -393,6 +447,7 @@ class NetPlan:
                 contribute_kernel(i, lambda out, addend, dY=dY, wT=wT, M=M, K=o.C, Nc=i.C: bwd.add(
                     "mny_pw_fwd", dY, None, None, ACT_NONE, wT, None, addend, out, None, M, K, Nc, self.stream,
                     meta=dict(flops=2 * M * K * Nc, bytes=4 * (M * K + M * Nc + K * Nc), shape="dgrad M%d K%d N%d" % (M, K, Nc))))
+            flush_shared()
             bwd.marks[o.name] = len(bwd.calls)
 
     # ------------------------------------------------------------------------------------------

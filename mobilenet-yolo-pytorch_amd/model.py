@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
-from .arch import mbv2_yolo_graph
+from .arch import mbv2_yolo_graph, mbv3_yolo_graph
 from .engine import NetPlan
 
 
@@ -75,6 +75,8 @@ class _TrainStep(torch.autograd.Function):
 
 
 class yolo(nn.Module):
+    ARCH = "mbv2"
+
     def __init__(self, config, sync_metrics=False):
         super().__init__()
         y = config["yolo"]
@@ -82,7 +84,10 @@ class yolo(nn.Module):
         self.num_anchors = y["num_anchors"]
         self.seg_num_classes = config["seg"]["num_classes"] if "seg" in config else None
         self.sync_metrics = sync_metrics          # True: metrics as python floats like the reference (forces a device sync)
-        self.graph = mbv2_yolo_graph(self.num_classes, self.num_anchors, self.seg_num_classes)
+        if self.ARCH == "mbv2":
+            self.graph = mbv2_yolo_graph(self.num_classes, self.num_anchors, self.seg_num_classes)
+        else:
+            self.graph = mbv3_yolo_graph(self.num_classes, self.num_anchors)
         self._build_modules()
         self.yolo_losses = [HeadState(y["anchors"], y["mask"][i], self.num_classes, [config["img_w"], config["img_h"]],
                                       y["ignore_thresh"][i], y["iou_thresh"], iou_weighting=config["iou_weighting"])
@@ -110,9 +115,9 @@ class yolo(nn.Module):
             if kind == "conv":
                 cin, cout, k, stride, groups, bias = a
                 mod = nn.Conv2d(cin, cout, k, stride, k // 2, groups=groups, bias=bias)
-                if path.startswith("backbone."):                              # mobilenetv2.py:146-152
+                if path.startswith("backbone.") and self.ARCH == "mbv2":      # mobilenetv2.py:146-152
                     mod.weight.data.normal_(0, math.sqrt(2.0 / (k * k * cout)))
-                elif not bias:                                                 # BasicConv: mbv2_yolo.py:32-36
+                elif not bias:                                                 # BasicConv: mbv2_yolo.py:32-36; mobilenetv3.py:113-116
                     nn.init.kaiming_normal_(mod.weight, mode="fan_out")
                 # biased head convs keep nn.Conv2d's default init (mbv2_yolo.py:82)
             else:

@@ -217,10 +217,66 @@ def gen_net():
         json.dump({"params": names, "grad_none": gnone, "running": rs_names}, f)
 
 
+def _ref_model_v3(cfg):
+    """mbv3_yolo.py imports `models.voc.*` (non-existent) and loads a local weight file: alias + patch."""
+    import types
+    import models.mobilenetv3 as B3
+    import models.yolo_loss as YL
+    voc = types.ModuleType("models.voc")
+    sys.modules["models.voc"] = voc
+    sys.modules["models.voc.mobilenetv3"] = B3
+    sys.modules["models.voc.yolo_loss"] = YL
+    B3.MobileNetV3 = lambda *_a, **_k: B3.MobileNetV3_Large()
+    import models.mbv3_yolo as M3
+    M3.MobileNetV3 = B3.MobileNetV3
+    torch.manual_seed(0)
+    return M3.yolo(cfg)
+
+
+def gen_net_v3():
+    cfg = yaml.safe_load(open(os.path.join(REF, "models", "voc", "config.yaml")))
+    m = _ref_model_v3(cfg)
+    keys = [[k, list(v.shape)] for k, v in m.state_dict().items()]
+    with open(os.path.join(OUT, "state_keys_mbv3.json"), "w") as f:
+        json.dump({"config": cfg, "keys": keys, "num_params": sum(p.numel() for p in m.parameters())}, f)
+    print("mbv3", len(keys), "keys")
+    procedural.fill_state_dict_(m)
+    grabbed = {}
+    m.yolo_headS32.register_forward_hook(lambda mod, i, o: grabbed.__setitem__("out0", o))
+    m.yolo_headS16.register_forward_hook(lambda mod, i, o: grabbed.__setitem__("out1", o))
+    import utils.box as UB
+    import models.yolo_loss as YL
+    UB.device = YL.device = torch.device("cpu")
+    m.eval()
+    for l in m.yolo_losses:
+        l.val_conf = 0.3
+    x = procedural.images(2, 128, 128, seed=20)
+    with torch.no_grad():
+        det = m(x)
+    out = {"ev_out0": _np(grabbed["out0"]), "ev_out1": _np(grabbed["out1"]), "ev_counts": np.array([len(d) for d in det])}
+    m.train()
+    x = procedural.images(2, 128, 128, seed=21)
+    tg = procedural.targets(2, seed=6, empty_every=0)
+    res = m(x, [t.clone() for t in tg])
+    sum(r[0] for r in res).backward()
+    names = [k for k, _ in m.named_parameters()]
+    out.update({"tr_out0": _np(grabbed["out0"]), "tr_out1": _np(grabbed["out1"]),
+                "tuple0": np.array([float(v) for v in res[0]]), "tuple1": np.array([float(v) for v in res[1]]),
+                "gnorm": np.array([p.grad.double().norm().item() for _, p in m.named_parameters()]),
+                "t_counts": np.array([len(t) for t in tg]), "t_all": _np(torch.cat(tg)),
+                "g_shared_dw": _np(m.connect_for_S16.conv[0].conv.weight.grad),
+                "g_gate": _np(m.backbone.bneck[3].se.se[3].weight.grad)})
+    sd = m.state_dict()
+    rs_names = [k for k in sd if k.endswith("running_mean") or k.endswith("running_var")]
+    out["rs_norm"] = np.array([sd[k].double().norm().item() for k in rs_names])
+    _save("net_v3.npz", **out)
+    with open(os.path.join(OUT, "net_v3_names.json"), "w") as f:
+        json.dump({"params": names, "running": rs_names}, f)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     _install_stubs()
-    gen_state_keys()
-    gen_iou_tables()
-    gen_loss_and_decode()
-    gen_net()
+    if "--only-v3" not in sys.argv:
+        gen_state_keys(); gen_iou_tables(); gen_loss_and_decode(); gen_net()
+    gen_net_v3()
