@@ -46,14 +46,16 @@ def parse():
     ap.add_argument("--batch", type=int, default=BATCH, help="images per GPU (the metric is quoted at 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-nms", action="store_true")
+    ap.add_argument("--arch", default="mbv2", choices=["mbv2", "mbv3"], help="mbv3 = BASELINE config 4 topology (fp32 here), not the headline")
+    ap.add_argument("--size", type=int, default=SIZE)
     ap.add_argument("--breakdown", action="store_true", help="print a per-entry-point time table to stderr")
     ap.add_argument("--detail", default="", help="comma list of entry points: print their per-call table to stderr")
     return ap.parse_args()
 
 
-def make_batch(batch, rank, device):
+def make_batch(batch, rank, device, size=SIZE):
     from mobilenet_yolo_pytorch_amd import synthetic
-    x = synthetic.images(batch, SIZE, SIZE, seed=rank).to(device)
+    x = synthetic.images(batch, size, size, seed=rank).to(device)
     tg = synthetic.targets(batch, seed=1 + rank, empty_every=16)
     return x, tg
 
@@ -173,12 +175,16 @@ def main():
 
     from mobilenet_yolo_pytorch_amd import synthetic, yolo
     torch.manual_seed(0)                      # identical init on every rank
-    model = yolo(synthetic.VOC_CONFIG).to(device).train()
+    if a.arch == "mbv3":
+        from mobilenet_yolo_pytorch_amd import mbv3
+        model = mbv3.yolo(synthetic.VOC_CONFIG).to(device).train()
+    else:
+        model = yolo(synthetic.VOC_CONFIG).to(device).train()
     reducer = None
     if world > 1:
         from mobilenet_yolo_pytorch_amd.dp import attach_data_parallel
         reducer = attach_data_parallel(model)
-    x, tg = make_batch(a.batch, rank, device)
+    x, tg = make_batch(a.batch, rank, device, a.size)
 
     def step():
         for p in model.parameters():
@@ -190,7 +196,7 @@ def main():
     for _ in range(max(a.warmup, 1)):
         out = step()
     torch.cuda.synchronize()
-    plan = model._plans[(a.batch, SIZE, SIZE, True)]
+    plan = model._plans[(a.batch, a.size, a.size, True)]
 
     # timed region: K steps, barrier + sync on both sides; the dominant kernels are bracketed by HIP events
     plan.enable_timing(only=None if a.breakdown else MFMA_KERNELS)
@@ -245,10 +251,12 @@ def main():
                 "algorithmic_gflop_per_step": round(d["flops"] / a.steps / 1e9, 2),
                 "algorithmic_hbm_gbs": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1)}
         res = {
-            "metric": "images/sec MobileNetV2-YOLO 352x352 fwd+bwd @ bs256", "value": round(world * a.batch * a.steps / dt, 2),
+            "metric": "images/sec MobileNetV2-YOLO 352x352 fwd+bwd @ bs256" if (a.arch, a.size, a.batch) == ("mbv2", SIZE, BATCH)
+            else "images/sec %s-YOLO %dx%d fwd+bwd @ bs%d (NOT the headline config)" % (a.arch, a.size, a.size, a.batch), "value": round(world * a.batch * a.steps / dt, 2),
             "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "MobileNetV2-YOLO 352x352 bs=%d/GPU fwd+loss+bwd fp32 (BASELINE configs[%d])" % (a.batch, 1 if world == 1 else 2),
+            "config": {"workload": "%s-YOLO %dx%d bs=%d/GPU fwd+loss+bwd fp32 (BASELINE configs[%s])" % (
+                "MobileNetV2" if a.arch == "mbv2" else "MobileNetV3", a.size, a.size, a.batch, ("1" if world == 1 else "2") if a.arch == "mbv2" else "3, fp32 instead of bf16"),
                        "global_batch": world * a.batch, "parallelism": "dp%d" % world,
                        "timed_region": "zero_grad + forward(net + 2 on-device YOLO losses) + backward; random-init weights",
                        "loss": round(loss, 5)},
