@@ -97,6 +97,112 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
     }
 }
 
+// ---- tiled variant: a block owns an 8x32 tile of output pixels of one image; the 17x65x3 input patch is staged in
+// LDS with loads that are contiguous along W (the NCHW fast axis), each thread keeps the 27 filter taps of its 4
+// output channels in registers and reads inputs as LDS broadcasts (the Cout/4 lanes of a pixel share an address).
+// Requires (Cout/4) to divide 256 (Cout = 16, 32, 64 ...).
+constexpr int ST_TH = 8, ST_TW = 32, ST_IH = 2 * ST_TH + 1, ST_IW = 2 * ST_TW + 1, ST_IWP = ST_IW + 1;
+
+template <int MODE>
+__global__ __launch_bounds__(256) void stem_tile_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        float* __restrict__ y, const float* __restrict__ dy,
+                                                        float* __restrict__ parts, StemGeom g, int tiles_h, int tiles_w) {
+    __shared__ float tile[3 * ST_IH * ST_IWP];
+    __shared__ float4 red[256 * 2];
+    const int tid = threadIdx.x;
+    const int cgn = g.cgb;                      // channel groups (divides 256)
+    const int cgl = tid % cgn, c = cgl * 4;
+    const int ppi = 256 / cgn;                  // pixels handled per pass
+    float4 wv[27];
+    if (MODE == 0) {
+#pragma unroll
+        for (int t = 0; t < 27; ++t) wv[t] = make_float4(w[(c + 0) * 27 + t], w[(c + 1) * 27 + t], w[(c + 2) * 27 + t], w[(c + 3) * 27 + t]);
+    } else {
+#pragma unroll
+        for (int t = 0; t < 27; ++t) wv[t] = f4zero();     // accumulators in MODE 1
+    }
+    float4 s1 = f4zero(), s2 = f4zero();
+    const int64_t plane = (int64_t)g.H * g.W;
+    const int64_t ntiles = (int64_t)g.N * tiles_h * tiles_w;
+    for (int64_t tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        const int tw = (int)(tl % tiles_w), th = (int)((tl / tiles_w) % tiles_h);
+        const int64_t n = tl / ((int64_t)tiles_w * tiles_h);
+        const int ho0 = th * ST_TH, wo0 = tw * ST_TW;
+        const int hi0 = 2 * ho0 - 1, wi0 = 2 * wo0 - 1;
+        __syncthreads();                        // previous tile fully consumed
+        for (int i = tid; i < 3 * ST_IH * ST_IW; i += 256) {
+            const int col = i % ST_IW, row = (i / ST_IW) % ST_IH, ci = i / (ST_IW * ST_IH);
+            const int hi = hi0 + row, wi = wi0 + col;
+            tile[(ci * ST_IH + row) * ST_IWP + col] =
+                (hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) ? x[(n * 3 + ci) * plane + (int64_t)hi * g.W + wi] : 0.f;
+        }
+        __syncthreads();
+        for (int pp = tid / cgn; pp < ST_TH * ST_TW; pp += ppi) {
+            const int pr = pp / ST_TW, pc = pp % ST_TW;
+            const int ho = ho0 + pr, wo = wo0 + pc;
+            if (ho >= g.Ho || wo >= g.Wo) continue;
+            const int64_t o = ((n * g.Ho + ho) * g.Wo + wo) * g.Cout + c;
+            const float* tp = tile + (2 * pr) * ST_IWP + 2 * pc;
+            if (MODE == 0) {
+                float4 acc = f4zero();
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw) {
+                            const float v = tp[(ci * ST_IH + kh) * ST_IWP + kw];
+                            const float4 ww = wv[ci * 9 + kh * 3 + kw];
+                            acc.x = fmaf(v, ww.x, acc.x); acc.y = fmaf(v, ww.y, acc.y); acc.z = fmaf(v, ww.z, acc.z); acc.w = fmaf(v, ww.w, acc.w);
+                        }
+                st4(y + o, acc);
+                add4(s1, acc);
+                fma4(s2, acc, acc);
+            } else {
+                const float4 d = ld4(dy + o);
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw) {
+                            const float v = tp[(ci * ST_IH + kh) * ST_IWP + kw];
+                            float4& a = wv[ci * 9 + kh * 3 + kw];
+                            a.x = fmaf(v, d.x, a.x); a.y = fmaf(v, d.y, a.y); a.z = fmaf(v, d.z, a.z); a.w = fmaf(v, d.w, a.w);
+                        }
+            }
+        }
+    }
+    if (!parts) return;
+    const int pix = tid / cgn;
+    if (MODE == 0) {
+        __syncthreads();
+        red[tid * 2] = s1; red[tid * 2 + 1] = s2;
+        __syncthreads();
+        if (pix == 0) {
+            float4 a = f4zero(), b = f4zero();
+            for (int q = 0; q < ppi; ++q) { add4(a, red[(q * cgn + cgl) * 2]); add4(b, red[(q * cgn + cgl) * 2 + 1]); }
+            st4(parts + (int64_t)blockIdx.x * 2 * g.Cout + c, a);
+            st4(parts + (int64_t)blockIdx.x * 2 * g.Cout + g.Cout + c, b);
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 27; ++t) {
+            __syncthreads();
+            red[tid] = wv[t];
+            __syncthreads();
+            if (pix == 0) {
+                float4 a = f4zero();
+                for (int q = 0; q < ppi; ++q) add4(a, red[q * cgn + cgl]);
+                float* dst = parts + (int64_t)blockIdx.x * g.Cout * 27;
+                dst[(c + 0) * 27 + t] = a.x; dst[(c + 1) * 27 + t] = a.y; dst[(c + 2) * 27 + t] = a.z; dst[(c + 3) * 27 + t] = a.w;
+            }
+        }
+    }
+}
+
+static bool stem_tiled_ok(int Cout) { const int cgn = Cout / 4; return cgn > 0 && 256 % cgn == 0; }
+
 static int stem_geom(StemGeom& g, int& gx, int N, int H, int W, int Cout) {
     MNY_REQUIRE(N > 0 && H > 0 && W > 0, "stem: empty tensor");
     MNY_REQUIRE(Cout % 4 == 0 && Cout >= 4 && Cout <= 256, "stem: Cout=%d must be a multiple of 4 in [4,256]", Cout);
@@ -104,7 +210,7 @@ static int stem_geom(StemGeom& g, int& gx, int N, int H, int W, int Cout) {
     g.Ho = (H + 2 - 3) / 2 + 1; g.Wo = (W + 2 - 3) / 2 + 1;
     g.cgb = Cout / 4; g.ppb = 256 / g.cgb;
     g.npix = (int64_t)N * g.Ho * g.Wo;
-    int64_t want = cdiv(g.npix, g.ppb);
+    int64_t want = stem_tiled_ok(Cout) ? (int64_t)N * cdiv(g.Ho, ST_TH) * cdiv(g.Wo, ST_TW) : cdiv(g.npix, g.ppb);
     gx = (int)(want < kMaxParts ? want : kMaxParts);
     return MNY_OK;
 }
@@ -125,6 +231,11 @@ extern "C" int mny_stem_fwd(const float* x_nchw, const float* w, float* y, float
     StemGeom g; int gx;
     int rc = stem_geom(g, gx, N, H, W, Cout);
     if (rc) return rc;
+    if (stem_tiled_ok(Cout)) {
+        hipLaunchKernelGGL((stem_tile_kernel<0>), dim3(gx), dim3(256), 0, (hipStream_t)stream, x_nchw, w, y, nullptr, stats, g,
+                           (int)cdiv(g.Ho, ST_TH), (int)cdiv(g.Wo, ST_TW));
+        return check_launch("stem_tile_kernel<fwd>");
+    }
     hipLaunchKernelGGL((stem_kernel<0>), dim3(gx), dim3(g.cgb * g.ppb), 0, (hipStream_t)stream, x_nchw, w, y, nullptr, stats, g);
     return check_launch("stem_kernel<fwd>");
 }
@@ -134,7 +245,11 @@ extern "C" int mny_stem_wgrad(const float* x_nchw, const float* dy, float* dw, f
     StemGeom g; int gx;
     int rc = stem_geom(g, gx, N, H, W, Cout);
     if (rc) return rc;
-    hipLaunchKernelGGL((stem_kernel<1>), dim3(gx), dim3(g.cgb * g.ppb), 0, (hipStream_t)stream, x_nchw, nullptr, nullptr, dy, ws, g);
+    if (stem_tiled_ok(Cout))
+        hipLaunchKernelGGL((stem_tile_kernel<1>), dim3(gx), dim3(256), 0, (hipStream_t)stream, x_nchw, nullptr, nullptr, dy, ws, g,
+                           (int)cdiv(g.Ho, ST_TH), (int)cdiv(g.Wo, ST_TW));
+    else
+        hipLaunchKernelGGL((stem_kernel<1>), dim3(gx), dim3(g.cgb * g.ppb), 0, (hipStream_t)stream, x_nchw, nullptr, nullptr, dy, ws, g);
     rc = check_launch("stem_kernel<wgrad>");
     if (rc) return rc;
     return launch_reduce_parts(ws, gx, Cout * 27, dw, (hipStream_t)stream);

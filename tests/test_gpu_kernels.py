@@ -155,7 +155,7 @@ def test_bn_train_forward_backward(ops, N, H, W, C, act):
     check(nchw(yd * sc2 + sh2), ze, 1e-4, 1e-5, "bn eval coeffs")
 
 
-@pytest.mark.parametrize("N,H,W,Co", [(2, 32, 32, 32), (3, 22, 18, 16), (1, 352, 352, 32)])
+@pytest.mark.parametrize("N,H,W,Co", [(2, 32, 32, 32), (3, 22, 18, 16), (1, 352, 352, 32), (2, 20, 26, 12), (2, 130, 70, 32)])
 def test_stem(ops, N, H, W, Co):
     x = rnd(N, 3, H, W, seed=1)
     w = rnd(Co, 3, 3, 3, seed=2, scale=0.3)
