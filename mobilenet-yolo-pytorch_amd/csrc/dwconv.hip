@@ -206,6 +206,57 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2_kernel(const float* __rest
     }
 }
 
+// 3x3 stride-2 backward-data, branch-free: a thread owns the 2x2 input quad (2i..2i+1, 2j..2j+1) of 4 channels.  With
+// pad 1 the quad depends on exactly dy[i..i+1][j..j+1], each with a statically known filter tap:
+//   dx[2i  ][2j  ] = dy[i][j]*w11
+//   dx[2i  ][2j+1] = dy[i][j]*w12 + dy[i][j+1]*w10
+//   dx[2i+1][2j  ] = dy[i][j]*w21 + dy[i+1][j]*w01
+//   dx[2i+1][2j+1] = dy[i][j]*w22 + dy[i][j+1]*w20 + dy[i+1][j]*w02 + dy[i+1][j+1]*w00
+// so the 4 loads are unconditional (clamped address, zeroed by select) and there is no control flow.
+__global__ __launch_bounds__(256) void dw_bwd_data_s2k3_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                               const float* __restrict__ addend, float* __restrict__ dx,
+                                                               int N, int H, int W, int C, int Ho, int Wo, int cgb, int cg_total) {
+    const int cgl = threadIdx.x % cgb, pix = threadIdx.x / cgb, ppb = blockDim.x / cgb;
+    const int cg = blockIdx.y * cgb + cgl;
+    if (cg >= cg_total) return;
+    const int c = cg * 4;
+    float4 wg[9];
+    load_weights<3>(w, c, false, wg);
+    const int Hq = (H + 1) / 2, Wq = (W + 1) / 2;
+    const int64_t nq = (int64_t)N * Hq * Wq;
+    for (int64_t q = (int64_t)blockIdx.x * ppb + pix; q < nq; q += (int64_t)gridDim.x * ppb) {
+        const int j = (int)(q % Wq), i = (int)((q / Wq) % Hq);
+        const int64_t n = q / ((int64_t)Wq * Hq);
+        const float* dn = dy + n * Ho * Wo * C + c;
+        const int i1 = min(i + 1, Ho - 1), j1 = min(j + 1, Wo - 1), i0 = min(i, Ho - 1), j0 = min(j, Wo - 1);
+        float4 d00 = ld4(dn + ((int64_t)i0 * Wo + j0) * C), d01 = ld4(dn + ((int64_t)i0 * Wo + j1) * C);
+        float4 d10 = ld4(dn + ((int64_t)i1 * Wo + j0) * C), d11 = ld4(dn + ((int64_t)i1 * Wo + j1) * C);
+        const bool vi0 = i < Ho, vj0 = j < Wo, vi1 = i + 1 < Ho, vj1 = j + 1 < Wo;
+        if (!(vi0 && vj0)) d00 = f4zero();
+        if (!(vi0 && vj1)) d01 = f4zero();
+        if (!(vi1 && vj0)) d10 = f4zero();
+        if (!(vi1 && vj1)) d11 = f4zero();
+        float4 o00 = f4zero(), o01 = f4zero(), o10 = f4zero(), o11 = f4zero();
+        fma4(o00, d00, wg[4]);
+        fma4(o01, d00, wg[5]); fma4(o01, d01, wg[3]);
+        fma4(o10, d00, wg[7]); fma4(o10, d10, wg[1]);
+        fma4(o11, d00, wg[8]); fma4(o11, d01, wg[6]); fma4(o11, d10, wg[2]); fma4(o11, d11, wg[0]);
+        const int h0 = 2 * i, w0 = 2 * j;
+        const int64_t base = ((n * H + h0) * W + w0) * C + c;
+        const bool hv = h0 + 1 < H, wv2 = w0 + 1 < W;
+        if (addend) {
+            add4(o00, ld4(addend + base));
+            if (wv2) add4(o01, ld4(addend + base + C));
+            if (hv) add4(o10, ld4(addend + base + (int64_t)W * C));
+            if (hv && wv2) add4(o11, ld4(addend + base + (int64_t)W * C + C));
+        }
+        st4(dx + base, o00);
+        if (wv2) st4(dx + base + C, o01);
+        if (hv) st4(dx + base + (int64_t)W * C, o10);
+        if (hv && wv2) st4(dx + base + (int64_t)W * C + C, o11);
+    }
+}
+
 static int dw_geom(DwGeom& g, CgLayout& L, int& gx, int N, int H, int W, int C, int K, int stride) {
     MNY_REQUIRE(K == 3 || K == 5, "dw: kernel size %d unsupported (3 or 5)", K);
     MNY_REQUIRE(stride == 1 || stride == 2, "dw: stride %d unsupported", stride);
@@ -276,7 +327,11 @@ extern "C" int mny_dw_bwd_data(const float* dy, const float* w, const float* add
     CgLayout L = make_cg_layout(C);
     int64_t want = cdiv((int64_t)N * H * W, L.ppb);
     dim3 grid((unsigned)(want < 8192 ? want : 8192), L.chunks), block(L.threads);
-    if (K == 3) hipLaunchKernelGGL((dw_bwd_data_s2_kernel<3>), grid, block, 0, (hipStream_t)stream, dy, w, addend, dx, N, H, W, C, Ho, Wo, L.cgb, L.cg_total);
+    if (K == 3) {
+        int64_t wq = cdiv((int64_t)N * ((H + 1) / 2) * ((W + 1) / 2), L.ppb);
+        dim3 gridq((unsigned)(wq < 8192 ? wq : 8192), L.chunks);
+        hipLaunchKernelGGL(dw_bwd_data_s2k3_kernel, gridq, block, 0, (hipStream_t)stream, dy, w, addend, dx, N, H, W, C, Ho, Wo, L.cgb, L.cg_total);
+    }
     else hipLaunchKernelGGL((dw_bwd_data_s2_kernel<5>), grid, block, 0, (hipStream_t)stream, dy, w, addend, dx, N, H, W, C, Ho, Wo, L.cgb, L.cg_total);
     return check_launch("dw_bwd_data_s2_kernel");
 }
