@@ -172,8 +172,14 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    force_dp = os.environ.get("MNY_FORCE_DP") == "1"      # run the RCCL path even with one rank (validation aid)
+    use_dp = world > 1 or force_dp
+    if use_dp:
         import torch.distributed as dist
+        if os.environ.get("NCCL_DEBUG", "").upper() in ("", "VERSION"):
+            os.environ["NCCL_DEBUG"] = "WARN"            # keep RCCL's version banner off stdout: rank 0 prints ONE JSON line
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=device)
 
     from mobilenet_yolo_pytorch_amd import synthetic, yolo
@@ -184,7 +190,7 @@ def main():
     else:
         model = yolo(synthetic.VOC_CONFIG).to(device).train()
     reducer = None
-    if world > 1:
+    if use_dp:
         from mobilenet_yolo_pytorch_amd.dp import attach_data_parallel
         reducer = attach_data_parallel(model)
     x, tg = make_batch(a.batch, rank, device, a.size)
@@ -225,7 +231,7 @@ def main():
             reducer.wait()
         torch.cuda.synchronize()
     timing = plan.disable_timing()
-    loss = float(out[0][0]) + float(out[1][0])
+    loss = float(out[0][0].detach()) + float(out[1][0].detach())
 
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -280,7 +286,7 @@ def main():
         if world == 1 and not a.no_nms:
             res["nms"] = nms_bench(device)
         print(json.dumps(res))
-    if world > 1:
+    if use_dp:
         dist.destroy_process_group()
 
 
