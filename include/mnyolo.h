@@ -93,6 +93,18 @@ int mny_pw_wgrad(const float* x, const float* in_scale, const float* in_shift, i
                  const float* dy, float* dw, float* dbias, float* ws,
                  int64_t M, int K, int Nc, void* stream);
 size_t mny_pw_wgrad_ws_floats(int64_t M, int K, int Nc);
+/* Fused BatchNorm-backward + weight gradient + data gradient of a pointwise unit whose input has <= 32 channels
+ * (the HBM-bound "expand" layers of models/mobilenetv2.py:75-77, e.g. 16->96 @176x176): replaces
+ * mny_bn_bwd_reduce/finalize/apply + mny_pw_wgrad + mny_transpose + mny_pw_fwd(dgrad) and never materialises dY
+ * (DESIGN.md §4).  g = dL/d act(scale*y+shift); x is read through its view; dx (optional) = data gradient wrt the
+ * activated input (+ addend).  ws: mny_pw_bnbwd_ws_floats() floats.  mny_pw_bnbwd_supported() tells whether a shape qualifies. */
+int mny_pw_bnbwd_supported(int64_t M, int K, int Nc);
+size_t mny_pw_bnbwd_ws_floats(int64_t M, int K, int Nc);
+int mny_pw_bnbwd(const float* g, const float* y, const float* scale, const float* shift, int act,
+                 const float* mean, const float* invstd, const float* gamma,
+                 const float* x, const float* in_scale, const float* in_shift, int in_act,
+                 const float* w, const float* addend, float* dx, float* dw, float* dgamma, float* dbeta,
+                 float* ws, int64_t M, int K, int Nc, void* stream);
 int mny_transpose(const float* src /*[R,Cc]*/, float* dst /*[Cc,R]*/, int R, int Cc, void* stream);
 
 /* ---- BatchNorm (training / eval), eps 1e-5, momentum 0.1 ---------------------------------

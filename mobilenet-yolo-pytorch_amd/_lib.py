@@ -38,6 +38,9 @@ _SIGS = {
     "mny_pw_stat_parts": (c_int, [c_int64, c_int, c_int]),
     "mny_pw_wgrad": (c_int, [P, P, P, c_int, P, P, P, P, c_int64, c_int, c_int, P]),
     "mny_pw_wgrad_ws_floats": (c_size_t, [c_int64, c_int, c_int]),
+    "mny_pw_bnbwd_supported": (c_int, [c_int64, c_int, c_int]),
+    "mny_pw_bnbwd_ws_floats": (c_size_t, [c_int64, c_int, c_int]),
+    "mny_pw_bnbwd": (c_int, [P, P, P, P, c_int, P, P, P, P, P, P, c_int, P, P, P, P, P, P, P, c_int64, c_int, c_int, P]),
     "mny_transpose": (c_int, [P, P, c_int, c_int, P]),
     "mny_bn_finalize": (c_int, [P, c_int, c_int64, P, P, c_float, c_float, P, P, P, P, P, P, c_int, P]),
     "mny_bn_eval_coeffs": (c_int, [P, P, P, P, c_float, P, P, c_int, P]),

@@ -963,6 +963,414 @@ __global__ void transpose_kernel(const float* __restrict__ src, float* __restric
 
 static int colsum_parts(int64_t M) { int64_t p = cdiv(M, 256); return (int)(p < 512 ? p : 512); }
 
+
+// ================================================================================================
+// Fused BatchNorm-backward for HBM-bound "expand" pointwise units (Cin <= 32, one 32-wide tile).
+//
+// Unit: Y = X W^T, A = act(sc*Y + sh) with batch statistics; G = dL/dA.  With dz = G*act'(sc*Y+sh) and the
+// per-channel BN-backward coefficients (ca, cb, cc):  dY = ca*dz + cb*Y + cc.  Hence
+//     dW = ca o (dz^T X) + cb o (W X^T X) + cc (x) colsum(X)          (Y^T X = W X^T X)
+//     dX = dz (ca o W) + Y (cb o W) + (cc . W)
+// so dY is never materialised and the unit's big output tensor is read 4 times instead of 7:
+//   stage 1 (one pass over G, Y, X): sum dz, sum dz*yhat, P1 = dz^T X, Gram = X^T X, colsum(X)
+//   finalize (tiny, fp64)          : dgamma, dbeta, ca/cb/cc, dW, B1 = ca o W^T, B2 = cb o W^T, bias = cc . W
+//   stage 2 (one pass over G, Y)   : dX = dz B1^T + Y B2^T + bias (+ addend)
+// Both streaming stages are LDS-DMA pipelines like the kernels above.
+// ================================================================================================
+struct BnwArgs {
+    const float* G; const float* Y; const float* sc; const float* sh; int act; const float* mean; const float* invstd;
+    const float* X; const float* xsc; const float* xsh; int xact;
+    float* partial; unsigned long long* mask;   // mask[i*npairs + m/2]: bit (m&1)*32 + c%32 = [act'(z) is the "on" value]
+    int64_t npairs; int64_t M; int K; int N; int64_t rows_per_block;
+};
+
+// partial layout per split: P1[N*K] | Gram[K*K] | s1[N] | s2[N] | s3[K]
+__host__ __device__ inline int64_t bnw_stride(int N, int K) { return (int64_t)N * K + (int64_t)K * K + 2 * N + K; }
+
+template <int TI>
+__global__ __launch_bounds__(256) void pw_bnbwd_stage1_kernel(BnwArgs p) {
+    constexpr int KC = 16, S = 3, BI = 32 * TI, BJ = 32;
+    constexpr int G_ST = KC * BI, X_ST = KC * BJ, STAGE = 2 * G_ST + X_ST;   // floats: G | Y | X
+    constexpr int NG = G_ST / 256, NX = X_ST / 256, NL = 2 * NG + NX;
+    constexpr int LPW = (NL + 3) / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, kk = lane >> 5;
+    const int64_t m_begin = (int64_t)blockIdx.x * p.rows_per_block;
+    const int64_t m_end = min(m_begin + p.rows_per_block, p.M);
+    const bool has_xf = p.xsc != nullptr;
+    const float xslope = act_slope(p.xact), xhi = act_hi(p.xact);
+    const float aslope = act_slope(p.act), ahi = act_hi(p.act);
+    const int krow0 = wave * (KC / 4);
+
+    float sc[TI], sh[TI], mu[TI], is[TI], s1[TI], s2[TI];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        const int co = i * 32 + li;
+        const bool ok = co < p.N;
+        sc[i] = ok ? p.sc[co] : 0.f; sh[i] = ok ? p.sh[co] : 0.f; mu[i] = ok ? p.mean[co] : 0.f; is[i] = ok ? p.invstd[co] : 0.f;
+        s1[i] = 0.f; s2[i] = 0.f;
+    }
+    const float xs = (has_xf && li < p.K) ? p.xsc[li] : 1.f, xh = (has_xf && li < p.K) ? p.xsh[li] : 0.f;
+    float s3 = 0.f;
+
+    const float* zero_src = reinterpret_cast<const float*>(&mny_zero16);
+    int d_row[LPW], d_lds[LPW], d_kind[LPW];
+    bool d_ok[LPW];
+    int d_off[LPW];
+#pragma unroll
+    for (int i = 0; i < LPW; ++i) {
+        int j = wave + 4 * i;
+        if (j >= NL) j = NL - 1;
+        d_kind[i] = j < NG ? 0 : (j < 2 * NG ? 1 : 2);                    // 0: G, 1: Y, 2: X
+        const int jj = d_kind[i] == 0 ? j : (d_kind[i] == 1 ? j - NG : j - 2 * NG);
+        const int q = jj * 64 + lane;
+        const int W4 = (d_kind[i] == 2 ? BJ : BI) / 4;
+        d_row[i] = q / W4;
+        const int c = (q % W4) * 4;
+        d_lds[i] = (d_kind[i] == 0 ? 0 : (d_kind[i] == 1 ? G_ST : 2 * G_ST)) + jj * 256;
+        d_ok[i] = c < (d_kind[i] == 2 ? p.K : p.N);
+        d_off[i] = c;
+    }
+    auto issue = [&](int64_t m0, int slot) {
+        float* stage = smem + slot * STAGE;
+#pragma unroll
+        for (int i = 0; i < LPW; ++i) {
+            const int64_t m = m0 + d_row[i];
+            const int64_t mc = m < m_end ? m : m_end - 1;
+            const float* src = zero_src;
+            if (d_ok[i]) {
+                if (d_kind[i] == 0) src = m < m_end ? p.G + m * p.N + d_off[i] : zero_src;   // dz = 0 past the slice
+                else if (d_kind[i] == 1) src = p.Y + mc * p.N + d_off[i];
+                else src = p.X + mc * p.K + d_off[i];
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(stage + d_lds[i]), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[TI], gram;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gram[r] = 0.f;
+
+    auto compute = [&](int64_t m0, int slot) {
+        const float* gb = smem + slot * STAGE + (krow0 + kk) * BI + li;
+        const float* yb = gb + G_ST;
+        const float* xb = smem + slot * STAGE + 2 * G_ST + (krow0 + kk) * BJ + li;
+#pragma unroll
+        for (int kp = 0; kp < KC / 8; ++kp) {
+            const bool rok = m0 + krow0 + kp * 2 + kk < m_end;
+            const float xz = fmaf(xb[kp * 2 * BJ], xs, xh);
+            const float b = rok ? fminf(fmaxf(xz, xslope * xz), xhi) : 0.f;     // rows past the slice contribute nothing
+            s3 += b;
+            float af[TI];
+            const int64_t pair = (m0 + krow0 + kp * 2) >> 1;                     // rows (2*pair, 2*pair+1) <-> kk
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                const float g = gb[kp * 2 * BI + i * 32], y = yb[kp * 2 * BI + i * 32];
+                const float z = fmaf(y, sc[i], sh[i]);
+                const bool on = z > 0.f && z < ahi;                                // act' = on ? 1 : slope
+                const unsigned long long bal = __ballot(on);
+                if (lane == 0 && m0 + krow0 + kp * 2 < m_end) p.mask[(int64_t)i * p.npairs + pair] = bal;
+                const float dz = on ? g : g * aslope;
+                s1[i] += dz;
+                s2[i] = fmaf(dz, (y - mu[i]) * is[i], s2[i]);
+                af[i] = dz;
+            }
+#pragma unroll
+            for (int i = 0; i < TI; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], b, acc[i], 0, 0, 0);
+            gram = __builtin_amdgcn_mfma_f32_32x32x2f32(b, b, gram, 0, 0, 0);
+        }
+    };
+
+    const int total = (int)((m_end - m_begin + KC - 1) / KC);
+    int i_t = 0, i_slot = 0, c_slot = 0, c_t = 0;
+    auto issue_next = [&]() { issue(m_begin + (int64_t)i_t * KC, i_slot); ++i_t; if (++i_slot == S) i_slot = 0; };
+    auto consume = [&]() { compute(m_begin + (int64_t)c_t * KC, c_slot); ++c_t; if (++c_slot == S) c_slot = 0; };
+    const int pre = total < S - 1 ? total : S - 1;
+    for (int t = 0; t < pre; ++t) issue_next();
+    for (int t = 0; t < total - pre; ++t) {
+        wait_vmcnt<LPW*(S - 2)>();
+        __builtin_amdgcn_s_barrier();
+        issue_next();
+        consume();
+    }
+    for (int t = 0; t < pre; ++t) {
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        consume();
+    }
+
+    // ---- block reduction over the 4 waves (fixed order) and the two k-halves, then one partial row
+    float* dst = p.partial + (int64_t)blockIdx.x * bnw_stride(p.N, p.K);
+    float* red = smem;                         // [3][16][64]
+    auto reduce_tile = [&](f32x16& t, float* out, int rows, int cols, int ld, int row0) {
+        __syncthreads();
+        if (wave > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((wave - 1) * 16 + r) * 64 + lane] = t[r];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = ((t[r] + red[(0 * 16 + r) * 64 + lane]) + red[(1 * 16 + r) * 64 + lane]) + red[(2 * 16 + r) * 64 + lane];
+                const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                if (row < rows && li < cols) out[(int64_t)row * ld + li] = v;
+            }
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < TI; ++i) reduce_tile(acc[i], dst, p.N, p.K, p.K, i * 32);
+    reduce_tile(gram, dst + (int64_t)p.N * p.K, p.K, p.K, p.K, 0);
+    // vectors: lanes l and l^32 hold the same channel
+    __syncthreads();
+    float* vred = smem;                        // [4][2*TI+1][32]
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        const float a = s1[i] + __shfl_xor(s1[i], 32), b2 = s2[i] + __shfl_xor(s2[i], 32);
+        if (kk == 0) { vred[(wave * (2 * TI + 1) + i) * 32 + li] = a; vred[(wave * (2 * TI + 1) + TI + i) * 32 + li] = b2; }
+    }
+    {
+        const float c3 = s3 + __shfl_xor(s3, 32);
+        if (kk == 0) vred[(wave * (2 * TI + 1) + 2 * TI) * 32 + li] = c3;
+    }
+    __syncthreads();
+    float* vdst = dst + (int64_t)p.N * p.K + (int64_t)p.K * p.K;
+    for (int e = tid; e < (2 * TI + 1) * 32; e += 256) {
+        const int v = e / 32, l = e % 32;
+        float a = 0.f;
+        for (int w = 0; w < 4; ++w) a += vred[(w * (2 * TI + 1) + v) * 32 + l];
+        if (v < TI) { const int co = v * 32 + l; if (co < p.N) vdst[co] = a; }
+        else if (v < 2 * TI) { const int co = (v - TI) * 32 + l; if (co < p.N) vdst[p.N + co] = a; }
+        else if (l < p.K) vdst[2 * p.N + l] = a;
+    }
+}
+
+// finalize: one block.  red = [P1 | Gram | s1 | s2 | s3] summed over splits.
+__global__ __launch_bounds__(256) void pw_bnbwd_finalize_kernel(const float* __restrict__ red, const float* __restrict__ W,
+                                                                const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, double count, int N, int K,
+                                                                float* __restrict__ dW, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                float* __restrict__ B1, float* __restrict__ Q, float* __restrict__ bias) {
+    extern __shared__ double sd[];             // ca[N] cb[N] cc[N]
+    double* ca = sd; double* cb = sd + N; double* cc = sd + 2 * N;
+    const float* P1 = red; const float* Gm = red + (int64_t)N * K; const float* s1 = Gm + (int64_t)K * K;
+    const float* s2 = s1 + N; const float* s3 = s2 + N;
+    for (int n = threadIdx.x; n < N; n += blockDim.x) {
+        const double a = (double)gamma[n] * (double)invstd[n];
+        const double b = -a * (double)invstd[n] * (double)s2[n] / count;
+        ca[n] = a; cb[n] = b; cc[n] = -a * (double)s1[n] / count - b * (double)mean[n];
+        dbeta[n] = s1[n]; dgamma[n] = s2[n];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < N * K; e += blockDim.x) {
+        const int n = e / K, k = e % K;
+        double wg = 0.0;
+        for (int j = 0; j < K; ++j) wg += (double)W[(int64_t)n * K + j] * (double)Gm[j * K + k];
+        dW[e] = (float)(ca[n] * (double)P1[e] + cb[n] * wg + cc[n] * (double)s3[k]);
+        B1[(int64_t)k * N + n] = (float)(ca[n] * (double)W[e]);      // [K][N]: rows = dX columns, contraction over n
+    }
+    for (int e = threadIdx.x; e < K * K; e += blockDim.x) {           // Y (cb o W) = X (W^T diag(cb) W): Q[kc][k], symmetric
+        const int kc = e / K, k = e % K;
+        double a = 0.0;
+        for (int n = 0; n < N; ++n) a += cb[n] * (double)W[(int64_t)n * K + kc] * (double)W[(int64_t)n * K + k];
+        Q[e] = (float)a;
+    }
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        double a = 0.0;
+        for (int n = 0; n < N; ++n) a += cc[n] * (double)W[(int64_t)n * K + k];
+        bias[k] = (float)a;
+    }
+}
+
+// stage 2: dX[M,Kc] = dz[M,N] B1[Kc,N]^T + act(X)[M,Kc] Q[Kc,Kc]^T + bias (+addend), dz = G * (mask ? 1 : slope).
+// Streams ONLY G (plus the 1-bit mask and the thin X).  Tile: 64 rows x 32-wide k-steps (full 128-B lines); waves
+// 2 (row halves) x 2 (k-chunk parity), summed once per tile; the last k-step of every tile is the (X, Q) product.
+struct BndArgs {
+    const float* G; const unsigned long long* mask; int act;
+    const float* X; const float* xsc; const float* xsh; int xact;
+    const float* B1; const float* Q; const float* bias; const float* addend; float* C;
+    int64_t npairs; int64_t M; int N; int Kc; int TI; int m_tiles, tiles_per_block;
+};
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void pw_bnbwd_dgrad_kernel(BndArgs p) {
+    constexpr int BMS = 64, BKD = 32, S = 3;
+    constexpr int A_ST = BMS * BKD, B_ST = 32 * BKD, STAGE = A_ST + B_ST;            // G(or X) | B1(or Q)   (12 KB)
+    constexpr int NA = A_ST / 256, NB = B_ST / 256, NL = NA + NB;                    // 8 + 4
+    constexpr int LPW = NL / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nkg = (p.N + BKD - 1) / BKD, nk = nkg + 1;                             // + the (X, Q) step
+    float* sXs = smem + S * STAGE;                                                   // [32] input-view scale / shift
+    float* sXh = sXs + 32;
+    float* xred = sXh + 32;                                                          // [2][16][64]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 1, wk = wv & 1;
+    const int lrow = lane & 31, khalf = lane >> 5;
+    if (tid < 32) {
+        sXs[tid] = (p.xsc && tid < p.Kc) ? p.xsc[tid] : (tid < p.Kc ? 1.f : 0.f);
+        sXh[tid] = (p.xsc && tid < p.Kc) ? p.xsh[tid] : 0.f;
+    }
+    const int mt_begin = blockIdx.x * p.tiles_per_block;
+    const int mt_end = min(mt_begin + p.tiles_per_block, p.m_tiles);
+    const int total = (mt_end - mt_begin) * nk;
+
+    const float* zero_src = reinterpret_cast<const float*>(&mny_zero16);
+    const int drow = lane >> 3, dpos = lane & 7;
+    int d_row[LPW], d_k[LPW], d_lds[LPW], d_kind[LPW];           // kind 0: streamed operand, 1: weights, 2: mask words
+#pragma unroll
+    for (int i = 0; i < LPW; ++i) {
+        int j = wv + 4 * i;
+        if (j >= NL) j = NL - 1;
+        d_kind[i] = j < NA ? 0 : (j < NA + NB ? 1 : 2);
+        const int jj = d_kind[i] == 0 ? j : j - NA;
+        const int row = jj * 8 + drow;
+        d_row[i] = row;
+        d_k[i] = (dpos ^ (row & 7)) * 4;
+        d_lds[i] = d_kind[i] == 2 ? A_ST + B_ST : (d_kind[i] == 0 ? 0 : A_ST) + jj * 256;
+    }
+    auto issue = [&](int mt, int kt, int slot) {
+        float* stage = smem + slot * STAGE;
+        const bool xstep = kt == nkg;
+        const int width = xstep ? p.Kc : p.N;                 // row length of the streamed operand / contraction length
+        const int k0 = xstep ? 0 : kt * BKD;
+#pragma unroll
+        for (int i = 0; i < LPW; ++i) {
+            const int k = k0 + d_k[i];
+            const bool kok = k < width;
+            const float* src;
+            if (d_kind[i] == 0) {
+                int m = mt * BMS + d_row[i];
+                if (m >= (int)p.M) m = (int)p.M - 1;
+                src = (xstep ? p.X : p.G) + (int64_t)m * width + (kok ? k : 0);
+            } else if (d_kind[i] == 1) {
+                const int n = d_row[i];
+                src = (n < p.Kc && kok) ? (xstep ? p.Q : p.B1) + (int64_t)n * width + k : zero_src;
+            } else {
+                src = zero_src;
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(stage + d_lds[i]), 16, 0, 0);
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int swz = lrow & 7;
+    const float aslope = act_slope(p.act);
+    const float xslope = act_slope(p.xact), xhi = act_hi(p.xact);
+    auto compute = [&](int mt, int kt, int slot) {
+        const float* st = smem + slot * STAGE;
+        const float* a_row = st + (wm * 32 + lrow) * BKD;
+        const float* b_row = st + A_ST + lrow * BKD;
+        const bool xstep = kt == nkg;
+        // (staging these words through the DMA ring instead was measured slower: 2.13 vs 1.74 ms on the 16->96 unit)
+        unsigned long long mw = 0ull;
+        if (!xstep) {
+            int64_t row = (int64_t)mt * BMS + wm * 32 + lrow;
+            if (row >= p.M) row = p.M - 1;
+            mw = p.mask[(int64_t)kt * p.npairs + (row >> 1)] >> ((row & 1) * 32);
+        }
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            const int chunk = (kc * 2 + wk) * 2 + khalf;
+            const int o = (chunk ^ swz) << 2;
+            float4 a = ld4(a_row + o);
+            const float4 b = ld4(b_row + o);
+            if (xstep) {
+                const float4 xs = ld4(sXs + chunk * 4), xh = ld4(sXh + chunk * 4);
+                float z;
+                z = fmaf(a.x, xs.x, xh.x); a.x = fminf(fmaxf(z, xslope * z), xhi);
+                z = fmaf(a.y, xs.y, xh.y); a.y = fminf(fmaxf(z, xslope * z), xhi);
+                z = fmaf(a.z, xs.z, xh.z); a.z = fminf(fmaxf(z, xslope * z), xhi);
+                z = fmaf(a.w, xs.w, xh.w); a.w = fminf(fmaxf(z, xslope * z), xhi);
+            } else {
+                const unsigned bits = (unsigned)(mw >> (chunk * 4)) & 15u;
+                a.x = (bits & 1u) ? a.x : a.x * aslope; a.y = (bits & 2u) ? a.y : a.y * aslope;
+                a.z = (bits & 4u) ? a.z : a.z * aslope; a.w = (bits & 8u) ? a.w : a.w * aslope;
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+        }
+    };
+    auto epilogue = [&](int mt) {
+        if (wk == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xred[(wm * 16 + r) * 64 + lane] = acc[r];
+        }
+        __syncthreads();
+        if (wk == 0) {
+            const int64_t m0 = (int64_t)mt * BMS;
+            const int col = lrow;
+            const bool cok = col < p.Kc;
+            const float bv = cok ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                float v = acc[r] + xred[(wm * 16 + r) * 64 + lane] + bv;
+                if (cok && row < p.M) {
+                    if (p.addend) v += p.addend[row * p.Kc + col];
+                    p.C[row * p.Kc + col] = v;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    };
+    __syncthreads();
+    int i_mt = mt_begin, i_kt = 0, i_slot = 0, c_mt = mt_begin, c_kt = 0, c_slot = 0;
+    auto issue_next = [&]() { issue(i_mt, i_kt, i_slot); if (++i_kt == nk) { i_kt = 0; ++i_mt; } if (++i_slot == S) i_slot = 0; };
+    auto consume = [&]() { compute(c_mt, c_kt, c_slot); if (++c_kt == nk) { epilogue(c_mt); c_kt = 0; ++c_mt; } if (++c_slot == S) c_slot = 0; };
+    const int pre = total < S - 1 ? total : S - 1;
+    for (int t = 0; t < pre; ++t) issue_next();
+    for (int t = 0; t < total - pre; ++t) {
+        wait_vmcnt<LPW*(S - 2)>();
+        __builtin_amdgcn_s_barrier();
+        issue_next();
+        consume();
+    }
+    for (int t = 0; t < pre; ++t) {
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        consume();
+    }
+}
+
+struct BnwPlan { int TI, splits; int64_t rows_per_block; size_t lds1, lds2; int gx2, tiles_per_block, m_tiles; };
+
+static bool bnw_supported(int64_t M, int K, int N) {
+    return M >= 4096 && K <= 32 && K % 4 == 0 && N % 4 == 0 && N <= 192 && N > K;
+}
+
+static BnwPlan bnw_plan(int64_t M, int K, int N) {
+    BnwPlan pl;
+    pl.TI = (int)cdiv(N, 32);
+    int64_t splits = 1024;
+    const int64_t max_splits = cdiv(M, 64);
+    if (splits > max_splits) splits = max_splits;
+    pl.rows_per_block = cdiv(cdiv(M, splits), 16) * 16;
+    pl.splits = (int)cdiv(M, pl.rows_per_block);
+    pl.lds1 = (size_t)3 * 16 * (2 * 32 * pl.TI + 32) * sizeof(float);
+    const size_t need = (size_t)4 * (2 * pl.TI + 1) * 32 * sizeof(float);
+    if (pl.lds1 < need) pl.lds1 = need;
+    if (pl.lds1 < 3 * 16 * 64 * sizeof(float)) pl.lds1 = 3 * 16 * 64 * sizeof(float);
+    pl.lds2 = (size_t)3 * (64 * 32 + 32 * 32) * sizeof(float) + 64 * sizeof(float) + 2 * 16 * 64 * sizeof(float);
+    pl.m_tiles = (int)cdiv(M, 64);
+    int gx = pl.m_tiles < 768 ? pl.m_tiles : 768;
+    pl.tiles_per_block = (int)cdiv(pl.m_tiles, gx);
+    pl.gx2 = (int)cdiv(pl.m_tiles, pl.tiles_per_block);
+    return pl;
+}
+
 }  // namespace mny
 
 using namespace mny;
@@ -1066,4 +1474,71 @@ extern "C" int mny_transpose(const float* src, float* dst, int R, int Cc, void* 
     MNY_REQUIRE(src && dst && R > 0 && Cc > 0, "transpose: bad arguments");
     hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)cdiv(Cc, 32), (unsigned)cdiv(R, 32)), dim3(32, 8), 0, (hipStream_t)stream, src, dst, R, Cc);
     return check_launch("transpose_kernel");
+}
+
+// ---- fused BN-backward + wgrad + dgrad for thin "expand" units ------------------------------------------------
+extern "C" int mny_pw_bnbwd_supported(int64_t M, int K, int Nc) { return bnw_supported(M, K, Nc) ? 1 : 0; }
+
+extern "C" size_t mny_pw_bnbwd_ws_floats(int64_t M, int K, int Nc) {
+    if (!bnw_supported(M, K, Nc)) return 0;
+    BnwPlan pl = bnw_plan(M, K, Nc);
+    // partials + reduced row + B1 + Q + bias + 1-bit activation mask (M/2 * TI 64-bit words)
+    return (size_t)(pl.splits + 1) * bnw_stride(Nc, K) + (size_t)Nc * K + (size_t)K * K + 64 + 64 + (size_t)((M / 2 + 66) / 2 * 2) * pl.TI * 2;
+}
+
+extern "C" int mny_pw_bnbwd(const float* g, const float* y, const float* scale, const float* shift, int act,
+                            const float* mean, const float* invstd, const float* gamma,
+                            const float* x, const float* in_scale, const float* in_shift, int in_act,
+                            const float* w, const float* addend, float* dx /* may be NULL: no data gradient */,
+                            float* dw, float* dgamma, float* dbeta, float* ws, int64_t M, int K, int Nc, void* stream) {
+    MNY_REQUIRE(g && y && scale && shift && mean && invstd && gamma && x && w && dw && dgamma && dbeta && ws, "pw_bnbwd: null pointer");
+    MNY_REQUIRE(bnw_supported(M, K, Nc), "pw_bnbwd: shape M=%lld K=%d N=%d not supported (need K<=32, N<=192, N>K)", (long long)M, K, Nc);
+    MNY_REQUIRE(in_act != MNY_ACT_HSWISH && in_act != MNY_ACT_HSIGMOID && act != MNY_ACT_HSWISH && act != MNY_ACT_HSIGMOID,
+                "pw_bnbwd: h-swish / h-sigmoid activations are not supported");
+    BnwPlan pl = bnw_plan(M, K, Nc);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t stride = bnw_stride(Nc, K);
+    float* red = ws + (size_t)pl.splits * stride;
+    float* B1 = red + stride;
+    float* Q = B1 + (size_t)Nc * K;
+    float* bias = Q + (size_t)K * K;
+    size_t moff = (size_t)(bias + 64 - ws);
+    moff = (moff + 15) / 16 * 16;                                      // 64-byte aligned mask words
+    unsigned long long* mask = reinterpret_cast<unsigned long long*>(ws + moff);
+    const int64_t npairs = (M / 2 + 66) / 2 * 2;                      // even (16-B aligned rows of words) + a tile of slack
+    BnwArgs a{g, y, scale, shift, act, mean, invstd, x, in_scale, in_shift, in_act, ws, mask, npairs, M, K, Nc, pl.rows_per_block};
+    dim3 grid(pl.splits), block(256);
+    static bool attr1 = false;
+    if (!attr1) {                                   // TI >= 5 needs more than 64 KB of dynamic LDS
+        if (hipFuncSetAttribute((const void*)pw_bnbwd_stage1_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ||
+            hipFuncSetAttribute((const void*)pw_bnbwd_stage1_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) {
+            set_error("pw_bnbwd: hipFuncSetAttribute failed"); return MNY_EHIP;
+        }
+        attr1 = true;
+    }
+    switch (pl.TI) {
+        case 1: hipLaunchKernelGGL((pw_bnbwd_stage1_kernel<1>), grid, block, pl.lds1, st, a); break;
+        case 2: hipLaunchKernelGGL((pw_bnbwd_stage1_kernel<2>), grid, block, pl.lds1, st, a); break;
+        case 3: hipLaunchKernelGGL((pw_bnbwd_stage1_kernel<3>), grid, block, pl.lds1, st, a); break;
+        case 4: hipLaunchKernelGGL((pw_bnbwd_stage1_kernel<4>), grid, block, pl.lds1, st, a); break;
+        case 5: hipLaunchKernelGGL((pw_bnbwd_stage1_kernel<5>), grid, block, pl.lds1, st, a); break;
+        default: hipLaunchKernelGGL((pw_bnbwd_stage1_kernel<6>), grid, block, pl.lds1, st, a); break;
+    }
+    int rc = check_launch("pw_bnbwd_stage1_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(stride, 32)), dim3(256), 0, st, ws, pl.splits, stride, red);
+    hipLaunchKernelGGL(pw_bnbwd_finalize_kernel, dim3(1), dim3(256), (size_t)3 * Nc * sizeof(double), st, red, w, gamma, mean, invstd,
+                       (double)M, Nc, K, dw, dgamma, dbeta, B1, Q, bias);
+    rc = check_launch("pw_bnbwd_finalize_kernel");
+    if (rc || !dx) return rc;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)pw_bnbwd_dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) {
+            set_error("pw_bnbwd: hipFuncSetAttribute failed"); return MNY_EHIP;
+        }
+        attr = true;
+    }
+    BndArgs d{g, mask, act, x, in_scale, in_shift, in_act, B1, Q, bias, addend, dx, npairs, M, Nc, K, pl.TI, pl.m_tiles, pl.tiles_per_block};
+    hipLaunchKernelGGL(pw_bnbwd_dgrad_kernel, dim3(pl.gx2), dim3(256), pl.lds2, st, d);
+    return check_launch("pw_bnbwd_dgrad_kernel");
 }

@@ -315,7 +315,8 @@ class NetPlan:
             shp = shape(o)
             M = shp[0] * shp[1] * shp[2]
             if nd.op in ("pw", "pwb"):
-                ws_floats = max(ws_floats, _lib.query("mny_pw_wgrad_ws_floats", M, nd.ins[0].C, o.C))
+                ws_floats = max(ws_floats, _lib.query("mny_pw_wgrad_ws_floats", M, nd.ins[0].C, o.C),
+                                _lib.query("mny_pw_bnbwd_ws_floats", M, nd.ins[0].C, o.C))
             elif nd.op == "dw":
                 ws_floats = max(ws_floats, max_parts * o.C * nd.k * nd.k)
             elif nd.op == "stem":
@@ -418,6 +419,22 @@ class NetPlan:
                             bwd.add("mny_axpy", ts.buf, None, nb, 0, nb.numel(), self.stream)
                             ts.buf, ts.shared = nb, False
                         emit(ts.buf, 1)
+                bwd.marks[o.name] = len(bwd.calls)
+                continue
+            if (nd.op == "pw" and nd.ins[0].act not in (_lib.ACT_HSWISH, _lib.ACT_HSIGMOID) and o.act not in (_lib.ACT_HSWISH, _lib.ACT_HSIGMOID)
+                    and os.environ.get("MNY_NO_BNFUSE") != "1" and _lib.query("mny_pw_bnbwd_supported", M, nd.ins[0].C, o.C) == 1):
+                # thin "expand" unit: BN-backward + wgrad + dgrad from (G, Y, X) in 4 passes, dY never materialised
+                u = self.units[o.id]
+                i = nd.ins[0]
+                xv = view(i)
+                dwv, dgv, dbv = gv(nd.conv + ".weight"), gv(nd.bn + ".weight"), gv(nd.bn + ".bias")
+                gam = P[nd.bn + ".weight"]
+                w = P[nd.conv + ".weight"]
+                contribute_kernel(i, lambda out, addend, G=G, u=u, xv=xv, w=w, gam=gam, dwv=dwv, dgv=dgv, dbv=dbv, M=M, K=i.C, Nc=o.C, act=o.act:
+                                  bwd.add("mny_pw_bnbwd", G, u.Y, u.scale, u.shift, act, u.mean, u.invstd, gam, xv[0], xv[1], xv[2], xv[3],
+                                          w, addend, out, dwv, dgv, dbv, self.ws, M, K, Nc, self.stream,
+                                          meta=dict(flops=6 * M * K * Nc, bytes=4 * (2 * 2 * M * Nc + 2 * M * K), shape="M%d K%d N%d" % (M, K, Nc))))
+                flush_shared()
                 bwd.marks[o.name] = len(bwd.calls)
                 continue
             if nd.op == "pwb":

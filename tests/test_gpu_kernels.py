@@ -193,3 +193,41 @@ def test_glue(ops):
     dst = torch.ones(1003).cuda()
     ops.axpy(v.cuda(), dst, alpha, accumulate=True)
     check(dst, 1 + 0.5 * v, 1e-6, 1e-6, "axpy")
+
+
+@pytest.mark.parametrize("M,K,Nc,act,xact", [(8192, 16, 96, 1, 0), (5000, 24, 144, 1, 0), (4100, 32, 192, 2, 1), (6000, 16, 64, 0, 1),
+                                             (4096, 32, 160, 3, 3)])
+def test_fused_bn_backward_expand_unit(ops, M, K, Nc, act, xact):
+    """dW, dgamma, dbeta, dX of conv1x1 -> BN(train) -> act from (G, Y, X) in 4 passes (no dY), vs torch autograd.
+    Tolerance 5e-4 relative to the tensor max: the decomposition sums large terms that partly cancel."""
+    acts = dict(ACTS)
+    acts[3] = torch.relu
+    x = rnd(M, K, seed=1)
+    w = rnd(Nc, K, seed=2, scale=K ** -0.5)
+    xs, xh = 1 + 0.2 * rnd(K, seed=3), 0.3 * rnd(K, seed=4)
+    gamma, beta = 1 + 0.3 * rnd(Nc, seed=5), 0.2 * rnd(Nc, seed=6)
+    xr = x.clone().requires_grad_(True)
+    wr, gr, br = w.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    a_in = acts[xact](xr * xs + xh)
+    a_in.retain_grad()
+    yv = a_in @ wr.t()
+    mu, var = yv.mean(0), yv.var(0, unbiased=False)
+    z = (yv - mu) / torch.sqrt(var + 1e-5) * gr + br
+    out = acts[act](z)
+    g = rnd(M, Nc, seed=7)
+    out.backward(g)
+    # device side: forward pieces through the regular kernels
+    xd = x.view(1, 1, M, K).cuda()
+    yd, st = ops.pw_fwd((xd, xs.cuda(), xh.cuda(), xact), w.cuda())
+    scale, shift, mean, invstd = ops.bn_finalize(st, M, gamma.cuda(), beta.cuda())
+    add = rnd(M, K, seed=8)
+    dx, dw, dgamma, dbeta = ops.pw_bnbwd(g.view(1, 1, M, Nc).cuda(), yd, scale, shift, act, mean, invstd, gamma.cuda(),
+                                         (xd, xs.cuda(), xh.cuda(), xact), w.cuda(), addend=add.view(1, 1, M, K).cuda())
+    def rel(a, b, tol, what):
+        a, b = a.detach().cpu().double().reshape(-1), b.detach().cpu().double().reshape(-1)
+        err = (a - b).abs().max().item()
+        assert err <= tol * (b.abs().max().item() + 1e-12), "%s rel err %.2e" % (what, err / (b.abs().max().item() + 1e-12))
+    rel(dw, wr.grad, 5e-4, "dW")
+    rel(dgamma, gr.grad, 5e-4, "dgamma")
+    rel(dbeta, br.grad, 5e-4, "dbeta")
+    rel(dx.view(M, K), a_in.grad + add, 5e-4, "dX")

@@ -41,6 +41,18 @@ def main():
             dy = torch.randn(1, 1, M, N, device=dev)
             ms = timeit(lambda: ops.pw_wgrad((x, sc, sh, 1), dy), reps)
         print("%s M%d K%d N%d: %.3f ms  %.1f TF/s  %.1f GB/s" % (kind, M, K, N, ms, 2 * M * K * N / ms / 1e9, 4 * (M * K + M * N) / ms / 1e6))
+    elif kind == "bnbwd":
+        M, K, N = args[:3]
+        reps = args[3] if len(args) > 3 else 10
+        x = torch.randn(1, 1, M, K, device=dev)
+        w = torch.randn(N, K, device=dev) * K ** -0.5
+        xs, xh = torch.rand(K, device=dev) + 0.5, torch.randn(K, device=dev) * 0.1
+        gamma, beta = torch.rand(N, device=dev) + 0.5, torch.randn(N, device=dev) * 0.1
+        y, st = ops.pw_fwd((x, xs, xh, 1), w)
+        scale, shift, mean, invstd = ops.bn_finalize(st, M, gamma, beta)
+        g = torch.randn(1, 1, M, N, device=dev)
+        ms = timeit(lambda: ops.pw_bnbwd(g, y, scale, shift, 1, mean, invstd, gamma, (x, xs, xh, 1), w), reps)
+        print("bnbwd M%d K%d N%d: %.3f ms  %.1f GB/s (4 passes over Y-sized tensors)" % (M, K, N, ms, 4 * (4 * M * N + 2 * M * K) / ms / 1e6))
     elif kind in ("dw", "dwplain", "dwbw", "dwbd"):
         N, H, W, C, s = args[:5]
         reps = args[5] if len(args) > 5 else 20
