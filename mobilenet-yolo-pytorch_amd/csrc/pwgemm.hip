@@ -23,6 +23,9 @@
 // and their autograd backward (convolution_backward = 57.5 % of the reference's CPU step).
 #include <stdlib.h>
 
+#include <map>
+#include <mutex>
+
 #include "common.h"
 
 namespace mny {
@@ -455,20 +458,19 @@ static size_t nt2_lds(int TN, int K, bool xf) {
     return (ring > red ? ring : red) + (xf ? 2 * Kpad * sizeof(float) : 0);
 }
 
-// resident workgroups per CU for (TN, XF) at a given dynamic-LDS size (queried once per combination)
+// resident workgroups per CU for (TN, XF) at a given dynamic-LDS size (queried once per distinct size)
 static int nt2_blocks_per_cu(int TN, int XF, size_t lds) {
-    static int cache[5][3][4];      // [TN][XF][lds bucket of 16 KB up to 64 KB]
-    int bucket = (int)((lds + 16383) / 16384) - 1;
-    if (bucket < 0) bucket = 0;
-    if (bucket > 3) bucket = 3;
-    int& c = cache[TN][XF][bucket];
-    if (c == 0) {
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)nt2_kernel(TN, XF), 256, (size_t)(bucket + 1) * 16384) != hipSuccess || nb < 1) nb = 1;
-        if (nb > 4) nb = 4;
-        c = nb;
-    }
-    return c;
+    static std::map<uint64_t, int> cache;
+    static std::mutex mu;
+    const uint64_t key = ((uint64_t)TN << 40) | ((uint64_t)XF << 32) | (uint64_t)lds;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)nt2_kernel(TN, XF), 256, lds) != hipSuccess || nb < 1) nb = 1;
+    if (nb > 4) nb = 4;
+    cache[key] = nb;
+    return nb;
 }
 
 static Nt2Plan nt2_plan(int64_t M, int K, int N, bool xf) {
