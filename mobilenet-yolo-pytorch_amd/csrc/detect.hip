@@ -382,7 +382,7 @@ __device__ __forceinline__ uint32_t desc_key(float s) {       // larger score ->
 // greedy suppression with block-parallel IoU passes, writes kept row indices to tmp[bucket_base + r].
 __global__ __launch_bounds__(256) void nms_bucket_kernel(const float* __restrict__ rows, const int32_t* __restrict__ seg_begin,
                                                          const int32_t* __restrict__ seg_count, int num_classes, double thr, int cap, int32_t* __restrict__ tmp,
-                                                         int32_t* __restrict__ bucket_base, int32_t* __restrict__ kept_count,
+                                                         float4* kbox, int32_t* __restrict__ bucket_base, int32_t* __restrict__ kept_count,
                                                          int32_t* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) unsigned char nms_smem[];
     unsigned long long* keys = (unsigned long long*)nms_smem;           // [cap2] (score key << 32 | position)
@@ -453,37 +453,81 @@ __global__ __launch_bounds__(256) void nms_bucket_kernel(const float* __restrict
             }
             __syncthreads();
         }
-    // 3. greedy suppression over the sorted order
-    if (threadIdx.x == 0) { s_next = 0; s_kept = 0; }
+    // 3. greedy suppression over the sorted order, 64 candidates at a time (identical result to the one-by-one loop):
+    //    a candidate survives iff no box KEPT from earlier tiles suppresses it (checked in parallel: candidate = lane,
+    //    the 4 waves split the kept list) and no earlier SURVIVOR of its own tile does (64x64 bitmask, resolved serially).
+    __shared__ float4 tbox[64];
+    __shared__ unsigned short tm16[64][4];
+    __shared__ int tsup[64];
+    __shared__ unsigned long long s_keepbits;
+    if (threadIdx.x == 0) s_kept = 0;
     __syncthreads();
-    while (true) {
-        __syncthreads();                                  // s_next settled (all atomicMin done)
-        const int cur = s_next;
-        if (cur >= n) break;
-        const int ri = rowidx[(unsigned)(keys[cur] & 0xFFFFFFFFull)];
-        const float* bi = rows + (int64_t)ri * 7;
-        const float ix1 = bi[0], iy1 = bi[1], ix2 = bi[2], iy2 = bi[3];
-        const float ia = (ix2 - ix1) * (iy2 - iy1);
-        __syncthreads();                                  // everyone has read s_next
-        if (threadIdx.x == 0) { tmp[bbase + s_kept] = ri; s_kept += 1; s_next = n; }
+    const int cnd = threadIdx.x & 63, part = threadIdx.x >> 6;
+    for (int tile0 = 0; tile0 < n; tile0 += 64) {
+        const int j = tile0 + cnd;
+        const bool valid = j < n;
+        int ri = 0;
+        float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) {
+            ri = rowidx[(unsigned)(keys[j] & 0xFFFFFFFFull)];
+            const float* b = rows + (int64_t)ri * 7;
+            bx = make_float4(b[0], b[1], b[2], b[3]);
+        }
+        const float aj = (bx.z - bx.x) * (bx.w - bx.y);
+        if (part == 0) { tbox[cnd] = bx; tsup[cnd] = valid ? 0 : 1; }
         __syncthreads();
-        int first_alive = n;
-        for (int j = cur + 1 + threadIdx.x; j < n; j += 256) {
-            if (dead[j]) continue;
-            const float* bj = rows + (int64_t)rowidx[(unsigned)(keys[j] & 0xFFFFFFFFull)] * 7;
-            const float xx1 = ix1 > bj[0] ? ix1 : bj[0], yy1 = iy1 > bj[1] ? iy1 : bj[1];
-            const float xx2 = ix2 < bj[2] ? ix2 : bj[2], yy2 = iy2 < bj[3] ? iy2 : bj[3];
+        const int K = s_kept;
+        bool sup = false;
+        for (int k = part; k < K; k += 4) {                       // kept boxes: same address for the whole wave (broadcast)
+            const float4 kb = kbox[bbase + k];
+            const float ia = (kb.z - kb.x) * (kb.w - kb.y);
+            const float xx1 = kb.x > bx.x ? kb.x : bx.x, yy1 = kb.y > bx.y ? kb.y : bx.y;
+            const float xx2 = kb.z < bx.z ? kb.z : bx.z, yy2 = kb.w < bx.w ? kb.w : bx.w;
             float w = xx2 - xx1; if (!(w > 0.f)) w = 0.f;
             float h = yy2 - yy1; if (!(h > 0.f)) h = 0.f;
             const float inter = w * h;
-            const float aj = (bj[2] - bj[0]) * (bj[3] - bj[1]);
             const float ovr = inter / (ia + aj - inter);
-            if ((double)ovr > thr) dead[j] = 1;
-            else if (j < first_alive) first_alive = j;
+            if ((double)ovr > thr) sup = true;
         }
-        if (first_alive < n) atomicMin(&s_next, first_alive);
+        if (sup && valid) tsup[cnd] = 1;                           // benign race: only ever set to 1
+        unsigned bits = 0;                                         // which of candidates part*16..+15 would `cnd` suppress
+        for (int q = 0; q < 16; ++q) {
+            const int o = part * 16 + q;
+            if (o <= cnd || tile0 + o >= n) continue;
+            const float4 ob = tbox[o];
+            const float ao = (ob.z - ob.x) * (ob.w - ob.y);
+            const float xx1 = bx.x > ob.x ? bx.x : ob.x, yy1 = bx.y > ob.y ? bx.y : ob.y;
+            const float xx2 = bx.z < ob.z ? bx.z : ob.z, yy2 = bx.w < ob.w ? bx.w : ob.w;
+            float w = xx2 - xx1; if (!(w > 0.f)) w = 0.f;
+            float h = yy2 - yy1; if (!(h > 0.f)) h = 0.f;
+            const float inter = w * h;
+            const float ovr = inter / (aj + ao - inter);
+            if ((double)ovr > thr) bits |= 1u << q;
+        }
+        tm16[cnd][part] = (unsigned short)bits;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long removed = 0ull, keep = 0ull;
+            const int lim = min(64, n - tile0);
+            for (int i = 0; i < lim; ++i) {
+                if (tsup[i] || ((removed >> i) & 1ull)) continue;
+                keep |= 1ull << i;
+                removed |= (unsigned long long)tm16[i][0] | ((unsigned long long)tm16[i][1] << 16) |
+                           ((unsigned long long)tm16[i][2] << 32) | ((unsigned long long)tm16[i][3] << 48);
+            }
+            s_keepbits = keep;
+        }
+        __syncthreads();
+        const unsigned long long keep = s_keepbits;
+        if (part == 0 && ((keep >> cnd) & 1ull)) {
+            const int r = K + __popcll(keep & ((1ull << cnd) - 1ull));
+            tmp[bbase + r] = ri;
+            kbox[bbase + r] = bx;
+        }
+        __syncthreads();                                           // kept boxes visible to the whole workgroup
+        if (threadIdx.x == 0) s_kept = K + __popcll(keep);
+        __syncthreads();
     }
-    __syncthreads();
     if (threadIdx.x == 0) kept_count[s * num_classes + c] = s_kept;
 }
 
@@ -584,8 +628,9 @@ static int nms_cap_for(int total) {
 
 extern "C" size_t mny_nms_ws_bytes(int S, int capacity, int num_classes) {
     if (S <= 0 || capacity < 0 || num_classes <= 0) return 0;
-    // tmp[capacity] + bucket_base[S*C] + kept_count[S*C] + prefix[S+1] + status
-    return align256((size_t)(capacity > 0 ? capacity : 1) * 4) + 2 * align256((size_t)S * num_classes * 4) + align256((size_t)(S + 1) * 4) + 256;
+    // tmp[capacity] + bucket_base[S*C] + kept_count[S*C] + prefix[S+1] + status + kept-box cache float4[capacity]
+    return align256((size_t)(capacity > 0 ? capacity : 1) * 4) + 2 * align256((size_t)S * num_classes * 4) + align256((size_t)(S + 1) * 4) + 256 +
+           align256((size_t)(capacity > 0 ? capacity : 1) * 16);
 }
 
 extern "C" size_t mny_nms_status_offset(int S, int capacity, int num_classes) {
@@ -607,6 +652,7 @@ extern "C" int mny_nms_per_class(const float* rows, const int32_t* seg_begin, co
     int32_t* kept = (int32_t*)((char*)bucket_base + align256((size_t)S * num_classes * 4));
     int32_t* prefix = (int32_t*)((char*)kept + align256((size_t)S * num_classes * 4));
     int32_t* status = (int32_t*)((char*)prefix + align256((size_t)(S + 1) * 4));   // largest bucket that did NOT fit (0 = ok)
+    float4* kbox = (float4*)((char*)status + 256);
     hipStream_t st = (hipStream_t)stream;
     const int cap = nms_cap_for(max_seg_rows > 0 && max_seg_rows < capacity ? max_seg_rows : capacity);
     const size_t lds = (size_t)cap * (8 + 4 + 1);
@@ -618,7 +664,7 @@ extern "C" int mny_nms_per_class(const float* rows, const int32_t* seg_begin, co
     }
     if (hipMemsetAsync(status, 0, 4, st) != hipSuccess) { set_error("nms: memset failed"); return MNY_EHIP; }
     hipLaunchKernelGGL(nms_bucket_kernel, dim3(S, num_classes), dim3(256), lds, st, rows, seg_begin, seg_count, num_classes, thr, cap, tmp,
-                       bucket_base, kept, status);
+                       kbox, bucket_base, kept, status);
     hipLaunchKernelGGL(nms_compact_kernel, dim3(S), dim3(256), 0, st, seg_begin, num_classes, tmp, bucket_base, kept, out_idx, out_counts);
     hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(256), 0, st, out_counts, S, prefix);
     if (out_rows)
