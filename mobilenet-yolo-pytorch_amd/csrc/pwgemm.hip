@@ -367,24 +367,74 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         }
     };
 
+    // Epilogue.  The MFMA layout gives a lane one COLUMN (16 rows of it); storing that directly is 64 four-byte
+    // stores per lane.  Instead each group of 4 accumulator registers (rows b..b+3 of the lane's column) is transposed
+    // across the lane's quad with two DPP butterfly stages, after which lane jq of a quad holds row b+jq, columns
+    // 4q..4q+3 -> one 16-byte store (4x fewer store instructions, full 128-B row segments per quad-row).
+    const bool nvec = (p.N & 3) == 0;
+    const int quad = lrow >> 2, jq = lane & 3;
     auto epilogue = [&](int mt) {
         const int64_t m0 = (int64_t)mt * BM;
+        if (!nvec) {                                              // unaligned rows (75-channel heads): scalar stores
+#pragma unroll
+            for (int u = 0; u < TN; ++u) {
+                const int col = n0 + u * 32 + lrow;
+                const bool cok = col < p.N;
+                const float bv = (p.bias && cok) ? p.bias[col] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t row = m0 + wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                    float v = acc[u][r] + bv;
+                    if (cok && row < p.M) {
+                        if (p.addend) v += p.addend[row * p.N + col];
+                        p.C[row * p.N + col] = v;
+                        s1[u] += v;
+                        s2[u] = fmaf(v, v, s2[u]);
+                    }
+                    acc[u][r] = 0.f;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < TN; ++u) {
-            const int col = n0 + u * 32 + lrow;
-            const bool cok = col < p.N;
-            const float bv = (p.bias && cok) ? p.bias[col] : 0.f;
+            const int colq = n0 + u * 32 + quad * 4;              // first of this lane's 4 output columns
+            const bool cok = colq < p.N;                          // N % 4 == 0: all four or none
+            float4 bv = f4zero();
+            if (p.bias && cok) bv = ld4(p.bias + colq);
+            if (p.stats) {                                        // column sums come from the un-transposed registers
+                const bool ccol = n0 + u * 32 + lrow < p.N;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t row = m0 + wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                float v = acc[u][r] + bv;
-                if (cok && row < p.M) {
-                    if (p.addend) v += p.addend[row * p.N + col];
-                    p.C[row * p.N + col] = v;
-                    s1[u] += v;
-                    s2[u] = fmaf(v, v, s2[u]);
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t row = m0 + wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                    if (ccol && row < p.M) { s1[u] += acc[u][r]; s2[u] = fmaf(acc[u][r], acc[u][r], s2[u]); }
                 }
-                acc[u][r] = 0.f;
+            }
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                float r0 = acc[u][gq * 4 + 0], r1 = acc[u][gq * 4 + 1], r2 = acc[u][gq * 4 + 2], r3 = acc[u][gq * 4 + 3];
+                {   // stage A: exchange with lane^1 inside the quad
+                    const bool odd = lane & 1;
+                    const float xa = odd ? r0 : r1, xb = odd ? r2 : r3;
+                    const float ya = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, xa), 0xB1, 0xF, 0xF, true));
+                    const float yb = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, xb), 0xB1, 0xF, 0xF, true));
+                    if (odd) { r0 = ya; r2 = yb; } else { r1 = ya; r3 = yb; }
+                }
+                {   // stage B: exchange with lane^2
+                    const bool hi2 = lane & 2;
+                    const float xa = hi2 ? r0 : r2, xb = hi2 ? r1 : r3;
+                    const float ya = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, xa), 0x4E, 0xF, 0xF, true));
+                    const float yb = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, xb), 0x4E, 0xF, 0xF, true));
+                    if (hi2) { r0 = ya; r1 = yb; } else { r2 = ya; r3 = yb; }
+                }
+                const int64_t row = m0 + wv * 32 + 8 * gq + 4 * khalf + jq;
+                if (cok && row < p.M) {
+                    float4 v = make_float4(r0 + bv.x, r1 + bv.y, r2 + bv.z, r3 + bv.w);
+                    if (p.addend) add4(v, ld4(p.addend + row * p.N + colq));
+                    st4(p.C + row * p.N + colq, v);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[u][gq * 4 + i] = 0.f;
             }
         }
     };
