@@ -35,7 +35,7 @@ PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
 BATCH = 256
 SIZE = 352
 
-MFMA_KERNELS = {"mny_pw_fwd", "mny_pw_wgrad"}
+MFMA_KERNELS = {"mny_pw_fwd", "mny_pw_wgrad", "mny_pw_fwd_bf16", "mny_pw_wgrad_bf16"}
 
 
 def parse():
@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--no-nms", action="store_true")
     ap.add_argument("--arch", default="mbv2", choices=["mbv2", "mbv3"], help="mbv3 = BASELINE config 4 topology (fp32 here), not the headline")
     ap.add_argument("--size", type=int, default=SIZE)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="activation storage type; bf16 = BASELINE config 4 (with --arch mbv3 --size 512), never the headline")
     ap.add_argument("--roofline-pass", choices=["inline", "after"], default="inline",
                     help="inline: bracket the MFMA kernels with HIP events inside the timed steps (eager replay); "
                          "after: time K hipGraph-replayed steps, then K more event-bracketed steps for the roofline object")
@@ -184,11 +186,12 @@ def main():
 
     from mobilenet_yolo_pytorch_amd import synthetic, yolo
     torch.manual_seed(0)                      # identical init on every rank
+    adt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
     if a.arch == "mbv3":
         from mobilenet_yolo_pytorch_amd import mbv3
-        model = mbv3.yolo(synthetic.VOC_CONFIG).to(device).train()
+        model = mbv3.yolo(synthetic.VOC_CONFIG, act_dtype=adt).to(device).train()
     else:
-        model = yolo(synthetic.VOC_CONFIG).to(device).train()
+        model = yolo(synthetic.VOC_CONFIG, act_dtype=adt).to(device).train()
     reducer = None
     if use_dp:
         from mobilenet_yolo_pytorch_amd.dp import attach_data_parallel
@@ -205,7 +208,7 @@ def main():
     for _ in range(max(a.warmup, 1)):
         out = step()
     torch.cuda.synchronize()
-    plan = model._plans[(a.batch, a.size, a.size, True)]
+    plan = model._plans[(a.batch, a.size, a.size, True) + (("bf16",) if a.dtype == "bf16" else ())]
 
     # timed region: K steps, barrier + sync on both sides; the dominant kernels are bracketed by HIP events
     inline = a.roofline_pass == "inline" or a.breakdown
@@ -270,12 +273,14 @@ def main():
                 "algorithmic_gflop_per_step": round(d["flops"] / a.steps / 1e9, 2),
                 "algorithmic_hbm_gbs": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1)}
         res = {
-            "metric": "images/sec MobileNetV2-YOLO 352x352 fwd+bwd @ bs256" if (a.arch, a.size, a.batch) == ("mbv2", SIZE, BATCH)
+            "metric": "images/sec MobileNetV2-YOLO 352x352 fwd+bwd @ bs256" if (a.arch, a.size, a.batch, a.dtype) == ("mbv2", SIZE, BATCH, "f32")
             else "images/sec %s-YOLO %dx%d fwd+bwd @ bs%d (NOT the headline config)" % (a.arch, a.size, a.size, a.batch), "value": round(world * a.batch * a.steps / dt, 2),
             "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s-YOLO %dx%d bs=%d/GPU fwd+loss+bwd fp32 (BASELINE configs[%s])" % (
-                "MobileNetV2" if a.arch == "mbv2" else "MobileNetV3", a.size, a.size, a.batch, ("1" if world == 1 else "2") if a.arch == "mbv2" else "3, fp32 instead of bf16"),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": "%s-YOLO %dx%d bs=%d/GPU fwd+loss+bwd %s (BASELINE configs[%s])" % (
+                "MobileNetV2" if a.arch == "mbv2" else "MobileNetV3", a.size, a.size, a.batch,
+                "fp32" if a.dtype == "f32" else "bf16 activation storage, fp32 weights/accumulate",
+                ("1" if world == 1 else "2") if a.arch == "mbv2" else ("3" if a.dtype == "bf16" else "3, fp32 instead of bf16")),
                        "global_batch": world * a.batch, "parallelism": "dp%d" % world,
                        "timed_region": "zero_grad + forward(net + 2 on-device YOLO losses) + backward; random-init weights",
                        "loss": round(loss, 5)},

@@ -204,6 +204,48 @@ size_t mny_nms_ws_bytes(int S, int capacity, int num_classes);
 size_t mny_nms_status_offset(int S, int capacity, int num_classes);
 size_t mny_nms_prefix_offset(int S, int capacity, int num_classes);
 
+/* ---- bf16 STORAGE twins (BASELINE config 4: MobileNetV3-YOLO 512x512 bf16) -----------------
+ * Every `mny_X_bf16` has the contract of `mny_X` above with ONE difference: the activation-sized tensors (the
+ * `void*` parameters: raw conv outputs, materialised sums, gradients wrt activations) are bf16 in HBM.  Kernels
+ * widen on load, compute and accumulate in fp32 and round once (RNE) on store; BN statistics are taken over the
+ * ROUNDED outputs (what the consumer will read).  Weights, biases, view coefficients, statistics, workspaces and
+ * parameter gradients stay fp32, so optimizers/checkpoints are unchanged.  The detection heads are converted to
+ * fp32 (mny_cvt_bf16_f32) before mny_yolo_loss / mny_yolo_decode, whose gradient re-enters through
+ * mny_cvt_f32_bf16.  Channel counts need the same alignment as the fp32 entry points (C % 4 == 0 for the
+ * stencil / elementwise kernels; any K, N for the pointwise GEMMs).                                          */
+int mny_stem_fwd_bf16(const float* x_nchw, const float* w, void* y, float* stats, int N, int H, int W, int Cout, void* stream);
+int mny_stem_wgrad_bf16(const float* x_nchw, const void* dy, float* dw, float* ws, int N, int H, int W, int Cout, void* stream);
+int mny_dw_fwd_bf16(const void* x, const float* in_scale, const float* in_shift, int in_act, const float* w, void* y,
+                    float* stats, int N, int H, int W, int C, int K, int stride, void* stream);
+int mny_dw_bwd_data_bf16(const void* dy, const float* w, const void* addend, void* dx, int N, int H, int W, int C, int K,
+                         int stride, void* stream);
+int mny_dw_bwd_weight_bf16(const void* x, const float* in_scale, const float* in_shift, int in_act, const void* dy,
+                           float* dw, float* ws, int N, int H, int W, int C, int K, int stride, void* stream);
+int mny_pw_fwd_bf16(const void* x, const float* in_scale, const float* in_shift, int in_act, const float* w,
+                    const float* bias, const void* addend, void* y, float* stats, int64_t M, int K, int Nc, void* stream);
+int mny_pw_stat_parts_bf16(int64_t M, int K, int Nc);
+int mny_pw_wgrad_bf16(const void* x, const float* in_scale, const float* in_shift, int in_act, const void* dy, float* dw,
+                      float* dbias, float* ws, int64_t M, int K, int Nc, void* stream);
+int mny_bn_bwd_reduce_bf16(const void* g, const void* y, const float* scale, const float* shift, int act, const float* mean,
+                           const float* invstd, float* red, int64_t M, int C, void* stream);
+int mny_bn_bwd_apply_bf16(const void* g, const void* y, const float* scale, const float* shift, int act, const float* coef,
+                          void* dy, int64_t M, int C, void* stream);
+int mny_add_views_bf16(const void* a, const float* a_scale, const float* a_shift, int a_act, const void* b,
+                       const float* b_scale, const float* b_shift, int b_act, const void* up, void* out, int N, int H, int W,
+                       int C, void* stream);
+int mny_mul_views_bf16(const void* a, const float* a_scale, const float* a_shift, int a_act, const void* b,
+                       const float* b_scale, const float* b_shift, int b_act, void* out, int64_t M, int C, void* stream);
+int mny_mul_views_bwd_bf16(const void* g, const void* o, const float* o_scale, const float* o_shift, int o_act,
+                           const void* addend, void* dst, int64_t M, int C, void* stream);
+int mny_partadd_up_bf16(const void* a, const float* a_scale, const float* a_shift, int a_act, const void* up, void* out,
+                        int N, int H, int W, int Ca, int Cb, void* stream);
+int mny_slice_channels_bf16(const void* src, void* dst, int accumulate, int64_t M, int Ca, int Cb, void* stream);
+int mny_upsample_bwd_bf16(const void* src, void* dst, int accumulate, int N, int H, int W, int C, void* stream);
+int mny_axpy_bf16(const void* src, const float* alpha, void* dst, int accumulate, int64_t n, void* stream);
+/* element-wise storage conversion, n elements (RNE to bf16, exact widening back) */
+int mny_cvt_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
+int mny_cvt_bf16_f32(const void* src, float* dst, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -63,6 +63,14 @@ _SIGS = {
     "mny_nms_status_offset": (c_size_t, [c_int, c_int, c_int]),
     "mny_nms_prefix_offset": (c_size_t, [c_int, c_int, c_int]),
 }
+# bf16-storage twins (activation tensors bf16, everything else as in the fp32 entry point): identical ctypes signature
+BF16_TWINS = ("mny_stem_fwd", "mny_stem_wgrad", "mny_dw_fwd", "mny_dw_bwd_data", "mny_dw_bwd_weight", "mny_pw_fwd",
+              "mny_pw_stat_parts", "mny_pw_wgrad", "mny_bn_bwd_reduce", "mny_bn_bwd_apply", "mny_add_views", "mny_mul_views",
+              "mny_mul_views_bwd", "mny_partadd_up", "mny_slice_channels", "mny_upsample_bwd", "mny_axpy")
+for _n in BF16_TWINS:
+    _SIGS[_n + "_bf16"] = _SIGS[_n]
+_SIGS["mny_cvt_f32_bf16"] = (c_int, [P, P, c_int64, P])
+_SIGS["mny_cvt_bf16_f32"] = (c_int, [P, P, c_int64, P])
 EXPORTS = tuple(_SIGS)
 
 _lib = None

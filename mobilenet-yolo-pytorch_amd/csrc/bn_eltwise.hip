@@ -57,7 +57,8 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
 }
 
 // ---- backward ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ g, const float* __restrict__ y,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ g, const T* __restrict__ y,
                                                             const float* __restrict__ scale, const float* __restrict__ shift, int act,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             float* __restrict__ red_out, int64_t M, int C, int cgb, int cg_total) {
@@ -125,9 +126,10 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
     }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ y,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ g, const T* __restrict__ y,
                                                            const float* __restrict__ scale, const float* __restrict__ shift, int act,
-                                                           const float* __restrict__ coef, float* __restrict__ dy,
+                                                           const float* __restrict__ coef, T* __restrict__ dy,
                                                            int64_t M, int C, int cgb, int cg_total) {
     const int cgl = threadIdx.x % cgb, pix = threadIdx.x / cgb, ppb = blockDim.x / cgb;
     const int cg = blockIdx.y * cgb + cgl;
@@ -149,11 +151,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 }
 
 // ---- residual add / upsample ---------------------------------------------------------------------
-__global__ __launch_bounds__(256) void add_views_kernel(const float* __restrict__ a, const float* __restrict__ a_scale,
+template <typename T>
+__global__ __launch_bounds__(256) void add_views_kernel(const T* __restrict__ a, const float* __restrict__ a_scale,
                                                         const float* __restrict__ a_shift, int a_act,
-                                                        const float* __restrict__ b, const float* __restrict__ b_scale,
+                                                        const T* __restrict__ b, const float* __restrict__ b_scale,
                                                         const float* __restrict__ b_shift, int b_act,
-                                                        const float* __restrict__ up, float* __restrict__ out,
+                                                        const T* __restrict__ up, T* __restrict__ out,
                                                         int N, int H, int W, int C, int cgb, int cg_total) {
     const int cgl = threadIdx.x % cgb, pix = threadIdx.x / cgb, ppb = blockDim.x / cgb;
     const int cg = blockIdx.y * cgb + cgl;
@@ -174,7 +177,8 @@ __global__ __launch_bounds__(256) void add_views_kernel(const float* __restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ src, float* __restrict__ dst, int accumulate,
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const T* __restrict__ src, T* __restrict__ dst, int accumulate,
                                                            int N, int H, int W, int C, int cgb, int cg_total) {
     const int cgl = threadIdx.x % cgb, pix = threadIdx.x / cgb, ppb = blockDim.x / cgb;
     const int cg = blockIdx.y * cgb + cgl;
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
     for (int64_t m = (int64_t)blockIdx.x * ppb + pix; m < M; m += (int64_t)gridDim.x * ppb) {
         const int wi = (int)(m % Wh), hi = (int)((m / Wh) % Hh);
         const int64_t n = m / ((int64_t)Wh * Hh);
-        const float* s = src + ((n * H + 2 * hi) * W + 2 * wi) * C + c;
+        const T* s = src + ((n * H + 2 * hi) * W + 2 * wi) * C + c;
         float4 o = accumulate ? ld4(dst + m * C + c) : f4zero();
         add4(o, ld4(s)); add4(o, ld4(s + C));
         add4(o, ld4(s + (int64_t)W * C)); add4(o, ld4(s + (int64_t)W * C + C));
@@ -193,8 +197,9 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
     }
 }
 
-__global__ __launch_bounds__(256) void axpy_kernel(const float* __restrict__ src, const float* __restrict__ alpha,
-                                                   float* __restrict__ dst, int accumulate, int64_t n4, int64_t n) {
+template <typename T>
+__global__ __launch_bounds__(256) void axpy_kernel(const T* __restrict__ src, const float* __restrict__ alpha,
+                                                   T* __restrict__ dst, int accumulate, int64_t n4, int64_t n) {
     const float a = alpha ? alpha[0] : 1.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         float4 v = ld4(src + i * 4);
@@ -204,13 +209,14 @@ __global__ __launch_bounds__(256) void axpy_kernel(const float* __restrict__ src
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const int64_t i = n4 * 4 + threadIdx.x;
-        dst[i] = (accumulate ? dst[i] : 0.f) + a * src[i];
+        st1(dst + i, (accumulate ? ld1(dst + i) : 0.f) + a * ld1(src + i));
     }
 }
 
 
 // ---- scalar-channel variants (C not a multiple of 4: the 10-channel SE bottleneck of MobileNetV3) ---------
-__global__ __launch_bounds__(256) void bn_bwd_reduce_c1_kernel(const float* __restrict__ g, const float* __restrict__ y,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_c1_kernel(const T* __restrict__ g, const T* __restrict__ y,
                                                                const float* __restrict__ scale, const float* __restrict__ shift, int act,
                                                                const float* __restrict__ mean, const float* __restrict__ invstd,
                                                                float* __restrict__ red_out, int64_t M, int C, int cb) {
@@ -222,8 +228,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_c1_kernel(const float* __re
     if (c < C) {
         const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
         for (int64_t m = (int64_t)blockIdx.x * ppb + pix; m < M; m += (int64_t)gridDim.x * ppb) {
-            const float yv = y[m * C + c];
-            const float dz = g[m * C + c] * act_bwd(fmaf(yv, sc, sh), act);
+            const float yv = ld1(y + m * C + c);
+            const float dz = ld1(g + m * C + c) * act_bwd(fmaf(yv, sc, sh), act);
             s1 += dz;
             s2 = fmaf(dz, (yv - mu) * is, s2);
         }
@@ -238,24 +244,26 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_c1_kernel(const float* __re
     }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_apply_c1_kernel(const float* __restrict__ g, const float* __restrict__ y,
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_c1_kernel(const T* __restrict__ g, const T* __restrict__ y,
                                                               const float* __restrict__ scale, const float* __restrict__ shift, int act,
-                                                              const float* __restrict__ coef, float* __restrict__ dy, int64_t total, int C) {
+                                                              const float* __restrict__ coef, T* __restrict__ dy, int64_t total, int C) {
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(e % C);
         const float sc = scale ? scale[c] : 1.f, sh = scale ? shift[c] : 0.f;
         const float ca = coef ? coef[c] : 1.f, cb = coef ? coef[C + c] : 0.f, cc = coef ? coef[2 * C + c] : 0.f;
-        const float yv = y[e];
-        dy[e] = fmaf(ca, g[e] * act_bwd(fmaf(yv, sc, sh), act), fmaf(cb, yv, cc));
+        const float yv = ld1(y + e);
+        st1(dy + e, fmaf(ca, ld1(g + e) * act_bwd(fmaf(yv, sc, sh), act), fmaf(cb, yv, cc)));
     }
 }
 
 // ---- per-pixel gate (MobileNetV3 "SE") and PartAdd --------------------------------------------------------
-__global__ __launch_bounds__(256) void mul_views_kernel(const float* __restrict__ a, const float* __restrict__ a_scale,
+template <typename T>
+__global__ __launch_bounds__(256) void mul_views_kernel(const T* __restrict__ a, const float* __restrict__ a_scale,
                                                         const float* __restrict__ a_shift, int a_act,
-                                                        const float* __restrict__ b, const float* __restrict__ b_scale,
+                                                        const T* __restrict__ b, const float* __restrict__ b_scale,
                                                         const float* __restrict__ b_shift, int b_act,
-                                                        const float* __restrict__ addend, float* __restrict__ out,
+                                                        const T* __restrict__ addend, T* __restrict__ out,
                                                         int64_t M, int C, int cgb, int cg_total, int bwd) {
     const int cgl = threadIdx.x % cgb, pix = threadIdx.x / cgb, ppb = blockDim.x / cgb;
     const int cg = blockIdx.y * cgb + cgl;
@@ -273,9 +281,10 @@ __global__ __launch_bounds__(256) void mul_views_kernel(const float* __restrict_
     }
 }
 
-__global__ __launch_bounds__(256) void partadd_up_kernel(const float* __restrict__ a, const float* __restrict__ a_scale,
+template <typename T>
+__global__ __launch_bounds__(256) void partadd_up_kernel(const T* __restrict__ a, const float* __restrict__ a_scale,
                                                          const float* __restrict__ a_shift, int a_act,
-                                                         const float* __restrict__ up, float* __restrict__ out,
+                                                         const T* __restrict__ up, T* __restrict__ out,
                                                          int N, int H, int W, int Ca, int Cb, int cgb, int cg_total) {
     const int cgl = threadIdx.x % cgb, pix = threadIdx.x / cgb, ppb = blockDim.x / cgb;
     const int cg = blockIdx.y * cgb + cgl;
@@ -293,7 +302,8 @@ __global__ __launch_bounds__(256) void partadd_up_kernel(const float* __restrict
     }
 }
 
-__global__ __launch_bounds__(256) void slice_channels_kernel(const float* __restrict__ src, float* __restrict__ dst, int accumulate,
+template <typename T>
+__global__ __launch_bounds__(256) void slice_channels_kernel(const T* __restrict__ src, T* __restrict__ dst, int accumulate,
                                                              int64_t M, int Ca, int Cb, int cgb, int cg_total) {
     const int cgl = threadIdx.x % cgb, pix = threadIdx.x / cgb, ppb = blockDim.x / cgb;
     const int cg = blockIdx.y * cgb + cgl;
@@ -304,6 +314,14 @@ __global__ __launch_bounds__(256) void slice_channels_kernel(const float* __rest
         add4(o, ld4(src + m * Cb + c));
         st4(dst + m * Ca + c, o);
     }
+}
+
+// ---- storage conversion at the fp32 <-> bf16 boundary (detection heads, which stay fp32) -------------------
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void cvt_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int64_t n4, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+        st4(dst + i * 4, ld4(src + i * 4));
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) st1(dst + n4 * 4 + threadIdx.x, ld1(src + n4 * 4 + threadIdx.x));
 }
 
 static inline dim3 rows_grid(int64_t M, const CgLayout& L, int cap) {
@@ -347,20 +365,29 @@ extern "C" int mny_bn_bwd_parts(int64_t M, int C) {
     return (int)rows_grid(M, L, 1024).x;
 }
 
-extern "C" int mny_bn_bwd_reduce(const float* g, const float* y, const float* scale, const float* shift, int act,
+template <typename T>
+static int bn_bwd_reduce_impl(const T* g, const T* y, const float* scale, const float* shift, int act,
                                  const float* mean, const float* invstd, float* red, int64_t M, int C, void* stream) {
     MNY_REQUIRE(g && y && scale && shift && mean && invstd && red, "bn_bwd_reduce: null pointer");
     MNY_REQUIRE(M > 0 && C > 0, "bn_bwd_reduce: bad shape M=%lld C=%d", (long long)M, C);
     if (C % 4) {
         int cb, ch, gx; c1_layout(M, C, cb, ch, gx);
         const int ppb = 256 / cb > 0 ? 256 / cb : 1;
-        hipLaunchKernelGGL(bn_bwd_reduce_c1_kernel, dim3(gx, ch), dim3(cb * ppb), 0, (hipStream_t)stream, g, y, scale, shift, act, mean, invstd, red, M, C, cb);
+        hipLaunchKernelGGL((bn_bwd_reduce_c1_kernel<T>), dim3(gx, ch), dim3(cb * ppb), 0, (hipStream_t)stream, g, y, scale, shift, act, mean, invstd, red, M, C, cb);
         return check_launch("bn_bwd_reduce_c1_kernel");
     }
     CgLayout L = make_cg_layout(C);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, rows_grid(M, L, 1024), dim3(L.threads), 0, (hipStream_t)stream, g, y, scale, shift, act,
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), rows_grid(M, L, 1024), dim3(L.threads), 0, (hipStream_t)stream, g, y, scale, shift, act,
                        mean, invstd, red, M, C, L.cgb, L.cg_total);
     return check_launch("bn_bwd_reduce_kernel");
+}
+extern "C" int mny_bn_bwd_reduce(const float* g, const float* y, const float* scale, const float* shift, int act,
+                                 const float* mean, const float* invstd, float* red, int64_t M, int C, void* stream) {
+    return bn_bwd_reduce_impl<float>(g, y, scale, shift, act, mean, invstd, red, M, C, stream);
+}
+extern "C" int mny_bn_bwd_reduce_bf16(const void* g, const void* y, const float* scale, const float* shift, int act,
+                                 const float* mean, const float* invstd, float* red, int64_t M, int C, void* stream) {
+    return bn_bwd_reduce_impl<bf16_t>((const bf16_t*)g, (const bf16_t*)y, scale, shift, act, mean, invstd, red, M, C, stream);
 }
 
 extern "C" int mny_bn_bwd_finalize(const float* red, int parts, int64_t count, const float* gamma, const float* mean,
@@ -371,82 +398,166 @@ extern "C" int mny_bn_bwd_finalize(const float* red, int parts, int64_t count, c
     return check_launch("bn_bwd_finalize_kernel");
 }
 
-extern "C" int mny_bn_bwd_apply(const float* g, const float* y, const float* scale, const float* shift, int act, const float* coef,
-                                float* dy, int64_t M, int C, void* stream) {
+template <typename T>
+static int bn_bwd_apply_impl(const T* g, const T* y, const float* scale, const float* shift, int act, const float* coef,
+                                T* dy, int64_t M, int C, void* stream) {
     MNY_REQUIRE(g && y && dy, "bn_bwd_apply: null pointer");
     MNY_REQUIRE(M > 0 && C > 0, "bn_bwd_apply: bad shape");
     if (C % 4) {
         int64_t blocks = cdiv(M * C, 256); if (blocks > 8192) blocks = 8192;
-        hipLaunchKernelGGL(bn_bwd_apply_c1_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, y, scale, shift, act, coef, dy, M * C, C);
+        hipLaunchKernelGGL((bn_bwd_apply_c1_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, y, scale, shift, act, coef, dy, M * C, C);
         return check_launch("bn_bwd_apply_c1_kernel");
     }
     CgLayout L = make_cg_layout(C);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, rows_grid(M, L, 8192), dim3(L.threads), 0, (hipStream_t)stream, g, y, scale, shift, act,
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<T>), rows_grid(M, L, 8192), dim3(L.threads), 0, (hipStream_t)stream, g, y, scale, shift, act,
                        coef, dy, M, C, L.cgb, L.cg_total);
     return check_launch("bn_bwd_apply_kernel");
 }
+extern "C" int mny_bn_bwd_apply(const float* g, const float* y, const float* scale, const float* shift, int act, const float* coef,
+                                float* dy, int64_t M, int C, void* stream) {
+    return bn_bwd_apply_impl<float>(g, y, scale, shift, act, coef, dy, M, C, stream);
+}
+extern "C" int mny_bn_bwd_apply_bf16(const void* g, const void* y, const float* scale, const float* shift, int act, const float* coef,
+                                void* dy, int64_t M, int C, void* stream) {
+    return bn_bwd_apply_impl<bf16_t>((const bf16_t*)g, (const bf16_t*)y, scale, shift, act, coef, (bf16_t*)dy, M, C, stream);
+}
 
-extern "C" int mny_add_views(const float* a, const float* a_scale, const float* a_shift, int a_act, const float* b,
-                             const float* b_scale, const float* b_shift, int b_act, const float* up, float* out, int N, int H,
+template <typename T>
+static int add_views_impl(const T* a, const float* a_scale, const float* a_shift, int a_act, const T* b,
+                             const float* b_scale, const float* b_shift, int b_act, const T* up, T* out, int N, int H,
                              int W, int C, void* stream) {
     MNY_REQUIRE(a && out, "add_views: null pointer");
     MNY_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "add_views: bad shape");
     MNY_REQUIRE(!up || (H % 2 == 0 && W % 2 == 0), "add_views: upsample operand needs even H,W");
     CgLayout L = make_cg_layout(C);
-    hipLaunchKernelGGL(add_views_kernel, rows_grid((int64_t)N * H * W, L, 8192), dim3(L.threads), 0, (hipStream_t)stream, a, a_scale,
+    hipLaunchKernelGGL((add_views_kernel<T>), rows_grid((int64_t)N * H * W, L, 8192), dim3(L.threads), 0, (hipStream_t)stream, a, a_scale,
                        a_shift, a_act, b, b_scale, b_shift, b_act, up, out, N, H, W, C, L.cgb, L.cg_total);
     return check_launch("add_views_kernel");
 }
+extern "C" int mny_add_views(const float* a, const float* a_scale, const float* a_shift, int a_act, const float* b,
+                             const float* b_scale, const float* b_shift, int b_act, const float* up, float* out, int N, int H,
+                             int W, int C, void* stream) {
+    return add_views_impl<float>(a, a_scale, a_shift, a_act, b, b_scale, b_shift, b_act, up, out, N, H, W, C, stream);
+}
+extern "C" int mny_add_views_bf16(const void* a, const float* a_scale, const float* a_shift, int a_act, const void* b,
+                             const float* b_scale, const float* b_shift, int b_act, const void* up, void* out, int N, int H,
+                             int W, int C, void* stream) {
+    return add_views_impl<bf16_t>((const bf16_t*)a, a_scale, a_shift, a_act, (const bf16_t*)b, b_scale, b_shift, b_act, (const bf16_t*)up, (bf16_t*)out, N, H, W, C, stream);
+}
 
-extern "C" int mny_upsample_bwd(const float* src, float* dst, int accumulate, int N, int H, int W, int C, void* stream) {
+template <typename T>
+static int upsample_bwd_impl(const T* src, T* dst, int accumulate, int N, int H, int W, int C, void* stream) {
     MNY_REQUIRE(src && dst && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "upsample_bwd: bad arguments");
     CgLayout L = make_cg_layout(C);
-    hipLaunchKernelGGL(upsample_bwd_kernel, rows_grid((int64_t)N * (H / 2) * (W / 2), L, 8192), dim3(L.threads), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL((upsample_bwd_kernel<T>), rows_grid((int64_t)N * (H / 2) * (W / 2), L, 8192), dim3(L.threads), 0, (hipStream_t)stream,
                        src, dst, accumulate, N, H, W, C, L.cgb, L.cg_total);
     return check_launch("upsample_bwd_kernel");
 }
+extern "C" int mny_upsample_bwd(const float* src, float* dst, int accumulate, int N, int H, int W, int C, void* stream) {
+    return upsample_bwd_impl<float>(src, dst, accumulate, N, H, W, C, stream);
+}
+extern "C" int mny_upsample_bwd_bf16(const void* src, void* dst, int accumulate, int N, int H, int W, int C, void* stream) {
+    return upsample_bwd_impl<bf16_t>((const bf16_t*)src, (bf16_t*)dst, accumulate, N, H, W, C, stream);
+}
 
-extern "C" int mny_axpy(const float* src, const float* alpha, float* dst, int accumulate, int64_t n, void* stream) {
+template <typename T>
+static int axpy_impl(const T* src, const float* alpha, T* dst, int accumulate, int64_t n, void* stream) {
     MNY_REQUIRE(src && dst && n > 0, "axpy: bad arguments");
     const int64_t n4 = n / 4;
     int64_t blocks = cdiv(n4 > 0 ? n4 : 1, 256);
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, alpha, dst, accumulate, n4, n);
+    hipLaunchKernelGGL((axpy_kernel<T>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, alpha, dst, accumulate, n4, n);
     return check_launch("axpy_kernel");
 }
-
-extern "C" int mny_mul_views(const float* a, const float* a_scale, const float* a_shift, int a_act, const float* b,
-                             const float* b_scale, const float* b_shift, int b_act, float* out, int64_t M, int C, void* stream) {
-    MNY_REQUIRE(a && b && out && M > 0 && C > 0 && C % 4 == 0, "mul_views: bad arguments");
-    CgLayout L = make_cg_layout(C);
-    hipLaunchKernelGGL(mul_views_kernel, rows_grid(M, L, 8192), dim3(L.threads), 0, (hipStream_t)stream, a, a_scale, a_shift, a_act, b, b_scale,
-                       b_shift, b_act, nullptr, out, M, C, L.cgb, L.cg_total, 0);
-    return check_launch("mul_views_kernel");
+extern "C" int mny_axpy(const float* src, const float* alpha, float* dst, int accumulate, int64_t n, void* stream) {
+    return axpy_impl<float>(src, alpha, dst, accumulate, n, stream);
+}
+extern "C" int mny_axpy_bf16(const void* src, const float* alpha, void* dst, int accumulate, int64_t n, void* stream) {
+    return axpy_impl<bf16_t>((const bf16_t*)src, alpha, (bf16_t*)dst, accumulate, n, stream);
 }
 
-extern "C" int mny_mul_views_bwd(const float* g, const float* o, const float* o_scale, const float* o_shift, int o_act,
-                                 const float* addend, float* dst, int64_t M, int C, void* stream) {
+template <typename T>
+static int mul_views_impl(const T* a, const float* a_scale, const float* a_shift, int a_act, const T* b,
+                             const float* b_scale, const float* b_shift, int b_act, T* out, int64_t M, int C, void* stream) {
+    MNY_REQUIRE(a && b && out && M > 0 && C > 0 && C % 4 == 0, "mul_views: bad arguments");
+    CgLayout L = make_cg_layout(C);
+    hipLaunchKernelGGL((mul_views_kernel<T>), rows_grid(M, L, 8192), dim3(L.threads), 0, (hipStream_t)stream, a, a_scale, a_shift, a_act, b, b_scale,
+                       b_shift, b_act, (const T*)nullptr, out, M, C, L.cgb, L.cg_total, 0);
+    return check_launch("mul_views_kernel");
+}
+extern "C" int mny_mul_views(const float* a, const float* a_scale, const float* a_shift, int a_act, const float* b,
+                             const float* b_scale, const float* b_shift, int b_act, float* out, int64_t M, int C, void* stream) {
+    return mul_views_impl<float>(a, a_scale, a_shift, a_act, b, b_scale, b_shift, b_act, out, M, C, stream);
+}
+extern "C" int mny_mul_views_bf16(const void* a, const float* a_scale, const float* a_shift, int a_act, const void* b,
+                             const float* b_scale, const float* b_shift, int b_act, void* out, int64_t M, int C, void* stream) {
+    return mul_views_impl<bf16_t>((const bf16_t*)a, a_scale, a_shift, a_act, (const bf16_t*)b, b_scale, b_shift, b_act, (bf16_t*)out, M, C, stream);
+}
+
+template <typename T>
+static int mul_views_bwd_impl(const T* g, const T* o, const float* o_scale, const float* o_shift, int o_act,
+                                 const T* addend, T* dst, int64_t M, int C, void* stream) {
     MNY_REQUIRE(g && o && dst && M > 0 && C > 0 && C % 4 == 0, "mul_views_bwd: bad arguments");
     CgLayout L = make_cg_layout(C);
-    hipLaunchKernelGGL(mul_views_kernel, rows_grid(M, L, 8192), dim3(L.threads), 0, (hipStream_t)stream, g, nullptr, nullptr, MNY_ACT_NONE, o,
+    hipLaunchKernelGGL((mul_views_kernel<T>), rows_grid(M, L, 8192), dim3(L.threads), 0, (hipStream_t)stream, g, (const float*)nullptr, (const float*)nullptr, MNY_ACT_NONE, o,
                        o_scale, o_shift, o_act, addend, dst, M, C, L.cgb, L.cg_total, 1);
     return check_launch("mul_views_kernel(bwd)");
 }
+extern "C" int mny_mul_views_bwd(const float* g, const float* o, const float* o_scale, const float* o_shift, int o_act,
+                                 const float* addend, float* dst, int64_t M, int C, void* stream) {
+    return mul_views_bwd_impl<float>(g, o, o_scale, o_shift, o_act, addend, dst, M, C, stream);
+}
+extern "C" int mny_mul_views_bwd_bf16(const void* g, const void* o, const float* o_scale, const float* o_shift, int o_act,
+                                 const void* addend, void* dst, int64_t M, int C, void* stream) {
+    return mul_views_bwd_impl<bf16_t>((const bf16_t*)g, (const bf16_t*)o, o_scale, o_shift, o_act, (const bf16_t*)addend, (bf16_t*)dst, M, C, stream);
+}
 
-extern "C" int mny_partadd_up(const float* a, const float* a_scale, const float* a_shift, int a_act, const float* up, float* out,
+template <typename T>
+static int partadd_up_impl(const T* a, const float* a_scale, const float* a_shift, int a_act, const T* up, T* out,
                               int N, int H, int W, int Ca, int Cb, void* stream) {
     MNY_REQUIRE(a && up && out && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0, "partadd_up: bad arguments");
     MNY_REQUIRE(Ca > 0 && Ca <= Cb && Ca % 4 == 0 && Cb % 4 == 0, "partadd_up: need Ca <= Cb, both multiples of 4");
     CgLayout L = make_cg_layout(Cb);
-    hipLaunchKernelGGL(partadd_up_kernel, rows_grid((int64_t)N * H * W, L, 8192), dim3(L.threads), 0, (hipStream_t)stream, a, a_scale, a_shift,
+    hipLaunchKernelGGL((partadd_up_kernel<T>), rows_grid((int64_t)N * H * W, L, 8192), dim3(L.threads), 0, (hipStream_t)stream, a, a_scale, a_shift,
                        a_act, up, out, N, H, W, Ca, Cb, L.cgb, L.cg_total);
     return check_launch("partadd_up_kernel");
 }
+extern "C" int mny_partadd_up(const float* a, const float* a_scale, const float* a_shift, int a_act, const float* up, float* out,
+                              int N, int H, int W, int Ca, int Cb, void* stream) {
+    return partadd_up_impl<float>(a, a_scale, a_shift, a_act, up, out, N, H, W, Ca, Cb, stream);
+}
+extern "C" int mny_partadd_up_bf16(const void* a, const float* a_scale, const float* a_shift, int a_act, const void* up, void* out,
+                              int N, int H, int W, int Ca, int Cb, void* stream) {
+    return partadd_up_impl<bf16_t>((const bf16_t*)a, a_scale, a_shift, a_act, (const bf16_t*)up, (bf16_t*)out, N, H, W, Ca, Cb, stream);
+}
 
-extern "C" int mny_slice_channels(const float* src, float* dst, int accumulate, int64_t M, int Ca, int Cb, void* stream) {
+template <typename T>
+static int slice_channels_impl(const T* src, T* dst, int accumulate, int64_t M, int Ca, int Cb, void* stream) {
     MNY_REQUIRE(src && dst && M > 0 && Ca > 0 && Ca <= Cb && Ca % 4 == 0 && Cb % 4 == 0, "slice_channels: bad arguments");
     CgLayout L = make_cg_layout(Ca);
-    hipLaunchKernelGGL(slice_channels_kernel, rows_grid(M, L, 8192), dim3(L.threads), 0, (hipStream_t)stream, src, dst, accumulate, M, Ca, Cb,
+    hipLaunchKernelGGL((slice_channels_kernel<T>), rows_grid(M, L, 8192), dim3(L.threads), 0, (hipStream_t)stream, src, dst, accumulate, M, Ca, Cb,
                        L.cgb, L.cg_total);
     return check_launch("slice_channels_kernel");
+}
+extern "C" int mny_slice_channels(const float* src, float* dst, int accumulate, int64_t M, int Ca, int Cb, void* stream) {
+    return slice_channels_impl<float>(src, dst, accumulate, M, Ca, Cb, stream);
+}
+extern "C" int mny_slice_channels_bf16(const void* src, void* dst, int accumulate, int64_t M, int Ca, int Cb, void* stream) {
+    return slice_channels_impl<bf16_t>((const bf16_t*)src, (bf16_t*)dst, accumulate, M, Ca, Cb, stream);
+}
+
+extern "C" int mny_cvt_f32_bf16(const float* src, void* dst, int64_t n, void* stream) {
+    MNY_REQUIRE(src && dst && n > 0, "cvt_f32_bf16: bad arguments");
+    int64_t blocks = cdiv(n / 4 > 0 ? n / 4 : 1, 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL((cvt_kernel<float, bf16_t>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n / 4, n);
+    return check_launch("cvt_kernel");
+}
+
+extern "C" int mny_cvt_bf16_f32(const void* src, float* dst, int64_t n, void* stream) {
+    MNY_REQUIRE(src && dst && n > 0, "cvt_bf16_f32: bad arguments");
+    int64_t blocks = cdiv(n / 4 > 0 ? n / 4 : 1, 256);
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL((cvt_kernel<bf16_t, float>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, dst, n / 4, n);
+    return check_launch("cvt_kernel");
 }

@@ -55,6 +55,36 @@ __device__ __forceinline__ float4 xform4(float4 v, float4 sc, float4 sh, int act
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// bf16 STORAGE type of the `*_bf16` entry points: activations / activation gradients live in HBM as bf16, every kernel
+// widens on load and rounds (RNE, v_cvt_pk_bf16_f32) on store; arithmetic, statistics and weights stay fp32.
+// ld4/st4/ld1/st1 are overloaded on the pointer type so a kernel templated on T reads the same for both.
+struct bf16_t { uint16_t v; };
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf2_t;
+    typedef __attribute__((ext_vector_type(2))) float f2_t;
+    const f2_t f = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf2_t));
+}
+__device__ __forceinline__ float4 ld4(const bf16_t* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ void st4(bf16_t* p, float4 v) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+}
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ float ld1(const bf16_t* p) { return __uint_as_float((uint32_t)p->v << 16); }
+__device__ __forceinline__ void st1(bf16_t* p, float v) { p->v = (uint16_t)(pack_bf16x2(v, 0.f) & 0xffffu); }
+// the value a consumer will read back after a store of v as T (BN statistics are taken over THESE values)
+template <typename T> __device__ __forceinline__ float stored(float v);
+template <> __device__ __forceinline__ float stored<float>(float v) { return v; }
+template <> __device__ __forceinline__ float stored<bf16_t>(float v) { return __uint_as_float(pack_bf16x2(v, 0.f) << 16); }
+template <typename T> __device__ __forceinline__ float4 stored4(float4 v) {
+    return make_float4(stored<T>(v.x), stored<T>(v.y), stored<T>(v.z), stored<T>(v.w));
+}
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ float4 f4one() { return make_float4(1.f, 1.f, 1.f, 1.f); }
 __device__ __forceinline__ void fma4(float4& acc, float4 a, float4 b) {

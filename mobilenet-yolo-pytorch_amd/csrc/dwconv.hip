@@ -36,12 +36,12 @@ __device__ __forceinline__ void load_weights(const float* __restrict__ w, int c,
 // MODE 1: backward-weight (accumulate dy * view(x) per tap)
 // XF: 0 = input used as is, 1 = scale/shift + min(max(z, slope*z), hi), 2 = scale/shift + hswish (compile-time: the
 // inner loop must stay free of control flow)
-template <int KS, int S, int MODE, int XF>
+template <typename T, int KS, int S, int MODE, int XF>
 __global__ __launch_bounds__(256) void dw_slide_kernel(
-    const float* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift, int in_act,
-    const float* __restrict__ w, int flip, const float* __restrict__ addend,
-    float* __restrict__ y,            // MODE 0: output; MODE 1: unused
-    const float* __restrict__ dy,     // MODE 1: output gradient
+    const T* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift, int in_act,
+    const float* __restrict__ w, int flip, const T* __restrict__ addend,
+    T* __restrict__ y,            // MODE 0: output; MODE 1: unused
+    const T* __restrict__ dy,     // MODE 1: output gradient
     float* __restrict__ parts,        // MODE 0: stats [grid.x][2][C] (may be null); MODE 1: [grid.x][C*KK]
     DwGeom g) {
     constexpr int P = KS / 2;
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void dw_slide_kernel(
             const int n = (int)(strip / ((int64_t)g.Wo * g.nHS));
             const int ho0 = hs * g.TH;
             const int ho1 = min(ho0 + g.TH, g.Ho);
-            const float* xn = x + (int64_t)n * g.H * g.W * g.C + c;
+            const T* xn = x + (int64_t)n * g.H * g.W * g.C + c;
             float4 win[KS][KS];
             const float slope = act_slope(in_act), hi_clip = act_hi(in_act);
             auto tap_ok = [&](int hi, int q) { const int wi = wo * S - P + q; return hi >= 0 && hi < g.H && wi >= 0 && wi < g.W; };
@@ -126,6 +126,7 @@ __global__ __launch_bounds__(256) void dw_slide_kernel(
 #pragma unroll
                         for (int q = 0; q < KS; ++q) fma4(out, win[r][q], wg[r * KS + q]);
                     st4(y + o, out);
+                    out = stored4<T>(out);                       // statistics over the values the consumer will read
                     add4(acc_s1, out);
                     fma4(acc_s2, out, out);
                 } else {
@@ -169,9 +170,9 @@ __global__ __launch_bounds__(256) void dw_slide_kernel(
 }
 
 // stride-2 backward-data as a gather over the (at most ceil(K/2)^2) contributing taps
-template <int KS>
-__global__ __launch_bounds__(256) void dw_bwd_data_s2_kernel(const float* __restrict__ dy, const float* __restrict__ w,
-                                                             const float* __restrict__ addend, float* __restrict__ dx,
+template <typename T, int KS>
+__global__ __launch_bounds__(256) void dw_bwd_data_s2_kernel(const T* __restrict__ dy, const float* __restrict__ w,
+                                                             const T* __restrict__ addend, T* __restrict__ dx,
                                                              int N, int H, int W, int C, int Ho, int Wo, int cgb, int cg_total) {
     constexpr int P = KS / 2;
     constexpr int KK = KS * KS;
@@ -213,8 +214,9 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2_kernel(const float* __rest
 //   dx[2i+1][2j  ] = dy[i][j]*w21 + dy[i+1][j]*w01
 //   dx[2i+1][2j+1] = dy[i][j]*w22 + dy[i][j+1]*w20 + dy[i+1][j]*w02 + dy[i+1][j+1]*w00
 // so the 4 loads are unconditional (clamped address, zeroed by select) and there is no control flow.
-__global__ __launch_bounds__(256) void dw_bwd_data_s2k3_kernel(const float* __restrict__ dy, const float* __restrict__ w,
-                                                               const float* __restrict__ addend, float* __restrict__ dx,
+template <typename T>
+__global__ __launch_bounds__(256) void dw_bwd_data_s2k3_kernel(const T* __restrict__ dy, const float* __restrict__ w,
+                                                               const T* __restrict__ addend, T* __restrict__ dx,
                                                                int N, int H, int W, int C, int Ho, int Wo, int cgb, int cg_total) {
     const int cgl = threadIdx.x % cgb, pix = threadIdx.x / cgb, ppb = blockDim.x / cgb;
     const int cg = blockIdx.y * cgb + cgl;
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2k3_kernel(const float* __re
     for (int64_t q = (int64_t)blockIdx.x * ppb + pix; q < nq; q += (int64_t)gridDim.x * ppb) {
         const int j = (int)(q % Wq), i = (int)((q / Wq) % Hq);
         const int64_t n = q / ((int64_t)Wq * Hq);
-        const float* dn = dy + n * Ho * Wo * C + c;
+        const T* dn = dy + n * Ho * Wo * C + c;
         const int i1 = min(i + 1, Ho - 1), j1 = min(j + 1, Wo - 1), i0 = min(i, Ho - 1), j0 = min(j, Wo - 1);
         float4 d00 = ld4(dn + ((int64_t)i0 * Wo + j0) * C), d01 = ld4(dn + ((int64_t)i0 * Wo + j1) * C);
         float4 d10 = ld4(dn + ((int64_t)i1 * Wo + j0) * C), d11 = ld4(dn + ((int64_t)i1 * Wo + j1) * C);
@@ -277,18 +279,18 @@ static int dw_geom(DwGeom& g, CgLayout& L, int& gx, int N, int H, int W, int C, 
     return MNY_OK;
 }
 
-template <int MODE>
-static int dw_launch(const float* x, const float* sc, const float* sh, int act, const float* w, int flip,
-                     const float* addend, float* y, const float* dy, float* parts,
+template <int MODE, typename T>
+static int dw_launch(const T* x, const float* sc, const float* sh, int act, const float* w, int flip,
+                     const T* addend, T* y, const T* dy, float* parts,
                      int N, int H, int W, int C, int K, int stride, hipStream_t st) {
     DwGeom g; CgLayout L; int gx;
     int rc = dw_geom(g, L, gx, N, H, W, C, K, stride);
     if (rc) return rc;
     dim3 grid(gx, L.chunks), block(L.threads);
     const int xf = (sc == nullptr && act == MNY_ACT_NONE) ? 0 : (act == MNY_ACT_HSWISH ? 2 : 1);
-#define MNY_DW(KS_, S_) do { if (xf == 0) hipLaunchKernelGGL((dw_slide_kernel<KS_, S_, MODE, 0>), grid, block, 0, st, x, sc, sh, act, w, flip, addend, y, dy, parts, g); \
-        else if (xf == 1) hipLaunchKernelGGL((dw_slide_kernel<KS_, S_, MODE, 1>), grid, block, 0, st, x, sc, sh, act, w, flip, addend, y, dy, parts, g); \
-        else hipLaunchKernelGGL((dw_slide_kernel<KS_, S_, MODE, 2>), grid, block, 0, st, x, sc, sh, act, w, flip, addend, y, dy, parts, g); } while (0)
+#define MNY_DW(KS_, S_) do { if (xf == 0) hipLaunchKernelGGL((dw_slide_kernel<T, KS_, S_, MODE, 0>), grid, block, 0, st, x, sc, sh, act, w, flip, addend, y, dy, parts, g); \
+        else if (xf == 1) hipLaunchKernelGGL((dw_slide_kernel<T, KS_, S_, MODE, 1>), grid, block, 0, st, x, sc, sh, act, w, flip, addend, y, dy, parts, g); \
+        else hipLaunchKernelGGL((dw_slide_kernel<T, KS_, S_, MODE, 2>), grid, block, 0, st, x, sc, sh, act, w, flip, addend, y, dy, parts, g); } while (0)
     if (K == 3 && stride == 1) MNY_DW(3, 1);
     else if (K == 3 && stride == 2) MNY_DW(3, 2);
     else if (K == 5 && stride == 1) MNY_DW(5, 1);
@@ -310,17 +312,27 @@ extern "C" int mny_dw_wgrad_parts(int N, int H, int W, int C, int K, int stride)
     return mny_dw_stat_parts(N, H, W, C, K, stride);
 }
 
+template <typename T>
+static int dw_fwd_impl(const T* x, const float* in_scale, const float* in_shift, int in_act, const float* w,
+                       T* y, float* stats, int N, int H, int W, int C, int K, int stride, void* stream) {
+    MNY_REQUIRE(x && w && y, "dw_fwd: null pointer");
+    return dw_launch<0, T>(x, in_scale, in_shift, in_act, w, 0, nullptr, y, nullptr, stats, N, H, W, C, K, stride, (hipStream_t)stream);
+}
 extern "C" int mny_dw_fwd(const float* x, const float* in_scale, const float* in_shift, int in_act, const float* w,
                           float* y, float* stats, int N, int H, int W, int C, int K, int stride, void* stream) {
-    MNY_REQUIRE(x && w && y, "dw_fwd: null pointer");
-    return dw_launch<0>(x, in_scale, in_shift, in_act, w, 0, nullptr, y, nullptr, stats, N, H, W, C, K, stride, (hipStream_t)stream);
+    return dw_fwd_impl<float>(x, in_scale, in_shift, in_act, w, y, stats, N, H, W, C, K, stride, stream);
+}
+extern "C" int mny_dw_fwd_bf16(const void* x, const float* in_scale, const float* in_shift, int in_act, const float* w,
+                               void* y, float* stats, int N, int H, int W, int C, int K, int stride, void* stream) {
+    return dw_fwd_impl<bf16_t>((const bf16_t*)x, in_scale, in_shift, in_act, w, (bf16_t*)y, stats, N, H, W, C, K, stride, stream);
 }
 
-extern "C" int mny_dw_bwd_data(const float* dy, const float* w, const float* addend, float* dx,
-                               int N, int H, int W, int C, int K, int stride, void* stream) {
+template <typename T>
+static int dw_bwd_data_impl(const T* dy, const float* w, const T* addend, T* dx,
+                            int N, int H, int W, int C, int K, int stride, void* stream) {
     MNY_REQUIRE(dy && w && dx, "dw_bwd_data: null pointer");
     if (stride == 1)   // transposed conv == correlation with the flipped filter
-        return dw_launch<0>(dy, nullptr, nullptr, MNY_ACT_NONE, w, 1, addend, dx, nullptr, nullptr, N, H, W, C, K, 1, (hipStream_t)stream);
+        return dw_launch<0, T>(dy, nullptr, nullptr, MNY_ACT_NONE, w, 1, addend, dx, nullptr, nullptr, N, H, W, C, K, 1, (hipStream_t)stream);
     MNY_REQUIRE(stride == 2 && (K == 3 || K == 5) && C % 4 == 0, "dw_bwd_data: unsupported K=%d stride=%d C=%d", K, stride, C);
     const int P = K / 2;
     const int Ho = (H + 2 * P - K) / 2 + 1, Wo = (W + 2 * P - K) / 2 + 1;
@@ -330,17 +342,34 @@ extern "C" int mny_dw_bwd_data(const float* dy, const float* w, const float* add
     if (K == 3) {
         int64_t wq = cdiv((int64_t)N * ((H + 1) / 2) * ((W + 1) / 2), L.ppb);
         dim3 gridq((unsigned)(wq < 8192 ? wq : 8192), L.chunks);
-        hipLaunchKernelGGL(dw_bwd_data_s2k3_kernel, gridq, block, 0, (hipStream_t)stream, dy, w, addend, dx, N, H, W, C, Ho, Wo, L.cgb, L.cg_total);
+        hipLaunchKernelGGL((dw_bwd_data_s2k3_kernel<T>), gridq, block, 0, (hipStream_t)stream, dy, w, addend, dx, N, H, W, C, Ho, Wo, L.cgb, L.cg_total);
     }
-    else hipLaunchKernelGGL((dw_bwd_data_s2_kernel<5>), grid, block, 0, (hipStream_t)stream, dy, w, addend, dx, N, H, W, C, Ho, Wo, L.cgb, L.cg_total);
+    else hipLaunchKernelGGL((dw_bwd_data_s2_kernel<T, 5>), grid, block, 0, (hipStream_t)stream, dy, w, addend, dx, N, H, W, C, Ho, Wo, L.cgb, L.cg_total);
     return check_launch("dw_bwd_data_s2_kernel");
 }
+extern "C" int mny_dw_bwd_data(const float* dy, const float* w, const float* addend, float* dx,
+                               int N, int H, int W, int C, int K, int stride, void* stream) {
+    return dw_bwd_data_impl<float>(dy, w, addend, dx, N, H, W, C, K, stride, stream);
+}
+extern "C" int mny_dw_bwd_data_bf16(const void* dy, const float* w, const void* addend, void* dx,
+                                    int N, int H, int W, int C, int K, int stride, void* stream) {
+    return dw_bwd_data_impl<bf16_t>((const bf16_t*)dy, w, (const bf16_t*)addend, (bf16_t*)dx, N, H, W, C, K, stride, stream);
+}
 
-extern "C" int mny_dw_bwd_weight(const float* x, const float* in_scale, const float* in_shift, int in_act, const float* dy,
-                                 float* dw, float* ws, int N, int H, int W, int C, int K, int stride, void* stream) {
+template <typename T>
+static int dw_bwd_weight_impl(const T* x, const float* in_scale, const float* in_shift, int in_act, const T* dy,
+                              float* dw, float* ws, int N, int H, int W, int C, int K, int stride, void* stream) {
     MNY_REQUIRE(x && dy && dw && ws, "dw_bwd_weight: null pointer");
-    int rc = dw_launch<1>(x, in_scale, in_shift, in_act, nullptr, 0, nullptr, nullptr, dy, ws, N, H, W, C, K, stride, (hipStream_t)stream);
+    int rc = dw_launch<1, T>(x, in_scale, in_shift, in_act, nullptr, 0, nullptr, nullptr, dy, ws, N, H, W, C, K, stride, (hipStream_t)stream);
     if (rc) return rc;
     const int parts = mny_dw_wgrad_parts(N, H, W, C, K, stride);
     return launch_reduce_parts(ws, parts, C * K * K, dw, (hipStream_t)stream);
+}
+extern "C" int mny_dw_bwd_weight(const float* x, const float* in_scale, const float* in_shift, int in_act, const float* dy,
+                                 float* dw, float* ws, int N, int H, int W, int C, int K, int stride, void* stream) {
+    return dw_bwd_weight_impl<float>(x, in_scale, in_shift, in_act, dy, dw, ws, N, H, W, C, K, stride, stream);
+}
+extern "C" int mny_dw_bwd_weight_bf16(const void* x, const float* in_scale, const float* in_shift, int in_act, const void* dy,
+                                      float* dw, float* ws, int N, int H, int W, int C, int K, int stride, void* stream) {
+    return dw_bwd_weight_impl<bf16_t>((const bf16_t*)x, in_scale, in_shift, in_act, (const bf16_t*)dy, dw, ws, N, H, W, C, K, stride, stream);
 }

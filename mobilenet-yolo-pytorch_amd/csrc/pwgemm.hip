@@ -34,16 +34,19 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128;
 
-struct GemmArgs {
-    const float* A; const float* in_scale; const float* in_shift; int in_act;
-    const float* B; const float* bias; const float* addend; float* C; float* stats;
+struct GemmArgs {   // A / addend / C are T* (float or bf16_t) of the kernel instantiation
+    const void* A; const float* in_scale; const float* in_shift; int in_act;
+    const float* B; const float* bias; const void* addend; void* C; float* stats;
     int64_t M; int K; int N;
     int m_tiles; int tiles_per_block;
 };
 
-template <int TN, int BK>
+template <typename T, int TN, int BK>
 __global__ __launch_bounds__(256) void pw_gemm_nt_kernel(GemmArgs p) {
     constexpr int BN = 32 * TN;
+    const T* pA = (const T*)p.A;
+    const T* pAdd = (const T*)p.addend;
+    T* pC = (T*)p.C;
     constexpr int LDP = BK + 4;   // LDS row pitch (floats): 20 / 36 -> conflict-free ds_read_b128 fragments
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                           // [2][BM][LDP]
@@ -102,9 +105,9 @@ __global__ __launch_bounds__(256) void pw_gemm_nt_kernel(GemmArgs p) {
                 const int k = k0 + kq * 4;
                 float4 v = f4zero();
                 if (m < p.M && k < p.K) {
-                    const float* src = p.A + m * p.K + k;
+                    const T* src = pA + m * p.K + k;
                     if (kvec) v = ld4(src);
-                    else { v.x = src[0]; if (k + 1 < p.K) v.y = src[1]; if (k + 2 < p.K) v.z = src[2]; if (k + 3 < p.K) v.w = src[3]; }
+                    else { v.x = ld1(src); if (k + 1 < p.K) v.y = ld1(src + 1); if (k + 2 < p.K) v.z = ld1(src + 2); if (k + 3 < p.K) v.w = ld1(src + 3); }
                     if (do_xf) {
                         v = xform4(v, ld4(sScale + k), ld4(sShift + k), p.in_act);
                         if (!kvec) { if (k + 1 >= p.K) v.y = 0.f; if (k + 2 >= p.K) v.z = 0.f; if (k + 3 >= p.K) v.w = 0.f; }
@@ -183,8 +186,9 @@ __global__ __launch_bounds__(256) void pw_gemm_nt_kernel(GemmArgs p) {
                 const int64_t row = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
                 float v = acc[t][r] + bv;
                 if (cok && row < p.M) {
-                    if (p.addend) v += p.addend[row * p.N + col];
-                    p.C[row * p.N + col] = v;
+                    if (pAdd) v += ld1(pAdd + row * p.N + col);
+                    st1(pC + row * p.N + col, v);
+                    v = stored<T>(v);
                     s1[t] += v;
                     s2[t] = fmaf(v, v, s2[t]);
                 }
@@ -585,14 +589,14 @@ static NtPlan nt_plan(int64_t M, int K, int N, bool xf = true) {
 //                     32-row chunk four ways; a fixed-order LDS reduction combines them at the end.
 // Partials [split][N][K] are then summed in a fixed order by reduce_parts_kernel (deterministic).
 // ------------------------------------------------------------------------------------------------
-struct WgradArgs {
-    const float* X; const float* in_scale; const float* in_shift; int in_act;
-    const float* dY; float* partial;
+struct WgradArgs {   // X / dY are T* of the kernel instantiation
+    const void* X; const float* in_scale; const float* in_shift; int in_act;
+    const void* dY; float* partial;
     int64_t M; int K; int N;
     int64_t rows_per_block;
 };
 
-template <int MODE, int TI, int TJ>
+template <typename T, int MODE, int TI, int TJ>
 __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgradArgs p) {
     constexpr int KC = MODE == 0 ? 16 : 32;
     constexpr int BI = (MODE == 0 ? 64 : 32) * TI;
@@ -646,9 +650,9 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgradArgs p) {
                 const int64_t m = m0 + row;
                 const int co = co0 + c;
                 if (m < m_end && co < p.N) {
-                    const float* src = p.dY + m * p.N + co;
+                    const T* src = (const T*)p.dY + m * p.N + co;
                     if (vecA) v = ld4(src);
-                    else { v.x = src[0]; if (co + 1 < p.N) v.y = src[1]; if (co + 2 < p.N) v.z = src[2]; if (co + 3 < p.N) v.w = src[3]; }
+                    else { v.x = ld1(src); if (co + 1 < p.N) v.y = ld1(src + 1); if (co + 2 < p.N) v.z = ld1(src + 2); if (co + 3 < p.N) v.w = ld1(src + 3); }
                 }
             }
             ra[i] = v;
@@ -662,9 +666,9 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgradArgs p) {
                 const int64_t m = m0 + row;
                 const int ci = ci0 + c;
                 if (m < m_end && ci < p.K) {
-                    const float* src = p.X + m * p.K + ci;
+                    const T* src = (const T*)p.X + m * p.K + ci;
                     if (vecB) v = ld4(src);
-                    else { v.x = src[0]; if (ci + 1 < p.K) v.y = src[1]; if (ci + 2 < p.K) v.z = src[2]; if (ci + 3 < p.K) v.w = src[3]; }
+                    else { v.x = ld1(src); if (ci + 1 < p.K) v.y = ld1(src + 1); if (ci + 2 < p.K) v.z = ld1(src + 2); if (ci + 3 < p.K) v.w = ld1(src + 3); }
                     if (do_xf) {
                         v = xform4(v, ld4(sScale + c), ld4(sShift + c), p.in_act);
                         if (!vecB) { if (ci + 1 >= p.K) v.y = 0.f; if (ci + 2 >= p.K) v.z = 0.f; if (ci + 3 >= p.K) v.w = 0.f; }
@@ -818,8 +822,8 @@ __global__ __launch_bounds__(256) void pw_wgrad_dma_kernel(WgradArgs p) {
         for (int i = 0; i < LPW; ++i) {
             const int64_t m = m0 + d_row[i];
             const float* src;
-            if (d_isA[i]) src = (d_ok[i] && m < m_end) ? p.dY + m * p.N + d_off[i] : zero_src;
-            else src = d_ok[i] ? p.X + (m < m_end ? m : m_end - 1) * p.K + d_off[i] : zero_src;
+            if (d_isA[i]) src = (d_ok[i] && m < m_end) ? (const float*)p.dY + m * p.N + d_off[i] : zero_src;
+            else src = d_ok[i] ? (const float*)p.X + (m < m_end ? m : m_end - 1) * p.K + d_off[i] : zero_src;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(stage + d_lds[i]), 16, 0, 0);
         }
@@ -984,7 +988,8 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restri
 }
 
 // column sums of a [M][C] matrix -> partial rows; used for the head convs' bias gradient
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ y, float* __restrict__ parts, int64_t M, int C,
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ y, float* __restrict__ parts, int64_t M, int C,
                                                      int64_t rows_per_block) {
     const int c = blockIdx.y * 64 + (threadIdx.x & 63);
     const int slot = threadIdx.x >> 6;
@@ -993,7 +998,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ y
     const int64_t m1 = min(m0 + rows_per_block, M);
     float s = 0.f;
     if (c < C)
-        for (int64_t m = m0 + slot; m < m1; m += 4) s += y[m * C + c];
+        for (int64_t m = m0 + slot; m < m1; m += 4) s += ld1(y + m * C + c);
     red[slot][threadIdx.x & 63] = s;
     __syncthreads();
     if (slot == 0 && c < C) parts[(int64_t)blockIdx.x * C + c] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
@@ -1432,6 +1437,39 @@ extern "C" int mny_pw_stat_parts(int64_t M, int K, int Nc) {
     if ((K & 3) == 0 && getenv("MNY_GEMM_V1") == nullptr) return nt2_plan(M, K, Nc, true).gx;
     return nt_plan(M, K, Nc).gx;
 }
+extern "C" int mny_pw_stat_parts_bf16(int64_t M, int K, int Nc) {
+    if (M <= 0 || K <= 0 || Nc <= 0) return MNY_EINVAL;
+    return nt_plan(M, K, Nc).gx;
+}
+
+// register-staged NT kernel (any K, any storage type)
+template <typename T>
+static int pw_fwd_v1(const T* x, const float* in_scale, const float* in_shift, int in_act, const float* w, const float* bias,
+                     const T* addend, T* y, float* stats, int64_t M, int K, int Nc, hipStream_t st) {
+    const bool xf = in_scale != nullptr || in_act != MNY_ACT_NONE;
+    NtPlan pl = nt_plan(M, K, Nc, xf);
+    MNY_REQUIRE(pl.lds <= 160 * 1024, "pw_fwd: K=%d too large for the LDS scale cache", K);
+    GemmArgs a{x, in_scale, in_shift, in_act, w, bias, addend, y, stats, M, K, Nc, pl.m_tiles, pl.tiles_per_block};
+    dim3 grid(pl.gx, pl.n_tiles), block(256);
+    static bool attr_done = false;
+    if (!attr_done) {                             // > 64 KB of dynamic LDS needs an explicit opt-in per kernel
+        const void* ks[] = {(const void*)pw_gemm_nt_kernel<T, 1, 16>, (const void*)pw_gemm_nt_kernel<T, 2, 16>, (const void*)pw_gemm_nt_kernel<T, 3, 16>,
+                            (const void*)pw_gemm_nt_kernel<T, 4, 16>, (const void*)pw_gemm_nt_kernel<T, 1, 32>, (const void*)pw_gemm_nt_kernel<T, 2, 32>,
+                            (const void*)pw_gemm_nt_kernel<T, 3, 32>, (const void*)pw_gemm_nt_kernel<T, 4, 32>};
+        for (const void* k : ks)
+            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                set_error("pw_fwd: hipFuncSetAttribute failed"); return MNY_EHIP;
+            }
+        attr_done = true;
+    }
+#define MNY_NT(TN_, B) hipLaunchKernelGGL((pw_gemm_nt_kernel<T, TN_, B>), grid, block, pl.lds, st, a)
+    switch (pl.TN * 100 + pl.BK) {
+        case 116: MNY_NT(1, 16); break; case 216: MNY_NT(2, 16); break; case 316: MNY_NT(3, 16); break; case 416: MNY_NT(4, 16); break;
+        case 132: MNY_NT(1, 32); break; case 232: MNY_NT(2, 32); break; case 332: MNY_NT(3, 32); break; default: MNY_NT(4, 32); break;
+    }
+#undef MNY_NT
+    return check_launch("pw_gemm_nt_kernel");
+}
 
 extern "C" int mny_pw_fwd(const float* x, const float* in_scale, const float* in_shift, int in_act, const float* w,
                           const float* bias, const float* addend, float* y, float* stats, int64_t M, int K, int Nc,
@@ -1451,29 +1489,17 @@ extern "C" int mny_pw_fwd(const float* x, const float* in_scale, const float* in
         hipLaunchKernelGGL(nt2_kernel(p2.TN, XF), grid2, block2, p2.lds, st, g);
         return check_launch("pw_gemm_nt_dma_kernel");
     }
-    NtPlan pl = nt_plan(M, K, Nc, xf);
-    MNY_REQUIRE(pl.lds <= 160 * 1024, "pw_fwd: K=%d too large for the LDS scale cache", K);
-    GemmArgs a{x, in_scale, in_shift, in_act, w, bias, addend, y, stats, M, K, Nc, pl.m_tiles, pl.tiles_per_block};
-    dim3 grid(pl.gx, pl.n_tiles), block(256);
-    static bool attr_done = false;
-    if (!attr_done) {                             // > 64 KB of dynamic LDS needs an explicit opt-in per kernel
-        const void* ks[] = {(const void*)pw_gemm_nt_kernel<1, 16>, (const void*)pw_gemm_nt_kernel<2, 16>, (const void*)pw_gemm_nt_kernel<3, 16>,
-                            (const void*)pw_gemm_nt_kernel<4, 16>, (const void*)pw_gemm_nt_kernel<1, 32>, (const void*)pw_gemm_nt_kernel<2, 32>,
-                            (const void*)pw_gemm_nt_kernel<3, 32>, (const void*)pw_gemm_nt_kernel<4, 32>};
-        for (const void* k : ks)
-            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-                set_error("pw_fwd: hipFuncSetAttribute failed"); return MNY_EHIP;
-            }
-        attr_done = true;
-    }
-#define MNY_NT(T, B) hipLaunchKernelGGL((pw_gemm_nt_kernel<T, B>), grid, block, pl.lds, st, a)
-    switch (pl.TN * 100 + pl.BK) {
-        case 116: MNY_NT(1, 16); break; case 216: MNY_NT(2, 16); break; case 316: MNY_NT(3, 16); break; case 416: MNY_NT(4, 16); break;
-        case 132: MNY_NT(1, 32); break; case 232: MNY_NT(2, 32); break; case 332: MNY_NT(3, 32); break; default: MNY_NT(4, 32); break;
-    }
-#undef MNY_NT
+    return pw_fwd_v1<float>(x, in_scale, in_shift, in_act, w, bias, addend, y, stats, M, K, Nc, st);
+}
 
-    return check_launch("pw_gemm_nt_kernel");
+extern "C" int mny_pw_fwd_bf16(const void* x, const float* in_scale, const float* in_shift, int in_act, const float* w,
+                               const float* bias, const void* addend, void* y, float* stats, int64_t M, int K, int Nc,
+                               void* stream) {
+    MNY_REQUIRE(x && w && y, "pw_fwd: null pointer");
+    MNY_REQUIRE(M > 0 && K > 0 && Nc > 0, "pw_fwd: empty problem");
+    MNY_REQUIRE(!(stats && bias), "pw_fwd: stats and bias are mutually exclusive");
+    return pw_fwd_v1<bf16_t>((const bf16_t*)x, in_scale, in_shift, in_act, w, bias, (const bf16_t*)addend, (bf16_t*)y, stats, M, K, Nc,
+                             (hipStream_t)stream);
 }
 
 extern "C" size_t mny_pw_wgrad_ws_floats(int64_t M, int K, int Nc) {
@@ -1482,8 +1508,9 @@ extern "C" size_t mny_pw_wgrad_ws_floats(int64_t M, int K, int Nc) {
     return (size_t)pl.splits * Nc * K + (size_t)colsum_parts(M) * Nc;
 }
 
-extern "C" int mny_pw_wgrad(const float* x, const float* in_scale, const float* in_shift, int in_act, const float* dy,
-                            float* dw, float* dbias, float* ws, int64_t M, int K, int Nc, void* stream) {
+template <typename T>
+static int pw_wgrad_impl(const T* x, const float* in_scale, const float* in_shift, int in_act, const T* dy,
+                         float* dw, float* dbias, float* ws, int64_t M, int K, int Nc, void* stream) {
     MNY_REQUIRE(x && dy && dw && ws, "pw_wgrad: null pointer");
     MNY_REQUIRE(M > 0 && K > 0 && Nc > 0, "pw_wgrad: empty problem");
     WgPlan pl = wg_plan(M, K, Nc);
@@ -1491,10 +1518,11 @@ extern "C" int mny_pw_wgrad(const float* x, const float* in_scale, const float* 
     dim3 grid(pl.gx, pl.gy, pl.splits), block(256);
     hipStream_t st = (hipStream_t)stream;
     static const bool force_v1 = getenv("MNY_WGRAD_V1") != nullptr;
-    WgKernel dk = ((Nc & 3) == 0 && (K & 3) == 0 && in_act != MNY_ACT_HSWISH && !force_v1) ? wg_dma_kernel(pl.mode, pl.TI, pl.TJ) : nullptr;
+    constexpr bool is_f32 = sizeof(T) == 4;      // the LDS-DMA kernel reads raw fp32 chunks
+    WgKernel dk = (is_f32 && (Nc & 3) == 0 && (K & 3) == 0 && in_act != MNY_ACT_HSWISH && !force_v1) ? wg_dma_kernel(pl.mode, pl.TI, pl.TJ) : nullptr;
     const int key = dk ? -1 : pl.mode * 100 + pl.TI * 10 + pl.TJ;
     if (dk) hipLaunchKernelGGL(dk, grid, block, pl.lds_dma, st, a);
-#define MNY_WG(MD, I, J) hipLaunchKernelGGL((pw_wgrad_kernel<MD, I, J>), grid, block, pl.lds, st, a)
+#define MNY_WG(MD, I, J) hipLaunchKernelGGL((pw_wgrad_kernel<T, MD, I, J>), grid, block, pl.lds, st, a)
     switch (key) {
         case -1: break;
         case 11: MNY_WG(0, 1, 1); break; case 12: MNY_WG(0, 1, 2); break; case 21: MNY_WG(0, 2, 1); break; case 22: MNY_WG(0, 2, 2); break;
@@ -1515,11 +1543,19 @@ extern "C" int mny_pw_wgrad(const float* x, const float* in_scale, const float* 
         const int parts = colsum_parts(M);
         float* cs = ws + (size_t)pl.splits * Nc * K;
         const int64_t rpb = cdiv(M, parts);
-        hipLaunchKernelGGL(colsum_kernel, dim3(parts, (unsigned)cdiv(Nc, 64)), dim3(256), 0, st, dy, cs, M, Nc, rpb);
+        hipLaunchKernelGGL((colsum_kernel<T>), dim3(parts, (unsigned)cdiv(Nc, 64)), dim3(256), 0, st, dy, cs, M, Nc, rpb);
         hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(Nc, 32)), dim3(256), 0, st, cs, parts, (int64_t)Nc, dbias);
         rc = check_launch("colsum");
     }
     return rc;
+}
+extern "C" int mny_pw_wgrad(const float* x, const float* in_scale, const float* in_shift, int in_act, const float* dy,
+                            float* dw, float* dbias, float* ws, int64_t M, int K, int Nc, void* stream) {
+    return pw_wgrad_impl<float>(x, in_scale, in_shift, in_act, dy, dw, dbias, ws, M, K, Nc, stream);
+}
+extern "C" int mny_pw_wgrad_bf16(const void* x, const float* in_scale, const float* in_shift, int in_act, const void* dy,
+                                 float* dw, float* dbias, float* ws, int64_t M, int K, int Nc, void* stream) {
+    return pw_wgrad_impl<bf16_t>((const bf16_t*)x, in_scale, in_shift, in_act, (const bf16_t*)dy, dw, dbias, ws, M, K, Nc, stream);
 }
 
 extern "C" int mny_transpose(const float* src, float* dst, int R, int Cc, void* stream) {

@@ -12,9 +12,9 @@ namespace mny {
 
 struct StemGeom { int N, H, W, Ho, Wo, Cout, cgb, ppb; int64_t npix; };
 
-template <int MODE>   // 0: forward (+stats), 1: weight gradient
+template <typename T, int MODE>   // 0: forward (+stats), 1: weight gradient
 __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                   float* __restrict__ y, const float* __restrict__ dy,
+                                                   T* __restrict__ y, const T* __restrict__ dy,
                                                    float* __restrict__ parts, StemGeom g) {
     __shared__ float4 wl[27 * 64];      // [tap][cg] (Cout <= 256)
     __shared__ float4 red[256 * 2];
@@ -59,6 +59,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
                 o.z = fmaf(in[t], wv.z, o.z); o.w = fmaf(in[t], wv.w, o.w);
             }
             st4(y + p * g.Cout + c, o);
+            o = stored4<T>(o);
             add4(s1, o);
             fma4(s2, o, o);
         } else {
@@ -103,9 +104,9 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
 // Requires (Cout/4) to divide 256 (Cout = 16, 32, 64 ...).
 constexpr int ST_TH = 8, ST_TW = 32, ST_IH = 2 * ST_TH + 1, ST_IW = 2 * ST_TW + 1, ST_IWP = ST_IW + 1;
 
-template <int MODE>
+template <typename T, int MODE>
 __global__ __launch_bounds__(256) void stem_tile_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                        float* __restrict__ y, const float* __restrict__ dy,
+                                                        T* __restrict__ y, const T* __restrict__ dy,
                                                         float* __restrict__ parts, StemGeom g, int tiles_h, int tiles_w) {
     __shared__ float tile[3 * ST_IH * ST_IWP];
     __shared__ float4 red[256 * 2];
@@ -156,6 +157,7 @@ __global__ __launch_bounds__(256) void stem_tile_kernel(const float* __restrict_
                             acc.x = fmaf(v, ww.x, acc.x); acc.y = fmaf(v, ww.y, acc.y); acc.z = fmaf(v, ww.z, acc.z); acc.w = fmaf(v, ww.w, acc.w);
                         }
                 st4(y + o, acc);
+                acc = stored4<T>(acc);
                 add4(s1, acc);
                 fma4(s2, acc, acc);
             } else {
@@ -226,31 +228,45 @@ extern "C" int mny_stem_stat_parts(int N, int H, int W, int Cout) {
 }
 extern "C" int mny_stem_wgrad_parts(int N, int H, int W, int Cout) { return mny_stem_stat_parts(N, H, W, Cout); }
 
-extern "C" int mny_stem_fwd(const float* x_nchw, const float* w, float* y, float* stats, int N, int H, int W, int Cout, void* stream) {
+template <typename T>
+static int stem_fwd_impl(const float* x_nchw, const float* w, T* y, float* stats, int N, int H, int W, int Cout, void* stream) {
     MNY_REQUIRE(x_nchw && w && y, "stem_fwd: null pointer");
     StemGeom g; int gx;
     int rc = stem_geom(g, gx, N, H, W, Cout);
     if (rc) return rc;
     if (stem_tiled_ok(Cout)) {
-        hipLaunchKernelGGL((stem_tile_kernel<0>), dim3(gx), dim3(256), 0, (hipStream_t)stream, x_nchw, w, y, nullptr, stats, g,
+        hipLaunchKernelGGL((stem_tile_kernel<T, 0>), dim3(gx), dim3(256), 0, (hipStream_t)stream, x_nchw, w, y, (const T*)nullptr, stats, g,
                            (int)cdiv(g.Ho, ST_TH), (int)cdiv(g.Wo, ST_TW));
         return check_launch("stem_tile_kernel<fwd>");
     }
-    hipLaunchKernelGGL((stem_kernel<0>), dim3(gx), dim3(g.cgb * g.ppb), 0, (hipStream_t)stream, x_nchw, w, y, nullptr, stats, g);
+    hipLaunchKernelGGL((stem_kernel<T, 0>), dim3(gx), dim3(g.cgb * g.ppb), 0, (hipStream_t)stream, x_nchw, w, y, (const T*)nullptr, stats, g);
     return check_launch("stem_kernel<fwd>");
 }
+extern "C" int mny_stem_fwd(const float* x_nchw, const float* w, float* y, float* stats, int N, int H, int W, int Cout, void* stream) {
+    return stem_fwd_impl<float>(x_nchw, w, y, stats, N, H, W, Cout, stream);
+}
+extern "C" int mny_stem_fwd_bf16(const float* x_nchw, const float* w, void* y, float* stats, int N, int H, int W, int Cout, void* stream) {
+    return stem_fwd_impl<bf16_t>(x_nchw, w, (bf16_t*)y, stats, N, H, W, Cout, stream);
+}
 
-extern "C" int mny_stem_wgrad(const float* x_nchw, const float* dy, float* dw, float* ws, int N, int H, int W, int Cout, void* stream) {
+template <typename T>
+static int stem_wgrad_impl(const float* x_nchw, const T* dy, float* dw, float* ws, int N, int H, int W, int Cout, void* stream) {
     MNY_REQUIRE(x_nchw && dy && dw && ws, "stem_wgrad: null pointer");
     StemGeom g; int gx;
     int rc = stem_geom(g, gx, N, H, W, Cout);
     if (rc) return rc;
     if (stem_tiled_ok(Cout))
-        hipLaunchKernelGGL((stem_tile_kernel<1>), dim3(gx), dim3(256), 0, (hipStream_t)stream, x_nchw, nullptr, nullptr, dy, ws, g,
+        hipLaunchKernelGGL((stem_tile_kernel<T, 1>), dim3(gx), dim3(256), 0, (hipStream_t)stream, x_nchw, (const float*)nullptr, (T*)nullptr, dy, ws, g,
                            (int)cdiv(g.Ho, ST_TH), (int)cdiv(g.Wo, ST_TW));
     else
-        hipLaunchKernelGGL((stem_kernel<1>), dim3(gx), dim3(g.cgb * g.ppb), 0, (hipStream_t)stream, x_nchw, nullptr, nullptr, dy, ws, g);
+        hipLaunchKernelGGL((stem_kernel<T, 1>), dim3(gx), dim3(g.cgb * g.ppb), 0, (hipStream_t)stream, x_nchw, (const float*)nullptr, (T*)nullptr, dy, ws, g);
     rc = check_launch("stem_kernel<wgrad>");
     if (rc) return rc;
     return launch_reduce_parts(ws, gx, Cout * 27, dw, (hipStream_t)stream);
+}
+extern "C" int mny_stem_wgrad(const float* x_nchw, const float* dy, float* dw, float* ws, int N, int H, int W, int Cout, void* stream) {
+    return stem_wgrad_impl<float>(x_nchw, dy, dw, ws, N, H, W, Cout, stream);
+}
+extern "C" int mny_stem_wgrad_bf16(const float* x_nchw, const void* dy, float* dw, float* ws, int N, int H, int W, int Cout, void* stream) {
+    return stem_wgrad_impl<bf16_t>(x_nchw, (const bf16_t*)dy, dw, ws, N, H, W, Cout, stream);
 }

@@ -84,10 +84,17 @@ class _Unit:
 
 
 class NetPlan:
-    def __init__(self, net, N, H, W, training):
+    def __init__(self, net, N, H, W, training, act_dtype=torch.float32):
         self.net, self.N, self.H, self.W, self.training = net, N, H, W, training
         dev = net.device
         self.dev = dev
+        # storage type of activations / activation gradients.  bf16 selects the `*_bf16` twins of the entry points
+        # (same arithmetic in fp32 registers, half the HBM bytes); weights, BN statistics, parameter gradients and the
+        # detection heads seen by loss / decode stay fp32.
+        assert act_dtype in (torch.float32, torch.bfloat16), act_dtype
+        self.adt = act_dtype
+        self.bf16 = act_dtype == torch.bfloat16
+        self.eb = 2 if self.bf16 else 4
         assert H % 32 == 0 and W % 32 == 0, "input height/width must be multiples of 32 (got %dx%d)" % (H, W)
         g = net.graph
         self.stream = _vp(0)
@@ -102,9 +109,13 @@ class NetPlan:
         self.eager_steps = 0
         self.x_static = None
         self.fwd = CallList()
+        self.head32 = {}         # bf16 storage: value id -> fp32 copy of a detection head
         self.units = {}          # value id -> _Unit
         self.reals = {}          # value id -> tensor
         f32 = dict(device=dev, dtype=torch.float32)
+        act = dict(device=dev, dtype=self.adt)
+        K = self.K
+        eb = self.eb
         max_parts = _lib.query("mny_max_parts")
         maxC = max(v.C for v in g.values)
         self.stats_ws = torch.empty(max_parts * 2 * maxC, **f32)
@@ -128,7 +139,7 @@ class NetPlan:
             M = shp[0] * shp[1] * shp[2]
             if nd.op in ("stem", "dw", "pw"):
                 u = _Unit()
-                u.Y = torch.empty(shp, **f32)
+                u.Y = torch.empty(shp, **act)
                 u.coef4 = torch.empty(4, o.C, **f32)
                 u.scale, u.shift, u.mean, u.invstd = u.coef4[0], u.coef4[1], u.coef4[2], u.coef4[3]
                 u.act, u.C, u.M, u.shape = o.act, o.C, M, shp
@@ -137,22 +148,22 @@ class NetPlan:
                 stats = self.stats_ws if training else None
                 if nd.op == "stem":
                     parts = _lib.query("mny_stem_stat_parts", N, H, W, o.C)
-                    self.fwd.add("mny_stem_fwd", self.x_ptr, w, u.Y, stats, N, H, W, o.C, self.stream,
-                                 meta=dict(flops=2 * M * o.C * 27, bytes=4 * (N * 3 * H * W + M * o.C)))
+                    self.fwd.add(K("mny_stem_fwd"), self.x_ptr, w, u.Y, stats, N, H, W, o.C, self.stream,
+                                 meta=dict(flops=2 * M * o.C * 27, bytes=4 * N * 3 * H * W + eb * M * o.C))
                 elif nd.op == "dw":
                     i = nd.ins[0]
                     ish = shape(i)
                     xv = view(i)
                     parts = _lib.query("mny_dw_stat_parts", N, ish[1], ish[2], o.C, nd.k, nd.stride)
-                    self.fwd.add("mny_dw_fwd", xv[0], xv[1], xv[2], xv[3], w, u.Y, stats, N, ish[1], ish[2], o.C, nd.k, nd.stride, self.stream,
-                                 meta=dict(flops=2 * M * o.C * nd.k * nd.k, bytes=4 * (N * ish[1] * ish[2] * o.C + M * o.C + o.C * nd.k * nd.k),
+                    self.fwd.add(K("mny_dw_fwd"), xv[0], xv[1], xv[2], xv[3], w, u.Y, stats, N, ish[1], ish[2], o.C, nd.k, nd.stride, self.stream,
+                                 meta=dict(flops=2 * M * o.C * nd.k * nd.k, bytes=eb * (N * ish[1] * ish[2] * o.C + M * o.C) + 4 * o.C * nd.k * nd.k,
                                            shape="C%d H%d s%d" % (o.C, ish[1], nd.stride)))
                 else:
                     i = nd.ins[0]
                     xv = view(i)
-                    parts = _lib.query("mny_pw_stat_parts", M, i.C, o.C)
-                    self.fwd.add("mny_pw_fwd", xv[0], xv[1], xv[2], xv[3], w, None, None, u.Y, stats, M, i.C, o.C, self.stream,
-                                 meta=dict(flops=2 * M * i.C * o.C, bytes=4 * (M * i.C + M * o.C + i.C * o.C), shape="M%d K%d N%d" % (M, i.C, o.C)))
+                    parts = _lib.query(K("mny_pw_stat_parts"), M, i.C, o.C)
+                    self.fwd.add(K("mny_pw_fwd"), xv[0], xv[1], xv[2], xv[3], w, None, None, u.Y, stats, M, i.C, o.C, self.stream,
+                                 meta=dict(flops=2 * M * i.C * o.C, bytes=eb * (M * i.C + M * o.C) + 4 * i.C * o.C, shape="M%d K%d N%d" % (M, i.C, o.C)))
                 gam, bet = P[nd.bn + ".weight"], P[nd.bn + ".bias"]
                 rm, rv = P[nd.bn + ".running_mean"], P[nd.bn + ".running_var"]
                 if training:
@@ -163,10 +174,14 @@ class NetPlan:
             elif nd.op == "pwb":
                 i = nd.ins[0]
                 xv = view(i)
-                t = torch.empty(shp, **f32)
+                t = torch.empty(shp, **act)
                 self.reals[o.id] = t
-                self.fwd.add("mny_pw_fwd", xv[0], xv[1], xv[2], xv[3], P[nd.conv + ".weight"], P[nd.conv + ".bias"], None, t, None,
-                             M, i.C, o.C, self.stream, meta=dict(flops=2 * M * i.C * o.C, bytes=4 * (M * i.C + M * o.C + i.C * o.C), shape="M%d K%d N%d" % (M, i.C, o.C)))
+                self.fwd.add(K("mny_pw_fwd"), xv[0], xv[1], xv[2], xv[3], P[nd.conv + ".weight"], P[nd.conv + ".bias"], None, t, None,
+                             M, i.C, o.C, self.stream, meta=dict(flops=2 * M * i.C * o.C, bytes=eb * (M * i.C + M * o.C) + 4 * i.C * o.C, shape="M%d K%d N%d" % (M, i.C, o.C)))
+                if self.bf16:                    # loss / decode read the head in fp32
+                    t32 = torch.empty(shp, **f32)
+                    self.fwd.add("mny_cvt_bf16_f32", t, t32, t.numel(), self.stream)
+                    self.head32[o.id] = t32
             elif nd.op == "add":
                 a = view(nd.ins[0])
                 has_b, has_up = nd.k & 1, nd.k & 2
@@ -174,24 +189,24 @@ class NetPlan:
                 up = self.reals[nd.ins[-1].id] if has_up else None
                 if has_up:
                     assert nd.ins[-1].kind == "real"
-                t = torch.empty(shp, **f32)
+                t = torch.empty(shp, **act)
                 self.reals[o.id] = t
-                self.fwd.add("mny_add_views", a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], up, t, shp[0], shp[1], shp[2], shp[3], self.stream)
+                self.fwd.add(K("mny_add_views"), a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], up, t, shp[0], shp[1], shp[2], shp[3], self.stream)
             elif nd.op == "mul":
                 a, b = view(nd.ins[0]), view(nd.ins[1])
-                t = torch.empty(shp, **f32)
+                t = torch.empty(shp, **act)
                 self.reals[o.id] = t
-                self.fwd.add("mny_mul_views", a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], t, M, o.C, self.stream)
+                self.fwd.add(K("mny_mul_views"), a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], t, M, o.C, self.stream)
             elif nd.op == "partadd":
                 a = view(nd.ins[0])
                 up = self.reals[nd.ins[1].id]
-                t = torch.empty(shp, **f32)
+                t = torch.empty(shp, **act)
                 self.reals[o.id] = t
-                self.fwd.add("mny_partadd_up", a[0], a[1], a[2], a[3], up, t, shp[0], shp[1], shp[2], nd.ins[0].C, o.C, self.stream)
+                self.fwd.add(K("mny_partadd_up"), a[0], a[1], a[2], a[3], up, t, shp[0], shp[1], shp[2], nd.ins[0].C, o.C, self.stream)
             else:
                 raise AssertionError(nd.op)
 
-        self.heads = [self.reals[o.id] for o in g.outputs]
+        self.heads = [self.head32.get(o.id, self.reals[o.id]) for o in g.outputs]
         self._build_detection()
         if training:
             self._build_backward()
@@ -251,6 +266,8 @@ class NetPlan:
         net, g, N = self.net, self.net.graph, self.N
         dev = self.dev
         f32 = dict(device=dev, dtype=torch.float32)
+        act = dict(device=dev, dtype=self.adt)
+        K, eb = self.K, self.eb
         P = net.param_tensors
         bwd = self.bwd = CallList()
         view, shape = self._view, self._shape
@@ -337,7 +354,7 @@ class NetPlan:
         self.grad_bufs = []
 
         def alloc(v):
-            t = torch.empty(shape(v), **f32)
+            t = torch.empty(shape(v), **act)
             self.grad_bufs.append(t)
             return t
 
@@ -348,9 +365,9 @@ class NetPlan:
                 return
             if s.shared:
                 nb = alloc(v)
-                bwd.add("mny_axpy", s.buf, None, nb, 0, nb.numel(), self.stream)
+                bwd.add(K("mny_axpy"), s.buf, None, nb, 0, nb.numel(), self.stream)
                 s.buf, s.shared = nb, False
-            bwd.add("mny_axpy", buf, None, s.buf, 1, s.buf.numel(), self.stream)
+            bwd.add(K("mny_axpy"), buf, None, s.buf, 1, s.buf.numel(), self.stream)
 
         def contribute_kernel(v, emit):
             """emit(out, addend) appends the producing call."""
@@ -366,8 +383,13 @@ class NetPlan:
                 s.buf, s.shared = nb, False
 
         for hi, o in enumerate(g.outputs):
-            gs[o.id].buf = self.dheads[hi]
             bwd.add("mny_axpy", self.dheads[hi], self.g_scale[hi:hi + 1], self.dheads[hi], 0, self.dheads[hi].numel(), self.stream)
+            if self.bf16:
+                d16 = torch.empty(self.dheads[hi].shape, **act)
+                bwd.add("mny_cvt_f32_bf16", self.dheads[hi], d16, d16.numel(), self.stream)
+                gs[o.id].buf = d16
+            else:
+                gs[o.id].buf = self.dheads[hi]
 
         for nd in order:
             o = nd.out
@@ -386,29 +408,29 @@ class NetPlan:
                     us = gs[upv.id]
                     if us.buf is None:
                         us.buf, us.shared = alloc(upv), False
-                        bwd.add("mny_upsample_bwd", G, us.buf, 0, shp[0], shp[1], shp[2], shp[3], self.stream)
+                        bwd.add(K("mny_upsample_bwd"), G, us.buf, 0, shp[0], shp[1], shp[2], shp[3], self.stream)
                     else:
                         if us.shared:
                             nb = alloc(upv)
-                            bwd.add("mny_axpy", us.buf, None, nb, 0, nb.numel(), self.stream)
+                            bwd.add(K("mny_axpy"), us.buf, None, nb, 0, nb.numel(), self.stream)
                             us.buf, us.shared = nb, False
-                        bwd.add("mny_upsample_bwd", G, us.buf, 1, shp[0], shp[1], shp[2], shp[3], self.stream)
+                        bwd.add(K("mny_upsample_bwd"), G, us.buf, 1, shp[0], shp[1], shp[2], shp[3], self.stream)
                 bwd.marks[o.name] = len(bwd.calls)
                 continue
             if nd.op == "mul":
                 va, vb = view(nd.ins[0]), view(nd.ins[1])
                 contribute_kernel(nd.ins[0], lambda out, addend, G=G, vb=vb, M=M, C=o.C: bwd.add(
-                    "mny_mul_views_bwd", G, vb[0], vb[1], vb[2], vb[3], addend, out, M, C, self.stream))
+                    K("mny_mul_views_bwd"), G, vb[0], vb[1], vb[2], vb[3], addend, out, M, C, self.stream))
                 contribute_kernel(nd.ins[1], lambda out, addend, G=G, va=va, M=M, C=o.C: bwd.add(
-                    "mny_mul_views_bwd", G, va[0], va[1], va[2], va[3], addend, out, M, C, self.stream))
+                    K("mny_mul_views_bwd"), G, va[0], va[1], va[2], va[3], addend, out, M, C, self.stream))
                 bwd.marks[o.name] = len(bwd.calls)
                 continue
             if nd.op == "partadd":
                 av, upv = nd.ins[0], nd.ins[1]
                 for tgt, emit in ((av, lambda dst, acc, G=G, M=M, Ca=av.C, Cb=o.C: bwd.add(
-                                        "mny_slice_channels", G, dst, acc, M, Ca, Cb, self.stream)),
+                                        K("mny_slice_channels"), G, dst, acc, M, Ca, Cb, self.stream)),
                                   (upv, lambda dst, acc, G=G, shp=shp: bwd.add(
-                                        "mny_upsample_bwd", G, dst, acc, shp[0], shp[1], shp[2], shp[3], self.stream))):
+                                        K("mny_upsample_bwd"), G, dst, acc, shp[0], shp[1], shp[2], shp[3], self.stream))):
                     ts = gs[tgt.id]
                     if ts.buf is None:
                         ts.buf, ts.shared = alloc(tgt), False
@@ -416,13 +438,13 @@ class NetPlan:
                     else:
                         if ts.shared:
                             nb = alloc(tgt)
-                            bwd.add("mny_axpy", ts.buf, None, nb, 0, nb.numel(), self.stream)
+                            bwd.add(K("mny_axpy"), ts.buf, None, nb, 0, nb.numel(), self.stream)
                             ts.buf, ts.shared = nb, False
                         emit(ts.buf, 1)
                 bwd.marks[o.name] = len(bwd.calls)
                 continue
             if (nd.op == "pw" and nd.ins[0].act not in (_lib.ACT_HSWISH, _lib.ACT_HSIGMOID) and o.act not in (_lib.ACT_HSWISH, _lib.ACT_HSIGMOID)
-                    and os.environ.get("MNY_NO_BNFUSE") != "1" and _lib.query("mny_pw_bnbwd_supported", M, nd.ins[0].C, o.C) == 1):
+                    and os.environ.get("MNY_NO_BNFUSE") != "1" and not self.bf16 and _lib.query("mny_pw_bnbwd_supported", M, nd.ins[0].C, o.C) == 1):
                 # thin "expand" unit: BN-backward + wgrad + dgrad from (G, Y, X) in 4 passes, dY never materialised
                 u = self.units[o.id]
                 i = nd.ins[0]
@@ -444,39 +466,45 @@ class NetPlan:
                 parts = _lib.query("mny_bn_bwd_parts", M, o.C)
                 gam = P[nd.bn + ".weight"]
                 dY = G if not s.shared else alloc(o)
-                bwd.add("mny_bn_bwd_reduce", G, u.Y, u.scale, u.shift, o.act, u.mean, u.invstd, self.red_ws, M, o.C, self.stream)
+                bwd.add(K("mny_bn_bwd_reduce"), G, u.Y, u.scale, u.shift, o.act, u.mean, u.invstd, self.red_ws, M, o.C, self.stream,
+                        meta=dict(flops=0, bytes=2 * eb * M * o.C, shape="M%d C%d" % (M, o.C)))
                 bwd.add("mny_bn_bwd_finalize", self.red_ws, parts, M, gam, u.mean, u.invstd, gv(nd.bn + ".weight"), gv(nd.bn + ".bias"),
                         self.coef_ws, o.C, self.stream)
-                bwd.add("mny_bn_bwd_apply", G, u.Y, u.scale, u.shift, o.act, self.coef_ws, dY, M, o.C, self.stream)
+                bwd.add(K("mny_bn_bwd_apply"), G, u.Y, u.scale, u.shift, o.act, self.coef_ws, dY, M, o.C, self.stream,
+                        meta=dict(flops=0, bytes=3 * eb * M * o.C, shape="M%d C%d" % (M, o.C)))
             w = P[nd.conv + ".weight"]
             if nd.op == "stem":
-                bwd.add("mny_stem_wgrad", self.x_ptr, dY, gv(nd.conv + ".weight"), self.ws, N, self.H, self.W, o.C, self.stream)
+                bwd.add(K("mny_stem_wgrad"), self.x_ptr, dY, gv(nd.conv + ".weight"), self.ws, N, self.H, self.W, o.C, self.stream)
             elif nd.op == "dw":
                 i = nd.ins[0]
                 ish = shape(i)
                 xv = view(i)
-                dwb = 4 * (N * ish[1] * ish[2] * o.C + M * o.C)
-                bwd.add("mny_dw_bwd_weight", xv[0], xv[1], xv[2], xv[3], dY, gv(nd.conv + ".weight"), self.ws, N, ish[1], ish[2], o.C,
+                dwb = eb * (N * ish[1] * ish[2] * o.C + M * o.C)
+                bwd.add(K("mny_dw_bwd_weight"), xv[0], xv[1], xv[2], xv[3], dY, gv(nd.conv + ".weight"), self.ws, N, ish[1], ish[2], o.C,
                         nd.k, nd.stride, self.stream, meta=dict(flops=2 * M * o.C * nd.k * nd.k, bytes=dwb, shape="C%d H%d s%d" % (o.C, ish[1], nd.stride)))
                 contribute_kernel(i, lambda out, addend, dY=dY, w=w, ish=ish, nd=nd, C=o.C, M=M, dwb=dwb: bwd.add(
-                    "mny_dw_bwd_data", dY, w, addend, out, N, ish[1], ish[2], C, nd.k, nd.stride, self.stream,
+                    K("mny_dw_bwd_data"), dY, w, addend, out, N, ish[1], ish[2], C, nd.k, nd.stride, self.stream,
                     meta=dict(flops=2 * M * C * nd.k * nd.k, bytes=dwb, shape="C%d H%d s%d" % (C, ish[1], nd.stride))))
             else:   # pw / pwb
                 i = nd.ins[0]
                 xv = view(i)
                 db = gv(nd.conv + ".bias") if nd.bias else None
-                bwd.add("mny_pw_wgrad", xv[0], xv[1], xv[2], xv[3], dY, gv(nd.conv + ".weight"), db, self.ws, M, i.C, o.C, self.stream,
-                        meta=dict(flops=2 * M * i.C * o.C, bytes=4 * (M * i.C + M * o.C + i.C * o.C), shape="M%d K%d N%d" % (M, i.C, o.C)))
+                bwd.add(K("mny_pw_wgrad"), xv[0], xv[1], xv[2], xv[3], dY, gv(nd.conv + ".weight"), db, self.ws, M, i.C, o.C, self.stream,
+                        meta=dict(flops=2 * M * i.C * o.C, bytes=eb * (M * i.C + M * o.C) + 4 * i.C * o.C, shape="M%d K%d N%d" % (M, i.C, o.C)))
                 wT = torch.empty(i.C, o.C, **f32)
                 self.wT[nd.conv] = wT
                 bwd.add("mny_transpose", w, wT, o.C, i.C, self.stream)
                 contribute_kernel(i, lambda out, addend, dY=dY, wT=wT, M=M, K=o.C, Nc=i.C: bwd.add(
-                    "mny_pw_fwd", dY, None, None, ACT_NONE, wT, None, addend, out, None, M, K, Nc, self.stream,
-                    meta=dict(flops=2 * M * K * Nc, bytes=4 * (M * K + M * Nc + K * Nc), shape="dgrad M%d K%d N%d" % (M, K, Nc))))
+                    self.K("mny_pw_fwd"), dY, None, None, ACT_NONE, wT, None, addend, out, None, M, K, Nc, self.stream,
+                    meta=dict(flops=2 * M * K * Nc, bytes=self.eb * (M * K + M * Nc) + 4 * K * Nc, shape="dgrad M%d K%d N%d" % (M, K, Nc))))
             flush_shared()
             bwd.marks[o.name] = len(bwd.calls)
 
     # ------------------------------------------------------------------------------------------
+    def K(self, name):
+        """Entry point for the plan's activation storage type."""
+        return name + "_bf16" if self.bf16 else name
+
     def stale(self):
         return any(t.data_ptr() != p for t, p in self.param_ptrs)
 

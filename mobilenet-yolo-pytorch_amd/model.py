@@ -77,8 +77,12 @@ class _TrainStep(torch.autograd.Function):
 class yolo(nn.Module):
     ARCH = "mbv2"
 
-    def __init__(self, config, sync_metrics=False):
+    def __init__(self, config, sync_metrics=False, act_dtype=torch.float32):
+        """`act_dtype=torch.bfloat16` stores activations / activation gradients in bf16 (BASELINE config 4); parameters,
+        their gradients, BN statistics and the detection heads stay fp32, so optimizers and checkpoints are unchanged."""
         super().__init__()
+        assert act_dtype in (torch.float32, torch.bfloat16), "act_dtype must be torch.float32 or torch.bfloat16"
+        self.act_dtype = act_dtype
         y = config["yolo"]
         self.num_classes = y["num_classes"]
         self.num_anchors = y["num_anchors"]
@@ -137,14 +141,14 @@ class yolo(nn.Module):
 
     # ---- plans --------------------------------------------------------------------------------
     def _plan(self, N, H, W, training):
-        key = (N, H, W, training)
+        key = (N, H, W, training) if self.act_dtype == torch.float32 else (N, H, W, training, "bf16")
         p = self._plans.get(key)
         if p is None or p.stale():
             if not torch.cuda.is_available() or self.device.type != "cuda":
                 raise _lib.MnyError("yolo runs only on an MI355X (HIP) device: move the module and inputs to cuda; "
                                     "there is no CPU fallback")
             _lib.load()
-            p = NetPlan(self, N, H, W, training)
+            p = NetPlan(self, N, H, W, training, self.act_dtype)
             self._plans[key] = p
             if len(self._plans) > 8:                                            # multi-scale training: bound resident plans
                 self._plans.pop(next(iter(self._plans)))

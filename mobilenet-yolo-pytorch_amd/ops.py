@@ -1,7 +1,8 @@
 """Thin torch-tensor wrappers over the C ABI (include/mnyolo.h).
 
 PyTorch is plumbing here: it owns device memory and the stream; every arithmetic op is a HIP kernel
-of libmnyolo.so.  All tensors are fp32, contiguous, on a CUDA(=HIP) device; activations are NHWC.
+of libmnyolo.so.  All tensors are contiguous, on a CUDA(=HIP) device; activations are NHWC, fp32 or — selecting the
+`*_bf16` twins of the entry points — bf16; weights, BN coefficients, statistics and workspaces are always fp32.
 A `view` is the tuple (tensor, scale|None, shift|None, act) — see mnyolo.h "View arguments".
 """
 import ctypes
@@ -18,8 +19,8 @@ BN_MOMENTUM = 0.1
 def _p(t):
     if t is None:
         return None
-    assert t.is_cuda and t.dtype in (torch.float32, torch.int32) and t.is_contiguous(), \
-        "libmnyolo needs contiguous fp32/int32 device tensors (got %s %s)" % (t.device, t.dtype)
+    assert t.is_cuda and t.dtype in (torch.float32, torch.int32, torch.bfloat16) and t.is_contiguous(), \
+        "libmnyolo needs contiguous fp32/bf16/int32 device tensors (got %s %s)" % (t.device, t.dtype)
     return ctypes.c_void_p(t.data_ptr())
 
 
@@ -31,14 +32,19 @@ def _new(*shape, like=None, dtype=torch.float32):
     return torch.empty(shape, device=like.device, dtype=dtype)
 
 
+def _k(name, t):
+    """entry point for the storage type of activation tensor `t`"""
+    return name + "_bf16" if t.dtype == torch.bfloat16 else name
+
+
 # ---- stem -------------------------------------------------------------------------------------------
-def stem_fwd(x_nchw, w, want_stats=True):
+def stem_fwd(x_nchw, w, want_stats=True, dtype=torch.float32):
     N, _, H, W = x_nchw.shape
     Co = w.shape[0]
-    y = _new(N, (H + 1) // 2, (W + 1) // 2, Co, like=x_nchw)
+    y = _new(N, (H + 1) // 2, (W + 1) // 2, Co, like=x_nchw, dtype=dtype)
     parts = query("mny_stem_stat_parts", N, H, W, Co)
     stats = _new(parts, 2, Co, like=x_nchw) if want_stats else None
-    call("mny_stem_fwd", _p(x_nchw), _p(w), _p(y), _p(stats), N, H, W, Co, _st())
+    call(_k("mny_stem_fwd", y), _p(x_nchw), _p(w), _p(y), _p(stats), N, H, W, Co, _st())
     return y, stats
 
 
@@ -48,7 +54,7 @@ def stem_wgrad(x_nchw, dy):
     parts = query("mny_stem_wgrad_parts", N, H, W, Co)
     ws = _new(parts, Co * 27, like=dy)
     dw = _new(Co, 3, 3, 3, like=dy)
-    call("mny_stem_wgrad", _p(x_nchw), _p(dy), _p(dw), _p(ws), N, H, W, Co, _st())
+    call(_k("mny_stem_wgrad", dy), _p(x_nchw), _p(dy), _p(dw), _p(ws), N, H, W, Co, _st())
     return dw
 
 
@@ -58,9 +64,9 @@ def dw_fwd(view, w, stride, want_stats=True):
     N, H, W, C = x.shape
     K = w.shape[-1]
     Ho, Wo = (H + 2 * (K // 2) - K) // stride + 1, (W + 2 * (K // 2) - K) // stride + 1
-    y = _new(N, Ho, Wo, C, like=x)
+    y = _new(N, Ho, Wo, C, like=x, dtype=x.dtype)
     stats = _new(query("mny_dw_stat_parts", N, H, W, C, K, stride), 2, C, like=x) if want_stats else None
-    call("mny_dw_fwd", _p(x), _p(sc), _p(sh), act, _p(w), _p(y), _p(stats), N, H, W, C, K, stride, _st())
+    call(_k("mny_dw_fwd", x), _p(x), _p(sc), _p(sh), act, _p(w), _p(y), _p(stats), N, H, W, C, K, stride, _st())
     return y, stats
 
 
@@ -68,8 +74,8 @@ def dw_bwd_data(dy, w, in_hw, stride, addend=None, out=None):
     N, _, _, C = dy.shape
     H, W = in_hw
     K = w.shape[-1]
-    dx = out if out is not None else _new(N, H, W, C, like=dy)
-    call("mny_dw_bwd_data", _p(dy), _p(w), _p(addend), _p(dx), N, H, W, C, K, stride, _st())
+    dx = out if out is not None else _new(N, H, W, C, like=dy, dtype=dy.dtype)
+    call(_k("mny_dw_bwd_data", dy), _p(dy), _p(w), _p(addend), _p(dx), N, H, W, C, K, stride, _st())
     return dx
 
 
@@ -78,7 +84,7 @@ def dw_bwd_weight(view, dy, K, stride):
     N, H, W, C = x.shape
     ws = _new(query("mny_dw_wgrad_parts", N, H, W, C, K, stride), C * K * K, like=x)
     dw = _new(C, 1, K, K, like=x)
-    call("mny_dw_bwd_weight", _p(x), _p(sc), _p(sh), act, _p(dy), _p(dw), _p(ws), N, H, W, C, K, stride, _st())
+    call(_k("mny_dw_bwd_weight", x), _p(x), _p(sc), _p(sh), act, _p(dy), _p(dw), _p(ws), N, H, W, C, K, stride, _st())
     return dw
 
 
@@ -88,9 +94,9 @@ def pw_fwd(view, w2d, bias=None, addend=None, want_stats=True, out=None):
     K = x.shape[-1]
     M = x.numel() // K
     Nc = w2d.shape[0]
-    y = out if out is not None else _new(*x.shape[:-1], Nc, like=x)
-    stats = _new(query("mny_pw_stat_parts", M, K, Nc), 2, Nc, like=x) if want_stats else None
-    call("mny_pw_fwd", _p(x), _p(sc), _p(sh), act, _p(w2d), _p(bias), _p(addend), _p(y), _p(stats), M, K, Nc, _st())
+    y = out if out is not None else _new(*x.shape[:-1], Nc, like=x, dtype=x.dtype)
+    stats = _new(query(_k("mny_pw_stat_parts", x), M, K, Nc), 2, Nc, like=x) if want_stats else None
+    call(_k("mny_pw_fwd", x), _p(x), _p(sc), _p(sh), act, _p(w2d), _p(bias), _p(addend), _p(y), _p(stats), M, K, Nc, _st())
     return y, stats
 
 
@@ -102,7 +108,7 @@ def pw_wgrad(view, dy, want_dbias=False):
     ws = _new(query("mny_pw_wgrad_ws_floats", M, K, Nc), like=x)
     dw = _new(Nc, K, like=x)
     db = _new(Nc, like=x) if want_dbias else None
-    call("mny_pw_wgrad", _p(x), _p(sc), _p(sh), act, _p(dy), _p(dw), _p(db), _p(ws), M, K, Nc, _st())
+    call(_k("mny_pw_wgrad", x), _p(x), _p(sc), _p(sh), act, _p(dy), _p(dw), _p(db), _p(ws), M, K, Nc, _st())
     return dw, db
 
 
@@ -149,11 +155,11 @@ def bn_backward(g, y, scale, shift, act, gamma, mean, invstd, out=None):
     M = y.numel() // C
     parts = query("mny_bn_bwd_parts", M, C)
     red = _new(parts, 2, C, like=y)
-    call("mny_bn_bwd_reduce", _p(g), _p(y), _p(scale), _p(shift), act, _p(mean), _p(invstd), _p(red), M, C, _st())
+    call(_k("mny_bn_bwd_reduce", y), _p(g), _p(y), _p(scale), _p(shift), act, _p(mean), _p(invstd), _p(red), M, C, _st())
     dgamma, dbeta, coef = _new(C, like=y), _new(C, like=y), _new(3, C, like=y)
     call("mny_bn_bwd_finalize", _p(red), parts, M, _p(gamma), _p(mean), _p(invstd), _p(dgamma), _p(dbeta), _p(coef), C, _st())
     dy = out if out is not None else torch.empty_like(y)
-    call("mny_bn_bwd_apply", _p(g), _p(y), _p(scale), _p(shift), act, _p(coef), _p(dy), M, C, _st())
+    call(_k("mny_bn_bwd_apply", y), _p(g), _p(y), _p(scale), _p(shift), act, _p(coef), _p(dy), M, C, _st())
     return dy, dgamma, dbeta
 
 
@@ -163,19 +169,19 @@ def add_views(a, b=None, up=None, out=None):
     N, H, W, C = x.shape
     o = out if out is not None else torch.empty_like(x)
     bt, bsc, bsh, bact = b if b is not None else (None, None, None, ACT_NONE)
-    call("mny_add_views", _p(a[0]), _p(a[1]), _p(a[2]), a[3], _p(bt), _p(bsc), _p(bsh), bact, _p(up), _p(o), N, H, W, C, _st())
+    call(_k("mny_add_views", x), _p(a[0]), _p(a[1]), _p(a[2]), a[3], _p(bt), _p(bsc), _p(bsh), bact, _p(up), _p(o), N, H, W, C, _st())
     return o
 
 
 def upsample_bwd(src, dst=None, accumulate=False):
     N, H, W, C = src.shape
-    d = dst if dst is not None else _new(N, H // 2, W // 2, C, like=src)
-    call("mny_upsample_bwd", _p(src), _p(d), int(accumulate), N, H, W, C, _st())
+    d = dst if dst is not None else _new(N, H // 2, W // 2, C, like=src, dtype=src.dtype)
+    call(_k("mny_upsample_bwd", src), _p(src), _p(d), int(accumulate), N, H, W, C, _st())
     return d
 
 
 def axpy(src, dst, alpha=None, accumulate=False):
-    call("mny_axpy", _p(src), _p(alpha), _p(dst), int(accumulate), src.numel(), _st())
+    call(_k("mny_axpy", src), _p(src), _p(alpha), _p(dst), int(accumulate), src.numel(), _st())
     return dst
 
 
