@@ -221,8 +221,12 @@ int mny_dw_bwd_data_bf16(const void* dy, const float* w, const void* addend, voi
                          int stride, void* stream);
 int mny_dw_bwd_weight_bf16(const void* x, const float* in_scale, const float* in_shift, int in_act, const void* dy,
                            float* dw, float* ws, int N, int H, int W, int C, int K, int stride, void* stream);
-int mny_pw_fwd_bf16(const void* x, const float* in_scale, const float* in_shift, int in_act, const float* w,
+/* the pointwise GEMM also takes its WEIGHTS in bf16 ([Nc][K], e.g. mny_cvt_f32_bf16 of the fp32 master copy, or
+ * mny_transpose_bf16 for the data-gradient): K % 8 == 0 runs LDS-DMA + v_mfma_f32_32x32x16_bf16, other K the
+ * register-staged fp32-MFMA kernel */
+int mny_pw_fwd_bf16(const void* x, const float* in_scale, const float* in_shift, int in_act, const void* w_bf16,
                     const float* bias, const void* addend, void* y, float* stats, int64_t M, int K, int Nc, void* stream);
+int mny_transpose_bf16(const float* src /*[R][Cc] fp32*/, void* dst /*[Cc][R] bf16*/, int R, int Cc, void* stream);
 int mny_pw_stat_parts_bf16(int64_t M, int K, int Nc);
 int mny_pw_wgrad_bf16(const void* x, const float* in_scale, const float* in_shift, int in_act, const void* dy, float* dw,
                       float* dbias, float* ws, int64_t M, int K, int Nc, void* stream);

@@ -69,6 +69,7 @@ BF16_TWINS = ("mny_stem_fwd", "mny_stem_wgrad", "mny_dw_fwd", "mny_dw_bwd_data",
               "mny_mul_views_bwd", "mny_partadd_up", "mny_slice_channels", "mny_upsample_bwd", "mny_axpy")
 for _n in BF16_TWINS:
     _SIGS[_n + "_bf16"] = _SIGS[_n]
+_SIGS["mny_transpose_bf16"] = _SIGS["mny_transpose"]
 _SIGS["mny_cvt_f32_bf16"] = (c_int, [P, P, c_int64, P])
 _SIGS["mny_cvt_bf16_f32"] = (c_int, [P, P, c_int64, P])
 EXPORTS = tuple(_SIGS)

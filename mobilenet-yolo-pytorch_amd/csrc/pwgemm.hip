@@ -24,6 +24,7 @@
 #include <stdlib.h>
 
 #include <map>
+#include <type_traits>
 #include <mutex>
 
 #include "common.h"
@@ -34,9 +35,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128;
 
-struct GemmArgs {   // A / addend / C are T* (float or bf16_t) of the kernel instantiation
+struct GemmArgs {   // A / addend / C are T* (float or bf16_t) of the kernel instantiation, B is T* as well
     const void* A; const float* in_scale; const float* in_shift; int in_act;
-    const float* B; const float* bias; const void* addend; void* C; float* stats;
+    const void* B; const float* bias; const void* addend; void* C; float* stats;
     int64_t M; int K; int N;
     int m_tiles; int tiles_per_block;
 };
@@ -124,9 +125,9 @@ __global__ __launch_bounds__(256) void pw_gemm_nt_kernel(GemmArgs p) {
                     const int n = n0 + row;
                     const int k = k0 + kq * 4;
                     if (n < p.N && k < p.K) {
-                        const float* src = p.B + (int64_t)n * p.K + k;
+                        const T* src = (const T*)p.B + (int64_t)n * p.K + k;
                         if (kvec) v = ld4(src);
-                        else { v.x = src[0]; if (k + 1 < p.K) v.y = src[1]; if (k + 2 < p.K) v.z = src[2]; if (k + 3 < p.K) v.w = src[3]; }
+                        else { v.x = ld1(src); if (k + 1 < p.K) v.y = ld1(src + 1); if (k + 2 < p.K) v.z = ld1(src + 2); if (k + 3 < p.K) v.w = ld1(src + 3); }
                     }
                 }
                 rb[i] = v;
@@ -236,7 +237,10 @@ __global__ __launch_bounds__(256) void pw_gemm_nt_kernel(GemmArgs p) {
 //   * the LDS image is lane-linear per DMA instruction (hardware rule), so bank conflicts are removed by
 //     XOR-swizzling the 16-B chunk index on the SOURCE address and on the fragment read (chunk ^ (row>>2)&3);
 //   * block id -> (m-run, n-tile) puts the n-tiles that share an A panel on the same XCD (bid % 8).
-// Requirements: K % 4 == 0 (16-B aligned rows); anything else takes the register-staged kernel.
+// Requirements: K % 4 == 0 (16-B aligned rows) and N % 4 == 0 (the epilogue stores 4-column groups); anything else
+// — the 75-channel detection heads, MobileNetV3's 10-channel gate bottleneck — takes the register-staged kernel.
+// (A scalar-store tail inside THIS kernel, fully unrolled over 16*TN accumulators, cost ~40 VGPRs and made the
+// TN >= 3 main loops spill to scratch; keeping it out brings every variant under 155 VGPRs.)
 // Out-of-range rows are clamped to a valid row (their outputs are never stored); k-chunks past K re-read the
 // row start and are annihilated by zeroed B fragments (and zero scale/shift).
 // ------------------------------------------------------------------------------------------------
@@ -245,16 +249,29 @@ __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)
 
 __device__ const float4 mny_zero16 = {0.f, 0.f, 0.f, 0.f};   // DMA source for B chunks past K
 
-struct Gemm2Args {
-    const float* A; const float* in_scale; const float* in_shift; int in_act;
-    const float* B; const float* bias; const float* addend; float* C; float* stats;
+struct Gemm2Args {   // A / B / addend / C: float* (BF = 0) or bf16_t* (BF = 1)
+    const void* A; const float* in_scale; const float* in_shift; int in_act;
+    const void* B; const float* bias; const void* addend; void* C; float* stats;
     int64_t M; int K; int N;
     int m_tiles, tiles_per_block, gx, n_tiles;
 };
 
 // XF: 0 = A used as is, 1 = scale/shift + min(max(z, slope*z), hi) activation, 2 = scale/shift + hswish
-template <int TN, int XF>
+// BF: 0 = fp32 operands, v_mfma_f32_32x32x2_f32;  1 = bf16 operands (A, B, addend, C), v_mfma_f32_32x32x16_bf16.
+//     The LDS image is the same in bytes (64-B rows of four 16-B chunks): a chunk is 4 fp32 or 8 bf16 k-values, a stage
+//     covers 16 or 32 k, and the lane's 16-B fragment read IS the bf16 MFMA operand (k-block = lane>>5), so the bf16
+//     main loop is 2 MFMAs per accumulator per stage instead of 16.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+
+template <int TN, int XF, int BF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void pw_gemm_nt_dma_kernel(Gemm2Args p) {
+    using T = typename std::conditional<BF != 0, bf16_t, float>::type;
+    constexpr int EPC = BF ? 8 : 4;                                           // elements per 16-B chunk
+    constexpr int BKE = 4 * EPC;                                              // k-values per stage
+    const T* pA = (const T*)p.A;
+    const T* pB = (const T*)p.B;
+    const T* pAdd = (const T*)p.addend;
+    T* pC = (T*)p.C;
     constexpr int BN = 32 * TN, BKD = 16, S = 3;
     constexpr int A_ST = BM * BKD, B_ST = BN * BKD, STAGE = A_ST + B_ST;     // floats
     constexpr int NA = BM / 16, NB = BN / 16, NL = NA + NB;                   // 1-KiB DMA instructions per stage
@@ -272,8 +289,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lrow = lane & 31, khalf = lane >> 5;
     const int swz = (lrow >> 2) & 3;
-    const int nk = (p.K + BKD - 1) / BKD;
-    const int Kpad = nk * BKD;
+    const int nk = (p.K + BKE - 1) / BKE;
+    const int Kpad = nk * BKE;
     float* sShift = sScale + Kpad;
     const float slope = act_slope(p.in_act), hi = act_hi(p.in_act);
     if (XF != 0) {
@@ -287,42 +304,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     const int mt_end = min(mt_begin + p.tiles_per_block, p.m_tiles);
     const int total = (mt_end - mt_begin) * nk;
 
-    // per-lane constants of this wave's LPW DMA instructions: instruction j covers tile rows 16j..16j+15, 4 lanes per row
-    const int drow = lane >> 2, dpos = lane & 3;
-    int d_row[LPW], d_k[LPW], d_lds[LPW];
+    // DMA instruction j (wave-uniform, j = wv + 4i) covers tile rows 16j..16j+15, 4 lanes per row.  Per-lane state is kept
+    // to the minimum — the row-in-group, ONE swizzled chunk offset (the swizzle depends on row & 15 only) and the B row
+    // pointers; everything else is scalar.  (Per-instruction row/offset arrays pushed the TN >= 3 kernels over the
+    // 168-VGPR budget of 3 waves/SIMD and the main loop spilled to scratch.)
+    const int drow = lane >> 2;
+    const int dk = ((lane & 3) ^ ((drow >> 2) & 3)) * EPC;       // swizzled source chunk, in elements
+    int d_lds[LPW], d_row0[LPW];
     bool d_isA[LPW];
-    const float* d_bptr[LPW];
+    const T* d_bptr[LPW];
 #pragma unroll
     for (int i = 0; i < LPW; ++i) {
         int j = wv + 4 * i;
         if (j >= NL) j = NL - 1;
         d_isA[i] = j < NA;
-        const int row = (d_isA[i] ? j : j - NA) * 16 + drow;
-        d_row[i] = row;
-        d_k[i] = (dpos ^ ((row >> 2) & 3)) * 4;                  // swizzled source chunk
-        d_lds[i] = d_isA[i] ? j * 256 : A_ST + (j - NA) * 256;
-        int n = n0 + row;
+        d_row0[i] = (d_isA[i] ? j : j - NA) * 16;                 // scalar
+        d_lds[i] = d_isA[i] ? j * 256 : A_ST + (j - NA) * 256;   // scalar
+        int n = n0 + d_row0[i] + drow;
         if (n >= p.N) n = p.N - 1;
-        d_bptr[i] = p.B + (int64_t)n * p.K + d_k[i];
+        d_bptr[i] = pB + (int64_t)n * p.K + dk;
     }
-    const float* zero_src = reinterpret_cast<const float*>(&mny_zero16);
-    const bool ragged_k = (p.K % BKD) != 0;
+    const T* zero_src = reinterpret_cast<const T*>(&mny_zero16);
+    const bool ragged_k = (p.K % BKE) != 0;
 
     auto issue = [&](int mt, int kt, int slot) {
         float* stage = smem + slot * STAGE;
         const bool tail = ragged_k && kt == nk - 1;
+        const bool kout = tail && kt * BKE + dk >= p.K;           // this lane's chunk lies past K
 #pragma unroll
         for (int i = 0; i < LPW; ++i) {
-            const float* src;
+            const T* src;
             if (d_isA[i]) {
-                int m = mt * BM + d_row[i];
+                int m = mt * BM + d_row0[i] + drow;
                 if (m >= (int)p.M) m = (int)p.M - 1;
-                int k = kt * BKD + d_k[i];
-                if (tail && k >= p.K) k = 0;                      // finite filler, annihilated by zero B / zero scale
-                src = p.A + (int64_t)m * p.K + k;
+                src = pA + (int64_t)m * p.K + (kout ? 0 : kt * BKE + dk);   // finite filler, annihilated by zero B / zero scale
             } else {
-                src = d_bptr[i] + kt * BKD;
-                if (tail && kt * BKD + d_k[i] >= p.K) src = zero_src;
+                src = kout ? zero_src : d_bptr[i] + kt * BKE;
             }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(stage + d_lds[i]), 16, 0, 0);
@@ -342,6 +359,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         const float* stA = smem + slot * STAGE;
         const float* stB = stA + A_ST;
         const float* a_row = stA + (wv * 32 + lrow) * BKD;
+        if constexpr (BF != 0) {
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) {
+                const int chunk = kc * 2 + khalf;
+                uint4 au = *reinterpret_cast<const uint4*>(a_row + ((chunk ^ swz) << 2));
+                uint4 bu[TN];
+#pragma unroll
+                for (int u = 0; u < TN; ++u) bu[u] = *reinterpret_cast<const uint4*>(stB + (u * 32 + lrow) * BKD + ((chunk ^ swz) << 2));
+                if (XF != 0) {
+                    const int kbase = kt * BKE + chunk * 8;
+                    const float4 sc0 = ld4(sScale + kbase), sc1 = ld4(sScale + kbase + 4);
+                    const float4 sh0 = ld4(sShift + kbase), sh1 = ld4(sShift + kbase + 4);
+                    float z[8] = {__uint_as_float(au.x << 16), __uint_as_float(au.x & 0xffff0000u), __uint_as_float(au.y << 16),
+                                  __uint_as_float(au.y & 0xffff0000u), __uint_as_float(au.z << 16), __uint_as_float(au.z & 0xffff0000u),
+                                  __uint_as_float(au.w << 16), __uint_as_float(au.w & 0xffff0000u)};
+                    const float scv[8] = {sc0.x, sc0.y, sc0.z, sc0.w, sc1.x, sc1.y, sc1.z, sc1.w};
+                    const float shv[8] = {sh0.x, sh0.y, sh0.z, sh0.w, sh1.x, sh1.y, sh1.z, sh1.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float zz = fmaf(z[e], scv[e], shv[e]);
+                        z[e] = XF == 1 ? fminf(fmaxf(zz, slope * zz), hi) : zz * fminf(fmaxf(zz + 3.f, 0.f), 6.f) / 6.f;
+                    }
+                    au = make_uint4(pack_bf16x2(z[0], z[1]), pack_bf16x2(z[2], z[3]), pack_bf16x2(z[4], z[5]), pack_bf16x2(z[6], z[7]));
+                }
+                const bf16x8_t a8 = __builtin_bit_cast(bf16x8_t, au);
+#pragma unroll
+                for (int u = 0; u < TN; ++u)
+                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, __builtin_bit_cast(bf16x8_t, bu[u]), acc[u], 0, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int kc = 0; kc < BKD / 8; ++kc) {
             const int chunk = kc * 2 + khalf;
@@ -375,31 +423,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     // stores per lane.  Instead each group of 4 accumulator registers (rows b..b+3 of the lane's column) is transposed
     // across the lane's quad with two DPP butterfly stages, after which lane jq of a quad holds row b+jq, columns
     // 4q..4q+3 -> one 16-byte store (4x fewer store instructions, full 128-B row segments per quad-row).
-    const bool nvec = (p.N & 3) == 0;
     const int quad = lrow >> 2, jq = lane & 3;
     auto epilogue = [&](int mt) {
         const int64_t m0 = (int64_t)mt * BM;
-        if (!nvec) {                                              // unaligned rows (75-channel heads): scalar stores
-#pragma unroll
-            for (int u = 0; u < TN; ++u) {
-                const int col = n0 + u * 32 + lrow;
-                const bool cok = col < p.N;
-                const float bv = (p.bias && cok) ? p.bias[col] : 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t row = m0 + wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                    float v = acc[u][r] + bv;
-                    if (cok && row < p.M) {
-                        if (p.addend) v += p.addend[row * p.N + col];
-                        p.C[row * p.N + col] = v;
-                        s1[u] += v;
-                        s2[u] = fmaf(v, v, s2[u]);
-                    }
-                    acc[u][r] = 0.f;
-                }
-            }
-            return;
-        }
 #pragma unroll
         for (int u = 0; u < TN; ++u) {
             const int colq = n0 + u * 32 + quad * 4;              // first of this lane's 4 output columns
@@ -411,7 +437,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int64_t row = m0 + wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                    if (ccol && row < p.M) { s1[u] += acc[u][r]; s2[u] = fmaf(acc[u][r], acc[u][r], s2[u]); }
+                    const float q = stored<T>(acc[u][r]);
+                    if (ccol && row < p.M) { s1[u] += q; s2[u] = fmaf(q, q, s2[u]); }
                 }
             }
 #pragma unroll
@@ -434,11 +461,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                 const int64_t row = m0 + wv * 32 + 8 * gq + 4 * khalf + jq;
                 if (cok && row < p.M) {
                     float4 v = make_float4(r0 + bv.x, r1 + bv.y, r2 + bv.z, r3 + bv.w);
-                    if (p.addend) add4(v, ld4(p.addend + row * p.N + colq));
-                    st4(p.C + row * p.N + colq, v);
+                    if (pAdd) add4(v, ld4(pAdd + row * p.N + colq));
+                    st4(pC + row * p.N + colq, v);
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[u][gq * 4 + i] = 0.f;
+                // keep the 4*TN store groups sequential: letting the scheduler hoist every addend load / transpose ahead of
+                // the first store raised the kernel's peak VGPR demand by ~27 and made the TN >= 3 main loops spill
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
@@ -497,37 +527,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
 }
 
 typedef void (*Nt2Kernel)(Gemm2Args);
-static Nt2Kernel nt2_kernel(int TN, int XF) {
-#define MNY_K(T) (XF == 0 ? (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 0> : XF == 1 ? (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 1> : (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 2>)
+static Nt2Kernel nt2_kernel(int TN, int XF, int BF = 0) {
+#define MNY_K(T) (BF ? (XF == 0 ? (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 0, 1> : XF == 1 ? (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 1, 1> : (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 2, 1>) \
+                     : (XF == 0 ? (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 0, 0> : XF == 1 ? (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 1, 0> : (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 2, 0>))
     switch (TN) { case 1: return MNY_K(1); case 2: return MNY_K(2); case 3: return MNY_K(3); default: return MNY_K(4); }
 #undef MNY_K
 }
 
 struct Nt2Plan { int TN, n_tiles, m_tiles, gx, tiles_per_block, grid; size_t lds; };
 
-static size_t nt2_lds(int TN, int K, bool xf) {
-    const int Kpad = (int)cdiv(K, 16) * 16;
+static size_t nt2_lds(int TN, int K, bool xf, int BF = 0) {
+    const int Kpad = (int)cdiv(K, BF ? 32 : 16) * (BF ? 32 : 16);
     size_t ring = (size_t)3 * (BM * 16 + 32 * TN * 16) * sizeof(float);
     size_t red = (size_t)4 * 32 * TN * 2 * sizeof(float);
     return (ring > red ? ring : red) + (xf ? 2 * Kpad * sizeof(float) : 0);
 }
 
 // resident workgroups per CU for (TN, XF) at a given dynamic-LDS size (queried once per distinct size)
-static int nt2_blocks_per_cu(int TN, int XF, size_t lds) {
+static int nt2_blocks_per_cu(int TN, int XF, size_t lds, int BF = 0) {
     static std::map<uint64_t, int> cache;
     static std::mutex mu;
-    const uint64_t key = ((uint64_t)TN << 40) | ((uint64_t)XF << 32) | (uint64_t)lds;
+    const uint64_t key = ((uint64_t)BF << 48) | ((uint64_t)TN << 40) | ((uint64_t)XF << 32) | (uint64_t)lds;
     std::lock_guard<std::mutex> lock(mu);
     auto it = cache.find(key);
     if (it != cache.end()) return it->second;
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)nt2_kernel(TN, XF), 256, lds) != hipSuccess || nb < 1) nb = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)nt2_kernel(TN, XF, BF), 256, lds) != hipSuccess || nb < 1) nb = 1;
     if (nb > 4) nb = 4;
     cache[key] = nb;
     return nb;
 }
 
-static Nt2Plan nt2_plan(int64_t M, int K, int N, bool xf) {
+static Nt2Plan nt2_plan(int64_t M, int K, int N, bool xf, int BF = 0) {
     Nt2Plan pl;
     int best = 1, best_pad = 1 << 30;
     for (int tn = 4; tn >= 1; --tn) {
@@ -535,7 +566,7 @@ static Nt2Plan nt2_plan(int64_t M, int K, int N, bool xf) {
         if (pad < best_pad) { best_pad = pad; best = tn; }
     }
     // grid depends only on (M,K,N): occupancy is taken for the transform variant so stat_parts() and fwd agree
-    const int blocks_per_cu = nt2_blocks_per_cu(best, 1, nt2_lds(best, K, true));
+    const int blocks_per_cu = nt2_blocks_per_cu(best, 1, nt2_lds(best, K, true, BF), BF);
     pl.TN = best;
     pl.n_tiles = (int)cdiv(N, 32 * best);
     pl.m_tiles = (int)cdiv(M, BM);
@@ -546,7 +577,7 @@ static Nt2Plan nt2_plan(int64_t M, int K, int N, bool xf) {
     pl.tiles_per_block = (int)cdiv(pl.m_tiles, gx);
     pl.gx = (int)cdiv(pl.m_tiles, pl.tiles_per_block);
     pl.grid = (int)cdiv(pl.gx, 8) * 8 * pl.n_tiles;
-    pl.lds = nt2_lds(best, K, xf);
+    pl.lds = nt2_lds(best, K, xf, BF);
     return pl;
 }
 
@@ -1004,7 +1035,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ y, fl
     if (slot == 0 && c < C) parts[(int64_t)blockIdx.x * C + c] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
-__global__ void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int R, int Cc) {
+template <typename T>
+__global__ void transpose_kernel(const float* __restrict__ src, T* __restrict__ dst, int R, int Cc) {
     __shared__ float tile[32][33];
     const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
     for (int j = threadIdx.y; j < 32; j += 8) {
@@ -1014,7 +1046,7 @@ __global__ void transpose_kernel(const float* __restrict__ src, float* __restric
     __syncthreads();
     for (int j = threadIdx.y; j < 32; j += 8) {
         const int c = bx + j, r = by + threadIdx.x;
-        if (r < R && c < Cc) dst[(int64_t)c * R + r] = tile[threadIdx.x][j];
+        if (r < R && c < Cc) st1(dst + (int64_t)c * R + r, tile[threadIdx.x][j]);
     }
 }
 
@@ -1434,17 +1466,18 @@ using namespace mny;
 
 extern "C" int mny_pw_stat_parts(int64_t M, int K, int Nc) {
     if (M <= 0 || K <= 0 || Nc <= 0) return MNY_EINVAL;
-    if ((K & 3) == 0 && getenv("MNY_GEMM_V1") == nullptr) return nt2_plan(M, K, Nc, true).gx;
+    if ((K & 3) == 0 && (Nc & 3) == 0 && getenv("MNY_GEMM_V1") == nullptr) return nt2_plan(M, K, Nc, true).gx;
     return nt_plan(M, K, Nc).gx;
 }
 extern "C" int mny_pw_stat_parts_bf16(int64_t M, int K, int Nc) {
     if (M <= 0 || K <= 0 || Nc <= 0) return MNY_EINVAL;
+    if ((K & 7) == 0 && (Nc & 3) == 0 && getenv("MNY_GEMM_V1") == nullptr) return nt2_plan(M, K, Nc, true, 1).gx;
     return nt_plan(M, K, Nc).gx;
 }
 
 // register-staged NT kernel (any K, any storage type)
 template <typename T>
-static int pw_fwd_v1(const T* x, const float* in_scale, const float* in_shift, int in_act, const float* w, const float* bias,
+static int pw_fwd_v1(const T* x, const float* in_scale, const float* in_shift, int in_act, const T* w, const float* bias,
                      const T* addend, T* y, float* stats, int64_t M, int K, int Nc, hipStream_t st) {
     const bool xf = in_scale != nullptr || in_act != MNY_ACT_NONE;
     NtPlan pl = nt_plan(M, K, Nc, xf);
@@ -1480,7 +1513,7 @@ extern "C" int mny_pw_fwd(const float* x, const float* in_scale, const float* in
     hipStream_t st = (hipStream_t)stream;
     const bool xf = in_scale != nullptr || in_act != MNY_ACT_NONE;
     static const bool force_v1 = getenv("MNY_GEMM_V1") != nullptr;   // A/B switch for profiling
-    if ((K & 3) == 0 && !force_v1) {                // LDS-DMA pipeline (v2)
+    if ((K & 3) == 0 && (Nc & 3) == 0 && !force_v1) {   // LDS-DMA pipeline (v2): 16-B aligned input rows, 16-B output groups
         Nt2Plan p2 = nt2_plan(M, K, Nc, xf);
         MNY_REQUIRE(p2.lds <= 64 * 1024, "pw_fwd: K=%d too large for the LDS scale cache", K);
         Gemm2Args g{x, in_scale, in_shift, in_act, w, bias, addend, y, stats, M, K, Nc, p2.m_tiles, p2.tiles_per_block, p2.gx, p2.n_tiles};
@@ -1492,14 +1525,25 @@ extern "C" int mny_pw_fwd(const float* x, const float* in_scale, const float* in
     return pw_fwd_v1<float>(x, in_scale, in_shift, in_act, w, bias, addend, y, stats, M, K, Nc, st);
 }
 
-extern "C" int mny_pw_fwd_bf16(const void* x, const float* in_scale, const float* in_shift, int in_act, const float* w,
+extern "C" int mny_pw_fwd_bf16(const void* x, const float* in_scale, const float* in_shift, int in_act, const void* w,
                                const float* bias, const void* addend, void* y, float* stats, int64_t M, int K, int Nc,
                                void* stream) {
     MNY_REQUIRE(x && w && y, "pw_fwd: null pointer");
     MNY_REQUIRE(M > 0 && K > 0 && Nc > 0, "pw_fwd: empty problem");
     MNY_REQUIRE(!(stats && bias), "pw_fwd: stats and bias are mutually exclusive");
-    return pw_fwd_v1<bf16_t>((const bf16_t*)x, in_scale, in_shift, in_act, w, bias, (const bf16_t*)addend, (bf16_t*)y, stats, M, K, Nc,
-                             (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    const bool xf = in_scale != nullptr || in_act != MNY_ACT_NONE;
+    static const bool force_v1 = getenv("MNY_GEMM_V1") != nullptr;
+    if ((K & 7) == 0 && (Nc & 3) == 0 && !force_v1) {   // LDS-DMA pipeline on the bf16 matrix cores (16-B aligned bf16 rows)
+        Nt2Plan p2 = nt2_plan(M, K, Nc, xf, 1);
+        MNY_REQUIRE(p2.lds <= 64 * 1024, "pw_fwd: K=%d too large for the LDS scale cache", K);
+        Gemm2Args g{x, in_scale, in_shift, in_act, w, bias, addend, y, stats, M, K, Nc, p2.m_tiles, p2.tiles_per_block, p2.gx, p2.n_tiles};
+        const int XF = !xf ? 0 : (in_act == MNY_ACT_HSWISH ? 2 : 1);
+        hipLaunchKernelGGL(nt2_kernel(p2.TN, XF, 1), dim3(p2.grid), dim3(256), p2.lds, st, g);
+        return check_launch("pw_gemm_nt_dma_kernel<bf16>");
+    }
+    return pw_fwd_v1<bf16_t>((const bf16_t*)x, in_scale, in_shift, in_act, (const bf16_t*)w, bias, (const bf16_t*)addend, (bf16_t*)y, stats,
+                             M, K, Nc, st);
 }
 
 extern "C" size_t mny_pw_wgrad_ws_floats(int64_t M, int K, int Nc) {
@@ -1560,8 +1604,14 @@ extern "C" int mny_pw_wgrad_bf16(const void* x, const float* in_scale, const flo
 
 extern "C" int mny_transpose(const float* src, float* dst, int R, int Cc, void* stream) {
     MNY_REQUIRE(src && dst && R > 0 && Cc > 0, "transpose: bad arguments");
-    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)cdiv(Cc, 32), (unsigned)cdiv(R, 32)), dim3(32, 8), 0, (hipStream_t)stream, src, dst, R, Cc);
+    hipLaunchKernelGGL((transpose_kernel<float>), dim3((unsigned)cdiv(Cc, 32), (unsigned)cdiv(R, 32)), dim3(32, 8), 0, (hipStream_t)stream, src, dst, R, Cc);
     return check_launch("transpose_kernel");
+}
+extern "C" int mny_transpose_bf16(const float* src, void* dst, int R, int Cc, void* stream) {
+    MNY_REQUIRE(src && dst && R > 0 && Cc > 0, "transpose: bad arguments");
+    hipLaunchKernelGGL((transpose_kernel<bf16_t>), dim3((unsigned)cdiv(Cc, 32), (unsigned)cdiv(R, 32)), dim3(32, 8), 0, (hipStream_t)stream, src,
+                       (bf16_t*)dst, R, Cc);
+    return check_launch("transpose_kernel<bf16>");
 }
 
 // ---- fused BN-backward + wgrad + dgrad for thin "expand" units ------------------------------------------------

@@ -162,7 +162,7 @@ class NetPlan:
                     i = nd.ins[0]
                     xv = view(i)
                     parts = _lib.query(K("mny_pw_stat_parts"), M, i.C, o.C)
-                    self.fwd.add(K("mny_pw_fwd"), xv[0], xv[1], xv[2], xv[3], w, None, None, u.Y, stats, M, i.C, o.C, self.stream,
+                    self.fwd.add(K("mny_pw_fwd"), xv[0], xv[1], xv[2], xv[3], self._gemm_weight(w), None, None, u.Y, stats, M, i.C, o.C, self.stream,
                                  meta=dict(flops=2 * M * i.C * o.C, bytes=eb * (M * i.C + M * o.C) + 4 * i.C * o.C, shape="M%d K%d N%d" % (M, i.C, o.C)))
                 gam, bet = P[nd.bn + ".weight"], P[nd.bn + ".bias"]
                 rm, rv = P[nd.bn + ".running_mean"], P[nd.bn + ".running_var"]
@@ -176,7 +176,7 @@ class NetPlan:
                 xv = view(i)
                 t = torch.empty(shp, **act)
                 self.reals[o.id] = t
-                self.fwd.add(K("mny_pw_fwd"), xv[0], xv[1], xv[2], xv[3], P[nd.conv + ".weight"], P[nd.conv + ".bias"], None, t, None,
+                self.fwd.add(K("mny_pw_fwd"), xv[0], xv[1], xv[2], xv[3], self._gemm_weight(P[nd.conv + ".weight"]), P[nd.conv + ".bias"], None, t, None,
                              M, i.C, o.C, self.stream, meta=dict(flops=2 * M * i.C * o.C, bytes=eb * (M * i.C + M * o.C) + 4 * i.C * o.C, shape="M%d K%d N%d" % (M, i.C, o.C)))
                 if self.bf16:                    # loss / decode read the head in fp32
                     t32 = torch.empty(shp, **f32)
@@ -491,9 +491,9 @@ class NetPlan:
                 db = gv(nd.conv + ".bias") if nd.bias else None
                 bwd.add(K("mny_pw_wgrad"), xv[0], xv[1], xv[2], xv[3], dY, gv(nd.conv + ".weight"), db, self.ws, M, i.C, o.C, self.stream,
                         meta=dict(flops=2 * M * i.C * o.C, bytes=eb * (M * i.C + M * o.C) + 4 * i.C * o.C, shape="M%d K%d N%d" % (M, i.C, o.C)))
-                wT = torch.empty(i.C, o.C, **f32)
+                wT = torch.empty(i.C, o.C, **act)       # the data-gradient GEMM reads W^T in the activation storage type
                 self.wT[nd.conv] = wT
-                bwd.add("mny_transpose", w, wT, o.C, i.C, self.stream)
+                bwd.add(K("mny_transpose"), w, wT, o.C, i.C, self.stream)
                 contribute_kernel(i, lambda out, addend, dY=dY, wT=wT, M=M, K=o.C, Nc=i.C: bwd.add(
                     self.K("mny_pw_fwd"), dY, None, None, ACT_NONE, wT, None, addend, out, None, M, K, Nc, self.stream,
                     meta=dict(flops=2 * M * K * Nc, bytes=self.eb * (M * K + M * Nc) + 4 * K * Nc, shape="dgrad M%d K%d N%d" % (M, K, Nc))))
@@ -501,6 +501,15 @@ class NetPlan:
             bwd.marks[o.name] = len(bwd.calls)
 
     # ------------------------------------------------------------------------------------------
+    def _gemm_weight(self, w):
+        """Weight operand of a forward pointwise GEMM: the fp32 parameter itself, or (bf16 storage) a bf16 shadow copy
+        refreshed by a conversion call placed right before the GEMM — the fp32 master copy is what optimizers update."""
+        if not self.bf16:
+            return w
+        w16 = torch.empty(w.shape, device=self.dev, dtype=torch.bfloat16)
+        self.fwd.add("mny_cvt_f32_bf16", w, w16, w.numel(), self.stream)
+        return w16
+
     def K(self, name):
         """Entry point for the plan's activation storage type."""
         return name + "_bf16" if self.bf16 else name

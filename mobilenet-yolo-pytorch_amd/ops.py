@@ -90,7 +90,9 @@ def dw_bwd_weight(view, dy, K, stride):
 
 # ---- pointwise --------------------------------------------------------------------------------------
 def pw_fwd(view, w2d, bias=None, addend=None, want_stats=True, out=None):
+    """bf16 activations take bf16 weights (mny_pw_fwd_bf16)."""
     x, sc, sh, act = view
+    assert w2d.dtype == x.dtype, "pw_fwd: weight dtype %s must match the activation storage type %s" % (w2d.dtype, x.dtype)
     K = x.shape[-1]
     M = x.numel() // K
     Nc = w2d.shape[0]
@@ -126,10 +128,10 @@ def pw_bnbwd(g, y, scale, shift, act, mean, invstd, gamma, xview, w2d, addend=No
     return dx, dw, dgamma, dbeta
 
 
-def transpose(w2d):
+def transpose(w2d, dtype=torch.float32):
     R, C = w2d.shape
-    out = _new(C, R, like=w2d)
-    call("mny_transpose", _p(w2d), _p(out), R, C, _st())
+    out = _new(C, R, like=w2d, dtype=dtype)
+    call(_k("mny_transpose", out), _p(w2d), _p(out), R, C, _st())
     return out
 
 
