@@ -951,7 +951,208 @@ __global__ __launch_bounds__(256) void pw_wgrad_dma_kernel(WgradArgs p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// weight gradient, bf16 operands (dY, X in bf16): same tile decomposition and LDS-DMA ring, on
+// v_mfma_f32_32x32x16_bf16.  The MFMA wants, per lane, 8 consecutive REDUCTION indices (rows m) of one
+// channel, but the chunk image is [row][channel] with channels contiguous — exactly the case gfx950's
+// transposing LDS read exists for: ds_read_b64_tr_b16 hands lane c of a 16-lane group the 4 rows of column c of a
+// [4 rows][16 channels] block (each lane supplies the address of 4 contiguous channels of row i/4), so two such
+// reads build one operand with no shuffles.  BN-apply + activation of X runs on the transposed fragment, where
+// a lane holds ONE channel (scalar scale/shift per lane).  MODE 0: 16-row chunks, 2x2 waves over the tile;
+// MODE 1: 64-row chunks, each wave a 16-row quarter of the whole (thin) dW, combined through LDS at the end.
+// Requires N % 8 == 0 and K % 8 == 0 (16-B chunks of 8 bf16); anything else takes the register-staged kernel.
+// ------------------------------------------------------------------------------------------------
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+
+template <int MODE, int TI, int TJ, int XF>
+__global__ __launch_bounds__(256) void pw_wgrad_bf16_kernel(WgradArgs p) {
+    constexpr int KC = MODE == 0 ? 16 : 64, S = 3;
+    constexpr int BI = (MODE == 0 ? 64 : 32) * TI;
+    constexpr int BJ = (MODE == 0 ? 64 : 32) * TJ;
+    constexpr int A_ST = KC * BI, B_ST = KC * BJ, STAGE = A_ST + B_ST;      // bf16 elements
+    constexpr int NA = A_ST / 512, NB = B_ST / 512, NL = NA + NB;           // 1-KiB DMA instructions per stage
+    constexpr int LPW = (NL + 3) / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    bf16_t* smem = reinterpret_cast<bf16_t*>(smem_f);
+    const bf16_t* pX = (const bf16_t*)p.X;
+    const bf16_t* pdY = (const bf16_t*)p.dY;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, kk = lane >> 5;
+    const int co0 = blockIdx.x * BI, ci0 = blockIdx.y * BJ;
+    const int64_t m_begin = (int64_t)blockIdx.z * p.rows_per_block;
+    const int64_t m_end = min(m_begin + p.rows_per_block, p.M);
+    const bool has_xf = p.in_scale != nullptr;
+    const float slope = act_slope(p.in_act), hi = act_hi(p.in_act);
+
+    const int ioff = MODE == 0 ? (wave >> 1) * 32 * TI : 0;
+    const int joff = MODE == 0 ? (wave & 1) * 32 * TJ : 0;
+    const int krow0 = MODE == 0 ? 0 : wave * 16;
+
+    float sc[TJ], sh[TJ];
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) {
+        const int ci = ci0 + joff + j * 32 + li;
+        sc[j] = (has_xf && ci < p.K) ? p.in_scale[ci] : 1.f;
+        sh[j] = (has_xf && ci < p.K) ? p.in_shift[ci] : 0.f;
+    }
+
+    const bf16_t* zero_src = reinterpret_cast<const bf16_t*>(&mny_zero16);
+    int d_row[LPW], d_lds[LPW];
+    bool d_isA[LPW], d_ok[LPW];
+    int d_off[LPW];
+#pragma unroll
+    for (int i = 0; i < LPW; ++i) {
+        int j = wave + 4 * i;
+        if (j >= NL) j = NL - 1;
+        d_isA[i] = j < NA;
+        const int q = (d_isA[i] ? j : j - NA) * 64 + lane;          // 16-B chunk index inside the tile
+        const int W8 = (d_isA[i] ? BI : BJ) / 8;
+        d_row[i] = q / W8;
+        const int c = (q % W8) * 8;
+        d_lds[i] = d_isA[i] ? j * 512 : A_ST + (j - NA) * 512;     // bf16 elements
+        if (d_isA[i]) { d_ok[i] = co0 + c < p.N; d_off[i] = co0 + c; }
+        else { d_ok[i] = ci0 + c < p.K; d_off[i] = ci0 + c; }
+    }
+
+    auto issue = [&](int64_t m0, int slot) {
+        bf16_t* stage = smem + slot * STAGE;
+#pragma unroll
+        for (int i = 0; i < LPW; ++i) {
+            const int64_t m = m0 + d_row[i];
+            const bf16_t* src;
+            if (d_isA[i]) src = (d_ok[i] && m < m_end) ? pdY + m * p.N + d_off[i] : zero_src;
+            else src = d_ok[i] ? pX + (m < m_end ? m : m_end - 1) * p.K + d_off[i] : zero_src;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(stage + d_lds[i]), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // transposing read: 16-lane group g = (lane>>4)&1 covers channels 16g..16g+15 of the lane's 32-channel tile; lane i of
+    // the group addresses row i/4, channels 4(i%4)..+3 of the [4][16] block and RECEIVES rows 0..3 of channel i.
+    const int tr_row = (lane & 15) >> 2;
+    const int tr_col = ((lane >> 4) & 1) * 16 + (lane & 3) * 4;
+    auto frag = [&](const bf16_t* tile, int pitch, int col0) -> uint4 {
+        const bf16_t* base = tile + (krow0 + 8 * kk + tr_row) * pitch + col0 + tr_col;
+        const v4s_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(base));
+        const v4s_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4s_t*)(base + 4 * pitch));
+        const uint2 a = __builtin_bit_cast(uint2, lo), b = __builtin_bit_cast(uint2, hi4);
+        return make_uint4(a.x, a.y, b.x, b.y);                    // k = 8*kk + 0..7 of this lane's channel
+    };
+
+    auto compute = [&](int slot) {
+        const bf16_t* tA = smem + slot * STAGE;
+        const bf16_t* tB = tA + A_ST;
+        uint4 af[TI], bf[TJ];
+#pragma unroll
+        for (int i = 0; i < TI; ++i) af[i] = frag(tA, BI, ioff + i * 32);
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            uint4 u = frag(tB, BJ, joff + j * 32);
+            if (XF != 0) {
+                float z[8] = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                              __uint_as_float(u.y & 0xffff0000u), __uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u),
+                              __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u)};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float zz = fmaf(z[e], sc[j], sh[j]);
+                    z[e] = XF == 1 ? fminf(fmaxf(zz, slope * zz), hi) : zz * fminf(fmaxf(zz + 3.f, 0.f), 6.f) / 6.f;
+                }
+                u = make_uint4(pack_bf16x2(z[0], z[1]), pack_bf16x2(z[2], z[3]), pack_bf16x2(z[4], z[5]), pack_bf16x2(z[6], z[7]));
+            }
+            bf[j] = u;
+        }
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[i]), __builtin_bit_cast(bf16x8_t, bf[j]),
+                                                                    acc[i][j], 0, 0, 0);
+    };
+
+    const int total = (int)((m_end - m_begin + KC - 1) / KC);
+    int i_t = 0, i_slot = 0, c_slot = 0;
+    auto issue_next = [&]() {
+        issue(m_begin + (int64_t)i_t * KC, i_slot);
+        ++i_t;
+        if (++i_slot == S) i_slot = 0;
+    };
+    const int pre = total < S - 1 ? total : S - 1;
+    for (int t = 0; t < pre; ++t) issue_next();
+    const int steady = total - pre;
+    for (int t = 0; t < steady; ++t) {
+        wait_vmcnt<LPW*(S - 2)>();
+        __builtin_amdgcn_s_barrier();
+        issue_next();
+        compute(c_slot);
+        if (++c_slot == S) c_slot = 0;
+    }
+    for (int t = 0; t < pre; ++t) {
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        compute(c_slot);
+        if (++c_slot == S) c_slot = 0;
+    }
+
+    float* dst = p.partial + (int64_t)blockIdx.z * p.N * p.K;
+    if (MODE == 0) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const int ci = ci0 + joff + j * 32 + li;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + ioff + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                    if (co < p.N && ci < p.K) dst[(int64_t)co * p.K + ci] = acc[i][j][r];
+                }
+            }
+    } else {
+        float* red = smem_f;               // [3][16][64] floats (12 KB <= ring)
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                __syncthreads();
+                if (wave > 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[((wave - 1) * 16 + r) * 64 + lane] = acc[i][j][r];
+                }
+                __syncthreads();
+                if (wave == 0) {
+                    const int ci = ci0 + j * 32 + li;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = ((acc[i][j][r] + red[(0 * 16 + r) * 64 + lane]) + red[(1 * 16 + r) * 64 + lane]) + red[(2 * 16 + r) * 64 + lane];
+                        const int co = co0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                        if (co < p.N && ci < p.K) dst[(int64_t)co * p.K + ci] = v;
+                    }
+                }
+            }
+    }
+}
+
 typedef void (*WgKernel)(WgradArgs);
+static WgKernel wg_bf16_kernel(int mode, int TI, int TJ, int XF) {
+    switch (mode * 100 + TI * 10 + TJ) {
+#define MNY_W(MD, I, J) case MD * 100 + I * 10 + J: return XF == 0 ? (WgKernel)pw_wgrad_bf16_kernel<MD, I, J, 0> : XF == 1 ? (WgKernel)pw_wgrad_bf16_kernel<MD, I, J, 1> : (WgKernel)pw_wgrad_bf16_kernel<MD, I, J, 2>;
+        MNY_W(0, 1, 1) MNY_W(0, 1, 2) MNY_W(0, 2, 1) MNY_W(0, 2, 2)
+        MNY_W(1, 1, 1) MNY_W(1, 1, 2) MNY_W(1, 1, 3) MNY_W(1, 1, 4) MNY_W(1, 1, 5) MNY_W(1, 1, 6) MNY_W(1, 2, 1) MNY_W(1, 2, 2) MNY_W(1, 2, 3)
+        MNY_W(1, 3, 1) MNY_W(1, 3, 2) MNY_W(1, 4, 1) MNY_W(1, 5, 1) MNY_W(1, 6, 1)
+#undef MNY_W
+        default: return nullptr;
+    }
+}
+
 static WgKernel wg_dma_kernel(int mode, int TI, int TJ) {
     switch (mode * 100 + TI * 10 + TJ) {
 #define MNY_W(MD, I, J) case MD * 100 + I * 10 + J: return (WgKernel)pw_wgrad_dma_kernel<MD, I, J>;
@@ -970,12 +1171,12 @@ static int pick_block(int c) {      // 64 or 128: minimise the padded extent, ti
     return p128 <= p64 ? 128 : 64;
 }
 
-static WgPlan wg_plan(int64_t M, int K, int N) {
+static WgPlan wg_plan(int64_t M, int K, int N, bool bf16 = false) {
     WgPlan pl;
     const int nco = (int)cdiv(N, 32), nci = (int)cdiv(K, 32);
     int BI, BJ, KC;
     if (nco * nci <= 6) {
-        pl.mode = 1; pl.TI = nco; pl.TJ = nci; BI = 32 * nco; BJ = 32 * nci; KC = 32;
+        pl.mode = 1; pl.TI = nco; pl.TJ = nci; BI = 32 * nco; BJ = 32 * nci; KC = bf16 ? 64 : 32;
         pl.gx = pl.gy = 1;
     } else {
         pl.mode = 0; BI = pick_block(N); BJ = pick_block(K); KC = 16;
@@ -990,10 +1191,11 @@ static WgPlan wg_plan(int64_t M, int K, int N) {
     const int64_t rpb = cdiv(cdiv(M, splits), KC) * KC;
     pl.rows_per_block = rpb;
     pl.splits = (int)cdiv(M, rpb);
-    size_t stage = (size_t)2 * KC * (BI + BJ) * sizeof(float);
+    size_t stage = (size_t)2 * (bf16 ? 32 : KC) * (BI + BJ) * sizeof(float);    // register-staged kernel: fp32 image, its own KC
+    if (pl.mode == 0) stage = (size_t)2 * 16 * (BI + BJ) * sizeof(float);
     if (stage < 3 * 16 * 64 * sizeof(float)) stage = 3 * 16 * 64 * sizeof(float);
     pl.lds = stage + 2 * BJ * sizeof(float);
-    pl.lds_dma = (size_t)3 * 16 * (BI + BJ) * sizeof(float);
+    pl.lds_dma = bf16 ? (size_t)3 * KC * (BI + BJ) * 2 : (size_t)3 * 16 * (BI + BJ) * sizeof(float);
     if (pl.lds_dma < 3 * 16 * 64 * sizeof(float)) pl.lds_dma = 3 * 16 * 64 * sizeof(float);
     return pl;
 }
@@ -1557,13 +1759,30 @@ static int pw_wgrad_impl(const T* x, const float* in_scale, const float* in_shif
                          float* dw, float* dbias, float* ws, int64_t M, int K, int Nc, void* stream) {
     MNY_REQUIRE(x && dy && dw && ws, "pw_wgrad: null pointer");
     MNY_REQUIRE(M > 0 && K > 0 && Nc > 0, "pw_wgrad: empty problem");
-    WgPlan pl = wg_plan(M, K, Nc);
+    constexpr bool is_f32 = sizeof(T) == 4;
+    WgPlan pl = wg_plan(M, K, Nc, !is_f32);
     WgradArgs a{x, in_scale, in_shift, in_act, dy, ws, M, K, Nc, pl.rows_per_block};
     dim3 grid(pl.gx, pl.gy, pl.splits), block(256);
     hipStream_t st = (hipStream_t)stream;
     static const bool force_v1 = getenv("MNY_WGRAD_V1") != nullptr;
-    constexpr bool is_f32 = sizeof(T) == 4;      // the LDS-DMA kernel reads raw fp32 chunks
-    WgKernel dk = (is_f32 && (Nc & 3) == 0 && (K & 3) == 0 && in_act != MNY_ACT_HSWISH && !force_v1) ? wg_dma_kernel(pl.mode, pl.TI, pl.TJ) : nullptr;
+    WgKernel dk = nullptr;                       // LDS-DMA kernels read raw 16-B chunks: aligned rows only
+    if (is_f32) {
+        if ((Nc & 3) == 0 && (K & 3) == 0 && in_act != MNY_ACT_HSWISH && !force_v1) dk = wg_dma_kernel(pl.mode, pl.TI, pl.TJ);
+    } else if ((Nc & 7) == 0 && (K & 7) == 0 && !force_v1) {
+        const int XF = (in_scale == nullptr && in_act == MNY_ACT_NONE) ? 0 : (in_act == MNY_ACT_HSWISH ? 2 : 1);
+        dk = wg_bf16_kernel(pl.mode, pl.TI, pl.TJ, XF);
+        if (dk && pl.lds_dma > 64 * 1024) {      // > 64 KB of dynamic LDS needs a per-kernel opt-in (once)
+            static std::map<const void*, bool> done;
+            static std::mutex mu;
+            std::lock_guard<std::mutex> lock(mu);
+            if (!done[(const void*)dk]) {
+                if (hipFuncSetAttribute((const void*)dk, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+                    set_error("pw_wgrad: hipFuncSetAttribute failed"); return MNY_EHIP;
+                }
+                done[(const void*)dk] = true;
+            }
+        }
+    }
     const int key = dk ? -1 : pl.mode * 100 + pl.TI * 10 + pl.TJ;
     if (dk) hipLaunchKernelGGL(dk, grid, block, pl.lds_dma, st, a);
 #define MNY_WG(MD, I, J) hipLaunchKernelGGL((pw_wgrad_kernel<T, MD, I, J>), grid, block, pl.lds, st, a)
