@@ -530,7 +530,7 @@ typedef void (*Nt2Kernel)(Gemm2Args);
 static Nt2Kernel nt2_kernel(int TN, int XF, int BF = 0) {
 #define MNY_K(T) (BF ? (XF == 0 ? (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 0, 1> : XF == 1 ? (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 1, 1> : (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 2, 1>) \
                      : (XF == 0 ? (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 0, 0> : XF == 1 ? (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 1, 0> : (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 2, 0>))
-    switch (TN) { case 1: return MNY_K(1); case 2: return MNY_K(2); case 3: return MNY_K(3); default: return MNY_K(4); }
+    switch (TN) { case 1: return MNY_K(1); case 2: return MNY_K(2); case 3: return MNY_K(3); case 4: return MNY_K(4); default: return MNY_K(5); }
 #undef MNY_K
 }
 
@@ -553,7 +553,7 @@ static int nt2_blocks_per_cu(int TN, int XF, size_t lds, int BF = 0) {
     if (it != cache.end()) return it->second;
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)nt2_kernel(TN, XF, BF), 256, lds) != hipSuccess || nb < 1) nb = 1;
-    if (nb > 4) nb = 4;
+    if (nb > 8) nb = 8;
     cache[key] = nb;
     return nb;
 }
@@ -561,8 +561,9 @@ static int nt2_blocks_per_cu(int TN, int XF, size_t lds, int BF = 0) {
 static Nt2Plan nt2_plan(int64_t M, int K, int N, bool xf, int BF = 0) {
     Nt2Plan pl;
     int best = 1, best_pad = 1 << 30;
-    for (int tn = 4; tn >= 1; --tn) {
-        int pad = (int)cdiv(N, 32 * tn) * 32 * tn;
+    static const int max_tn = getenv("MNY_NT_MAXTN") ? atoi(getenv("MNY_NT_MAXTN")) : 5;
+    for (int tn = max_tn; tn >= 1; --tn) {        // minimise the padded width; ties -> the wider tile (A read fewer times,
+        int pad = (int)cdiv(N, 32 * tn) * 32 * tn;   // longer contiguous output rows)
         if (pad < best_pad) { best_pad = pad; best = tn; }
     }
     // grid depends only on (M,K,N): occupancy is taken for the transform variant so stat_parts() and fwd agree
