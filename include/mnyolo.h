@@ -204,6 +204,19 @@ size_t mny_nms_ws_bytes(int S, int capacity, int num_classes);
 size_t mny_nms_status_offset(int S, int capacity, int num_classes);
 size_t mny_nms_prefix_offset(int S, int capacity, int num_classes);
 
+/* ---- fused backward of a depthwise 3x3 stride-1 conv + BN + activation unit ----------------------------
+ * One pass over (g, y, x) instead of bn_bwd_apply + dw_bwd_weight + dw_bwd_data (7 tensor passes -> 4): rebuilds
+ * dY = ca*g*act'(scale*y+shift) + cb*y + cc in registers from the coefficients `coef` = [3][C] written by
+ * mny_bn_bwd_finalize, and produces dx (gradient wrt the ACTIVATED input view, + optional addend) and dw [C,1,3,3].
+ * `ws`: [mny_dw_bnbwd_parts()][C*9] floats.  Only K == 3, stride == 1 (mny_dw_bnbwd_supported()).
+ * replaces the backward of mobilenetv2.py:65-67,79-81 / mbv2_yolo.py:22-24 for those units.                  */
+int mny_dw_bnbwd_supported(int K, int stride);
+int mny_dw_bnbwd_parts(int N, int H, int W, int C);
+int mny_dw_bnbwd(const float* g, const float* y, const float* scale, const float* shift, int act, const float* coef,
+                 const float* x, const float* in_scale, const float* in_shift, int in_act, const float* w,
+                 const float* addend, float* dx, float* dw, float* ws, int N, int H, int W, int C, int K, int stride,
+                 void* stream);
+
 /* ---- bf16 STORAGE twins (BASELINE config 4: MobileNetV3-YOLO 512x512 bf16) -----------------
  * Every `mny_X_bf16` has the contract of `mny_X` above with ONE difference: the activation-sized tensors (the
  * `void*` parameters: raw conv outputs, materialised sums, gradients wrt activations) are bf16 in HBM.  Kernels
@@ -245,6 +258,10 @@ int mny_partadd_up_bf16(const void* a, const float* a_scale, const float* a_shif
                         int N, int H, int W, int Ca, int Cb, void* stream);
 int mny_slice_channels_bf16(const void* src, void* dst, int accumulate, int64_t M, int Ca, int Cb, void* stream);
 int mny_upsample_bwd_bf16(const void* src, void* dst, int accumulate, int N, int H, int W, int C, void* stream);
+int mny_dw_bnbwd_bf16(const void* g, const void* y, const float* scale, const float* shift, int act, const float* coef,
+                      const void* x, const float* in_scale, const float* in_shift, int in_act, const float* w,
+                      const void* addend, void* dx, float* dw, float* ws, int N, int H, int W, int C, int K, int stride,
+                      void* stream);
 int mny_axpy_bf16(const void* src, const float* alpha, void* dst, int accumulate, int64_t n, void* stream);
 /* element-wise storage conversion, n elements (RNE to bf16, exact widening back) */
 int mny_cvt_f32_bf16(const float* src, void* dst, int64_t n, void* stream);

@@ -1,0 +1,243 @@
+// Fused backward of a depthwise 3x3 stride-1 conv+BN+activation unit.
+//
+// Unfused, the unit's backward touches its (hidden-width) tensors 7 times after the BN reduction:
+//     bn_bwd_apply : read G, Y -> write dY          dw_bwd_weight : read dY, X          dw_bwd_data : read dY -> write dX
+// Here one kernel reads G, Y, X once and writes dX once (4 passes): dY = ca*G*act'(sc*Y+sh) + cb*Y + cc is rebuilt in
+// registers from (G, Y) and the per-channel coefficients of mny_bn_bwd_finalize, and both gradients are taken from it.
+//
+// Thread = 4 channels x one column, walking DOWN a strip of rows with row-sized state only:
+//   * data gradient as a scatter: dY row r (columns w-1..w+1) updates the three partial output rows r-1, r, r+1 of column
+//     w; row r-1 is complete after that and is stored (3 float4 of state instead of a 3x3 window of dY);
+//   * weight gradient with the input row delayed by one step: input row r-1 meets the centre-column dY of rows r, r-1, r-2
+//     (2 float4 of history instead of a 3x3 window of X).
+// Halo rows/columns are re-read by neighbouring threads/strips from L2; strips are 16 rows (19 loaded rows per 16).
+// All loads are unconditional with clamped addresses and zeroed by select (no control flow in the row loop).
+//
+// replaces, for these units, the autograd backward of nn.Conv2d(groups=C) + nn.BatchNorm2d + ReLU6 / LeakyReLU
+// (models/mobilenetv2.py:65-67,79-81, models/mbv2_yolo.py:22-24).
+#include "common.h"
+
+namespace mny {
+
+struct DwbGeom {
+    int N, H, W, C;
+    int TH, nHS;
+    int64_t nstrips;
+    int cg_total, cgb;
+};
+
+// AM: activation of THIS unit: 0 = none (act' = 1), 1 = min(max(z, slope z), hi) family, 2 = hswish
+// XF: view of the input: 0 = as is, 1 = scale/shift + clamp family, 2 = scale/shift + hswish
+template <typename T, int AM, int XF>
+__global__ __launch_bounds__(256) void dw_bnbwd_s1k3_kernel(
+    const T* __restrict__ g, const T* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift, int act,
+    const float* __restrict__ coef, const T* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+    int in_act, const float* __restrict__ w, const T* __restrict__ addend, T* __restrict__ dx, float* __restrict__ parts, DwbGeom gm) {
+    __shared__ float4 red[256];
+    // per-channel constants (9 filter taps + 7 coefficient vectors) live in LDS, [16][cgb] float4, read where used: keeping
+    // them in registers put the kernel at ~200 VGPRs = 2 waves/SIMD, too few loads in flight for an HBM-bound stream
+    extern __shared__ __attribute__((aligned(16))) float4 cst[];
+    const int tid = threadIdx.x;
+    const int cgl = tid % gm.cgb, pix = tid / gm.cgb, ppb = blockDim.x / gm.cgb;
+    const int cg = blockIdx.y * gm.cgb + cgl;
+    const bool cvalid = cg < gm.cg_total;
+    const int c = cg * 4;
+
+    float4 wacc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wacc[t] = f4zero();
+
+    if (pix == 0 && cvalid) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) cst[t * gm.cgb + cgl] = make_float4(w[(c + 0) * 9 + t], w[(c + 1) * 9 + t], w[(c + 2) * 9 + t], w[(c + 3) * 9 + t]);
+        cst[9 * gm.cgb + cgl] = ld4(scale + c);
+        cst[10 * gm.cgb + cgl] = ld4(shift + c);
+        cst[11 * gm.cgb + cgl] = ld4(coef + c);
+        cst[12 * gm.cgb + cgl] = ld4(coef + gm.C + c);
+        cst[13 * gm.cgb + cgl] = ld4(coef + 2 * gm.C + c);
+        cst[14 * gm.cgb + cgl] = (XF != 0 && in_scale) ? ld4(in_scale + c) : f4one();
+        cst[15 * gm.cgb + cgl] = (XF != 0 && in_scale) ? ld4(in_shift + c) : f4zero();
+    }
+    __syncthreads();
+    if (cvalid) {
+#define WG(t) my[(t) * gm.cgb]
+        const float slope = act_slope(act), hi = act_hi(act);
+        const float xslope = act_slope(in_act), xhi = act_hi(in_act);
+
+        auto dy1 = [&](float gv, float yv, float s, float h, float a, float b, float cterm) {
+            float d = gv;
+            if (AM == 1) { const float z = fmaf(yv, s, h); d = gv * ((z > 0.f ? 1.f : slope) * (z < hi ? 1.f : 0.f)); }
+            if (AM == 2) { const float z = fmaf(yv, s, h); d = gv * (z <= -3.f ? 0.f : (z >= 3.f ? 1.f : (2.f * z + 3.f) / 6.f)); }
+            return fmaf(a, d, fmaf(b, yv, cterm));
+        };
+        auto xf1 = [&](float v, float s, float h) {
+            if (XF == 0) return v;
+            const float z = fmaf(v, s, h);
+            return XF == 1 ? fminf(fmaxf(z, xslope * z), xhi) : z * fminf(fmaxf(z + 3.f, 0.f), 6.f) / 6.f;
+        };
+
+        for (int64_t strip = (int64_t)blockIdx.x * ppb + pix; strip < gm.nstrips; strip += (int64_t)gridDim.x * ppb) {
+            const int wo = (int)(strip % gm.W);
+            const int hs = (int)((strip / gm.W) % gm.nHS);
+            const int n = (int)(strip / ((int64_t)gm.W * gm.nHS));
+            const int h0 = hs * gm.TH;
+            const int h1 = min(h0 + gm.TH, gm.H);
+            const int64_t img = (int64_t)n * gm.H * gm.W * gm.C + c;
+            int col[3];
+            bool cok[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { const int wi = wo - 1 + q; cok[q] = wi >= 0 && wi < gm.W; col[q] = min(max(wi, 0), gm.W - 1); }
+
+            float4 P0 = f4zero(), P1 = f4zero();
+            float4 aprev[3] = {f4zero(), f4zero(), f4zero()};
+            float4 dc1 = f4zero(), dc2 = f4zero();
+            for (int r = h0 - 1; r <= h1; ++r) {
+                int lo = cgl;
+                asm volatile("" : "+v"(lo));                       // opaque per iteration: keeps the LDS constant reads IN the loop
+                const float4* my = cst + lo;                      // (hoisted, they are 64 VGPRs live across it)
+                const int rc = min(max(r, 0), gm.H - 1);
+                const bool rok = r >= 0 && r < gm.H;
+                const int64_t rowoff = img + (int64_t)rc * gm.W * gm.C;
+                float4 gv[3], yv[3], xv[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const int64_t o = rowoff + (int64_t)col[q] * gm.C;
+                    gv[q] = ld4(g + o); yv[q] = ld4(y + o); xv[q] = ld4(x + o);
+                }
+                float4 dyr[3], ar[3];
+                const float4 sc = my[9 * gm.cgb], sh = my[10 * gm.cgb], ca = my[11 * gm.cgb], cb = my[12 * gm.cgb], cc = my[13 * gm.cgb];
+                const float4 xsc = my[14 * gm.cgb], xsh = my[15 * gm.cgb];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    float4 d, a;
+                    d.x = dy1(gv[q].x, yv[q].x, sc.x, sh.x, ca.x, cb.x, cc.x); d.y = dy1(gv[q].y, yv[q].y, sc.y, sh.y, ca.y, cb.y, cc.y);
+                    d.z = dy1(gv[q].z, yv[q].z, sc.z, sh.z, ca.z, cb.z, cc.z); d.w = dy1(gv[q].w, yv[q].w, sc.w, sh.w, ca.w, cb.w, cc.w);
+                    a.x = xf1(xv[q].x, xsc.x, xsh.x); a.y = xf1(xv[q].y, xsc.y, xsh.y);
+                    a.z = xf1(xv[q].z, xsc.z, xsh.z); a.w = xf1(xv[q].w, xsc.w, xsh.w);
+                    const bool ok = rok && cok[q];                 // dY and the activated input are 0 outside the image
+                    dyr[q] = ok ? d : f4zero();
+                    ar[q] = ok ? a : f4zero();
+                }
+                // data gradient: dX[i][w] += sum_kq dY[r][w+1-kq] * wt[i-r+1][kq]  (dyr[q] sits at column w-1+q -> q = 2-kq)
+                float4 P2 = f4zero();
+#pragma unroll
+                for (int kq = 0; kq < 3; ++kq) {
+                    fma4(P0, dyr[2 - kq], WG(0 + kq));
+                    fma4(P1, dyr[2 - kq], WG(3 + kq));
+                    fma4(P2, dyr[2 - kq], WG(6 + kq));
+                }
+                if (r - 1 >= h0) {                                  // row r-1 is complete (r-1 < h1 by the loop bound)
+                    const int64_t o = img + ((int64_t)(r - 1) * gm.W + wo) * gm.C;
+                    float4 out = P0;
+                    if (addend) add4(out, ld4(addend + o));
+                    st4(dx + o, out);
+                }
+                P0 = P1; P1 = P2;
+                // weight gradient: input row r-1 against the centre dY of rows r, r-1, r-2 (only rows this strip owns)
+                const float4 dc0 = (r >= h0 && r < h1) ? dyr[1] : f4zero();
+#pragma unroll
+                for (int kq = 0; kq < 3; ++kq) {
+                    fma4(wacc[0 + kq], aprev[kq], dc0);
+                    fma4(wacc[3 + kq], aprev[kq], dc1);
+                    fma4(wacc[6 + kq], aprev[kq], dc2);
+                }
+                dc2 = dc1; dc1 = dc0;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) aprev[q] = ar[q];
+            }
+            // tail: input row h1 meets the centre dY of row h1-1 (kr = 2)
+#pragma unroll
+            for (int kq = 0; kq < 3; ++kq) fma4(wacc[6 + kq], aprev[kq], dc2);
+        }
+#undef WG
+    }
+
+    // deterministic block reduction of the 9 tap accumulators over the `ppb` pixel slots
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        __syncthreads();
+        red[tid] = wacc[t];
+        __syncthreads();
+        if (pix == 0 && cvalid) {
+            float4 a = f4zero();
+            for (int p = 0; p < ppb; ++p) add4(a, red[p * gm.cgb + cgl]);
+            float* dst = parts + (int64_t)blockIdx.x * gm.C * 9;
+            dst[(c + 0) * 9 + t] = a.x; dst[(c + 1) * 9 + t] = a.y;
+            dst[(c + 2) * 9 + t] = a.z; dst[(c + 3) * 9 + t] = a.w;
+        }
+    }
+}
+
+static int dwb_geom(DwbGeom& g, CgLayout& L, int& gx, int N, int H, int W, int C) {
+    MNY_REQUIRE(C % 4 == 0 && C > 0, "dw_bnbwd: C=%d must be a positive multiple of 4", C);
+    MNY_REQUIRE(N > 0 && H > 0 && W > 0, "dw_bnbwd: empty tensor");
+    g.N = N; g.H = H; g.W = W; g.C = C;
+    const int ns = (int)cdiv(H, 16);
+    g.TH = (int)cdiv(H, ns);
+    g.nHS = (int)cdiv(H, g.TH);
+    g.nstrips = (int64_t)N * W * g.nHS;
+    L.cg_total = C / 4;                                   // channel groups per block capped at 128: <= 32 KB of LDS constants
+    L.chunks = (int)cdiv(L.cg_total, 128);
+    L.cgb = (int)cdiv(L.cg_total, L.chunks);
+    L.ppb = 256 / L.cgb; if (L.ppb < 1) L.ppb = 1;
+    L.threads = L.cgb * L.ppb;
+    g.cg_total = L.cg_total; g.cgb = L.cgb;
+    int64_t want = cdiv(g.nstrips, L.ppb);
+    gx = (int)(want < kMaxParts ? want : kMaxParts);
+    return MNY_OK;
+}
+
+template <typename T>
+static int dw_bnbwd_impl(const T* g, const T* y, const float* scale, const float* shift, int act, const float* coef,
+                         const T* x, const float* in_scale, const float* in_shift, int in_act, const float* w,
+                         const T* addend, T* dx, float* dw, float* ws, int N, int H, int W, int C, int K, int stride, void* stream) {
+    MNY_REQUIRE(g && y && scale && shift && coef && x && w && dx && dw && ws, "dw_bnbwd: null pointer");
+    MNY_REQUIRE(K == 3 && stride == 1, "dw_bnbwd: only 3x3 stride 1 is fused (got K=%d stride=%d); use bn_bwd_apply + dw_bwd_*", K, stride);
+    MNY_REQUIRE(act != MNY_ACT_HSIGMOID && in_act != MNY_ACT_HSIGMOID, "dw_bnbwd: h-sigmoid views are not supported");
+    DwbGeom gm; CgLayout L; int gx;
+    int rc = dwb_geom(gm, L, gx, N, H, W, C);
+    if (rc) return rc;
+    dim3 grid(gx, L.chunks), block(L.threads);
+    hipStream_t st = (hipStream_t)stream;
+    const int am = act == MNY_ACT_NONE ? 0 : (act == MNY_ACT_HSWISH ? 2 : 1);
+    const int xf = (in_scale == nullptr && in_act == MNY_ACT_NONE) ? 0 : (in_act == MNY_ACT_HSWISH ? 2 : 1);
+    const size_t lds = (size_t)16 * L.cgb * sizeof(float4);
+#define MNY_L(A_, X_) hipLaunchKernelGGL((dw_bnbwd_s1k3_kernel<T, A_, X_>), grid, block, lds, st, g, y, scale, shift, act, coef, x, in_scale, in_shift, \
+                                         in_act, w, addend, dx, ws, gm)
+    switch (am * 3 + xf) {
+        case 0: MNY_L(0, 0); break; case 1: MNY_L(0, 1); break; case 2: MNY_L(0, 2); break;
+        case 3: MNY_L(1, 0); break; case 4: MNY_L(1, 1); break; case 5: MNY_L(1, 2); break;
+        case 6: MNY_L(2, 0); break; case 7: MNY_L(2, 1); break; default: MNY_L(2, 2); break;
+    }
+#undef MNY_L
+    rc = check_launch("dw_bnbwd_s1k3_kernel");
+    if (rc) return rc;
+    return launch_reduce_parts(ws, gx, C * 9, dw, st);
+}
+
+}  // namespace mny
+
+using namespace mny;
+
+extern "C" int mny_dw_bnbwd_supported(int K, int stride) { return (K == 3 && stride == 1) ? 1 : 0; }
+
+extern "C" int mny_dw_bnbwd_parts(int N, int H, int W, int C) {
+    DwbGeom g; CgLayout L; int gx;
+    if (dwb_geom(g, L, gx, N, H, W, C)) return MNY_EINVAL;
+    return gx;
+}
+
+extern "C" int mny_dw_bnbwd(const float* g, const float* y, const float* scale, const float* shift, int act, const float* coef,
+                            const float* x, const float* in_scale, const float* in_shift, int in_act, const float* w,
+                            const float* addend, float* dx, float* dw, float* ws, int N, int H, int W, int C, int K, int stride,
+                            void* stream) {
+    return dw_bnbwd_impl<float>(g, y, scale, shift, act, coef, x, in_scale, in_shift, in_act, w, addend, dx, dw, ws, N, H, W, C, K, stride, stream);
+}
+
+extern "C" int mny_dw_bnbwd_bf16(const void* g, const void* y, const float* scale, const float* shift, int act, const float* coef,
+                                 const void* x, const float* in_scale, const float* in_shift, int in_act, const float* w,
+                                 const void* addend, void* dx, float* dw, float* ws, int N, int H, int W, int C, int K, int stride,
+                                 void* stream) {
+    return dw_bnbwd_impl<bf16_t>((const bf16_t*)g, (const bf16_t*)y, scale, shift, act, coef, (const bf16_t*)x, in_scale, in_shift, in_act, w,
+                                 (const bf16_t*)addend, (bf16_t*)dx, dw, ws, N, H, W, C, K, stride, stream);
+}

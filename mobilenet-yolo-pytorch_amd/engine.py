@@ -465,6 +465,25 @@ class NetPlan:
                 u = self.units[o.id]
                 parts = _lib.query("mny_bn_bwd_parts", M, o.C)
                 gam = P[nd.bn + ".weight"]
+                if (nd.op == "dw" and os.environ.get("MNY_NO_DWFUSE") != "1" and _lib.query("mny_dw_bnbwd_supported", nd.k, nd.stride) == 1
+                        and o.act != _lib.ACT_HSIGMOID and nd.ins[0].act != _lib.ACT_HSIGMOID):
+                    # 3x3 stride-1 depthwise unit: dY is rebuilt in registers, one pass over (G, Y, X) yields dX and dW
+                    i = nd.ins[0]
+                    ish = shape(i)
+                    xv = view(i)
+                    bwd.add(K("mny_bn_bwd_reduce"), G, u.Y, u.scale, u.shift, o.act, u.mean, u.invstd, self.red_ws, M, o.C, self.stream,
+                            meta=dict(flops=0, bytes=2 * eb * M * o.C, shape="M%d C%d" % (M, o.C)))
+                    bwd.add("mny_bn_bwd_finalize", self.red_ws, parts, M, gam, u.mean, u.invstd, gv(nd.bn + ".weight"), gv(nd.bn + ".bias"),
+                            self.coef_ws, o.C, self.stream)
+                    dwv = gv(nd.conv + ".weight")
+                    wt = P[nd.conv + ".weight"]
+                    contribute_kernel(i, lambda out, addend, G=G, u=u, xv=xv, wt=wt, dwv=dwv, ish=ish, C=o.C, act=o.act, M=M: bwd.add(
+                        self.K("mny_dw_bnbwd"), G, u.Y, u.scale, u.shift, act, self.coef_ws, xv[0], xv[1], xv[2], xv[3], wt, addend, out, dwv, self.ws,
+                        N, ish[1], ish[2], C, 3, 1, self.stream,
+                        meta=dict(flops=4 * M * C * 9, bytes=self.eb * 4 * M * C, shape="C%d H%d" % (C, ish[1]))))
+                    flush_shared()
+                    bwd.marks[o.name] = len(bwd.calls)
+                    continue
                 dY = G if not s.shared else alloc(o)
                 bwd.add(K("mny_bn_bwd_reduce"), G, u.Y, u.scale, u.shift, o.act, u.mean, u.invstd, self.red_ws, M, o.C, self.stream,
                         meta=dict(flops=0, bytes=2 * eb * M * o.C, shape="M%d C%d" % (M, o.C)))

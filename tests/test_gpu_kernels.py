@@ -231,3 +231,56 @@ def test_fused_bn_backward_expand_unit(ops, M, K, Nc, act, xact):
     rel(dgamma, gr.grad, 5e-4, "dgamma")
     rel(dbeta, br.grad, 5e-4, "dbeta")
     rel(dx.view(M, K), a_in.grad + add, 5e-4, "dX")
+
+
+@pytest.mark.parametrize("N,H,W,C,act,xact,dtype", [(2, 11, 11, 32, 1, 1, "f32"), (3, 22, 19, 96, 2, 2, "f32"), (2, 37, 8, 144, 1, 0, "f32"),
+                                                    (1, 5, 5, 960, 0, 1, "f32"), (2, 16, 16, 72, 3, 3, "f32"), (2, 20, 20, 120, 4, 4, "f32"),
+                                                    (2, 33, 17, 64, 1, 1, "bf16"), (2, 9, 9, 240, 4, 4, "bf16")])
+def test_fused_dw_unit_backward(ops, N, H, W, C, act, xact, dtype):
+    """mny_dw_bnbwd: BN-backward-apply + depthwise weight- and data-gradient of a 3x3 stride-1 unit in one pass over
+    (G, Y, X), against torch autograd through conv(groups=C) -> BN(train) -> act.  fp32: 2e-4; bf16 storage: the inputs are
+    bf16-representable, dX is rounded once on store (2^-7), dW / dgamma / dbeta are fp32 outputs."""
+    acts = dict(ACTS)
+    acts[3] = torch.relu
+    acts[4] = lambda z: z * F.relu6(z + 3) / 6
+    bf = dtype == "bf16"
+    q = (lambda t: t.to(torch.bfloat16).float()) if bf else (lambda t: t)
+    x = q(rnd(N, C, H, W, seed=1))
+    w = rnd(C, 1, 3, 3, seed=2, scale=0.4)
+    xs, xh = 1 + 0.2 * rnd(C, seed=3), 0.3 * rnd(C, seed=4)
+    gamma, beta = 1 + 0.3 * rnd(C, seed=5), 0.2 * rnd(C, seed=6)
+    a_in = (acts[xact](x * xs.view(1, -1, 1, 1) + xh.view(1, -1, 1, 1)) if xact or True else x).detach().requires_grad_(True)
+    wr, gr, br = w.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y_raw = q(F.conv2d(a_in, wr, None, 1, 1, 1, C).detach())           # the stored (possibly bf16) conv output
+    yr = y_raw.clone().requires_grad_(True)
+    out = acts[act](F.batch_norm(yr, None, None, gr, br, True, 0.1, 1e-5))
+    g = q(rnd(*out.shape, seed=7))
+    out.backward(g)
+    dy_ref = yr.grad                                                     # dL/dY through BN(train)+act
+    F.conv2d(a_in, wr, None, 1, 1, 1, C).backward(dy_ref)
+    dev = (lambda t: nhwc(t).to(torch.bfloat16)) if bf else nhwc
+    yd, gd, xd = dev(y_raw), dev(g), dev(x)
+    M = N * H * W
+    y32 = yd.float().view(M, C)
+    st = torch.stack((y32.sum(0), (y32 ** 2).sum(0))).view(1, 2, C).contiguous()
+    scale, shift, mean, invstd = ops.bn_finalize(st, M, gamma.cuda(), beta.cuda())
+    # coefficients exactly as the engine produces them: reduce -> finalize
+    import ctypes
+    from mobilenet_yolo_pytorch_amd import _lib
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    parts = _lib.query("mny_bn_bwd_parts", M, C)
+    red = torch.empty(parts, 2, C, device="cuda")
+    gam_d = gamma.cuda()
+    _lib.call("mny_bn_bwd_reduce" + ("_bf16" if bf else ""), p(gd), p(yd), p(scale), p(shift), act, p(mean), p(invstd), p(red), M, C, stream)
+    dgamma, dbeta, coef = torch.empty(C, device="cuda"), torch.empty(C, device="cuda"), torch.empty(3, C, device="cuda")
+    _lib.call("mny_bn_bwd_finalize", p(red), parts, M, p(gam_d), p(mean), p(invstd), p(dgamma), p(dbeta), p(coef), C, stream)
+    add = q(rnd(N, C, H, W, seed=8))
+    addd = dev(add)
+    dx, dw = ops.dw_bnbwd(gd, yd, scale, shift, act, coef, (xd, xs.cuda(), xh.cuda(), xact), w.cuda().contiguous(), addend=addd)
+    rt, at = (2.0 ** -7, 4e-3) if bf else (2e-4, 2e-5)
+    check(nchw(dx.float()), a_in.grad + add, rt, at * max(1.0, a_in.grad.abs().max().item()), "fused dw: dX")
+    tol_w = 2e-3 if bf else 3e-4
+    check(dw, wr.grad, tol_w, tol_w * wr.grad.abs().max().item(), "fused dw: dW")
+    check(dgamma, gr.grad, 5e-4, 5e-4 * max(1.0, gr.grad.abs().max().item()), "dgamma")
+    check(dbeta, br.grad, 5e-4, 5e-4 * max(1.0, br.grad.abs().max().item()), "dbeta")
