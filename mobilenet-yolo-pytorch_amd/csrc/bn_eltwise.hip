@@ -324,6 +324,10 @@ __global__ __launch_bounds__(256) void cvt_kernel(const TS* __restrict__ src, TD
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) st1(dst + n4 * 4 + threadIdx.x, ld1(src + n4 * 4 + threadIdx.x));
 }
 
+// partial rows of bn_bwd_reduce (mny_bn_bwd_parts()).  2048 (all 8 resident workgroups per CU) was measured slower:
+// 4.87 -> 5.05 ms/step for the reduce itself plus +0.6 ms in the finalize that sums the rows
+constexpr int kBnBwdParts = 1024;
+
 static inline dim3 rows_grid(int64_t M, const CgLayout& L, int cap) {
     int64_t want = cdiv(M, L.ppb);
     return dim3((unsigned)(want < cap ? want : cap), L.chunks);
@@ -362,7 +366,7 @@ extern "C" int mny_bn_bwd_parts(int64_t M, int C) {
     if (M <= 0 || C <= 0) return MNY_EINVAL;
     if (C % 4) { int cb, ch, gx; c1_layout(M, C, cb, ch, gx); return gx; }
     CgLayout L = make_cg_layout(C);
-    return (int)rows_grid(M, L, 1024).x;
+    return (int)rows_grid(M, L, kBnBwdParts).x;
 }
 
 template <typename T>
@@ -377,7 +381,7 @@ static int bn_bwd_reduce_impl(const T* g, const T* y, const float* scale, const 
         return check_launch("bn_bwd_reduce_c1_kernel");
     }
     CgLayout L = make_cg_layout(C);
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), rows_grid(M, L, 1024), dim3(L.threads), 0, (hipStream_t)stream, g, y, scale, shift, act,
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<T>), rows_grid(M, L, kBnBwdParts), dim3(L.threads), 0, (hipStream_t)stream, g, y, scale, shift, act,
                        mean, invstd, red, M, C, L.cgb, L.cg_total);
     return check_launch("bn_bwd_reduce_kernel");
 }

@@ -183,7 +183,8 @@ static int dwb_geom(DwbGeom& g, CgLayout& L, int& gx, int N, int H, int W, int C
     L.threads = L.cgb * L.ppb;
     g.cg_total = L.cg_total; g.cgb = L.cgb;
     int64_t want = cdiv(g.nstrips, L.ppb);
-    gx = (int)(want < kMaxParts ? want : kMaxParts);
+    const int cap = 768 / L.chunks > 0 ? 768 / L.chunks : 1;   // 3 resident workgroups per CU (<= 168 VGPRs): one full wave of blocks
+    gx = (int)(want < cap ? want : cap);
     return MNY_OK;
 }
 

@@ -213,7 +213,8 @@ static int stem_geom(StemGeom& g, int& gx, int N, int H, int W, int Cout) {
     g.cgb = Cout / 4; g.ppb = 256 / g.cgb;
     g.npix = (int64_t)N * g.Ho * g.Wo;
     int64_t want = stem_tiled_ok(Cout) ? (int64_t)N * cdiv(g.Ho, ST_TH) * cdiv(g.Wo, ST_TW) : cdiv(g.npix, g.ppb);
-    gx = (int)(want < kMaxParts ? want : kMaxParts);
+    const int64_t cap = 768;            // 160 VGPRs -> 3 resident workgroups per CU: one full wave of blocks, no tail
+    gx = (int)(want < cap ? want : cap);
     return MNY_OK;
 }
 

@@ -340,7 +340,7 @@ class NetPlan:
                 ws_floats = max(ws_floats, max_parts * o.C * 27)
         self.ws = torch.empty(ws_floats, **f32)
         maxC = max(v.C for v in g.values)
-        self.red_ws = torch.empty(1024 * 2 * maxC, **f32)
+        self.red_ws = torch.empty(2048 * 2 * maxC, **f32)      # >= mny_bn_bwd_parts() rows of [2][C]
         self.coef_ws = torch.empty(3 * maxC, **f32)
         self.g_scale = torch.ones(2, **f32)           # upstream dL/dloss_i, written by backward()
         self.wT = {}
