@@ -1280,7 +1280,7 @@ struct BnwArgs {
 __host__ __device__ inline int64_t bnw_stride(int N, int K) { return (int64_t)N * K + (int64_t)K * K + 2 * N + K; }
 
 template <int TI>
-__global__ __launch_bounds__(256) void pw_bnbwd_stage1_kernel(BnwArgs p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) void pw_bnbwd_stage1_kernel(BnwArgs p) {
     constexpr int KC = 16, S = 3, BI = 32 * TI, BJ = 32;
     constexpr int G_ST = KC * BI, X_ST = KC * BJ, STAGE = 2 * G_ST + X_ST;   // floats: G | Y | X
     constexpr int NG = G_ST / 256, NX = X_ST / 256, NL = 2 * NG + NX;
@@ -1646,7 +1646,8 @@ static bool bnw_supported(int64_t M, int K, int N) {
 static BnwPlan bnw_plan(int64_t M, int K, int N) {
     BnwPlan pl;
     pl.TI = (int)cdiv(N, 32);
-    int64_t splits = 1024;
+    // whole waves of resident workgroups: TI <= 3 -> 168 VGPRs, 3 per CU (768); TI 4,5 -> 2 per CU (512); TI 6 -> 1 per CU
+    int64_t splits = pl.TI <= 3 ? 768 : 1024;
     const int64_t max_splits = cdiv(M, 64);
     if (splits > max_splits) splits = max_splits;
     pl.rows_per_block = cdiv(cdiv(M, splits), 16) * 16;
