@@ -1,0 +1,74 @@
+"""Summarise rocprofv3 CSV output (kernel stats + separate FETCH_SIZE / WRITE_SIZE PMC passes) into profiles/.
+
+usage: python tools/prof_summary.py <stats_dir> <fetch_dir> <write_dir> <steps_stats> <steps_pmc> <tag>
+  *_dir: rocprofv3 -d directories (with run_kernel_stats.csv / run_counter_collection.csv)
+  steps_*: total bench steps (warmup + timed) of the run, to normalise per step
+Counter unit is KiB; on gfx950 FETCH_SIZE counts the 128-B requests of wide coalesced streams as 64 B (MI355X_MICROARCH.md,
+HBM section) -> `fetch x2` is the corrected read volume for 16-B/lane streams.
+"""
+import csv
+import re
+import shutil
+import sys
+from collections import defaultdict
+
+
+def family(name):
+    n = re.sub(r"^void ", "", name)
+    n = re.sub(r"^mny::", "", n)
+    n = re.sub(r"\(.*$", "", n)
+    n = n.replace("float", "f32").replace("mny::bf16_t", "bf16")
+    return n[:64]
+
+
+def pmc(dirname, counter):
+    tot, cnt = defaultdict(float), defaultdict(int)
+    with open(dirname + "/run_counter_collection.csv") as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] != counter:
+                continue
+            k = family(r["Kernel_Name"])
+            tot[k] += float(r["Counter_Value"])
+            cnt[k] += 1
+    return tot, cnt
+
+
+def main():
+    stats_dir, fetch_dir, write_dir, steps_stats, steps_pmc, tag = sys.argv[1:7]
+    steps_stats, steps_pmc = int(steps_stats), int(steps_pmc)
+    shutil.copy(stats_dir + "/run_kernel_stats.csv", "profiles/%s_rocprofv3_kernel_stats.csv" % tag)
+    dur, calls = {}, {}
+    with open(stats_dir + "/run_kernel_stats.csv") as f:
+        for r in csv.DictReader(f):
+            k = family(r["Name"])
+            dur[k] = dur.get(k, 0.0) + float(r["TotalDurationNs"])
+            calls[k] = calls.get(k, 0) + int(r["Calls"])
+    fe, fc = pmc(fetch_dir, "FETCH_SIZE")
+    wr, _ = pmc(write_dir, "WRITE_SIZE")
+    rows = []
+    for k in dur:
+        ms = dur[k] / steps_stats / 1e6
+        f_gb = fe.get(k, 0.0) * 1024 / steps_pmc / 1e9
+        w_gb = wr.get(k, 0.0) * 1024 / steps_pmc / 1e9
+        rows.append((ms, k, calls[k] / steps_stats, f_gb, w_gb))
+    rows.sort(reverse=True)
+    with open("profiles/%s_kernels_time_and_hbm.md" % tag, "w") as o:
+        o.write("# Per-kernel time (rocprofv3 --kernel-trace --stats) and HBM traffic (separate --pmc FETCH_SIZE / WRITE_SIZE passes)\n\n")
+        o.write("`python bench.py` bs=256, 352x352, fp32, 1 MI355X; per training step.  Counter unit KiB; `fetch x2` applies the gfx950 "
+                "correction for wide coalesced streams (MI355X_MICROARCH.md); WRITE_SIZE is uncalibrated.  "
+                "`GB/s` = (fetch x2 + write) / time.\n\n")
+        o.write("| kernel | launches/step | ms/step | avg us | FETCH_SIZE GB | fetch x2 GB | WRITE_SIZE GB | GB/s |\n|---|---|---|---|---|---|---|---|\n")
+        tms = tf = tw = 0.0
+        for ms, k, n, f_gb, w_gb in rows:
+            tms += ms; tf += f_gb; tw += w_gb
+            if ms < 0.05:
+                continue
+            o.write("| `%s` | %.0f | %.3f | %.1f | %.2f | %.2f | %.2f | %.0f |\n" % (k, n, ms, ms * 1e3 / max(n, 1), f_gb, 2 * f_gb, w_gb,
+                                                                               (2 * f_gb + w_gb) / ms * 1e3 if ms else 0))
+        o.write("\nTotal per step: kernel time %.2f ms; FETCH_SIZE %.1f GB (x2 = %.1f GB), WRITE_SIZE %.1f GB -> %.2f TB/s average.\n" % (
+            tms, tf, 2 * tf, tw, (2 * tf + tw) / tms))
+    print(open("profiles/%s_kernels_time_and_hbm.md" % tag).read())
+
+
+if __name__ == "__main__":
+    main()
