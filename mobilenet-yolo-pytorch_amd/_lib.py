@@ -5,7 +5,7 @@ import os
 from ctypes import c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmnyolo.so")
+LIB_PATH = os.environ.get("MNY_LIB") or os.path.join(HERE, "libmnyolo.so")     # MNY_LIB: A/B another build on the same GPU box
 
 ACT_NONE, ACT_RELU6, ACT_LEAKY, ACT_RELU, ACT_HSWISH, ACT_HSIGMOID = 0, 1, 2, 3, 4, 5
 
