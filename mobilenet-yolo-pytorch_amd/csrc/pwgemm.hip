@@ -1557,18 +1557,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     const int swz = lrow & 7;
     const float aslope = act_slope(p.act);
     const float xslope = act_slope(p.xact), xhi = act_hi(p.xact);
-    auto compute = [&](int mt, int kt, int slot) {
+    // The act' mask word of a step is an ordinary global load.  Loaded where it is used, the compiler has to drain the whole
+    // VM queue (vmcnt(0)) in front of it — including the DMA stages just issued — so every step exposed a full memory latency
+    // (2.5 TB/s).  It is therefore fetched ONE STEP AHEAD, before that step's DMA batch is issued: by the time it is consumed
+    // the counted wait at the top of the next iteration has already covered it and the ring stays two stages deep.
+    // (Staging the words through the DMA ring instead was measured slower: 2.13 vs 1.74 ms on the 16->96 unit.)
+    auto load_mask = [&](int mt, int kt) -> unsigned long long {            // branch-free: clamped, the (X, Q) step ignores it
+        const int64_t row = min((int64_t)mt * BMS + wm * 32 + lrow, p.M - 1);
+        const int kc = min(kt, nkg - 1);
+        return p.mask[(int64_t)kc * p.npairs + (row >> 1)] >> ((row & 1) * 32);
+    };
+    auto compute = [&](int mt, int kt, int slot, unsigned long long mw) {
         const float* st = smem + slot * STAGE;
         const float* a_row = st + (wm * 32 + lrow) * BKD;
         const float* b_row = st + A_ST + lrow * BKD;
         const bool xstep = kt == nkg;
-        // (staging these words through the DMA ring instead was measured slower: 2.13 vs 1.74 ms on the 16->96 unit)
-        unsigned long long mw = 0ull;
-        if (!xstep) {
-            int64_t row = (int64_t)mt * BMS + wm * 32 + lrow;
-            if (row >= p.M) row = p.M - 1;
-            mw = p.mask[(int64_t)kt * p.npairs + (row >> 1)] >> ((row & 1) * 32);
-        }
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc) {
             const int chunk = (kc * 2 + wk) * 2 + khalf;
@@ -1593,6 +1596,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
         }
     };
+    // Epilogue: the two k-parity waves of a row half are summed through LDS; the owner then transposes each group of 4
+    // accumulator registers across its lane quad (DPP butterfly, as in the NT kernel) so a lane holds 4 consecutive output
+    // columns of one row: 4 float4 addend loads issued together + 4 float4 stores per tile instead of 16 dependent scalar
+    // load -> wait -> store chains (which made this kernel latency-bound at 2.5 TB/s).
+    const int quad = lrow >> 2, jq = lane & 3;
     auto epilogue = [&](int mt) {
         if (wk == 1) {
 #pragma unroll
@@ -1601,17 +1609,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         __syncthreads();
         if (wk == 0) {
             const int64_t m0 = (int64_t)mt * BMS;
-            const int col = lrow;
-            const bool cok = col < p.Kc;
-            const float bv = cok ? p.bias[col] : 0.f;
+            const int colq = quad * 4;
+            const bool cok = colq < p.Kc;                          // Kc % 4 == 0: all four columns or none
+            const int colc = cok ? colq : 0;
+            const float4 bv = ld4(p.bias + colc);
+            float4 ad[4];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                float v = acc[r] + xred[(wm * 16 + r) * 64 + lane] + bv;
-                if (cok && row < p.M) {
-                    if (p.addend) v += p.addend[row * p.Kc + col];
-                    p.C[row * p.Kc + col] = v;
+            for (int gq = 0; gq < 4; ++gq) {
+                const int64_t row = min(m0 + wm * 32 + 8 * gq + 4 * khalf + jq, p.M - 1);
+                ad[gq] = p.addend ? ld4(p.addend + row * p.Kc + colc) : f4zero();
+            }
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                float r0 = acc[gq * 4 + 0] + xred[(wm * 16 + gq * 4 + 0) * 64 + lane], r1 = acc[gq * 4 + 1] + xred[(wm * 16 + gq * 4 + 1) * 64 + lane];
+                float r2 = acc[gq * 4 + 2] + xred[(wm * 16 + gq * 4 + 2) * 64 + lane], r3 = acc[gq * 4 + 3] + xred[(wm * 16 + gq * 4 + 3) * 64 + lane];
+                {   // stage A: exchange with lane^1 inside the quad
+                    const bool odd = lane & 1;
+                    const float xa = odd ? r0 : r1, xb = odd ? r2 : r3;
+                    const float ya = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, xa), 0xB1, 0xF, 0xF, true));
+                    const float yb = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, xb), 0xB1, 0xF, 0xF, true));
+                    if (odd) { r0 = ya; r2 = yb; } else { r1 = ya; r3 = yb; }
                 }
+                {   // stage B: exchange with lane^2
+                    const bool hi2 = lane & 2;
+                    const float xa = hi2 ? r0 : r2, xb = hi2 ? r1 : r3;
+                    const float ya = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, xa), 0x4E, 0xF, 0xF, true));
+                    const float yb = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, xb), 0x4E, 0xF, 0xF, true));
+                    if (hi2) { r0 = ya; r1 = yb; } else { r2 = ya; r3 = yb; }
+                }
+                const int64_t row = m0 + wm * 32 + 8 * gq + 4 * khalf + jq;
+                if (cok && row < p.M)
+                    st4(p.C + row * p.Kc + colq, make_float4(r0 + bv.x + ad[gq].x, r1 + bv.y + ad[gq].y, r2 + bv.z + ad[gq].z, r3 + bv.w + ad[gq].w));
             }
         }
         __syncthreads();
@@ -1621,19 +1649,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     __syncthreads();
     int i_mt = mt_begin, i_kt = 0, i_slot = 0, c_mt = mt_begin, c_kt = 0, c_slot = 0;
     auto issue_next = [&]() { issue(i_mt, i_kt, i_slot); if (++i_kt == nk) { i_kt = 0; ++i_mt; } if (++i_slot == S) i_slot = 0; };
-    auto consume = [&]() { compute(c_mt, c_kt, c_slot); if (++c_kt == nk) { epilogue(c_mt); c_kt = 0; ++c_mt; } if (++c_slot == S) c_slot = 0; };
+    unsigned long long mw_cur = total > 0 ? load_mask(c_mt, c_kt) : 0ull;     // issued before any DMA: oldest entry of the queue
+    auto consume = [&](unsigned long long mw) {
+        compute(c_mt, c_kt, c_slot, mw);
+        if (++c_kt == nk) { epilogue(c_mt); c_kt = 0; ++c_mt; }
+        if (++c_slot == S) c_slot = 0;
+    };
+    auto next_mask = [&](bool more) -> unsigned long long {                  // mask of the step AFTER the one about to be consumed
+        int n_kt = c_kt + 1, n_mt = c_mt;
+        if (n_kt == nk) { n_kt = 0; ++n_mt; }
+        if (!more) { n_mt = c_mt; n_kt = c_kt; }                              // past the end: re-read a valid word (unused)
+        return load_mask(n_mt, n_kt);
+    };
     const int pre = total < S - 1 ? total : S - 1;
     for (int t = 0; t < pre; ++t) issue_next();
-    for (int t = 0; t < total - pre; ++t) {
+    const int steady = total - pre;
+    for (int t = 0; t < steady; ++t) {
         wait_vmcnt<LPW*(S - 2)>();
         __builtin_amdgcn_s_barrier();
+        const unsigned long long mw_next = next_mask(t + 1 < total);
         issue_next();
-        consume();
+        consume(mw_cur);
+        mw_cur = mw_next;
     }
     for (int t = 0; t < pre; ++t) {
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
-        consume();
+        const unsigned long long mw_next = next_mask(steady + t + 1 < total);
+        consume(mw_cur);
+        mw_cur = mw_next;
     }
 }
 
