@@ -244,6 +244,32 @@ __global__ __launch_bounds__(256) void pw_gemm_nt_kernel(GemmArgs p) {
 // Out-of-range rows are clamped to a valid row (their outputs are never stored); k-chunks past K re-read the
 // row start and are annihilated by zeroed B fragments (and zero scale/shift).
 // ------------------------------------------------------------------------------------------------
+// ---- LDS reads the compiler cannot see ------------------------------------------------------------------------------
+// hipcc treats every LDS read after a `global_load_lds` as possibly aliasing the DMA's LDS write and puts `s_waitcnt vmcnt(0)`
+// in front of it (SIInsertWaitcnts; no alias-scope information survives from HIP source).  In a multi-stage ring that wait
+// sits right after the NEXT stages have been issued, i.e. it drains the whole queue every k-step and the ring degenerates to
+// "issue, wait for everything, compute".  The fragment reads of the pipelined loops are therefore raw `ds_read_b128`
+// (volatile inline asm) followed by an explicit `s_waitcnt lgkmcnt(0)` that carries the destination registers as in/out
+// operands, so every use is ordered after the wait; the counted `s_waitcnt vmcnt(N)` + `s_barrier` at the top of the loop
+// are what guarantee that the stage being read has landed.
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned lds_off(const void* p) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+__device__ __forceinline__ v4f_t lds_read_f4(const float* p) {
+    v4f_t v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(lds_off(p)) : "memory");
+    return v;
+}
+__device__ __forceinline__ v4u_t lds_read_u4(const float* p) {
+    v4u_t v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(lds_off(p)) : "memory");
+    return v;
+}
+#define MNY_LGKM_WAIT(first) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(first))
+#define MNY_LGKM_DEP(x) asm volatile("" : "+v"(x))
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -363,14 +389,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
 #pragma unroll
             for (int kc = 0; kc < 2; ++kc) {
                 const int chunk = kc * 2 + khalf;
-                uint4 au = *reinterpret_cast<const uint4*>(a_row + ((chunk ^ swz) << 2));
-                uint4 bu[TN];
+                v4u_t au = lds_read_u4(a_row + ((chunk ^ swz) << 2));
+                v4u_t bu[TN];
 #pragma unroll
-                for (int u = 0; u < TN; ++u) bu[u] = *reinterpret_cast<const uint4*>(stB + (u * 32 + lrow) * BKD + ((chunk ^ swz) << 2));
+                for (int u = 0; u < TN; ++u) bu[u] = lds_read_u4(stB + (u * 32 + lrow) * BKD + ((chunk ^ swz) << 2));
+                v4f_t sc0, sc1, sh0, sh1;
                 if (XF != 0) {
                     const int kbase = kt * BKE + chunk * 8;
-                    const float4 sc0 = ld4(sScale + kbase), sc1 = ld4(sScale + kbase + 4);
-                    const float4 sh0 = ld4(sShift + kbase), sh1 = ld4(sShift + kbase + 4);
+                    sc0 = lds_read_f4(sScale + kbase); sc1 = lds_read_f4(sScale + kbase + 4);
+                    sh0 = lds_read_f4(sShift + kbase); sh1 = lds_read_f4(sShift + kbase + 4);
+                }
+                MNY_LGKM_WAIT(au);
+#pragma unroll
+                for (int u = 0; u < TN; ++u) MNY_LGKM_DEP(bu[u]);
+                if (XF != 0) {
+                    MNY_LGKM_DEP(sc0); MNY_LGKM_DEP(sc1); MNY_LGKM_DEP(sh0); MNY_LGKM_DEP(sh1);
                     float z[8] = {__uint_as_float(au.x << 16), __uint_as_float(au.x & 0xffff0000u), __uint_as_float(au.y << 16),
                                   __uint_as_float(au.y & 0xffff0000u), __uint_as_float(au.z << 16), __uint_as_float(au.z & 0xffff0000u),
                                   __uint_as_float(au.w << 16), __uint_as_float(au.w & 0xffff0000u)};
@@ -381,7 +414,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                         const float zz = fmaf(z[e], scv[e], shv[e]);
                         z[e] = XF == 1 ? fminf(fmaxf(zz, slope * zz), hi) : zz * fminf(fmaxf(zz + 3.f, 0.f), 6.f) / 6.f;
                     }
-                    au = make_uint4(pack_bf16x2(z[0], z[1]), pack_bf16x2(z[2], z[3]), pack_bf16x2(z[4], z[5]), pack_bf16x2(z[6], z[7]));
+                    au = v4u_t{pack_bf16x2(z[0], z[1]), pack_bf16x2(z[2], z[3]), pack_bf16x2(z[4], z[5]), pack_bf16x2(z[6], z[7])};
                 }
                 const bf16x8_t a8 = __builtin_bit_cast(bf16x8_t, au);
 #pragma unroll
@@ -393,13 +426,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
 #pragma unroll
         for (int kc = 0; kc < BKD / 8; ++kc) {
             const int chunk = kc * 2 + khalf;
-            float4 af = ld4(a_row + ((chunk ^ swz) << 2));
-            float4 bf[TN];
+            v4f_t af = lds_read_f4(a_row + ((chunk ^ swz) << 2));
+            v4f_t bf[TN];
 #pragma unroll
-            for (int u = 0; u < TN; ++u) bf[u] = ld4(stB + (u * 32 + lrow) * BKD + ((chunk ^ swz) << 2));
+            for (int u = 0; u < TN; ++u) bf[u] = lds_read_f4(stB + (u * 32 + lrow) * BKD + ((chunk ^ swz) << 2));
+            v4f_t sc, sh;
             if (XF != 0) {
                 const int kbase = kt * BKD + chunk * 4;
-                const float4 sc = ld4(sScale + kbase), sh = ld4(sShift + kbase);
+                sc = lds_read_f4(sScale + kbase);
+                sh = lds_read_f4(sShift + kbase);
+            }
+            MNY_LGKM_WAIT(af);
+#pragma unroll
+            for (int u = 0; u < TN; ++u) MNY_LGKM_DEP(bf[u]);
+            if (XF != 0) {
+                MNY_LGKM_DEP(sc);
+                MNY_LGKM_DEP(sh);
                 float z0 = fmaf(af.x, sc.x, sh.x), z1 = fmaf(af.y, sc.y, sh.y), z2 = fmaf(af.z, sc.z, sh.z), z3 = fmaf(af.w, sc.w, sh.w);
                 if (XF == 1) {
                     af.x = fminf(fmaxf(z0, slope * z0), hi); af.y = fminf(fmaxf(z1, slope * z1), hi);
@@ -1649,35 +1691,55 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     __syncthreads();
     int i_mt = mt_begin, i_kt = 0, i_slot = 0, c_mt = mt_begin, c_kt = 0, c_slot = 0;
     auto issue_next = [&]() { issue(i_mt, i_kt, i_slot); if (++i_kt == nk) { i_kt = 0; ++i_mt; } if (++i_slot == S) i_slot = 0; };
-    unsigned long long mw_cur = total > 0 ? load_mask(c_mt, c_kt) : 0ull;     // issued before any DMA: oldest entry of the queue
-    auto consume = [&](unsigned long long mw) {
-        compute(c_mt, c_kt, c_slot, mw);
+    // Software pipeline.  The mask word of the NEXT step is fetched with a raw `global_load_dwordx2` (inline asm) placed before
+    // that step's DMA batch; the counted wait at the END of the iteration (all but the newest LPW VM operations retired — VM
+    // loads retire in issue order) covers it, and only then is it moved into the register the next iteration consumes.  Load,
+    // wait and move are volatile asm statements, so their order is fixed and the compiler — which would otherwise put a
+    // vmcnt(0) in front of any use of an ordinary load's result and drain the DMA ring every step — never sees a pending load.
+    unsigned long long m_next = 0ull, m_cur = 0ull;
+    auto mask_fetch = [&](int mt, int kt) {
+        const int64_t row = min((int64_t)mt * BMS + wm * 32 + lrow, p.M - 1);
+        const int kc = min(kt, nkg - 1);
+        const unsigned long long* ptr = p.mask + (int64_t)kc * p.npairs + (row >> 1);
+        asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(m_next) : "v"(ptr) : "memory");
+    };
+    auto mask_commit = [&]() { asm volatile("v_mov_b64 %0, %1" : "=v"(m_cur) : "v"(m_next)); };
+    auto mask_word = [&](int mt) -> unsigned long long {                    // the row's 32 bits of the committed pair word
+        const int64_t row = min((int64_t)mt * BMS + wm * 32 + lrow, p.M - 1);
+        return m_cur >> ((row & 1) * 32);
+    };
+    auto consume = [&]() {
+        compute(c_mt, c_kt, c_slot, mask_word(c_mt));
         if (++c_kt == nk) { epilogue(c_mt); c_kt = 0; ++c_mt; }
         if (++c_slot == S) c_slot = 0;
     };
-    auto next_mask = [&](bool more) -> unsigned long long {                  // mask of the step AFTER the one about to be consumed
+    auto fetch_next = [&](bool more) {                                        // mask of the step AFTER the one about to be consumed
         int n_kt = c_kt + 1, n_mt = c_mt;
         if (n_kt == nk) { n_kt = 0; ++n_mt; }
         if (!more) { n_mt = c_mt; n_kt = c_kt; }                              // past the end: re-read a valid word (unused)
-        return load_mask(n_mt, n_kt);
+        mask_fetch(n_mt, n_kt);
     };
+    if (total <= 0) return;
+    mask_fetch(c_mt, c_kt);                                                   // oldest entry of the VM queue
     const int pre = total < S - 1 ? total : S - 1;
     for (int t = 0; t < pre; ++t) issue_next();
     const int steady = total - pre;
+    if (steady > 0) wait_vmcnt<LPW*(S - 2)>(); else wait_vmcnt<0>();
+    mask_commit();
     for (int t = 0; t < steady; ++t) {
-        wait_vmcnt<LPW*(S - 2)>();
-        __builtin_amdgcn_s_barrier();
-        const unsigned long long mw_next = next_mask(t + 1 < total);
+        __builtin_amdgcn_s_barrier();                    // every wave's share of the stage to consume has landed
+        fetch_next(t + 1 < total);
         issue_next();
-        consume(mw_cur);
-        mw_cur = mw_next;
+        consume();
+        if (t + 1 < steady) wait_vmcnt<LPW*(S - 2)>(); else wait_vmcnt<0>();
+        mask_commit();
     }
     for (int t = 0; t < pre; ++t) {
-        wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
-        const unsigned long long mw_next = next_mask(steady + t + 1 < total);
-        consume(mw_cur);
-        mw_cur = mw_next;
+        fetch_next(steady + t + 1 < total);
+        consume();
+        wait_vmcnt<0>();
+        mask_commit();
     }
 }
 
