@@ -451,13 +451,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                     af.z = z2 * fminf(fmaxf(z2 + 3.f, 0.f), 6.f) / 6.f; af.w = z3 * fminf(fmaxf(z3 + 3.f, 0.f), 6.f) / 6.f;
                 }
             }
+            // accumulators interleaved: consecutive MFMAs never depend on each other
 #pragma unroll
-            for (int u = 0; u < TN; ++u) {
-                acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf[u].x, acc[u], 0, 0, 0);
-                acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf[u].y, acc[u], 0, 0, 0);
-                acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf[u].z, acc[u], 0, 0, 0);
-                acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf[u].w, acc[u], 0, 0, 0);
-            }
+            for (int u = 0; u < TN; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.x, bf[u].x, acc[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < TN; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.y, bf[u].y, acc[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < TN; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.z, bf[u].z, acc[u], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < TN; ++u) acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(af.w, bf[u].w, acc[u], 0, 0, 0);
         }
     };
 
@@ -1618,10 +1620,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         for (int kc = 0; kc < 2; ++kc) {
             const int chunk = (kc * 2 + wk) * 2 + khalf;
             const int o = (chunk ^ swz) << 2;
-            float4 a = ld4(a_row + o);
-            const float4 b = ld4(b_row + o);
+            v4f_t a = lds_read_f4(a_row + o);                      // raw LDS reads: see "LDS reads the compiler cannot see"
+            v4f_t b = lds_read_f4(b_row + o);
+            v4f_t xs = lds_read_f4(sXs + chunk * 4), xh = lds_read_f4(sXh + chunk * 4);
+            MNY_LGKM_WAIT(a);
+            MNY_LGKM_DEP(b); MNY_LGKM_DEP(xs); MNY_LGKM_DEP(xh);
             if (xstep) {
-                const float4 xs = ld4(sXs + chunk * 4), xh = ld4(sXh + chunk * 4);
                 float z;
                 z = fmaf(a.x, xs.x, xh.x); a.x = fminf(fmaxf(z, xslope * z), xhi);
                 z = fmaf(a.y, xs.y, xh.y); a.y = fminf(fmaxf(z, xslope * z), xhi);
