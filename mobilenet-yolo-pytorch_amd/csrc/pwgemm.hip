@@ -1488,7 +1488,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     }
 }
 
-// finalize: one block.  red = [P1 | Gram | s1 | s2 | s3] summed over splits.
+// finalize.  red = [P1 | Gram | s1 | s2 | s3] summed over splits.  Every block recomputes the N coefficient triples (cheap) and
+// takes a grid-stride share of the fp64 element loops (one block took 80 us per unit).
 __global__ __launch_bounds__(256) void pw_bnbwd_finalize_kernel(const float* __restrict__ red, const float* __restrict__ W,
                                                                 const float* __restrict__ gamma, const float* __restrict__ mean,
                                                                 const float* __restrict__ invstd, double count, int N, int K,
@@ -1498,27 +1499,28 @@ __global__ __launch_bounds__(256) void pw_bnbwd_finalize_kernel(const float* __r
     double* ca = sd; double* cb = sd + N; double* cc = sd + 2 * N;
     const float* P1 = red; const float* Gm = red + (int64_t)N * K; const float* s1 = Gm + (int64_t)K * K;
     const float* s2 = s1 + N; const float* s3 = s2 + N;
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
     for (int n = threadIdx.x; n < N; n += blockDim.x) {
         const double a = (double)gamma[n] * (double)invstd[n];
         const double b = -a * (double)invstd[n] * (double)s2[n] / count;
         ca[n] = a; cb[n] = b; cc[n] = -a * (double)s1[n] / count - b * (double)mean[n];
-        dbeta[n] = s1[n]; dgamma[n] = s2[n];
+        if (blockIdx.x == 0) { dbeta[n] = s1[n]; dgamma[n] = s2[n]; }
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < N * K; e += blockDim.x) {
+    for (int e = gtid; e < N * K; e += gsz) {
         const int n = e / K, k = e % K;
         double wg = 0.0;
         for (int j = 0; j < K; ++j) wg += (double)W[(int64_t)n * K + j] * (double)Gm[j * K + k];
         dW[e] = (float)(ca[n] * (double)P1[e] + cb[n] * wg + cc[n] * (double)s3[k]);
         B1[(int64_t)k * N + n] = (float)(ca[n] * (double)W[e]);      // [K][N]: rows = dX columns, contraction over n
     }
-    for (int e = threadIdx.x; e < K * K; e += blockDim.x) {           // Y (cb o W) = X (W^T diag(cb) W): Q[kc][k], symmetric
+    for (int e = gtid; e < K * K; e += gsz) {                         // Y (cb o W) = X (W^T diag(cb) W): Q[kc][k], symmetric
         const int kc = e / K, k = e % K;
         double a = 0.0;
         for (int n = 0; n < N; ++n) a += cb[n] * (double)W[(int64_t)n * K + kc] * (double)W[(int64_t)n * K + k];
         Q[e] = (float)a;
     }
-    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    for (int k = gtid; k < K; k += gsz) {
         double a = 0.0;
         for (int n = 0; n < N; ++n) a += cc[n] * (double)W[(int64_t)n * K + k];
         bias[k] = (float)a;
@@ -1996,7 +1998,7 @@ extern "C" int mny_pw_bnbwd(const float* g, const float* y, const float* scale, 
     int rc = check_launch("pw_bnbwd_stage1_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(stride, 32)), dim3(256), 0, st, ws, pl.splits, stride, red);
-    hipLaunchKernelGGL(pw_bnbwd_finalize_kernel, dim3(1), dim3(256), (size_t)3 * Nc * sizeof(double), st, red, w, gamma, mean, invstd,
+    hipLaunchKernelGGL(pw_bnbwd_finalize_kernel, dim3((unsigned)cdiv((int64_t)Nc * K, 256)), dim3(256), (size_t)3 * Nc * sizeof(double), st, red, w, gamma, mean, invstd,
                        (double)M, Nc, K, dw, dgamma, dbeta, B1, Q, bias);
     rc = check_launch("pw_bnbwd_finalize_kernel");
     if (rc || !dx) return rc;
