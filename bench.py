@@ -115,6 +115,30 @@ def cpu_baseline(budget_s=20.0):
                 n, bs, ncores, os.cpu_count() or 0)}
 
 
+def optimizer_bench(model):
+    """AdamW.step() on the model's parameters (train.py:283), reported beside the fwd+bwd metric, never inside it:
+    the fused multi-tensor kernel (SURVEY 8f #1) and torch.optim.AdamW on clones of the same tensors."""
+    from mobilenet_yolo_pytorch_amd.optim import AdamW
+    kw = dict(lr=7e-4, weight_decay=4e-4)
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in model.parameters()]
+    for r, p in zip(ref, model.parameters()):
+        r.grad = None if p.grad is None else p.grad.detach().clone()
+    out = {}
+    for name, opt in (("fused_ms", AdamW(model.parameters(), **kw)), ("torch_adamw_ms", torch.optim.AdamW(ref, **kw))):
+        for _ in range(3):
+            opt.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            opt.step()
+        torch.cuda.synchronize()
+        out[name] = round((time.perf_counter() - t0) / 20 * 1e3, 4)
+    out["tensors"] = sum(p.grad is not None for p in model.parameters())
+    out["parameters"] = sum(p.numel() for p in model.parameters() if p.grad is not None)
+    out["note"] = "not part of `value` (the metric is fwd+loss+bwd)"
+    return out
+
+
 def nms_bench(device):
     """BASELINE config 5: one image-segment of 100,000 rows, 20 classes (SURVEY §8d)."""
     import numpy as np
@@ -290,6 +314,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline()
         if world == 1 and not a.no_nms:
             res["nms"] = nms_bench(device)
+            res["optimizer"] = optimizer_bench(model)
         print(json.dumps(res))
     if use_dp:
         dist.destroy_process_group()

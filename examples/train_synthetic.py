@@ -33,7 +33,8 @@ def main():
         from mobilenet_yolo_pytorch_amd.dp import attach_data_parallel
         dist.init_process_group("nccl", device_id=dev)
         reducer = attach_data_parallel(model)
-    opt = torch.optim.AdamW(model.parameters(), lr=7e-4, weight_decay=4e-4)      # train.py:134,459-462
+    from mobilenet_yolo_pytorch_amd.optim import AdamW                            # fused multi-tensor step, torch.optim.AdamW semantics
+    opt = AdamW(model.parameters(), lr=7e-4, weight_decay=4e-4)                  # train.py:134,459-462
     first = last = None
     for step in range(a.steps):
         x = synthetic.images(a.batch, a.size, a.size, seed=step % 4 + 10 * rank).to(dev)   # 4 recurring batches: the loss must fall

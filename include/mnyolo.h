@@ -217,6 +217,22 @@ int mny_dw_bnbwd(const float* g, const float* y, const float* scale, const float
                  const float* addend, float* dx, float* dw, float* ws, int N, int H, int W, int C, int K, int stride,
                  void* stream);
 
+/* ---- fused multi-tensor AdamW --------------------------------------------------------------
+ * replaces optim.AdamW(...).step() at train.py:134,283 (torch semantics: decoupled weight decay, bias-corrected
+ * moments, amsgrad off).  `table_dev` is a DEVICE array of chunks; one workgroup updates one chunk (callers split
+ * large tensors into chunks of <= 64 Ki elements).  `vec4` = all four pointers 16-B aligned.  `step` is the
+ * 1-based step count used for the bias corrections.                                                            */
+typedef struct mny_adamw_chunk {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    int n;
+    int vec4;
+} mny_adamw_chunk;
+int mny_adamw_step(const mny_adamw_chunk* table_dev, int nchunks, double lr, double beta1, double beta2, double eps,
+                   double weight_decay, int64_t step, void* stream);
+
 /* ---- bf16 STORAGE twins (BASELINE config 4: MobileNetV3-YOLO 512x512 bf16) -----------------
  * Every `mny_X_bf16` has the contract of `mny_X` above with ONE difference: the activation-sized tensors (the
  * `void*` parameters: raw conv outputs, materialised sums, gradients wrt activations) are bf16 in HBM.  Kernels

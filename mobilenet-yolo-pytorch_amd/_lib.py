@@ -37,6 +37,7 @@ _SIGS = {
     "mny_dw_bnbwd_supported": (c_int, [c_int, c_int]),
     "mny_dw_bnbwd_parts": (c_int, [c_int] * 4),
     "mny_dw_bnbwd": (c_int, [P, P, P, P, c_int, P, P, P, P, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "mny_adamw_step": (c_int, [P, c_int, c_double, c_double, c_double, c_double, c_double, c_int64, P]),
     "mny_pw_fwd": (c_int, [P, P, P, c_int, P, P, P, P, P, c_int64, c_int, c_int, P]),
     "mny_pw_stat_parts": (c_int, [c_int64, c_int, c_int]),
     "mny_pw_wgrad": (c_int, [P, P, P, c_int, P, P, P, P, c_int64, c_int, c_int, P]),
