@@ -26,7 +26,8 @@ class AdamW(torch.optim.Optimizer):
         if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
             raise ValueError("invalid AdamW hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False))
-        self._tables = {}           # group index -> (signature, device table, nchunks)
+        self._tables = {}           # group index -> (signature, device table, nchunks, ids of the covered parameters)
+        self._t = {}                # group index -> current step count (per-parameter `step` tensors are synced lazily)
 
     def _ensure_state(self, group):
         new = [p for p in group["params"] if p.grad is not None and len(self.state[p]) == 0]
@@ -48,17 +49,23 @@ class AdamW(torch.optim.Optimizer):
             off += (n + 3) // 4 * 4
 
     def _table(self, gi, group):
+        """Device chunk table of group `gi`, rebuilt only when a parameter / gradient pointer changes (a step costs one pass
+        over the parameters reading two pointers each — the moments only move through load_state_dict, which drops the cache)."""
         live = [p for p in group["params"] if p.grad is not None]
-        sig = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr())
-                    for p in live)
+        sig = tuple((p.data_ptr(), p.grad.data_ptr()) for p in live)
         cached = self._tables.get(gi)
         if cached is not None and cached[0] == sig:
             return cached[1], cached[2], live
+        self._sync_steps(gi)                                      # counters of the parameters the old table covered
+        steps = {float(self.state[p]["step"]) for p in live}
+        if len(steps) != 1:
+            raise _lib.MnyError("fused AdamW: parameters of one group must share the step count (got %s)" % sorted(steps))
         rows = []
-        for p, (pp, gp, mp, vp) in zip(live, sig):
-            g = p.grad
+        for p, (pp, gp) in zip(live, sig):
+            g, st = p.grad, self.state[p]
             if not (g.is_cuda and g.dtype == torch.float32 and g.is_contiguous()):
                 raise _lib.MnyError("fused AdamW needs contiguous fp32 CUDA(HIP) gradients")
+            mp, vp = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
             n = p.numel()
             for o in range(0, n, CHUNK):
                 c = min(CHUNK, n - o)
@@ -66,8 +73,28 @@ class AdamW(torch.optim.Optimizer):
                 rows.append(ptrs + (c, int(all(q % 16 == 0 for q in ptrs))))
         host = np.array(rows, dtype=_CHUNK_DT)
         table = torch.from_numpy(host.view(np.uint8).reshape(-1)).to(live[0].device)
-        self._tables[gi] = (sig, table, len(rows))
+        self._tables[gi] = (sig, table, len(rows), {id(p) for p in live})
+        self._t[gi] = int(steps.pop())
         return table, len(rows), live
+
+    def _sync_steps(self, only=None):
+        """write the group step counters back into the per-parameter `step` tensors (torch's state layout)"""
+        for gi, group in enumerate(self.param_groups):
+            c = self._tables.get(gi)
+            if c is None or (only is not None and gi != only):
+                continue
+            for p in group["params"]:
+                if id(p) in c[3]:
+                    self.state[p]["step"].fill_(float(self._t[gi]))
+
+    def state_dict(self):
+        self._sync_steps()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._tables.clear()
+        self._t.clear()
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -80,13 +107,9 @@ class AdamW(torch.optim.Optimizer):
             if not any(p.grad is not None for p in group["params"]):
                 continue
             table, nchunks, live = self._table(gi, group)
-            steps = {float(self.state[p]["step"]) for p in live}
-            if len(steps) != 1:
-                raise _lib.MnyError("fused AdamW: parameters of one group must share the step count (got %s)" % sorted(steps))
-            t = int(steps.pop()) + 1
+            t = self._t[gi] + 1
             b1, b2 = group["betas"]
             _lib.call("mny_adamw_step", ctypes.c_void_p(table.data_ptr()), nchunks, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
                       float(group["weight_decay"]), t, ctypes.c_void_p(torch.cuda.current_stream(live[0].device).cuda_stream))
-            for p in live:
-                self.state[p]["step"] += 1
+            self._t[gi] = t
         return loss
