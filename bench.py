@@ -115,6 +115,41 @@ def cpu_baseline(budget_s=20.0):
                 n, bs, ncores, os.cpu_count() or 0)}
 
 
+def h2d_bench(step, x, steps=10):
+    """PCIe-inclusive rate (never `value`): the batch starts in pinned host memory and is copied to the device before every
+    step, on the compute stream (no overlap) and on a side stream one step ahead (the copy hides behind the previous step)."""
+    host = x.cpu().pin_memory()
+    dev = x
+    out = {}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        dev.copy_(host, non_blocking=True)
+        step()
+    torch.cuda.synchronize()
+    out["serial_ms_per_step"] = round((time.perf_counter() - t0) / steps * 1e3, 3)
+    side = torch.cuda.Stream()
+    stage = torch.empty_like(x)
+    ev_copy, ev_used = torch.cuda.Event(), torch.cuda.Event()
+    ev_used.record()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        with torch.cuda.stream(side):
+            side.wait_event(ev_used)                  # `stage` may be overwritten once the previous consumer copy is done
+            stage.copy_(host, non_blocking=True)
+            ev_copy.record(side)
+        torch.cuda.current_stream().wait_event(ev_copy)
+        dev.copy_(stage, non_blocking=True)          # device-to-device, 0.1 ms
+        ev_used.record()
+        step()
+    torch.cuda.synchronize()
+    out["prefetch_ms_per_step"] = round((time.perf_counter() - t0) / steps * 1e3, 3)
+    out["batch_mb"] = round(x.numel() * 4 / 1e6, 1)
+    out["note"] = "input batch copied from pinned host memory every step; not part of `value`"
+    return out
+
+
 def optimizer_bench(model):
     """AdamW.step() on the model's parameters (train.py:283), reported beside the fwd+bwd metric, never inside it:
     the fused multi-tensor kernel (SURVEY 8f #1) and torch.optim.AdamW on clones of the same tensors."""
@@ -315,6 +350,7 @@ def main():
         if world == 1 and not a.no_nms:
             res["nms"] = nms_bench(device)
             res["optimizer"] = optimizer_bench(model)
+            res["pcie_inclusive"] = h2d_bench(step, x)
         print(json.dumps(res))
     if use_dp:
         dist.destroy_process_group()
