@@ -19,11 +19,23 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
     const int cl = threadIdx.x & 31, slice = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     double s = 0.0, q = 0.0;
-    if (c < C)
-        for (int p = slice; p < parts; p += 32) {
+    if (c < C) {
+        // four partial rows in flight per thread (independent accumulators): the loop is pure load latency otherwise
+        double s1 = 0.0, q1 = 0.0, s2 = 0.0, q2 = 0.0, s3 = 0.0, q3 = 0.0;
+        int p = slice;
+        for (; p + 96 < parts; p += 128) {
+            s += (double)stats[((int64_t)p * 2 + 0) * C + c];         q += (double)stats[((int64_t)p * 2 + 1) * C + c];
+            s1 += (double)stats[((int64_t)(p + 32) * 2 + 0) * C + c]; q1 += (double)stats[((int64_t)(p + 32) * 2 + 1) * C + c];
+            s2 += (double)stats[((int64_t)(p + 64) * 2 + 0) * C + c]; q2 += (double)stats[((int64_t)(p + 64) * 2 + 1) * C + c];
+            s3 += (double)stats[((int64_t)(p + 96) * 2 + 0) * C + c]; q3 += (double)stats[((int64_t)(p + 96) * 2 + 1) * C + c];
+        }
+        for (; p < parts; p += 32) {
             s += (double)stats[((int64_t)p * 2 + 0) * C + c];
             q += (double)stats[((int64_t)p * 2 + 1) * C + c];
         }
+        s = (s + s1) + (s2 + s3);
+        q = (q + q1) + (q2 + q3);
+    }
     red[0][slice][cl] = s;
     red[1][slice][cl] = q;
     __syncthreads();
@@ -104,11 +116,23 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
     const int cl = threadIdx.x & 31, slice = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     double s = 0.0, q = 0.0;
-    if (c < C)
-        for (int p = slice; p < parts; p += 32) {
+    if (c < C) {
+        // four partial rows in flight per thread (independent accumulators): the loop is pure load latency otherwise
+        double s1 = 0.0, q1 = 0.0, s2 = 0.0, q2 = 0.0, s3 = 0.0, q3 = 0.0;
+        int p = slice;
+        for (; p + 96 < parts; p += 128) {
+            s += (double)red_in[((int64_t)p * 2 + 0) * C + c];         q += (double)red_in[((int64_t)p * 2 + 1) * C + c];
+            s1 += (double)red_in[((int64_t)(p + 32) * 2 + 0) * C + c]; q1 += (double)red_in[((int64_t)(p + 32) * 2 + 1) * C + c];
+            s2 += (double)red_in[((int64_t)(p + 64) * 2 + 0) * C + c]; q2 += (double)red_in[((int64_t)(p + 64) * 2 + 1) * C + c];
+            s3 += (double)red_in[((int64_t)(p + 96) * 2 + 0) * C + c]; q3 += (double)red_in[((int64_t)(p + 96) * 2 + 1) * C + c];
+        }
+        for (; p < parts; p += 32) {
             s += (double)red_in[((int64_t)p * 2 + 0) * C + c];
             q += (double)red_in[((int64_t)p * 2 + 1) * C + c];
         }
+        s = (s + s1) + (s2 + s3);
+        q = (q + q1) + (q2 + q3);
+    }
     red[0][slice][cl] = s;
     red[1][slice][cl] = q;
     __syncthreads();
