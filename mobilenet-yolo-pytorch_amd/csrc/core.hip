@@ -26,13 +26,16 @@ __global__ __launch_bounds__(256) void reduce_parts_f64_kernel(const float* __re
     __shared__ double red[8][32];
     const int ol = threadIdx.x & 31, slice = threadIdx.x >> 5;
     const int i = blockIdx.x * 32 + ol;
-    double s0 = 0.0, s1 = 0.0;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     if (i < n) {
         int p = slice;
-        for (; p + 8 < nparts; p += 16) { s0 += (double)parts[(int64_t)p * n + i]; s1 += (double)parts[(int64_t)(p + 8) * n + i]; }
-        if (p < nparts) s0 += (double)parts[(int64_t)p * n + i];
+        for (; p + 24 < nparts; p += 32) {                       // four rows in flight per thread
+            s0 += (double)parts[(int64_t)p * n + i];        s1 += (double)parts[(int64_t)(p + 8) * n + i];
+            s2 += (double)parts[(int64_t)(p + 16) * n + i]; s3 += (double)parts[(int64_t)(p + 24) * n + i];
+        }
+        for (; p < nparts; p += 8) s0 += (double)parts[(int64_t)p * n + i];
     }
-    red[slice][ol] = s0 + s1;
+    red[slice][ol] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (slice == 0 && i < n) {
         double s = 0.0;

@@ -1646,31 +1646,53 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     };
     // Epilogue: the two k-parity waves of a row half are summed through LDS; the owner then transposes each group of 4
     // accumulator registers across its lane quad (DPP butterfly, as in the NT kernel) so a lane holds 4 consecutive output
-    // columns of one row: 4 float4 addend loads issued together + 4 float4 stores per tile instead of 16 dependent scalar
-    // load -> wait -> store chains (which made this kernel latency-bound at 2.5 TB/s).
+    // columns of one row: 4 float4 addend loads + 4 float4 stores per tile instead of 16 dependent scalar load -> wait ->
+    // store chains.  Nothing here may make hipcc drain the VM queue (the next tiles' DMA stages are already in flight):
+    //   * the LDS exchange uses raw ds_write_b128 / ds_read_b128 + explicit lgkmcnt + raw s_barrier (a compiler-visible LDS
+    //     access, or __syncthreads, waits vmcnt(0));
+    //   * the tile's addend rows are fetched by raw global_load_dwordx4 when the tile's FIRST k-step is consumed, i.e. before
+    //     the following stages' DMA batches — VM loads retire in order, so the counted waits of the next steps cover them;
+    //   * the bias vector is loaded once, before the pipeline starts.
     const int quad = lrow >> 2, jq = lane & 3;
+    const int colq = quad * 4;
+    const bool cok = colq < p.Kc;                                  // Kc % 4 == 0: all four columns or none
+    const int colc = cok ? colq : 0;
+    const float4 bv = ld4(p.bias + colc);
+    float* xr_w = xred + ((wm * 4) * 64 + lane) * 4;               // [wm][q][lane][4]: lane-contiguous 16-B slots
+    v4f_t ad0, ad1, ad2, ad3;
+    auto addend_fetch = [&](int mt) {                              // raw loads: see above
+        const int64_t m0 = (int64_t)mt * BMS + wm * 32 + 4 * khalf + jq;
+        const float* a0 = p.addend + min(m0, p.M - 1) * p.Kc + colc;
+        const float* a1 = p.addend + min(m0 + 8, p.M - 1) * p.Kc + colc;
+        const float* a2 = p.addend + min(m0 + 16, p.M - 1) * p.Kc + colc;
+        const float* a3 = p.addend + min(m0 + 24, p.M - 1) * p.Kc + colc;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ad0) : "v"(a0) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ad1) : "v"(a1) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ad2) : "v"(a2) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(ad3) : "v"(a3) : "memory");
+    };
     auto epilogue = [&](int mt) {
         if (wk == 1) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) xred[(wm * 16 + r) * 64 + lane] = acc[r];
-        }
-        __syncthreads();
-        if (wk == 0) {
-            const int64_t m0 = (int64_t)mt * BMS;
-            const int colq = quad * 4;
-            const bool cok = colq < p.Kc;                          // Kc % 4 == 0: all four columns or none
-            const int colc = cok ? colq : 0;
-            const float4 bv = ld4(p.bias + colc);
-            float4 ad[4];
-#pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                const int64_t row = min(m0 + wm * 32 + 8 * gq + 4 * khalf + jq, p.M - 1);
-                ad[gq] = p.addend ? ld4(p.addend + row * p.Kc + colc) : f4zero();
+            for (int q = 0; q < 4; ++q) {
+                v4f_t v = {acc[q * 4 + 0], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]};
+                asm volatile("ds_write_b128 %0, %1" : : "v"(lds_off(xr_w + q * 256)), "v"(v) : "memory");
             }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (wk == 0) {
+            v4f_t xq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xq[q] = lds_read_f4(xr_w + q * 256);
+            MNY_LGKM_WAIT(xq[0]);
+            MNY_LGKM_DEP(xq[1]); MNY_LGKM_DEP(xq[2]); MNY_LGKM_DEP(xq[3]);
+            if (p.addend) { MNY_LGKM_DEP(ad0); MNY_LGKM_DEP(ad1); MNY_LGKM_DEP(ad2); MNY_LGKM_DEP(ad3); }
+            const int64_t m0 = (int64_t)mt * BMS;
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
-                float r0 = acc[gq * 4 + 0] + xred[(wm * 16 + gq * 4 + 0) * 64 + lane], r1 = acc[gq * 4 + 1] + xred[(wm * 16 + gq * 4 + 1) * 64 + lane];
-                float r2 = acc[gq * 4 + 2] + xred[(wm * 16 + gq * 4 + 2) * 64 + lane], r3 = acc[gq * 4 + 3] + xred[(wm * 16 + gq * 4 + 3) * 64 + lane];
+                float r0 = acc[gq * 4 + 0] + xq[gq].x, r1 = acc[gq * 4 + 1] + xq[gq].y;
+                float r2 = acc[gq * 4 + 2] + xq[gq].z, r3 = acc[gq * 4 + 3] + xq[gq].w;
                 {   // stage A: exchange with lane^1 inside the quad
                     const bool odd = lane & 1;
                     const float xa = odd ? r0 : r1, xb = odd ? r2 : r3;
@@ -1685,12 +1707,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                     const float yb = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, xb), 0x4E, 0xF, 0xF, true));
                     if (hi2) { r0 = ya; r1 = yb; } else { r2 = ya; r3 = yb; }
                 }
+                const v4f_t ad = gq == 0 ? ad0 : (gq == 1 ? ad1 : (gq == 2 ? ad2 : ad3));
+                float4 o = make_float4(r0 + bv.x, r1 + bv.y, r2 + bv.z, r3 + bv.w);
+                if (p.addend) { o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w; }
                 const int64_t row = m0 + wm * 32 + 8 * gq + 4 * khalf + jq;
-                if (cok && row < p.M)
-                    st4(p.C + row * p.Kc + colq, make_float4(r0 + bv.x + ad[gq].x, r1 + bv.y + ad[gq].y, r2 + bv.z + ad[gq].z, r3 + bv.w + ad[gq].w));
+                if (cok && row < p.M) st4(p.C + row * p.Kc + colq, o);
             }
         }
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                              // the exchange buffer may be rewritten by the next tile
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     };
@@ -1719,6 +1744,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         if (++c_kt == nk) { epilogue(c_mt); c_kt = 0; ++c_mt; }
         if (++c_slot == S) c_slot = 0;
     };
+    // addend rows of tile `mt` are requested when the loop is about to consume the tile's first step (before that
+    // iteration's DMA batch): nk >= 2 steps and their counted waits lie between the request and the epilogue
+    auto maybe_fetch_addend = [&]() { if (p.addend && c_kt == 0 && wk == 0) addend_fetch(c_mt); };
     auto fetch_next = [&](bool more) {                                        // mask of the step AFTER the one about to be consumed
         int n_kt = c_kt + 1, n_mt = c_mt;
         if (n_kt == nk) { n_kt = 0; ++n_mt; }
@@ -1735,6 +1763,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     for (int t = 0; t < steady; ++t) {
         __builtin_amdgcn_s_barrier();                    // every wave's share of the stage to consume has landed
         fetch_next(t + 1 < total);
+        maybe_fetch_addend();
         issue_next();
         consume();
         if (t + 1 < steady) wait_vmcnt<LPW*(S - 2)>(); else wait_vmcnt<0>();
@@ -1743,8 +1772,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     for (int t = 0; t < pre; ++t) {
         __builtin_amdgcn_s_barrier();
         fetch_next(steady + t + 1 < total);
+        maybe_fetch_addend();
+        wait_vmcnt<0>();                                 // drain phase: nothing newer is worth keeping in flight
         consume();
-        wait_vmcnt<0>();
         mask_commit();
     }
 }
