@@ -237,10 +237,10 @@ __global__ __launch_bounds__(256) void pw_gemm_nt_kernel(GemmArgs p) {
 //   * the LDS image is lane-linear per DMA instruction (hardware rule), so bank conflicts are removed by
 //     XOR-swizzling the 16-B chunk index on the SOURCE address and on the fragment read (chunk ^ (row>>2)&3);
 //   * block id -> (m-run, n-tile) puts the n-tiles that share an A panel on the same XCD (bid % 8).
-// Requirements: K % 4 == 0 (16-B aligned rows) and N % 4 == 0 (the epilogue stores 4-column groups); anything else
-// — the 75-channel detection heads, MobileNetV3's 10-channel gate bottleneck — takes the register-staged kernel.
-// (A scalar-store tail inside THIS kernel, fully unrolled over 16*TN accumulators, cost ~40 VGPRs and made the
-// TN >= 3 main loops spill to scratch; keeping it out brings every variant under 155 VGPRs.)
+// Requirements: K % 4 == 0 (16-B aligned input rows); other K (the 75-channel heads' data gradient, the 10-channel gate) take
+// the register-staged kernel.  A ragged output width (N % 4 != 0) is handled in the TRANSPOSED epilogue: up to four element
+// stores off one address per row.  (An earlier scalar tail on the un-transposed accumulators — 16*TN stores with 16*TN
+// addresses, fully unrolled — cost ~40 VGPRs and made the TN >= 3 main loops spill to scratch.)
 // Out-of-range rows are clamped to a valid row (their outputs are never stored); k-chunks past K re-read the
 // row start and are annihilated by zeroed B fragments (and zero scale/shift).
 // ------------------------------------------------------------------------------------------------
@@ -468,14 +468,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     // across the lane's quad with two DPP butterfly stages, after which lane jq of a quad holds row b+jq, columns
     // 4q..4q+3 -> one 16-byte store (4x fewer store instructions, full 128-B row segments per quad-row).
     const int quad = lrow >> 2, jq = lane & 3;
+    const bool nvec = (p.N & 3) == 0;
     auto epilogue = [&](int mt) {
         const int64_t m0 = (int64_t)mt * BM;
 #pragma unroll
         for (int u = 0; u < TN; ++u) {
             const int colq = n0 + u * 32 + quad * 4;              // first of this lane's 4 output columns
-            const bool cok = colq < p.N;                          // N % 4 == 0: all four or none
+            const bool cok = colq < p.N;                          // N % 4 == 0: all four or none; ragged N: per element below
             float4 bv = f4zero();
-            if (p.bias && cok) bv = ld4(p.bias + colq);
+            if (p.bias && cok) {
+                if (nvec) bv = ld4(p.bias + colq);
+                else {
+                    bv.x = p.bias[colq];
+                    if (colq + 1 < p.N) bv.y = p.bias[colq + 1];
+                    if (colq + 2 < p.N) bv.z = p.bias[colq + 2];
+                    if (colq + 3 < p.N) bv.w = p.bias[colq + 3];
+                }
+            }
             if (p.stats) {                                        // column sums come from the un-transposed registers
                 const bool ccol = n0 + u * 32 + lrow < p.N;
 #pragma unroll
@@ -505,8 +514,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                 const int64_t row = m0 + wv * 32 + 8 * gq + 4 * khalf + jq;
                 if (cok && row < p.M) {
                     float4 v = make_float4(r0 + bv.x, r1 + bv.y, r2 + bv.z, r3 + bv.w);
-                    if (pAdd) add4(v, ld4(pAdd + row * p.N + colq));
-                    st4(pC + row * p.N + colq, v);
+                    if (nvec) {
+                        if (pAdd) add4(v, ld4(pAdd + row * p.N + colq));
+                        st4(pC + row * p.N + colq, v);
+                    } else {
+                        // ragged width (75-channel heads, 10-channel gate): rows are not 16-B aligned -> up to four element stores
+                        // off ONE address (the transposed layout keeps this cheap: one row, consecutive columns)
+                        T* dst = pC + row * p.N + colq;
+                        const T* ad = pAdd ? pAdd + row * p.N + colq : nullptr;
+                        st1(dst, v.x + (ad ? ld1(ad) : 0.f));
+                        if (colq + 1 < p.N) st1(dst + 1, v.y + (ad ? ld1(ad + 1) : 0.f));
+                        if (colq + 2 < p.N) st1(dst + 2, v.z + (ad ? ld1(ad + 2) : 0.f));
+                        if (colq + 3 < p.N) st1(dst + 3, v.w + (ad ? ld1(ad + 3) : 0.f));
+                    }
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[u][gq * 4 + i] = 0.f;
@@ -1812,12 +1832,12 @@ using namespace mny;
 
 extern "C" int mny_pw_stat_parts(int64_t M, int K, int Nc) {
     if (M <= 0 || K <= 0 || Nc <= 0) return MNY_EINVAL;
-    if ((K & 3) == 0 && (Nc & 3) == 0 && getenv("MNY_GEMM_V1") == nullptr) return nt2_plan(M, K, Nc, true).gx;
+    if ((K & 3) == 0 && getenv("MNY_GEMM_V1") == nullptr) return nt2_plan(M, K, Nc, true).gx;
     return nt_plan(M, K, Nc).gx;
 }
 extern "C" int mny_pw_stat_parts_bf16(int64_t M, int K, int Nc) {
     if (M <= 0 || K <= 0 || Nc <= 0) return MNY_EINVAL;
-    if ((K & 7) == 0 && (Nc & 3) == 0 && getenv("MNY_GEMM_V1") == nullptr) return nt2_plan(M, K, Nc, true, 1).gx;
+    if ((K & 7) == 0 && getenv("MNY_GEMM_V1") == nullptr) return nt2_plan(M, K, Nc, true, 1).gx;
     return nt_plan(M, K, Nc).gx;
 }
 
@@ -1859,7 +1879,7 @@ extern "C" int mny_pw_fwd(const float* x, const float* in_scale, const float* in
     hipStream_t st = (hipStream_t)stream;
     const bool xf = in_scale != nullptr || in_act != MNY_ACT_NONE;
     static const bool force_v1 = getenv("MNY_GEMM_V1") != nullptr;   // A/B switch for profiling
-    if ((K & 3) == 0 && (Nc & 3) == 0 && !force_v1) {   // LDS-DMA pipeline (v2): 16-B aligned input rows, 16-B output groups
+    if ((K & 3) == 0 && !force_v1) {                // LDS-DMA pipeline (v2): 16-B aligned input rows
         Nt2Plan p2 = nt2_plan(M, K, Nc, xf);
         MNY_REQUIRE(p2.lds <= 64 * 1024, "pw_fwd: K=%d too large for the LDS scale cache", K);
         Gemm2Args g{x, in_scale, in_shift, in_act, w, bias, addend, y, stats, M, K, Nc, p2.m_tiles, p2.tiles_per_block, p2.gx, p2.n_tiles};
@@ -1880,7 +1900,7 @@ extern "C" int mny_pw_fwd_bf16(const void* x, const float* in_scale, const float
     hipStream_t st = (hipStream_t)stream;
     const bool xf = in_scale != nullptr || in_act != MNY_ACT_NONE;
     static const bool force_v1 = getenv("MNY_GEMM_V1") != nullptr;
-    if ((K & 7) == 0 && (Nc & 3) == 0 && !force_v1) {   // LDS-DMA pipeline on the bf16 matrix cores (16-B aligned bf16 rows)
+    if ((K & 7) == 0 && !force_v1) {                // LDS-DMA pipeline on the bf16 matrix cores (16-B aligned bf16 rows)
         Nt2Plan p2 = nt2_plan(M, K, Nc, xf, 1);
         MNY_REQUIRE(p2.lds <= 64 * 1024, "pw_fwd: K=%d too large for the LDS scale cache", K);
         Gemm2Args g{x, in_scale, in_shift, in_act, w, bias, addend, y, stats, M, K, Nc, p2.m_tiles, p2.tiles_per_block, p2.gx, p2.n_tiles};
