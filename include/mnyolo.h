@@ -217,6 +217,15 @@ int mny_dw_bnbwd(const float* g, const float* y, const float* scale, const float
                  const float* addend, float* dx, float* dw, float* ws, int N, int H, int W, int C, int K, int stride,
                  void* stream);
 
+/* ---- row padding for the detection heads' backward ---------------------------------------------------------
+ * The head gradient dL/dhead is [M][75] (yolo_loss.py:84 channel layout): rows are neither 16-B aligned nor a multiple
+ * of 4 wide, which would put its weight- and data-gradient GEMMs on the register-staged kernels.  mny_pad_rows copies it
+ * (times *alpha, the upstream dL/dloss; alpha may be NULL) into [M][Cp] with zeroed pad columns, mny_transpose_pad
+ * writes W^T as [Cin][Cp] with zeroed pad columns; the GEMMs then run with Cp channels (pad products are 0, the pad rows
+ * of dW land in the slack of the caller's gradient slot).                                                      */
+int mny_pad_rows(const float* src, const float* alpha, float* dst, int64_t M, int C, int Cp, void* stream);
+int mny_transpose_pad(const float* src /*[R][Cc]*/, float* dst /*[Cc][Rp]*/, int R, int Cc, int Rp, void* stream);
+
 /* ---- fused multi-tensor AdamW --------------------------------------------------------------
  * replaces optim.AdamW(...).step() at train.py:134,283 (torch semantics: decoupled weight decay, bias-corrected
  * moments, amsgrad off).  `table_dev` is a DEVICE array of chunks; one workgroup updates one chunk (callers split
@@ -278,6 +287,8 @@ int mny_dw_bnbwd_bf16(const void* g, const void* y, const float* scale, const fl
                       const void* x, const float* in_scale, const float* in_shift, int in_act, const float* w,
                       const void* addend, void* dx, float* dw, float* ws, int N, int H, int W, int C, int K, int stride,
                       void* stream);
+int mny_pad_rows_bf16(const float* src, const float* alpha, void* dst, int64_t M, int C, int Cp, void* stream);
+int mny_transpose_pad_bf16(const float* src, void* dst, int R, int Cc, int Rp, void* stream);
 int mny_axpy_bf16(const void* src, const float* alpha, void* dst, int accumulate, int64_t n, void* stream);
 /* element-wise storage conversion, n elements (RNE to bf16, exact widening back) */
 int mny_cvt_f32_bf16(const float* src, void* dst, int64_t n, void* stream);

@@ -46,6 +46,8 @@ _SIGS = {
     "mny_pw_bnbwd_ws_floats": (c_size_t, [c_int64, c_int, c_int]),
     "mny_pw_bnbwd": (c_int, [P, P, P, P, c_int, P, P, P, P, P, P, c_int, P, P, P, P, P, P, P, c_int64, c_int, c_int, P]),
     "mny_transpose": (c_int, [P, P, c_int, c_int, P]),
+    "mny_transpose_pad": (c_int, [P, P, c_int, c_int, c_int, P]),
+    "mny_pad_rows": (c_int, [P, P, P, c_int64, c_int, c_int, P]),
     "mny_bn_finalize": (c_int, [P, c_int, c_int64, P, P, c_float, c_float, P, P, P, P, P, P, c_int, P]),
     "mny_bn_eval_coeffs": (c_int, [P, P, P, P, c_float, P, P, c_int, P]),
     "mny_bn_bwd_reduce": (c_int, [P, P, P, P, c_int, P, P, P, c_int64, c_int, P]),
@@ -68,7 +70,7 @@ _SIGS = {
     "mny_nms_prefix_offset": (c_size_t, [c_int, c_int, c_int]),
 }
 # bf16-storage twins (activation tensors bf16, everything else as in the fp32 entry point): identical ctypes signature
-BF16_TWINS = ("mny_dw_bnbwd", "mny_stem_fwd", "mny_stem_wgrad", "mny_dw_fwd", "mny_dw_bwd_data", "mny_dw_bwd_weight", "mny_pw_fwd",
+BF16_TWINS = ("mny_pad_rows", "mny_transpose_pad", "mny_dw_bnbwd", "mny_stem_fwd", "mny_stem_wgrad", "mny_dw_fwd", "mny_dw_bwd_data", "mny_dw_bwd_weight", "mny_pw_fwd",
               "mny_pw_stat_parts", "mny_pw_wgrad", "mny_bn_bwd_reduce", "mny_bn_bwd_apply", "mny_add_views", "mny_mul_views",
               "mny_mul_views_bwd", "mny_partadd_up", "mny_slice_channels", "mny_upsample_bwd", "mny_axpy")
 for _n in BF16_TWINS:

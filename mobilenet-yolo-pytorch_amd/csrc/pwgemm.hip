@@ -1302,8 +1302,9 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ y, fl
     if (slot == 0 && c < C) parts[(int64_t)blockIdx.x * C + c] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
 }
 
+// dst[c][r] = src[r][c], destination row pitch Rp >= R, pad columns zeroed
 template <typename T>
-__global__ void transpose_kernel(const float* __restrict__ src, T* __restrict__ dst, int R, int Cc) {
+__global__ void transpose_kernel(const float* __restrict__ src, T* __restrict__ dst, int R, int Cc, int Rp) {
     __shared__ float tile[32][33];
     const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
     for (int j = threadIdx.y; j < 32; j += 8) {
@@ -1313,7 +1314,7 @@ __global__ void transpose_kernel(const float* __restrict__ src, T* __restrict__ 
     __syncthreads();
     for (int j = threadIdx.y; j < 32; j += 8) {
         const int c = bx + j, r = by + threadIdx.x;
-        if (r < R && c < Cc) st1(dst + (int64_t)c * R + r, tile[threadIdx.x][j]);
+        if (r < Rp && c < Cc) st1(dst + (int64_t)c * Rp + r, r < R ? tile[threadIdx.x][j] : 0.f);
     }
 }
 
@@ -1987,13 +1988,24 @@ extern "C" int mny_pw_wgrad_bf16(const void* x, const float* in_scale, const flo
 
 extern "C" int mny_transpose(const float* src, float* dst, int R, int Cc, void* stream) {
     MNY_REQUIRE(src && dst && R > 0 && Cc > 0, "transpose: bad arguments");
-    hipLaunchKernelGGL((transpose_kernel<float>), dim3((unsigned)cdiv(Cc, 32), (unsigned)cdiv(R, 32)), dim3(32, 8), 0, (hipStream_t)stream, src, dst, R, Cc);
+    hipLaunchKernelGGL((transpose_kernel<float>), dim3((unsigned)cdiv(Cc, 32), (unsigned)cdiv(R, 32)), dim3(32, 8), 0, (hipStream_t)stream, src, dst, R, Cc, R);
     return check_launch("transpose_kernel");
+}
+extern "C" int mny_transpose_pad(const float* src, float* dst, int R, int Cc, int Rp, void* stream) {
+    MNY_REQUIRE(src && dst && R > 0 && Cc > 0 && Rp >= R, "transpose_pad: bad arguments");
+    hipLaunchKernelGGL((transpose_kernel<float>), dim3((unsigned)cdiv(Cc, 32), (unsigned)cdiv(Rp, 32)), dim3(32, 8), 0, (hipStream_t)stream, src, dst, R, Cc, Rp);
+    return check_launch("transpose_kernel<pad>");
+}
+extern "C" int mny_transpose_pad_bf16(const float* src, void* dst, int R, int Cc, int Rp, void* stream) {
+    MNY_REQUIRE(src && dst && R > 0 && Cc > 0 && Rp >= R, "transpose_pad: bad arguments");
+    hipLaunchKernelGGL((transpose_kernel<bf16_t>), dim3((unsigned)cdiv(Cc, 32), (unsigned)cdiv(Rp, 32)), dim3(32, 8), 0, (hipStream_t)stream, src,
+                       (bf16_t*)dst, R, Cc, Rp);
+    return check_launch("transpose_kernel<pad,bf16>");
 }
 extern "C" int mny_transpose_bf16(const float* src, void* dst, int R, int Cc, void* stream) {
     MNY_REQUIRE(src && dst && R > 0 && Cc > 0, "transpose: bad arguments");
     hipLaunchKernelGGL((transpose_kernel<bf16_t>), dim3((unsigned)cdiv(Cc, 32), (unsigned)cdiv(R, 32)), dim3(32, 8), 0, (hipStream_t)stream, src,
-                       (bf16_t*)dst, R, Cc);
+                       (bf16_t*)dst, R, Cc, R);
     return check_launch("transpose_kernel<bf16>");
 }
 

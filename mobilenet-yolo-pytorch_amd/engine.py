@@ -287,6 +287,17 @@ class NetPlan:
         self.grad_params = []
         off = 0
         slots = {}
+        # detection heads: dL/dhead rows are padded to `head_cp` channels for the backward GEMMs (mny_pad_rows); the pad rows of
+        # dW / pad entries of dbias land in slack reserved behind the parameter's gradient slot
+        align = 8 if self.bf16 else 4
+        self.head_cp = {nd.out.id: (nd.out.C + align - 1) // align * align for nd in order
+                        if nd.op == "pwb" and nd.out.C % align and os.environ.get("MNY_NO_HEADPAD") != "1"}
+        slack = {}
+        for nd in order:
+            if nd.out.id in self.head_cp:
+                cp = self.head_cp[nd.out.id]
+                slack[nd.conv + ".weight"] = cp * nd.ins[0].C
+                slack[nd.conv + ".bias"] = cp
         for nd in order:
             names = []
             if nd.conv:
@@ -301,7 +312,7 @@ class NetPlan:
                 n = P[nm].numel()
                 slots[nm] = (off, n)
                 self.grad_params.append(nm)
-                off += (n + 3) // 4 * 4
+                off += (max(n, slack.get(nm, 0)) + 3) // 4 * 4
         self.gflat = torch.zeros(off, **f32)
         self.gviews = {nm: self.gflat[o:o + n].view(P[nm].shape) for nm, (o, n) in slots.items()}
         self.grad_slots = slots
@@ -332,7 +343,7 @@ class NetPlan:
             shp = shape(o)
             M = shp[0] * shp[1] * shp[2]
             if nd.op in ("pw", "pwb"):
-                ws_floats = max(ws_floats, _lib.query("mny_pw_wgrad_ws_floats", M, nd.ins[0].C, o.C),
+                ws_floats = max(ws_floats, _lib.query("mny_pw_wgrad_ws_floats", M, nd.ins[0].C, self.head_cp.get(o.id, o.C)),
                                 _lib.query("mny_pw_bnbwd_ws_floats", M, nd.ins[0].C, o.C))
             elif nd.op == "dw":
                 ws_floats = max(ws_floats, max_parts * o.C * nd.k * nd.k)
@@ -383,6 +394,13 @@ class NetPlan:
                 s.buf, s.shared = nb, False
 
         for hi, o in enumerate(g.outputs):
+            if o.id in self.head_cp:
+                cp = self.head_cp[o.id]
+                shp = shape(o)
+                gp = torch.empty(shp[0], shp[1], shp[2], cp, **act)
+                bwd.add(K("mny_pad_rows"), self.dheads[hi], self.g_scale[hi:hi + 1], gp, shp[0] * shp[1] * shp[2], o.C, cp, self.stream)
+                gs[o.id].buf = gp
+                continue
             bwd.add("mny_axpy", self.dheads[hi], self.g_scale[hi:hi + 1], self.dheads[hi], 0, self.dheads[hi].numel(), self.stream)
             if self.bf16:
                 d16 = torch.empty(self.dheads[hi].shape, **act)
@@ -508,12 +526,16 @@ class NetPlan:
                 i = nd.ins[0]
                 xv = view(i)
                 db = gv(nd.conv + ".bias") if nd.bias else None
-                bwd.add(K("mny_pw_wgrad"), xv[0], xv[1], xv[2], xv[3], dY, gv(nd.conv + ".weight"), db, self.ws, M, i.C, o.C, self.stream,
-                        meta=dict(flops=2 * M * i.C * o.C, bytes=eb * (M * i.C + M * o.C) + 4 * i.C * o.C, shape="M%d K%d N%d" % (M, i.C, o.C)))
-                wT = torch.empty(i.C, o.C, **act)       # the data-gradient GEMM reads W^T in the activation storage type
+                oc = self.head_cp.get(o.id, o.C)        # channel count of dY as the GEMMs see it (padded for the heads)
+                bwd.add(K("mny_pw_wgrad"), xv[0], xv[1], xv[2], xv[3], dY, gv(nd.conv + ".weight"), db, self.ws, M, i.C, oc, self.stream,
+                        meta=dict(flops=2 * M * i.C * o.C, bytes=eb * (M * i.C + M * o.C) + 4 * i.C * o.C, shape="M%d K%d N%d" % (M, i.C, oc)))
+                wT = torch.empty(i.C, oc, **act)        # the data-gradient GEMM reads W^T in the activation storage type
                 self.wT[nd.conv] = wT
-                bwd.add(K("mny_transpose"), w, wT, o.C, i.C, self.stream)
-                contribute_kernel(i, lambda out, addend, dY=dY, wT=wT, M=M, K=o.C, Nc=i.C: bwd.add(
+                if oc != o.C:
+                    bwd.add(K("mny_transpose_pad"), w, wT, o.C, i.C, oc, self.stream)
+                else:
+                    bwd.add(K("mny_transpose"), w, wT, o.C, i.C, self.stream)
+                contribute_kernel(i, lambda out, addend, dY=dY, wT=wT, M=M, K=oc, Nc=i.C: bwd.add(
                     self.K("mny_pw_fwd"), dY, None, None, ACT_NONE, wT, None, addend, out, None, M, K, Nc, self.stream,
                     meta=dict(flops=2 * M * K * Nc, bytes=self.eb * (M * K + M * Nc) + 4 * K * Nc, shape="dgrad M%d K%d N%d" % (M, K, Nc))))
             flush_shared()
