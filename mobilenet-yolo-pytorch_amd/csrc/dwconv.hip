@@ -11,6 +11,8 @@
 // per-block partial sums.
 //
 // replaces nn.Conv2d(groups=C) at models/mobilenetv2.py:65,79 and models/mbv2_yolo.py:22.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace mny {
@@ -268,7 +270,8 @@ static int dw_geom(DwGeom& g, CgLayout& L, int& gx, int N, int H, int W, int C, 
     g.N = N; g.H = H; g.W = W; g.C = C;
     g.Ho = (H + 2 * P - K) / stride + 1;
     g.Wo = (W + 2 * P - K) / stride + 1;
-    const int ns = (int)cdiv(g.Ho, 8);
+    static const int th = getenv("MNY_DW_TH") ? atoi(getenv("MNY_DW_TH")) : 16;   // strip height: 16 re-reads 2/16 halo rows (8: 2/8); 4.15 -> 4.05 ms
+    const int ns = (int)cdiv(g.Ho, th);
     g.TH = (int)cdiv(g.Ho, ns);
     g.nHS = (int)cdiv(g.Ho, g.TH);
     g.nstrips = (int64_t)N * g.Wo * g.nHS;
