@@ -50,11 +50,15 @@ class CallList:
                 conv.append(a)
         self.calls.append((fn, tuple(conv), name, meta))   # meta: algorithmic {flops, bytes} of the call
 
+    def add_py(self, fn, name="py"):
+        """A host-side step of the list (stream fork / join): any callable returning None."""
+        self.calls.append((fn, (), name, None))
+
     def run(self, begin=0, end=None):
         lib = _lib.load()
         for fn, args, name, _ in self.calls[begin:end]:
             rc = fn(*args)
-            if rc != 0:
+            if rc:
                 raise MnyError("%s failed (%d): %s" % (name, rc, lib.mny_last_error().decode()))
 
     def run_timed(self, events, only=None, begin=0, end=None):
@@ -71,7 +75,7 @@ class CallList:
                 b = torch.cuda.Event(enable_timing=True)
                 a.record()
             rc = fn(*args)
-            if rc != 0:
+            if rc:
                 raise MnyError("%s failed (%d): %s" % (name, rc, lib.mny_last_error().decode()))
             if timed:
                 b.record()
@@ -105,6 +109,13 @@ class NetPlan:
         # occupancy query) the call lists are captured once per segment and replayed.  Measured on MI355X: no gain
         # (68.1 vs 67.7 ms/step) — the eager list already keeps the GPU queue full — so it is off by default.
         self.use_graphs = training and os.environ.get("MNY_HIPGRAPH", "0") == "1"
+        # weight-gradient kernels on a side stream (MNY_SIDE_STREAM=1): they feed nothing downstream in the backward pass, so
+        # the MFMA-bound ones can overlap the HBM-bound BN / depthwise kernels of the following layers.  Fork = the side
+        # stream waits for what the main stream has enqueued (dY ready); join at the end of every replayed segment.
+        self.side_on = training and not self.use_graphs and os.environ.get("MNY_SIDE_STREAM", "0") == "1"
+        self.stream_side = _vp(0)
+        self._side_stream = torch.cuda.Stream(dev) if self.side_on else None
+        self._side_used = False
         self.graphs = {}
         self.eager_steps = 0
         self.x_static = None
@@ -350,6 +361,7 @@ class NetPlan:
             elif nd.op == "stem":
                 ws_floats = max(ws_floats, max_parts * o.C * 27)
         self.ws = torch.empty(ws_floats, **f32)
+        self.ws_side = torch.empty(ws_floats, **f32) if self.side_on else self.ws
         maxC = max(v.C for v in g.values)
         self.red_ws = torch.empty(2048 * 2 * maxC, **f32)      # >= mny_bn_bwd_parts() rows of [2][C]
         self.coef_ws = torch.empty(3 * maxC, **f32)
@@ -511,23 +523,36 @@ class NetPlan:
                         meta=dict(flops=0, bytes=3 * eb * M * o.C, shape="M%d C%d" % (M, o.C)))
             w = P[nd.conv + ".weight"]
             if nd.op == "stem":
-                bwd.add(K("mny_stem_wgrad"), self.x_ptr, dY, gv(nd.conv + ".weight"), self.ws, N, self.H, self.W, o.C, self.stream)
+                if self.side_on:
+                    bwd.add_py(self._fork_side, "fork")
+                bwd.add(K("mny_stem_wgrad"), self.x_ptr, dY, gv(nd.conv + ".weight"), self.ws_side, N, self.H, self.W, o.C, self.stream_side)
             elif nd.op == "dw":
                 i = nd.ins[0]
                 ish = shape(i)
                 xv = view(i)
                 dwb = eb * (N * ish[1] * ish[2] * o.C + M * o.C)
-                bwd.add(K("mny_dw_bwd_weight"), xv[0], xv[1], xv[2], xv[3], dY, gv(nd.conv + ".weight"), self.ws, N, ish[1], ish[2], o.C,
-                        nd.k, nd.stride, self.stream, meta=dict(flops=2 * M * o.C * nd.k * nd.k, bytes=dwb, shape="C%d H%d s%d" % (o.C, ish[1], nd.stride)))
+                n_sh = len(self.shared_tmp)
+                dwv_ = gv(nd.conv + ".weight")
+                on_side = self.side_on and len(self.shared_tmp) == n_sh
+                if on_side:
+                    bwd.add_py(self._fork_side, "fork")
+                bwd.add(K("mny_dw_bwd_weight"), xv[0], xv[1], xv[2], xv[3], dY, dwv_, self.ws_side if on_side else self.ws, N, ish[1], ish[2], o.C,
+                        nd.k, nd.stride, self.stream_side if on_side else self.stream, meta=dict(flops=2 * M * o.C * nd.k * nd.k, bytes=dwb, shape="C%d H%d s%d" % (o.C, ish[1], nd.stride)))
                 contribute_kernel(i, lambda out, addend, dY=dY, w=w, ish=ish, nd=nd, C=o.C, M=M, dwb=dwb: bwd.add(
                     K("mny_dw_bwd_data"), dY, w, addend, out, N, ish[1], ish[2], C, nd.k, nd.stride, self.stream,
                     meta=dict(flops=2 * M * C * nd.k * nd.k, bytes=dwb, shape="C%d H%d s%d" % (C, ish[1], nd.stride))))
             else:   # pw / pwb
                 i = nd.ins[0]
                 xv = view(i)
+                n_sh = len(self.shared_tmp)
                 db = gv(nd.conv + ".bias") if nd.bias else None
+                dwv_ = gv(nd.conv + ".weight")
+                on_side = self.side_on and len(self.shared_tmp) == n_sh
                 oc = self.head_cp.get(o.id, o.C)        # channel count of dY as the GEMMs see it (padded for the heads)
-                bwd.add(K("mny_pw_wgrad"), xv[0], xv[1], xv[2], xv[3], dY, gv(nd.conv + ".weight"), db, self.ws, M, i.C, oc, self.stream,
+                if on_side:
+                    bwd.add_py(self._fork_side, "fork")
+                bwd.add(K("mny_pw_wgrad"), xv[0], xv[1], xv[2], xv[3], dY, dwv_, db, self.ws_side if on_side else self.ws, M, i.C, oc,
+                        self.stream_side if on_side else self.stream,
                         meta=dict(flops=2 * M * i.C * o.C, bytes=eb * (M * i.C + M * o.C) + 4 * i.C * o.C, shape="M%d K%d N%d" % (M, i.C, oc)))
                 wT = torch.empty(i.C, oc, **act)        # the data-gradient GEMM reads W^T in the activation storage type
                 self.wT[nd.conv] = wT
@@ -629,6 +654,8 @@ class NetPlan:
 
     def backward(self, g_losses):
         self.stream.value = torch.cuda.current_stream(self.dev).cuda_stream
+        # event-bracketed runs (bench breakdown) keep everything on one stream so the brackets mean something
+        self.stream_side.value = self._side_stream.cuda_stream if (self.side_on and self.timing is None) else self.stream.value
         self.x_ptr.value = self.saved_x.data_ptr()
         self.g_scale.copy_(g_losses.reshape(2).to(self.g_scale.dtype))
         if self.reducer is not None:
@@ -637,8 +664,20 @@ class NetPlan:
             self.run_bwd_segment(0, None)
         self.eager_steps += 1
 
+    def _fork_side(self):
+        if self.side_on and self.timing is None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.dev))
+            self._side_stream.wait_event(ev)
+            self._side_used = True
+
     def run_bwd_segment(self, begin, end):
         self._replay("bwd", self.bwd, begin, end)
+        if self._side_used:                                  # join: gradients of this segment are complete on the main stream
+            ev = torch.cuda.Event()
+            ev.record(self._side_stream)
+            torch.cuda.current_stream(self.dev).wait_event(ev)
+            self._side_used = False
 
     def enable_timing(self, only=None):
         """Bracket calls with HIP events (bench.py roofline leg); disable with disable_timing()."""
