@@ -9,6 +9,8 @@
 //
 // replaces models/yolo_loss.py:53-60,77-178,180-204,206-236,257-293,425-434, utils/iou.py:4-49,
 // utils/box.py:11-31 and torchvision.ops.nms (third-party, see oracle/nms_ref.c for its semantics).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace mny {
@@ -380,14 +382,18 @@ __device__ __forceinline__ uint32_t desc_key(float s) {       // larger score ->
 
 // grid (S, C).  Fills the bucket in original row order (stable), sorts by (score desc, position asc),
 // greedy suppression with block-parallel IoU passes, writes kept row indices to tmp[bucket_base + r].
-__global__ __launch_bounds__(256) void nms_bucket_kernel(const float* __restrict__ rows, const int32_t* __restrict__ seg_begin,
-                                                         const int32_t* __restrict__ seg_count, int num_classes, double thr, int cap, int32_t* __restrict__ tmp,
-                                                         float4* kbox, int32_t* __restrict__ bucket_base, int32_t* __restrict__ kept_count,
-                                                         int32_t* __restrict__ status) {
+// SORT_ONLY (large buckets, see nms_mask_kernel): stops after the sort and writes the sorted boxes / row indices to
+// kbox / tmp at bucket_base + j and the bucket size to kept_count; blockDim.x = 1024 there (256 otherwise).
+template <bool SORT_ONLY>
+__global__ __launch_bounds__(1024) void nms_bucket_kernel(const float* __restrict__ rows, const int32_t* __restrict__ seg_begin,
+                                                          const int32_t* __restrict__ seg_count, int num_classes, double thr, int cap, int32_t* __restrict__ tmp,
+                                                          float4* kbox, int32_t* __restrict__ bucket_base, int32_t* __restrict__ kept_count,
+                                                          int32_t* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) unsigned char nms_smem[];
     unsigned long long* keys = (unsigned long long*)nms_smem;           // [cap2] (score key << 32 | position)
-    __shared__ int32_t s_wsum[2][4];
+    __shared__ int32_t s_wsum[2][16];
     __shared__ int32_t s_n, s_lower, s_next, s_kept;
+    const int BT = blockDim.x, NWV = BT >> 6;
     const int s = blockIdx.x, c = blockIdx.y;
     const int r0 = seg_begin[s], r1 = r0 + seg_count[s];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -397,7 +403,7 @@ __global__ __launch_bounds__(256) void nms_bucket_kernel(const float* __restrict
     // 1. stable fill (original row order) of the bucket's keys and row indices
     int32_t* rowidx = (int32_t*)(keys + cap);                           // [cap]
     unsigned char* dead = (unsigned char*)(rowidx + cap);               // [cap]
-    for (int c0 = r0; c0 < r1; c0 += 256) {
+    for (int c0 = r0; c0 < r1; c0 += BT) {
         const int i = c0 + threadIdx.x;
         bool mine = false, lower = false;
         float score = 0.f;
@@ -423,8 +429,10 @@ __global__ __launch_bounds__(256) void nms_bucket_kernel(const float* __restrict
         }
         __syncthreads();
         if (threadIdx.x == 0) {
-            s_n = base + s_wsum[0][0] + s_wsum[0][1] + s_wsum[0][2] + s_wsum[0][3];
-            s_lower += s_wsum[1][0] + s_wsum[1][1] + s_wsum[1][2] + s_wsum[1][3];
+            int a = 0, b = 0;
+            for (int w = 0; w < NWV; ++w) { a += s_wsum[0][w]; b += s_wsum[1][w]; }
+            s_n = base + a;
+            s_lower += b;
         }
         __syncthreads();
     }
@@ -437,13 +445,13 @@ __global__ __launch_bounds__(256) void nms_bucket_kernel(const float* __restrict
     }
     if (n == 0) { if (threadIdx.x == 0) kept_count[s * num_classes + c] = 0; return; }
     int n2 = 1; while (n2 < n) n2 <<= 1;
-    for (int i = n + threadIdx.x; i < n2; i += 256) keys[i] = ~0ull;     // pad: sorts last
-    for (int i = threadIdx.x; i < n; i += 256) dead[i] = 0;
+    for (int i = n + threadIdx.x; i < n2; i += BT) keys[i] = ~0ull;      // pad: sorts last
+    for (int i = threadIdx.x; i < n; i += BT) dead[i] = 0;
     __syncthreads();
     // 2. bitonic sort (ascending key == descending score, ties by original position: stable)
     for (int k = 2; k <= n2; k <<= 1)
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < n2; i += 256) {
+            for (int i = threadIdx.x; i < n2; i += BT) {
                 const int l = i ^ j;
                 if (l > i) {
                     const unsigned long long a = keys[i], b = keys[l];
@@ -453,6 +461,16 @@ __global__ __launch_bounds__(256) void nms_bucket_kernel(const float* __restrict
             }
             __syncthreads();
         }
+    if (SORT_ONLY) {                                                    // hand the sorted bucket to nms_mask_kernel / nms_resolve_kernel
+        for (int j = threadIdx.x; j < n; j += BT) {
+            const int ri = rowidx[(unsigned)(keys[j] & 0xFFFFFFFFull)];
+            const float* b = rows + (int64_t)ri * 7;
+            kbox[bbase + j] = make_float4(b[0], b[1], b[2], b[3]);
+            tmp[bbase + j] = ri;
+        }
+        if (threadIdx.x == 0) kept_count[s * num_classes + c] = n;
+        return;
+    }
     // 3. greedy suppression over the sorted order, 64 candidates at a time (identical result to the one-by-one loop):
     //    a candidate survives iff no box KEPT from earlier tiles suppresses it (checked in parallel: candidate = lane,
     //    the 4 waves split the kept list) and no earlier SURVIVOR of its own tile does (64x64 bitmask, resolved serially).
@@ -531,20 +549,134 @@ __global__ __launch_bounds__(256) void nms_bucket_kernel(const float* __restrict
     if (threadIdx.x == 0) kept_count[s * num_classes + c] = s_kept;
 }
 
-// grid S: concatenate the kept lists of a segment in class order
+// ---- large buckets: suppression bit-matrix + wave-serial resolve ------------------------------------------------------
+// One workgroup per (image, class) runs the greedy loop above on ONE CU; for a 100k-row segment with 20 classes that is 20 CUs
+// of 256 and a kept list re-scanned for every tile.  Large buckets instead go through
+//   nms_bucket_kernel<SORT_ONLY>  sort each bucket (1024 threads), write the sorted boxes
+//   nms_mask_kernel               grid (row tile, bucket): bit j of word jt of row i = "i suppresses j" for every later j
+//                                 (same IoU arithmetic and double compare as the loop above) — all CUs busy
+//   nms_resolve_kernel            one wave per bucket walks the sorted order tile by tile: in-tile survivors by a 64-step
+//                                 shuffle resolve, then ORs the kept rows' words into the `removed` bit set (batched loads)
+// The kept set is the one the sequential algorithm produces (a box is kept iff no earlier KEPT box has its bit).
+__global__ __launch_bounds__(512) void nms_mask_kernel(const float4* __restrict__ sbox, const int32_t* __restrict__ bucket_base,
+                                                       const int32_t* __restrict__ bucket_n, double thr, int NT,
+                                                       unsigned long long* __restrict__ mask) {
+    const int b = blockIdx.y;
+    const int n = bucket_n[b], bbase = bucket_base[b];
+    const int ntiles = (n + 63) >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // row tile blockIdx.x and its mirror ntiles-1-blockIdx.x: (ntiles - it) + (it + 1) column tiles per workgroup — the
+    // triangle folded into equal shares
+    for (int half = 0; half < 2; ++half) {
+        const int it = half == 0 ? (int)blockIdx.x : ntiles - 1 - (int)blockIdx.x;
+        if (it < 0 || it >= ntiles || (half == 1 && it <= (int)blockIdx.x)) continue;
+        const int i = it * 64 + lane;
+        const bool valid = i < n;
+        const float4 bx = valid ? sbox[bbase + i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float ai = (bx.z - bx.x) * (bx.w - bx.y);
+        for (int jt = it + wave; jt < ntiles; jt += 8) {                  // 8 waves per workgroup share the column tiles
+            unsigned long long bits = 0ull;
+            const int lim = min(64, n - jt * 64);
+#pragma unroll 4
+            for (int q = 0; q < lim; ++q) {
+                const float4 ob = sbox[bbase + jt * 64 + q];              // wave-uniform address: a scalar load
+                const float ao = (ob.z - ob.x) * (ob.w - ob.y);
+                const float xx1 = bx.x > ob.x ? bx.x : ob.x, yy1 = bx.y > ob.y ? bx.y : ob.y;
+                const float xx2 = bx.z < ob.z ? bx.z : ob.z, yy2 = bx.w < ob.w ? bx.w : ob.w;
+                float w = xx2 - xx1; if (!(w > 0.f)) w = 0.f;
+                float h = yy2 - yy1; if (!(h > 0.f)) h = 0.f;
+                const float inter = w * h;
+                const float ovr = inter / (ai + ao - inter);
+                if ((double)ovr > thr && (jt > it || q > lane)) bits |= 1ull << q;
+            }
+            if (valid) mask[(int64_t)(bbase + i) * NT + jt] = bits;
+        }
+    }
+}
+
+// one wave per bucket.  `srow` (= tmp) holds the sorted row indices on entry and the kept row indices on exit (in place:
+// the r-th kept box is never behind its sorted position).  Per 64-box tile T:
+//   removed = OR over every box kept so far of its word T   (independent 8-B loads, K/64 per lane, one wave-wide OR)
+//   survivors of the tile by the 64-step serial resolve on the tile's own words (readlane broadcasts, no memory)
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int l) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+__global__ __launch_bounds__(256) void nms_resolve_kernel(const unsigned long long* __restrict__ mask, int NT, int32_t* __restrict__ srow,
+                                                          const int32_t* __restrict__ bucket_base, int32_t* __restrict__ bucket_n_kept) {
+    __shared__ unsigned short kpos[NMS_CAP];                              // sorted position of the r-th kept box
+    __shared__ unsigned long long wred[4];
+    __shared__ int s_K;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = bucket_n_kept[b], bbase = bucket_base[b];
+    if (tid == 0) s_K = 0;
+    __syncthreads();
+    const int ntiles = (n + 63) >> 6;
+    for (int T = 0; T < ntiles; ++T) {
+        const int K = s_K;
+        // removed = OR over every kept box of its word T: all 4 waves, 8 independent loads per thread and batch
+        unsigned long long w = 0ull;
+        for (int k0 = 0; k0 < K; k0 += 256 * 8) {
+            unsigned long long t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u * 256 + tid;
+                t[u] = k < K ? mask[(int64_t)(bbase + kpos[k]) * NT + T] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) w |= t[u];
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) w |= __shfl_xor(w, d);
+        if (lane == 0) wred[wave] = w;
+        __syncthreads();
+        if (wave == 0) {
+            const int lim = min(64, n - T * 64);
+            const bool valid = lane < lim;
+            const unsigned long long own = valid ? mask[(int64_t)(bbase + T * 64 + lane) * NT + T] : 0ull;   // later boxes of this tile
+            const int ri = valid ? srow[bbase + T * 64 + lane] : 0;
+            unsigned long long removed = (wred[0] | wred[1]) | (wred[2] | wred[3]);
+            const unsigned long long in_tile = lim == 64 ? ~0ull : ((1ull << lim) - 1ull);
+            unsigned long long keep = 0ull, done = 0ull;
+            // serial resolve over the not-yet-removed candidates only (in order): each step keeps one box
+            for (;;) {
+                const unsigned long long cand = in_tile & ~removed & ~done;
+                if (!cand) break;
+                const int q = __ffsll((long long)cand) - 1;
+                keep |= 1ull << q;
+                done |= 1ull << q;
+                removed |= readlane64(own, q);
+            }
+            if ((keep >> lane) & 1ull) {
+                const int r = K + __popcll(keep & ((1ull << lane) - 1ull));
+                srow[bbase + r] = ri;
+                kpos[r] = (unsigned short)(T * 64 + lane);
+            }
+            if (lane == 0) s_K = K + __popcll(keep);
+        }
+        __syncthreads();
+    }
+    if (tid == 0) bucket_n_kept[b] = s_K;
+}
+
+// grid (S, slices): concatenate the kept lists of a segment in class order (every block walks the class offsets, copies its
+// slice of each class)
 __global__ __launch_bounds__(256) void nms_compact_kernel(const int32_t* __restrict__ seg_begin, int num_classes,
                                                           const int32_t* __restrict__ tmp, const int32_t* __restrict__ bucket_base,
                                                           const int32_t* __restrict__ kept_count, int32_t* __restrict__ out_idx,
                                                           int32_t* __restrict__ out_counts) {
     const int s = blockIdx.x;
     const int begin = seg_begin[s];
+    const int t0 = blockIdx.y * 256 + threadIdx.x, tstride = gridDim.y * 256;
     int off = begin;
     for (int c = 0; c < num_classes; ++c) {
         const int k = kept_count[s * num_classes + c], b = bucket_base[s * num_classes + c];
-        for (int i = threadIdx.x; i < k; i += 256) out_idx[off + i] = tmp[b + i];
+        for (int i = t0; i < k; i += tstride) out_idx[off + i] = tmp[b + i];
         off += k;
     }
-    if (threadIdx.x == 0) out_counts[s] = off - begin;
+    if (t0 == 0) out_counts[s] = off - begin;
 }
 
 // single block: exclusive scan of out_counts -> out_prefix[S+1]
@@ -578,7 +710,7 @@ __global__ __launch_bounds__(256) void nms_gather_kernel(const float* __restrict
                                                          const int32_t* __restrict__ prefix, float* __restrict__ out_rows) {
     const int s = blockIdx.x;
     const int k = out_counts[s], b = seg_begin[s], o = prefix[s];
-    for (int i = threadIdx.x; i < k * 7; i += 256) {
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < k * 7; i += gridDim.y * 256) {
         const int r = i / 7, f = i % 7;
         out_rows[(int64_t)(o + r) * 7 + f] = rows[(int64_t)out_idx[b + r] * 7 + f];
     }
@@ -587,6 +719,12 @@ __global__ __launch_bounds__(256) void nms_gather_kernel(const float* __restrict
 }  // namespace mny
 
 using namespace mny;
+
+static int nms_cap_for(int total) {
+    int cap = 1024;
+    while (cap < total && cap < NMS_CAP) cap <<= 1;
+    return cap;
+}
 
 extern "C" size_t mny_yolo_loss_ws_bytes(const mny_yolo_head* hp, int total_targets) {
     (void)total_targets;
@@ -620,17 +758,18 @@ extern "C" int mny_yolo_decode(const float* head, const float* anchors_all, cons
     return check_launch("yolo_decode_kernel");
 }
 
-static int nms_cap_for(int total) {
-    int cap = 1024;
-    while (cap < total && cap < NMS_CAP) cap <<= 1;
-    return cap;
-}
+
+// large-bucket path (bit-matrix): taken when the segments average more than 2048 rows
+static bool nms_large(int S, int capacity) { return capacity > 2048 * S && getenv("MNY_NMS_SMALL") == nullptr; }
 
 extern "C" size_t mny_nms_ws_bytes(int S, int capacity, int num_classes) {
     if (S <= 0 || capacity < 0 || num_classes <= 0) return 0;
-    // tmp[capacity] + bucket_base[S*C] + kept_count[S*C] + prefix[S+1] + status + kept-box cache float4[capacity]
-    return align256((size_t)(capacity > 0 ? capacity : 1) * 4) + 2 * align256((size_t)S * num_classes * 4) + align256((size_t)(S + 1) * 4) + 256 +
-           align256((size_t)(capacity > 0 ? capacity : 1) * 16);
+    // tmp[capacity] + bucket_base[S*C] + kept_count[S*C] + prefix[S+1] + status + box cache float4[capacity]
+    // (+ the suppression bit-matrix [capacity][cap/64] u64 on the large-bucket path)
+    size_t bytes = align256((size_t)(capacity > 0 ? capacity : 1) * 4) + 2 * align256((size_t)S * num_classes * 4) + align256((size_t)(S + 1) * 4) + 256 +
+                   align256((size_t)(capacity > 0 ? capacity : 1) * 16);
+    if (nms_large(S, capacity)) bytes += align256((size_t)capacity * (nms_cap_for(capacity) / 64) * 8);
+    return bytes;
 }
 
 extern "C" size_t mny_nms_status_offset(int S, int capacity, int num_classes) {
@@ -658,16 +797,26 @@ extern "C" int mny_nms_per_class(const float* rows, const int32_t* seg_begin, co
     const size_t lds = (size_t)cap * (8 + 4 + 1);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)nms_bucket_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, NMS_CAP * 13);
+        hipError_t e = hipFuncSetAttribute((const void*)nms_bucket_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, NMS_CAP * 13);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)nms_bucket_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, NMS_CAP * 13);
         if (e != hipSuccess) { set_error("nms: hipFuncSetAttribute: %s", hipGetErrorString(e)); return MNY_EHIP; }
         attr_set = true;
     }
     if (hipMemsetAsync(status, 0, 4, st) != hipSuccess) { set_error("nms: memset failed"); return MNY_EHIP; }
-    hipLaunchKernelGGL(nms_bucket_kernel, dim3(S, num_classes), dim3(256), lds, st, rows, seg_begin, seg_count, num_classes, thr, cap, tmp,
+    if (nms_large(S, capacity)) {
+        unsigned long long* mask = (unsigned long long*)((char*)kbox + align256((size_t)(capacity > 0 ? capacity : 1) * 16));
+        const int NT = cap / 64;
+        hipLaunchKernelGGL(nms_bucket_kernel<true>, dim3(S, num_classes), dim3(1024), lds, st, rows, seg_begin, seg_count, num_classes, thr, cap,
+                           tmp, kbox, bucket_base, kept, status);
+        hipLaunchKernelGGL(nms_mask_kernel, dim3((NT + 1) / 2, S * num_classes), dim3(512), 0, st, kbox, bucket_base, kept, thr, NT, mask);
+        hipLaunchKernelGGL(nms_resolve_kernel, dim3(S * num_classes), dim3(256), 0, st, mask, NT, tmp, bucket_base, kept);
+    } else
+    hipLaunchKernelGGL(nms_bucket_kernel<false>, dim3(S, num_classes), dim3(256), lds, st, rows, seg_begin, seg_count, num_classes, thr, cap, tmp,
                        kbox, bucket_base, kept, status);
-    hipLaunchKernelGGL(nms_compact_kernel, dim3(S), dim3(256), 0, st, seg_begin, num_classes, tmp, bucket_base, kept, out_idx, out_counts);
+    const int slices = nms_large(S, capacity) ? 64 : 1;                    // few huge segments: spread the copies over more blocks
+    hipLaunchKernelGGL(nms_compact_kernel, dim3(S, slices), dim3(256), 0, st, seg_begin, num_classes, tmp, bucket_base, kept, out_idx, out_counts);
     hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(256), 0, st, out_counts, S, prefix);
     if (out_rows)
-        hipLaunchKernelGGL(nms_gather_kernel, dim3(S), dim3(256), 0, st, rows, seg_begin, out_idx, out_counts, prefix, out_rows);
+        hipLaunchKernelGGL(nms_gather_kernel, dim3(S, slices), dim3(256), 0, st, rows, seg_begin, out_idx, out_counts, prefix, out_rows);
     return check_launch("nms kernels");
 }
