@@ -122,7 +122,9 @@ def _rand_rows(n, C, seed, quant=False):
 
 
 @pytest.mark.parametrize("sizes,C,quant", [([50, 0, 300, 7], 20, False), ([1815] * 6, 20, False), ([400, 33], 7, True),
-                                            ([0, 0], 20, False), ([20000], 20, False)])
+                                            ([0, 0], 20, False), ([20000], 20, False),
+                                            # large-bucket path (segments averaging > 2048 rows): bit-matrix + tile resolve
+                                            ([9000, 5000], 3, True), ([30000], 4, False), ([2500, 0, 7000], 5, False)])
 def test_nms_indices_bit_exact(ops, sizes, C, quant):
     """Same rows into both implementations -> identical kept indices, order included (Q13)."""
     segs = [_rand_rows(n, C, seed=11 + i, quant=quant) for i, n in enumerate(sizes)]
@@ -141,6 +143,22 @@ def test_nms_indices_bit_exact(ops, sizes, C, quant):
         assert out_counts[s] == len(ref_idx)
         assert np.array_equal(got, ref_idx.numpy())
         assert np.array_equal(out_rows[prefix[s]:prefix[s + 1]].cpu().numpy(), ref_rows.numpy())
+
+
+def test_nms_large_buckets_dense_overlap(ops):
+    """Heavily overlapping boxes (most are suppressed, long suppression chains) through the large-bucket path, and the same
+    rows through the one-workgroup path (MNY_NMS_SMALL is read per call): both equal the CPU restatement."""
+    r = np.random.RandomState(3)
+    n, C = 12000, 3
+    ctr = 0.5 + 0.05 * r.randn(n, 2).astype(np.float32)
+    wh = (0.2 + 0.1 * r.rand(n, 2)).astype(np.float32)
+    rows = torch.from_numpy(np.concatenate((ctr - wh / 2, ctr + wh / 2, r.rand(n, 2), r.randint(0, C, (n, 1))), 1).astype(np.float32))
+    ref_rows, ref_idx = nms_ref.nms_rows(rows, C, 0.45)
+    beg, cnt = torch.tensor([0], dtype=torch.int32).cuda(), torch.tensor([n], dtype=torch.int32).cuda()
+    out_idx, out_counts, out_rows, prefix, status = ops.nms_per_class(rows.cuda(), beg, cnt, C, 0.45)
+    assert int(status.cpu()) == 0 and int(out_counts.cpu()[0]) == len(ref_idx)
+    assert np.array_equal(out_idx[:len(ref_idx)].cpu().numpy(), ref_idx.numpy())
+    assert np.array_equal(out_rows[:len(ref_idx)].cpu().numpy(), ref_rows.numpy())
 
 
 def test_nms_reference_driver_fixture(ops):
