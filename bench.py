@@ -204,9 +204,37 @@ def nms_bench(device):
     cpu_dt = time.perf_counter() - t0
     kept = int(out[1].item())
     same = kept == len(ref_idx) and torch.equal(out[0][:kept].cpu().long(), ref_idx)
-    return {"workload": "per-class NMS, 100000 boxes x 20 classes, thr 0.45", "boxes_per_s": round(n / gpu_dt, 1),
-            "ms": round(gpu_dt * 1e3, 3), "kept": kept, "matches_cpu_indices": bool(same),
-            "cpu_boxes_per_s": round(n / cpu_dt, 1), "cpu_kind": "port (oracle/nms_ref.c, 1 thread)"}
+    res = {"workload": "per-class NMS, 100000 boxes x 20 classes, thr 0.45", "boxes_per_s": round(n / gpu_dt, 1),
+           "ms": round(gpu_dt * 1e3, 3), "kept": kept, "matches_cpu_indices": bool(same),
+           "cpu_boxes_per_s": round(n / cpu_dt, 1), "cpu_kind": "port (oracle/nms_ref.c, 1 thread)"}
+    # anchor decode (C5 i): both heads of 55 images at 352x352 = 99,825 candidates, confidence threshold low enough that ~all pass
+    from mobilenet_yolo_pytorch_amd import synthetic
+    y = synthetic.VOC_CONFIG["yolo"]
+    N, nc = 55, y["num_classes"]
+    anchors = torch.tensor([(aw / SIZE, ah / SIZE) for aw, ah in y["anchors"]], dtype=torch.float32, device=device)
+    g = torch.Generator().manual_seed(4)
+    heads, hps, masks = [], [], []
+    for hi, grid in enumerate((SIZE // 32, SIZE // 16)):
+        heads.append(torch.randn(N, grid, grid, len(y["mask"][hi]) * (5 + nc), generator=g).to(device))
+        hps.append(ops.make_head(N, grid, len(y["mask"][hi]), nc, len(y["anchors"]), 0.5, 0.213, 0.01))
+        masks.append(torch.tensor(y["mask"][hi], dtype=torch.int32, device=device))
+    cap = sum(hp.A * hp.g * hp.g for hp in hps)
+    rows_d = torch.zeros(N, cap, 7, device=device)
+
+    def decode():
+        _, c0 = ops.yolo_decode(heads[0], anchors, masks[0], hps[0], 1e-6, rows=rows_d, row_stride=cap)
+        _, c1 = ops.yolo_decode(heads[1], anchors, masks[1], hps[1], 1e-6, rows=rows_d, row_stride=cap, base_counts=c0)
+        return c1
+    c1 = decode()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        c1 = decode()
+    torch.cuda.synchronize()
+    dd = (time.perf_counter() - t0) / 10
+    res["decode"] = {"workload": "anchor decode + confidence compaction, 2 heads x 55 images @352 (%d candidates)" % (N * cap),
+                     "candidates_per_s": round(N * cap / dd, 1), "ms": round(dd * 1e3, 3), "passed": int(c1.sum().item())}
+    return res
 
 
 def roofline_from(events, calls_by_list):
