@@ -269,6 +269,7 @@ def main():
         import torch.distributed as dist
         if os.environ.get("NCCL_DEBUG", "").upper() in ("", "VERSION"):
             os.environ["NCCL_DEBUG"] = "WARN"            # keep RCCL's version banner off stdout: rank 0 prints ONE JSON line
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")   # ... and whatever RCCL still warns about goes to stderr
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29517", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=device)
