@@ -392,7 +392,7 @@ __global__ __launch_bounds__(1024) void nms_bucket_kernel(const float* __restric
     extern __shared__ __attribute__((aligned(16))) unsigned char nms_smem[];
     unsigned long long* keys = (unsigned long long*)nms_smem;           // [cap2] (score key << 32 | position)
     __shared__ int32_t s_wsum[2][16];
-    __shared__ int32_t s_n, s_lower, s_next, s_kept;
+    __shared__ int32_t s_n, s_lower, s_kept;
     const int BT = blockDim.x, NWV = BT >> 6;
     const int s = blockIdx.x, c = blockIdx.y;
     const int r0 = seg_begin[s], r1 = r0 + seg_count[s];

@@ -1629,11 +1629,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     // (2.5 TB/s).  It is therefore fetched ONE STEP AHEAD, before that step's DMA batch is issued: by the time it is consumed
     // the counted wait at the top of the next iteration has already covered it and the ring stays two stages deep.
     // (Staging the words through the DMA ring instead was measured slower: 2.13 vs 1.74 ms on the 16->96 unit.)
-    auto load_mask = [&](int mt, int kt) -> unsigned long long {            // branch-free: clamped, the (X, Q) step ignores it
-        const int64_t row = min((int64_t)mt * BMS + wm * 32 + lrow, p.M - 1);
-        const int kc = min(kt, nkg - 1);
-        return p.mask[(int64_t)kc * p.npairs + (row >> 1)] >> ((row & 1) * 32);
-    };
     auto compute = [&](int mt, int kt, int slot, unsigned long long mw) {
         const float* st = smem + slot * STAGE;
         const float* a_row = st + (wm * 32 + lrow) * BKD;
