@@ -1,0 +1,96 @@
+"""MI355X: seeded shape fuzzing of the pipelined kernels (LDS-DMA rings with counted waits, raw LDS reads, asm prefetches):
+ragged M / K / N tails, tiny problems, tile-boundary sizes.  fp32 against torch (float64 accumulation), 2e-4 relative."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    from mobilenet_yolo_pytorch_amd import ops as o
+    return o
+
+
+def _close(got, ref, rel=2e-4, what=""):
+    got, ref = got.detach().double().cpu(), ref.detach().double().cpu()
+    scale = ref.abs().max().item() + 1e-12
+    err = (got - ref).abs().max().item()
+    assert err <= rel * scale, "%s: err %.3e vs scale %.3e" % (what, err, scale)
+
+
+ACT = {0: lambda z: z, 1: lambda z: torch.clamp(z, 0, 6), 2: lambda z: F.leaky_relu(z, 0.1), 3: torch.relu}
+
+
+def test_pointwise_gemm_shapes(ops):
+    r = np.random.RandomState(0)
+    ks = [4, 8, 12, 16, 20, 24, 32, 36, 48, 64, 100, 160, 516]           # K % 4 == 0: DMA kernel, incl. ragged K % 16
+    ns = [1, 3, 4, 10, 16, 31, 32, 33, 75, 96, 100, 128, 144, 160, 161, 320, 512]
+    ms = [1, 5, 63, 64, 127, 128, 129, 255, 300, 1000, 4097]
+    for trial in range(40):
+        M, K, N = int(r.choice(ms)), int(r.choice(ks)), int(r.choice(ns))
+        act = int(r.randint(0, 4))
+        g = torch.Generator().manual_seed(trial)
+        x = torch.randn(M, K, generator=g)
+        w = torch.randn(N, K, generator=g) * K ** -0.5
+        sc, sh = 1 + 0.2 * torch.randn(K, generator=g), 0.3 * torch.randn(K, generator=g)
+        a = ACT[act](x * sc + sh)
+        xs = x.view(1, 1, M, K).cuda()
+        use_bias = N % 4 != 0 or trial % 3 == 0
+        b = torch.randn(N, generator=g) if use_bias else None
+        add = torch.randn(M, N, generator=g) if (trial % 2 and use_bias) else None   # (statistics are of conv outputs: never with an addend)
+        got, st = ops.pw_fwd((xs, sc.cuda(), sh.cuda(), act), w.cuda(), bias=b.cuda() if use_bias else None,
+                             addend=add.view(1, 1, M, N).cuda() if add is not None else None, want_stats=not use_bias)
+        ref = a.double() @ w.double().t() + (b.double() if use_bias else 0) + (add.double() if add is not None else 0)
+        _close(got.view(M, N), ref, what="pw_fwd M%d K%d N%d act%d" % (M, K, N, act))
+        if not use_bias:
+            _close(st[:, 0].double().sum(0), ref.sum(0), 3e-4, "stats sum M%d K%d N%d" % (M, K, N))
+            _close(st[:, 1].double().sum(0), (ref ** 2).sum(0), 3e-4, "stats sumsq M%d K%d N%d" % (M, K, N))
+        dy = torch.randn(M, N, generator=g)
+        dw, db = ops.pw_wgrad((xs, sc.cuda(), sh.cuda(), act), dy.view(1, 1, M, N).cuda(), want_dbias=True)
+        _close(dw, dy.double().t() @ a.double(), what="pw_wgrad M%d K%d N%d" % (M, K, N))
+        _close(db, dy.double().sum(0), what="dbias")
+
+
+def test_fused_units_shapes(ops):
+    r = np.random.RandomState(1)
+    import ctypes
+    from mobilenet_yolo_pytorch_amd import _lib
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
+    for trial in range(12):                                              # depthwise 3x3 s1 unit backward
+        N, H, W = int(r.choice([1, 2, 5])), int(r.choice([1, 2, 7, 16, 17, 33])), int(r.choice([1, 3, 8, 19, 40]))
+        C = int(r.choice([4, 8, 36, 96, 132, 516]))
+        act, xact = int(r.randint(0, 4)), int(r.randint(0, 4))
+        g = torch.Generator().manual_seed(100 + trial)
+        x = torch.randn(N, C, H, W, generator=g)
+        w = torch.randn(C, 1, 3, 3, generator=g) * 0.4
+        xs, xh = 1 + 0.2 * torch.randn(C, generator=g), 0.3 * torch.randn(C, generator=g)
+        gamma, beta = 1 + 0.3 * torch.randn(C, generator=g), 0.2 * torch.randn(C, generator=g)
+        a_in = ACT[xact](x * xs.view(1, -1, 1, 1) + xh.view(1, -1, 1, 1)).detach().requires_grad_(True)
+        wr, gr, br = w.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        y_raw = F.conv2d(a_in, wr, None, 1, 1, 1, C)
+        if N * H * W < 2:
+            continue                                                      # BatchNorm needs more than one value per channel
+        out = ACT[act](F.batch_norm(y_raw, None, None, gr, br, True, 0.1, 1e-5))
+        gg = torch.randn(*out.shape, generator=g)
+        out.backward(gg)
+        nh = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()        # noqa: E731
+        yd, gd, xd = nh(y_raw.detach()), nh(gg), nh(x)
+        M = N * H * W
+        y32 = yd.view(M, C)
+        st = torch.stack((y32.sum(0), (y32 ** 2).sum(0))).view(1, 2, C).contiguous()
+        scale, shift, mean, invstd = ops.bn_finalize(st, M, gamma.cuda(), beta.cuda())
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        parts = _lib.query("mny_bn_bwd_parts", M, C)
+        red = torch.empty(parts, 2, C, device="cuda")
+        gam_d = gamma.cuda()
+        _lib.call("mny_bn_bwd_reduce", p(gd), p(yd), p(scale), p(shift), act, p(mean), p(invstd), p(red), M, C, stream)
+        dgamma, dbeta, coef = torch.empty(C, device="cuda"), torch.empty(C, device="cuda"), torch.empty(3, C, device="cuda")
+        _lib.call("mny_bn_bwd_finalize", p(red), parts, M, p(gam_d), p(mean), p(invstd), p(dgamma), p(dbeta), p(coef), C, stream)
+        dx, dw = ops.dw_bnbwd(gd, yd, scale, shift, act, coef, (xd, xs.cuda(), xh.cuda(), xact), w.cuda().contiguous())
+        what = "dw_bnbwd N%d H%d W%d C%d act%d/%d" % (N, H, W, C, act, xact)
+        _close(dx.permute(0, 3, 1, 2), a_in.grad, 1e-3, what + " dX")    # train-mode BN on few samples amplifies rounding
+        _close(dw, wr.grad, 1e-3, what + " dW")

@@ -196,7 +196,10 @@ def test_glue(ops):
 
 
 @pytest.mark.parametrize("M,K,Nc,act,xact", [(8192, 16, 96, 1, 0), (5000, 24, 144, 1, 0), (4100, 32, 192, 2, 1), (6000, 16, 64, 0, 1),
-                                             (4096, 32, 160, 3, 3)])
+                                             (4096, 32, 160, 3, 3),
+                                             # tile-boundary / ragged shapes of the pipelined stages
+                                             (4097, 4, 8, 1, 1), (4159, 20, 100, 2, 0), (5001, 32, 36, 1, 2), (4100, 8, 192, 3, 1),
+                                             (6007, 12, 132, 1, 3), (4223, 28, 32, 0, 0), (70001, 16, 96, 1, 1)])
 def test_fused_bn_backward_expand_unit(ops, M, K, Nc, act, xact):
     """dW, dgamma, dbeta, dX of conv1x1 -> BN(train) -> act from (G, Y, X) in 4 passes (no dY), vs torch autograd.
     Tolerance 5e-4 relative to the tensor max: the decomposition sums large terms that partly cancel."""
