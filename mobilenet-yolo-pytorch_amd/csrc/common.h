@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/mnyolo.h"
 
@@ -112,6 +113,24 @@ inline CgLayout make_cg_layout(int C) {
     return L;
 }
 
+
+// Stencil kernels (a thread = 4 channels x one column) re-read one halo column on each side of a block's column span, and
+// neighbouring blocks sit on different XCDs / L2s: with <= 2 columns per block (C >= 512) the depthwise kernels fetched 2-2.7x
+// their input.  Channels are independent, so wide layers are split into channel chunks of <= `max_cgb` groups (grid.y) and a
+// block spans >= 256/max_cgb columns: halo ratio (ppb + 2) / ppb.  Measured (same box, ms/step dw_bnbwd + dw_fwd + s2 kernels):
+// 256: 13.0, 64: 12.1, 32: 12.8, 16: 13.3 -> 64 (narrower chunks lose more in per-pixel contiguity than they save in halo).
+// MNY_STENCIL_CGB overrides max_cgb (profiling).
+inline CgLayout make_stencil_layout(int C, int max_cgb = 64) {
+    static const int env = getenv("MNY_STENCIL_CGB") ? atoi(getenv("MNY_STENCIL_CGB")) : 0;
+    if (env > 0) max_cgb = env;
+    CgLayout L;
+    L.cg_total = C / 4;
+    L.chunks = (int)cdiv(L.cg_total, max_cgb);
+    L.cgb = (int)cdiv(L.cg_total, L.chunks);
+    L.ppb = 256 / L.cgb; if (L.ppb < 1) L.ppb = 1;
+    L.threads = L.cgb * L.ppb;
+    return L;
+}
 
 // partial rows [parts][n] -> out[n]: 32 outputs x 8 part-slices per block, fp64 combine, fixed order
 __global__ void reduce_parts_f64_kernel(const float* __restrict__ parts, int nparts, int n, float* __restrict__ out);

@@ -176,11 +176,7 @@ static int dwb_geom(DwbGeom& g, CgLayout& L, int& gx, int N, int H, int W, int C
     g.TH = (int)cdiv(H, ns);
     g.nHS = (int)cdiv(H, g.TH);
     g.nstrips = (int64_t)N * W * g.nHS;
-    L.cg_total = C / 4;                                   // channel groups per block capped at 128: <= 32 KB of LDS constants
-    L.chunks = (int)cdiv(L.cg_total, 128);
-    L.cgb = (int)cdiv(L.cg_total, L.chunks);
-    L.ppb = 256 / L.cgb; if (L.ppb < 1) L.ppb = 1;
-    L.threads = L.cgb * L.ppb;
+    L = make_stencil_layout(C);                            // <= 64 channel groups per block: >= 4 columns, <= 16 KB of LDS constants
     g.cg_total = L.cg_total; g.cgb = L.cgb;
     int64_t want = cdiv(g.nstrips, L.ppb);
     const int cap = 768 / L.chunks > 0 ? 768 / L.chunks : 1;   // 3 resident workgroups per CU (<= 168 VGPRs): one full wave of blocks

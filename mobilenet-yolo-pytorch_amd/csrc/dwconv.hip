@@ -275,10 +275,11 @@ static int dw_geom(DwGeom& g, CgLayout& L, int& gx, int N, int H, int W, int C, 
     g.TH = (int)cdiv(g.Ho, ns);
     g.nHS = (int)cdiv(g.Ho, g.TH);
     g.nstrips = (int64_t)N * g.Wo * g.nHS;
-    L = make_cg_layout(C);
+    L = make_stencil_layout(C);
     g.cg_total = L.cg_total; g.cgb = L.cgb;
     int64_t want = cdiv(g.nstrips, L.ppb);
-    gx = (int)(want < kMaxParts ? want : kMaxParts);
+    const int cap = kMaxParts / L.chunks > 0 ? kMaxParts / L.chunks : 1;      // gx * chunks workgroups = 4 per CU
+    gx = (int)(want < cap ? want : cap);
     return MNY_OK;
 }
 
@@ -339,7 +340,7 @@ static int dw_bwd_data_impl(const T* dy, const float* w, const T* addend, T* dx,
     MNY_REQUIRE(stride == 2 && (K == 3 || K == 5) && C % 4 == 0, "dw_bwd_data: unsupported K=%d stride=%d C=%d", K, stride, C);
     const int P = K / 2;
     const int Ho = (H + 2 * P - K) / 2 + 1, Wo = (W + 2 * P - K) / 2 + 1;
-    CgLayout L = make_cg_layout(C);
+    CgLayout L = make_stencil_layout(C);
     int64_t want = cdiv((int64_t)N * H * W, L.ppb);
     dim3 grid((unsigned)(want < 8192 ? want : 8192), L.chunks), block(L.threads);
     if (K == 3) {
