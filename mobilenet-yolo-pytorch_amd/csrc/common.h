@@ -94,6 +94,35 @@ __device__ __forceinline__ void fma4(float4& acc, float4 a, float4 b) {
 }
 __device__ __forceinline__ void add4(float4& acc, float4 a) { acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w; }
 
+// ---- LDS reads the compiler cannot see ------------------------------------------------------------------------------
+// hipcc treats every LDS read after a `global_load_lds` as possibly aliasing the DMA's LDS write and puts `s_waitcnt vmcnt(0)`
+// in front of it (SIInsertWaitcnts; no alias-scope information survives from HIP source).  In a multi-stage ring that wait
+// sits right after the NEXT stages have been issued, i.e. it drains the whole queue every k-step and the ring degenerates to
+// "issue, wait for everything, compute".  The fragment reads of the pipelined loops are therefore raw `ds_read_b128`
+// (volatile inline asm) followed by an explicit `s_waitcnt lgkmcnt(0)` that carries the destination registers as in/out
+// operands, so every use is ordered after the wait; the counted `s_waitcnt vmcnt(N)` + `s_barrier` at the top of the loop
+// are what guarantee that the stage being read has landed.
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned lds_off(const void* p) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+__device__ __forceinline__ v4f_t lds_read_f4(const float* p) {
+    v4f_t v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(lds_off(p)) : "memory");
+    return v;
+}
+__device__ __forceinline__ v4u_t lds_read_u4(const float* p) {
+    v4u_t v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(lds_off(p)) : "memory");
+    return v;
+}
+#define MNY_LGKM_WAIT(first) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(first))
+#define MNY_LGKM_DEP(x) asm volatile("" : "+v"(x))
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 // Channel-group thread layout shared by the NHWC stencil / elementwise kernels:
 // a thread owns 4 consecutive channels; `cgb` channel groups per block (<=256), `ppb` pixels per block.
 struct CgLayout {
@@ -131,6 +160,12 @@ inline CgLayout make_stencil_layout(int C, int max_cgb = 64) {
     L.threads = L.cgb * L.ppb;
     return L;
 }
+
+// LDS-DMA staged depthwise forward (dwstage.hip): eligibility, partial-row count and launch
+bool dws_supported(int N, int H, int W, int C, int K, int stride);
+int dws_parts(int N, int H, int W, int C, int stride);
+int dws_launch(const float* x, const float* sc, const float* sh, int act, const float* w, float* y, float* parts, int N, int H, int W,
+               int C, int stride, hipStream_t st);
 
 // partial rows [parts][n] -> out[n]: 32 outputs x 8 part-slices per block, fp64 combine, fixed order
 __global__ void reduce_parts_f64_kernel(const float* __restrict__ parts, int nparts, int n, float* __restrict__ out);

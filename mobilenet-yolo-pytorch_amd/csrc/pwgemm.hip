@@ -244,35 +244,6 @@ __global__ __launch_bounds__(256) void pw_gemm_nt_kernel(GemmArgs p) {
 // Out-of-range rows are clamped to a valid row (their outputs are never stored); k-chunks past K re-read the
 // row start and are annihilated by zeroed B fragments (and zero scale/shift).
 // ------------------------------------------------------------------------------------------------
-// ---- LDS reads the compiler cannot see ------------------------------------------------------------------------------
-// hipcc treats every LDS read after a `global_load_lds` as possibly aliasing the DMA's LDS write and puts `s_waitcnt vmcnt(0)`
-// in front of it (SIInsertWaitcnts; no alias-scope information survives from HIP source).  In a multi-stage ring that wait
-// sits right after the NEXT stages have been issued, i.e. it drains the whole queue every k-step and the ring degenerates to
-// "issue, wait for everything, compute".  The fragment reads of the pipelined loops are therefore raw `ds_read_b128`
-// (volatile inline asm) followed by an explicit `s_waitcnt lgkmcnt(0)` that carries the destination registers as in/out
-// operands, so every use is ordered after the wait; the counted `s_waitcnt vmcnt(N)` + `s_barrier` at the top of the loop
-// are what guarantee that the stage being read has landed.
-typedef float v4f_t __attribute__((ext_vector_type(4)));
-typedef unsigned v4u_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ unsigned lds_off(const void* p) {
-    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
-}
-__device__ __forceinline__ v4f_t lds_read_f4(const float* p) {
-    v4f_t v;
-    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(lds_off(p)) : "memory");
-    return v;
-}
-__device__ __forceinline__ v4u_t lds_read_u4(const float* p) {
-    v4u_t v;
-    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(lds_off(p)) : "memory");
-    return v;
-}
-#define MNY_LGKM_WAIT(first) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(first))
-#define MNY_LGKM_DEP(x) asm volatile("" : "+v"(x))
-
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
 __device__ const float4 mny_zero16 = {0.f, 0.f, 0.f, 0.f};   // DMA source for B chunks past K
 
 struct Gemm2Args {   // A / B / addend / C: float* (BF = 0) or bf16_t* (BF = 1)

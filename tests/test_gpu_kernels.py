@@ -287,3 +287,20 @@ def test_fused_dw_unit_backward(ops, N, H, W, C, act, xact, dtype):
     check(dw, wr.grad, tol_w, tol_w * wr.grad.abs().max().item(), "fused dw: dW")
     check(dgamma, gr.grad, 5e-4, 5e-4 * max(1.0, gr.grad.abs().max().item()), "dgamma")
     check(dbeta, br.grad, 5e-4, 5e-4 * max(1.0, br.grad.abs().max().item()), "dbeta")
+
+
+@pytest.mark.parametrize("N,H,W,C,s,act", [(1, 44, 44, 192, 2, 0), (2, 22, 22, 96, 2, 1), (1, 44, 44, 384, 1, 1), (4, 88, 88, 144, 2, 1),
+                                           (2, 11, 11, 960, 1, 1), (3, 33, 17, 32, 1, 2), (1, 7, 50, 200, 2, 0)])
+def test_dw_forward_lds_staged_variant(ops, N, H, W, C, s, act, monkeypatch):
+    """The opt-in LDS-DMA staged depthwise forward (MNY_DW_STAGED=1): same outputs and BN partial sums as torch, 1e-4."""
+    monkeypatch.setenv("MNY_DW_STAGED", "1")
+    x = rnd(N, C, H, W, seed=1)
+    w = rnd(C, 1, 3, 3, seed=2, scale=0.4)
+    sc, sh = 1 + 0.2 * rnd(C, seed=3), 0.3 * rnd(C, seed=4)
+    y = F.conv2d(view_ref(x, sc, sh, act), w, None, s, 1, 1, C)
+    got, st = ops.dw_fwd((nhwc(x), sc.cuda(), sh.cuda(), act), w.cuda().contiguous(), s)
+    check(nchw(got), y, 1e-4, 1e-5, "staged dw fwd")
+    s1, s2 = stats_got(st)
+    r1, r2 = stats_ref(y)
+    check(s1, r1, 1e-4, 1e-3, "staged dw stats sum")
+    check(s2, r2, 1e-4, 1e-3, "staged dw stats sumsq")
