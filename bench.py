@@ -358,10 +358,18 @@ def main():
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
         roof = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                "algorithmic_bytes_per_launch": round(d["bytes"] / max(d["n"], 1)),
                 "launches_per_step": d["n"] // a.steps, "measured": ("HIP events inside the timed steps" if inline else
                 "HIP events over %d further steps run right after the timed (hipGraph-replayed) steps" % a.steps), "ms_per_step": round(d["ms"] / a.steps, 3),
                 "algorithmic_gflop_per_step": round(d["flops"] / a.steps / 1e9, 2),
                 "algorithmic_hbm_gbs": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1)}
+        # HBM bytes per launch of the dominant entry point from the PMC counters: bench.py cannot run rocprofv3 on itself, so this is
+        # the committed result of the prescribed separate --pmc passes over this very command (profiles/README.md), headline config only
+        side = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01c_traffic_mny_pw_fwd.json")
+        if (a.arch, a.size, a.batch, a.dtype, world) == ("mbv2", SIZE, BATCH, "f32", 1) and dom == "mny_pw_fwd" and os.path.exists(side):
+            tj = json.load(open(side))
+            roof["traffic"] = round(tj["hbm_bytes_per_launch"])
+            roof["traffic_source"] = "profiles/r01c_traffic_mny_pw_fwd.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + --pmc WRITE_SIZE, separate passes"
         res = {
             "metric": "images/sec MobileNetV2-YOLO 352x352 fwd+bwd @ bs256" if (a.arch, a.size, a.batch, a.dtype) == ("mbv2", SIZE, BATCH, "f32")
             else "images/sec %s-YOLO %dx%d fwd+bwd @ bs%d (NOT the headline config)" % (a.arch, a.size, a.size, a.batch), "value": round(world * a.batch * a.steps / dt, 2),
