@@ -242,6 +242,32 @@ typedef struct mny_adamw_chunk {
 int mny_adamw_step(const mny_adamw_chunk* table_dev, int nchunks, double lr, double beta1, double beta2, double eps,
                    double weight_decay, int64_t step, void* stream);
 
+/* ---- evaluation consumer: VOC07 11-point mAP on the device -----------------------------
+ * Replaces utils/eval_mAP.py:134-187 (calculate_mAP), :69-132 (eval_class_ap), :8-65
+ * (eval_single_image_recall) and utils/iou.py:4-48 (find_jaccard_overlap) on a PACKED layout: the
+ * reference's per-image tensor lists laid back to back, image i = [off[i], off[i+1]).
+ * n_classes counts the background entry (train.py:58); classes 1..n_classes-1 are evaluated, labels are
+ * float like the reference's tensors (a label that is not an integer in that range is never evaluated).
+ * Semantics kept: within an image detections are matched in STORED order; best ground truth = first
+ * maximum of the fp32 IoU (NaN -> false positive); IoU > 0.5; a hit on a `difficult` (true_diff != 0)
+ * object counts as neither; a second hit on an object is a false positive.  Score ties in the global sort
+ * keep (image, stored) order (torch.sort leaves them unspecified).
+ * Outputs (device): ap[n_classes-1], tp_sum / fp_sum [n_classes-1] (exact counts as float),
+ * prec11 [(n_classes-1)*11] (the 11 interpolated precisions), mean_ap[1].
+ * Limits: n_classes <= 255, D <= 2^30.  ws: mny_map_ws_bytes(D, T) bytes.  No host sync. */
+size_t mny_map_ws_bytes(int64_t D, int64_t T);
+int mny_map_eval(const float* det_boxes /*[D,4]*/, const float* det_labels, const float* det_scores,
+                 const int32_t* det_off /*[n_images+1]*/, const float* true_boxes /*[T,4]*/,
+                 const float* true_labels, const float* true_diff, const int32_t* true_off, int n_images,
+                 int64_t D, int64_t T, int n_classes, float* ap, float* tp_sum, float* fp_sum, float* prec11,
+                 float* mean_ap, void* ws, void* stream);
+/* train.py:371-385 (the glue of test() between the detector and calculate_mAP): detection rows
+ * [D,7] (x1,y1,x2,y2,obj,cls_conf,cls) -> boxes, label = cls+1, score = obj*cls_conf; targets [T,5]
+ * (cls,cx,cy,w,h) -> corner boxes, label = cls as stored, difficulty 0.  Either half may be empty. */
+int mny_eval_pack(const float* rows, int64_t D, const float* targets, int64_t T, float* det_boxes,
+                  float* det_labels, float* det_scores, float* true_boxes, float* true_labels,
+                  float* true_diff, void* stream);
+
 /* ---- bf16 STORAGE twins (BASELINE config 4: MobileNetV3-YOLO 512x512 bf16) -----------------
  * Every `mny_X_bf16` has the contract of `mny_X` above with ONE difference: the activation-sized tensors (the
  * `void*` parameters: raw conv outputs, materialised sums, gradients wrt activations) are bf16 in HBM.  Kernels

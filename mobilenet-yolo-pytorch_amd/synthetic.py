@@ -35,3 +35,43 @@ def targets(n, num_classes=20, boxes_per_image=3, seed=1, empty_every=16):
         wh = (0.05 + 0.5 * r.rand(boxes_per_image, 2)).astype(np.float32)
         out.append(torch.from_numpy(np.concatenate((lab, cxy, wh), 1)))
     return out
+
+
+def map_case(n_images, n_classes, seed=0, mean_gt=2.5, crafted=False, no_detections=False, det_per_gt=1.6, clutter=6.0):
+    """Evaluation-set shaped input of the mAP stage (packed, float32): per image ~Poisson(mean_gt) ground-truth boxes
+    (10 % difficult), detections = jittered copies of ground truth (some twice: the duplicate-hit case, some with the
+    wrong label) + low-score clutter, stored per image in per-class, score-descending order like the NMS stage emits
+    them (every 5th image shuffled: matching follows stored order).  n_classes counts the background entry.
+    -> det_boxes [D,4], det_labels [D], det_scores [D], det_off [n+1], true_boxes [T,4], true_labels [T], true_diff [T], true_off [n+1]"""
+    r = np.random.RandomState(seed)
+    f = np.float32
+    db, dl, ds, do, tb, tl, td, to = [], [], [], [0], [], [], [], [0]
+    for i in range(n_images):
+        k = 0 if (crafted and i == 2) else r.poisson(mean_gt)
+        cxy, wh = 0.1 + 0.8 * r.rand(k, 2), 0.05 + 0.4 * r.rand(k, 2)
+        gtb = np.concatenate((cxy - wh / 2, cxy + wh / 2), 1).astype(f)
+        gtl = r.randint(1, n_classes, size=k).astype(f)
+        gtd = (r.rand(k) < 0.1).astype(f)
+        if crafted and i == 0 and k >= 2:                       # two objects of one class on top of each other (first-max tie-break)
+            gtb[1], gtl[1] = gtb[0], gtl[0]
+        boxes, labels, scores = [], [], []
+        for j in range(k):
+            for _ in range(r.poisson(det_per_gt)):
+                jit = r.randn(4) * 0.03 * (1 + 3 * (r.rand() < 0.25))
+                boxes.append(gtb[j] + jit.astype(f))
+                labels.append(gtl[j] if r.rand() > 0.1 else f(r.randint(1, n_classes)))
+                scores.append(0.3 + 0.7 * r.rand())
+        for _ in range(r.poisson(clutter)):
+            c, s = 0.1 + 0.8 * r.rand(2), 0.05 + 0.4 * r.rand(2)
+            boxes.append(np.concatenate((c - s / 2, c + s / 2)).astype(f))
+            labels.append(f(r.randint(1, n_classes)))
+            scores.append(0.02 + 0.4 * r.rand())
+        if no_detections or (crafted and i == 4):
+            boxes, labels, scores = [], [], []
+        b, l, s = np.array(boxes, f).reshape(-1, 4), np.array(labels, f), np.array(scores, f)
+        order = np.lexsort((-s, l)) if i % 5 != 3 else r.permutation(len(s))
+        db.append(b[order]); dl.append(l[order]); ds.append(s[order]); do.append(do[-1] + len(s))
+        tb.append(gtb); tl.append(gtl); td.append(gtd); to.append(to[-1] + k)
+    cat = lambda xs, shape: np.concatenate(xs).astype(f) if xs else np.zeros(shape, f)
+    return (cat(db, (0, 4)).reshape(-1, 4), cat(dl, (0,)), cat(ds, (0,)), np.array(do, np.int32),
+            cat(tb, (0, 4)).reshape(-1, 4), cat(tl, (0,)), cat(td, (0,)), np.array(to, np.int32))
