@@ -237,6 +237,35 @@ def nms_bench(device):
     return res
 
 
+def map_bench(device):
+    """VOC07-test shaped evaluation set (4 952 images, 20 classes + background) scored on the device;
+    CPU baseline = the oracle port of utils/eval_mAP.py on a bounded sample of the same set."""
+    import numpy as np
+    from mobilenet_yolo_pytorch_amd import evalmap, synthetic
+    from oracle import map_ref
+    nc, n_img = 21, 4952
+    case = synthetic.map_case(n_img, nc, seed=9, clutter=30.0)
+    dev = [torch.from_numpy(np.ascontiguousarray(a)).to(device) for a in case]
+    r = evalmap.map_eval(*dev, nc)
+    torch.cuda.synchronize()
+    reps = 10
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        r = evalmap.map_eval(*dev, nc)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    D = int(case[1].size)
+    t0 = time.perf_counter()
+    ap_o, m_o, tp_o, fp_o, p11_o = map_ref.calculate_map(*case, nc)             # the whole set: ~1.5 s of numpy
+    cpu_dt = time.perf_counter() - t0
+    same = bool(np.array_equal(r["tp"].cpu().numpy(), tp_o) and np.array_equal(r["fp"].cpu().numpy(), fp_o)
+                and np.array_equal(r["prec11"].cpu().numpy(), p11_o) and abs(float(r["mean_ap"]) - float(m_o)) < 1e-6)
+    return {"workload": "VOC07 11-point mAP, %d images, %d detections, %d objects, 20 classes" % (n_img, D, int(case[5].size)),
+            "detections_per_s": round(D / dt, 1), "ms": round(dt * 1e3, 3), "mean_ap": round(float(r["mean_ap"]), 6),
+            "matches_cpu_port": same, "cpu_detections_per_s": round(D / cpu_dt, 1),
+            "cpu_kind": "port (oracle/map_ref.py, numpy, 1 thread, same set; the reference's own torch loop ran 17 k detections/s in the build container)"}
+
+
 def roofline_from(events, calls_by_list):
     """Aggregate HIP-event durations per entry point; pick the dominant one."""
     agg = {}
@@ -388,6 +417,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline()
         if world == 1 and not a.no_nms:
             res["nms"] = nms_bench(device)
+            res["map"] = map_bench(device)
             res["optimizer"] = optimizer_bench(model)
             res["pcie_inclusive"] = h2d_bench(step, x)
         print(json.dumps(res))

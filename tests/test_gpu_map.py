@@ -176,3 +176,34 @@ def test_evaluator_from_detector_rows(em):
     assert abs(m - float(m_o)) < 1e-6
     assert ev.gt_box == to[-1] and ev.pred_box == do[-1]
     assert em.adjust_confidence(10, 31, .1) == pytest.approx(.11)
+
+
+def test_detector_to_map_end_to_end(em):
+    """The evaluation loop of train.py:359-421 on the device: eval-mode forward -> decode -> NMS -> Evaluator, scored
+    against the oracle fed with the very detections the GPU produced (so the check is the mAP stage, not the network)."""
+    from mobilenet_yolo_pytorch_amd import synthetic, yolo
+    from oracle import procedural
+    torch.manual_seed(0)
+    m = yolo(procedural.VOC_CONFIG)
+    procedural.fill_state_dict_(m)
+    m = m.cuda().eval()
+    for hs in m.yolo_losses:
+        hs.val_conf = 0.3
+    names = ["background"] + ["c%d" % i for i in range(1, 21)]
+    ev = em.Evaluator(names)
+    rows_all, tg_all, do, to = [], [], [0], [0]
+    for b in range(2):
+        x = procedural.images(4, 96, 96, seed=30 + b).cuda()
+        tg = synthetic.targets(4, seed=40 + b, empty_every=3)
+        det = m(x)
+        ev.add(det, tg)
+        for d, t in zip(det, tg):
+            rows_all.append(d.cpu().numpy().reshape(-1, 7)); tg_all.append(t.numpy().reshape(-1, 5))
+            do.append(do[-1] + len(rows_all[-1])); to.append(to[-1] + len(tg_all[-1]))
+    assert do[-1] > 20
+    aps, mAP, tp, fp = ev.compute()
+    db, dl, ds, tb, tl, td = map_ref.eval_pack(np.concatenate(rows_all), np.concatenate(tg_all))
+    ap_o, m_o, tp_o, fp_o, _ = map_ref.calculate_map(db, dl, ds, np.array(do, np.int32), tb, tl, td, np.array(to, np.int32), 21)
+    assert list(tp.values()) == tp_o.tolist() and list(fp.values()) == fp_o.tolist()
+    np.testing.assert_allclose(list(aps.values()), ap_o, atol=1e-6)
+    assert abs(mAP - float(m_o)) < 1e-6 and sum(fp.values()) > 0
