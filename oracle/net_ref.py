@@ -14,6 +14,7 @@ import torch.nn.functional as F
 
 from . import yolo_ref
 from . import nms_ref
+from . import seg_ref
 
 
 def _cbr6(cin, cout, k, stride, groups=1):
@@ -111,8 +112,8 @@ class Residual(nn.Module):                                          # mbv2_yolo.
 
 class RefYolo(nn.Module):
     """mbv2_yolo.py:105-173.  Same constructor config, forward contract and keys;
-    never downloads weights (Q11).  Seg *loss* (models/seg_loss.py) is out of scope:
-    a config with a ``seg`` key builds ``seg_headS16`` for key parity only."""
+    never downloads weights (Q11).  A config with a ``seg`` key adds ``seg_headS16`` and the
+    segmentation loss (oracle/seg_ref.py) exactly as :110-114,161-171 do."""
 
     def __init__(self, config):
         super().__init__()
@@ -141,14 +142,22 @@ class RefYolo(nn.Module):
         up = F.interpolate(s32, scale_factor=2, mode="nearest")
         s16 = torch.add(self.connect_for_S16(self.conv_for_S16(f1)), up)
         out1 = self.yolo_headS16(s16)
-        self.seg_connect_for_S16(self.seg_conv_for_S16(f1))         # always executed (Q10)
+        self.seg_branch = self.seg_connect_for_S16(self.seg_conv_for_S16(f1))         # always executed (Q10)
         return out0, out1
 
     def forward(self, x, targets=None, seg_maps=None):
         self.img_size = [x.size(2), x.size(3)]                      # :139-140 (Q8)
         out0, out1 = self.heads(x)
         if targets is not None:
-            return tuple(yolo_ref.loss_forward(o, targets, s, self.img_size)
-                         for o, s in zip((out0, out1), self.specs))
+            output = tuple(yolo_ref.loss_forward(o, targets, s, self.img_size)
+                           for o, s in zip((out0, out1), self.specs))
+            if self.has_seg:                                        # :167-170
+                self.out2 = self.seg_headS16(self.seg_branch)
+                return output, seg_ref.seg_loss(self.out2, seg_maps)
+            return output
         rows = tuple(yolo_ref.decode_rows(o, s, self.img_size) for o, s in zip((out0, out1), self.specs))
-        return nms_ref.nms_driver(rows, self.num_classes)
+        output = nms_ref.nms_driver(rows, self.num_classes)
+        if self.has_seg:                                            # :161-164
+            self.out2 = self.seg_headS16(self.seg_branch)
+            return output, seg_ref.seg_eval(self.out2)
+        return output
