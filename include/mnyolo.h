@@ -268,6 +268,19 @@ int mny_eval_pack(const float* rows, int64_t D, const float* targets, int64_t T,
                   float* det_labels, float* det_scores, float* true_boxes, float* true_labels,
                   float* true_diff, void* stream);
 
+/* ---- segmentation head of the BDD100K config ------------------------------------------------
+ * Replaces SegLoss.forward (models/seg_loss.py:51-80) and its autograd on the channels-last seg head
+ * [N,h,w,C] (the reference permutes seg_maps [N,h,w,C] to NCHW instead, :54): n = N*h*w*C elements.
+ * out3 = (0.05 * mean((sigmoid(x)-t)^2), mean sigmoid where t >= 0.5, mean sigmoid where t < 0.5) — an empty
+ * selection gives NaN like torch.mean; dhead = 0.05*2*(sigmoid(x)-t)/n: the reference's custom sigmoid passes the
+ * gradient through unchanged (:24-32).  ws: mny_seg_loss_ws_bytes(n).  Deterministic (fixed-order fp64 sums). */
+size_t mny_seg_loss_ws_bytes(int64_t n);
+int mny_seg_loss(const float* head, const float* seg_maps, int64_t n, float* out3, float* dhead, void* ws,
+                 void* stream);
+/* eval branch (:77-80): sigmoid of image 0 only, written channel-major [C,h,w] like the reference's numpy result */
+int mny_seg_sigmoid(const float* head /*[N,h,w,C], image 0 is read*/, int h, int w, int C, float* out,
+                    void* stream);
+
 /* ---- bf16 STORAGE twins (BASELINE config 4: MobileNetV3-YOLO 512x512 bf16) -----------------
  * Every `mny_X_bf16` has the contract of `mny_X` above with ONE difference: the activation-sized tensors (the
  * `void*` parameters: raw conv outputs, materialised sums, gradients wrt activations) are bf16 in HBM.  Kernels

@@ -33,6 +33,7 @@ class Graph:
         self.modules = []          # (path, kind, args) in forward order
         self.input = self._val("input", 3, 1, name="x")
         self.outputs = []
+        self.seg_out = None        # raw seg head (BDD100K config), a third loss input
 
     def _val(self, kind, C, down, act=ACT_NONE, name=""):
         v = Value(len(self.values), kind, C, down, act, name=name)
@@ -152,9 +153,7 @@ def mbv2_yolo_graph(num_classes, num_anchors, seg_classes=None):
     out1 = _head(g, s16, "yolo_headS16", 512, out_ch)                                                 # :153
     seg = _dw_pw_pw(g, f1, "seg_conv_for_S16", 32)                                                    # :155 (always runs, Q10)
     seg = _connect(g, seg, "seg_connect_for_S16")                                                     # :156
-    if seg_classes is not None:
-        # parameters exist for state_dict parity (mbv2_yolo.py:113); the seg loss itself is out of scope
-        _head(g, seg, "seg_headS16", 32, seg_classes)
+    g.seg_out = _head(g, seg, "seg_headS16", 32, seg_classes) if seg_classes is not None else None   # :113,162,168
     g.outputs = [out0, out1]
     g.modules.sort(key=lambda m: TOP_ORDER.index(m[0].split(".")[0]))   # stable: forward order inside a child
     return g

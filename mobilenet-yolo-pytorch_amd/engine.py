@@ -218,6 +218,8 @@ class NetPlan:
                 raise AssertionError(nd.op)
 
         self.heads = [self.head32.get(o.id, self.reals[o.id]) for o in g.outputs]
+        self.seg_head = self.head32.get(g.seg_out.id, self.reals[g.seg_out.id]) if g.seg_out is not None else None
+        self.loss_outputs = list(g.outputs) + ([g.seg_out] if g.seg_out is not None else [])     # values a loss reads
         self._build_detection()
         if training:
             self._build_backward()
@@ -249,6 +251,12 @@ class NetPlan:
                              ctypes.byref(self.hp[hi]), self.out14[hi], self.dheads[hi], ws, self.stream)
             self.t_dev = torch.zeros(max(4 * N, 64), 5, **f32)
             self.off_dev = torch.zeros(N + 1, device=dev, dtype=torch.int32)
+            if self.seg_head is not None:             # mbv2_yolo.py:167-170: SegLoss on the raw seg head
+                self.seg_out3 = torch.zeros(3, **f32)
+                self.seg_maps = torch.zeros_like(self.seg_head)                 # resident copy of the batch's seg_maps [N,h,w,C]
+                self.dheads.append(torch.empty_like(self.seg_head))
+                self.seg_ws = torch.empty(max(_lib.query("mny_seg_loss_ws_bytes", self.seg_head.numel()), 8), device=dev, dtype=torch.uint8)
+                self.fwd.add("mny_seg_loss", self.seg_head, self.seg_maps, self.seg_head.numel(), self.seg_out3, self.dheads[2], self.seg_ws, self.stream)
         else:
             C = net.num_classes
             self.cells = [hp.A * hp.g * hp.g for hp in self.hp]
@@ -271,6 +279,10 @@ class NetPlan:
                          self.out_idx, self.out_counts, self.out_rows, self.nms_ws, self.stream)
             so = _lib.query("mny_nms_status_offset", N, N * self.cap, C)
             self.nms_status = self.nms_ws[so:so + 4].view(torch.int32)
+            if self.seg_head is not None:             # mbv2_yolo.py:161-164 -> seg_loss.py:77-80: sigmoid of image 0, [C,h,w]
+                _, sh, sw, sc = self.seg_head.shape
+                self.seg_eval = torch.zeros(sc, sh, sw, **f32)
+                self.det.add("mny_seg_sigmoid", self.seg_head, sh, sw, sc, self.seg_eval, self.stream)
 
     # ------------------------------------------------------------------------------------------
     def _build_backward(self):
@@ -285,7 +297,8 @@ class NetPlan:
 
         # which nodes lie on a path to a loss
         needed = set()
-        stack = [o for o in g.outputs]
+        outs = self.loss_outputs
+        stack = [o for o in outs]
         while stack:
             v = stack.pop()
             if v.node is None or v.id in needed:
@@ -365,7 +378,7 @@ class NetPlan:
         maxC = max(v.C for v in g.values)
         self.red_ws = torch.empty(2048 * 2 * maxC, **f32)      # >= mny_bn_bwd_parts() rows of [2][C]
         self.coef_ws = torch.empty(3 * maxC, **f32)
-        self.g_scale = torch.ones(2, **f32)           # upstream dL/dloss_i, written by backward()
+        self.g_scale = torch.ones(len(outs), **f32)   # upstream dL/dloss_i, written by backward()
         self.wT = {}
 
         class GS:
@@ -405,7 +418,7 @@ class NetPlan:
                 emit(nb, s.buf)
                 s.buf, s.shared = nb, False
 
-        for hi, o in enumerate(g.outputs):
+        for hi, o in enumerate(outs):
             if o.id in self.head_cp:
                 cp = self.head_cp[o.id]
                 shp = shape(o)
@@ -645,9 +658,15 @@ class NetPlan:
         self.t_ptr.value = self.t_dev.data_ptr()
         self.off_ptr.value = self.off_dev.data_ptr()
 
-    def forward_train(self, x, targets):
+    def forward_train(self, x, targets, seg_maps=None):
         x = self._bind(x)
         self.set_targets(targets)
+        if self.seg_head is not None:
+            if seg_maps is None:
+                raise ValueError("this config has a `seg` section: training needs seg_maps [N,h,w,C] (train.py:257-258)")
+            if tuple(seg_maps.shape) != tuple(self.seg_maps.shape):
+                raise ValueError("seg_maps must be %s (N, H/16, W/16, seg classes), got %s" % (tuple(self.seg_maps.shape), tuple(seg_maps.shape)))
+            self.seg_maps.copy_(seg_maps, non_blocking=True)                    # seg_loss.py:53 (clone().to(device))
         self._replay("fwd", self.fwd)
         self.saved_x = x
         return self.out14
@@ -657,7 +676,7 @@ class NetPlan:
         # event-bracketed runs (bench breakdown) keep everything on one stream so the brackets mean something
         self.stream_side.value = self._side_stream.cuda_stream if (self.side_on and self.timing is None) else self.stream.value
         self.x_ptr.value = self.saved_x.data_ptr()
-        self.g_scale.copy_(g_losses.reshape(2).to(self.g_scale.dtype))
+        self.g_scale.copy_(g_losses.reshape(self.g_scale.numel()).to(self.g_scale.dtype))
         if self.reducer is not None:
             self.reducer.run_backward()             # segmented replay + bucketed RCCL all-reduce (dp.py)
         else:

@@ -60,18 +60,22 @@ class _TrainStep(torch.autograd.Function):
     returned through autograd, so no per-parameter AccumulateGrad work happens."""
 
     @staticmethod
-    def forward(ctx, x, anchor, model, plan, targets):
-        out14 = plan.forward_train(x, targets)
+    def forward(ctx, x, anchor, model, plan, targets, seg_maps=None):
+        out14 = plan.forward_train(x, targets, seg_maps)
         res = out14.clone()
         ctx.model, ctx.plan = model, plan
         losses, metrics = res[:, 0].contiguous(), res[:, 1:].contiguous()
+        if plan.seg_head is not None:             # third loss: SegLoss (mbv2_yolo.py:167-170); its two means ride along
+            seg3 = plan.seg_out3.clone()
+            losses = torch.cat((losses, seg3[:1]))
+            metrics = torch.cat((metrics.reshape(-1), seg3[1:]))
         ctx.mark_non_differentiable(metrics)
         return losses, metrics
 
     @staticmethod
     def backward(ctx, g_losses, _g_metrics):
         ctx.model._run_backward(ctx.plan, g_losses.contiguous())
-        return None, None, None, None, None
+        return None, None, None, None, None, None
 
 
 class yolo(nn.Module):
@@ -92,6 +96,7 @@ class yolo(nn.Module):
             self.graph = mbv2_yolo_graph(self.num_classes, self.num_anchors, self.seg_num_classes)
         else:
             self.graph = mbv3_yolo_graph(self.num_classes, self.num_anchors)
+        self.has_seg = self.graph.seg_out is not None
         self._build_modules()
         self.yolo_losses = [HeadState(y["anchors"], y["mask"][i], self.num_classes, [config["img_w"], config["img_h"]],
                                       y["ignore_thresh"][i], y["iou_thresh"], iou_weighting=config["iou_weighting"])
@@ -175,7 +180,12 @@ class yolo(nn.Module):
         if self.training:
             nbt = [b for k, b in self.named_buffers() if k.endswith("num_batches_tracked")]
             torch._foreach_add_(nbt, 1)
-        losses, metrics = _TrainStep.apply(x, self._anchor, self, plan, targets)
+        if self.has_seg and seg_maps is not None:
+            seg_maps = seg_maps.to(device=x.device, dtype=torch.float32)
+        losses, metrics = _TrainStep.apply(x, self._anchor, self, plan, targets, seg_maps if self.has_seg else None)
+        seg_metrics = None
+        if self.has_seg:
+            seg_metrics, metrics = metrics[12:], metrics[:12].view(2, 6)
         out = []
         if self.sync_metrics:
             m = metrics.tolist()
@@ -185,6 +195,9 @@ class yolo(nn.Module):
             else:
                 r = (losses[i],) + tuple(metrics[i, j] for j in range(6))
             out.append(r)
+        if seg_metrics is not None:               # (loss*0.05, mean(obj).item(), mean(no_obj).item())  seg_loss.py:76
+            sm = seg_metrics.tolist() if self.sync_metrics else (seg_metrics[0], seg_metrics[1])
+            return tuple(out), (losses[2], sm[0], sm[1])
         return tuple(out)
 
     def _run_backward(self, plan, g_losses):
@@ -221,4 +234,7 @@ class yolo(nn.Module):
                 raise _lib.MnyError("NMS: a class bucket of %d boxes exceeds the 8192-box LDS limit" % int(plan.nms_status.item()))
             total = sum(counts)
             dets = plan.out_rows[:total].clone()
-        return list(torch.split(dets, counts))                                  # list of [k_i,7] (mbv2_yolo.py:159-166)
+        dets = list(torch.split(dets, counts))                                  # list of [k_i,7] (mbv2_yolo.py:159-166)
+        if plan.seg_head is not None:
+            return dets, plan.seg_eval.cpu().numpy()                            # (output, seg_out) mbv2_yolo.py:161-164
+        return dets
