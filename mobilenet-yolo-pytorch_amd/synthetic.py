@@ -75,3 +75,22 @@ def map_case(n_images, n_classes, seed=0, mean_gt=2.5, crafted=False, no_detecti
     cat = lambda xs, shape: np.concatenate(xs).astype(f) if xs else np.zeros(shape, f)
     return (cat(db, (0, 4)).reshape(-1, 4), cat(dl, (0,)), cat(ds, (0,)), np.array(do, np.int32),
             cat(tb, (0, 4)).reshape(-1, 4), cat(tl, (0,)), cat(td, (0,)), np.array(to, np.int32))
+
+
+def photos(sizes, seed=0):
+    """Decoded-JPEG stand-ins for the input-prep stage: uint8 RGB [h,w,3] per (h,w) in `sizes` — smooth gradients + blocks +
+    noise, so resampling has real structure to average (pure noise would hide coefficient errors behind rounding)."""
+    r = np.random.RandomState(seed)
+    out = []
+    for h, w in sizes:
+        yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+        img = np.zeros((h, w, 3), np.float32)
+        for c in range(3):
+            fx, fy, ph = r.uniform(0.01, 0.2), r.uniform(0.01, 0.2), r.uniform(0, 6.28)
+            img[..., c] = 127 + 90 * np.sin(fx * xx + fy * yy + ph)
+        for _ in range(4):
+            y0, x0 = r.randint(0, h), r.randint(0, w)
+            img[y0:y0 + r.randint(2, max(3, h // 3)), x0:x0 + r.randint(2, max(3, w // 3))] = r.randint(0, 256, 3)
+        img += r.randn(h, w, 3) * 12
+        out.append(np.clip(img, 0, 255).astype(np.uint8))
+    return out
