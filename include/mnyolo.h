@@ -281,6 +281,26 @@ int mny_seg_loss(const float* head, const float* seg_maps, int64_t n, float* out
 int mny_seg_sigmoid(const float* head /*[N,h,w,C], image 0 is read*/, int h, int w, int C, float* out,
                     void* stream);
 
+/* ---- device-side batch input preparation ------------------------------------------------------
+ * Replaces the image half of collate_fn (folder2lmdb.py:223-256): per image transforms.Resize(size, BILINEAR) on
+ * the decoded PIL image, ToTensor, Normalize(mean, std), torch.stack — with the batch's one
+ * random.choice(train_img_size) made by the caller.  The resize is Pillow's ImagingResample (third-party, not
+ * vendored): antialiased triangle filter whose support grows with the down-scale factor, 22-bit fixed-point taps,
+ * horizontal pass then vertical pass, each rounded to uint8 — reproduced bit for bit; then
+ * out = (u8/255 - mean)/std in fp32 (same divisions as torch).
+ * src: decoded RGB uint8 images, HWC, anywhere in one device buffer; desc (DEVICE, [N]): byte offset + size of
+ * each.  max_in_h/max_in_w: caller's upper bounds on the source sizes (size the workspace and the tap tables); an
+ * image outside them is written as zeros and the int32 at ws+0 receives 1+its index (0 = ok).
+ * mean3/std3: HOST arrays of 3 floats, read during the call.  out: [N,3,out_h,out_w] fp32 (NCHW, what
+ * mny_stem_fwd reads).  ws: mny_prep_ws_bytes().  No host sync. */
+typedef struct mny_image_desc {
+    int64_t offset; /* bytes from src to pixel (0,0) */
+    int32_t h, w;
+} mny_image_desc;
+size_t mny_prep_ws_bytes(int N, int max_in_h, int max_in_w, int out_h, int out_w);
+int mny_prep_batch(const uint8_t* src, const mny_image_desc* desc, int N, int max_in_h, int max_in_w, int out_h,
+                   int out_w, const float* mean3, const float* std3, float* out, void* ws, void* stream);
+
 /* ---- bf16 STORAGE twins (BASELINE config 4: MobileNetV3-YOLO 512x512 bf16) -----------------
  * Every `mny_X_bf16` has the contract of `mny_X` above with ONE difference: the activation-sized tensors (the
  * `void*` parameters: raw conv outputs, materialised sums, gradients wrt activations) are bf16 in HBM.  Kernels

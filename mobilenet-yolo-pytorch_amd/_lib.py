@@ -73,6 +73,8 @@ _SIGS = {
     "mny_seg_loss_ws_bytes": (c_size_t, [c_int64]),
     "mny_seg_loss": (c_int, [P, P, c_int64, P, P, P, P]),
     "mny_seg_sigmoid": (c_int, [P, c_int, c_int, c_int, P, P]),
+    "mny_prep_ws_bytes": (c_size_t, [c_int] * 5),
+    "mny_prep_batch": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, P, P, P, P]),
     "mny_eval_pack": (c_int, [P, c_int64, P, c_int64, P, P, P, P, P, P, P]),
 }
 # bf16-storage twins (activation tensors bf16, everything else as in the fp32 entry point): identical ctypes signature

@@ -12,7 +12,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 BASE_FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 # detect.hip must round like the CPU kernels it replaces (bit-exact NMS): no FMA contraction there
-EXTRA = {"detect.hip": ["-ffp-contract=off"], "evalmap.hip": ["-ffp-contract=off"]}
+EXTRA = {"detect.hip": ["-ffp-contract=off"], "evalmap.hip": ["-ffp-contract=off"], "prep.hip": ["-ffp-contract=off"]}
 
 
 def sources():
