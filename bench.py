@@ -266,6 +266,64 @@ def map_bench(device):
             "cpu_kind": "port (oracle/map_ref.py, numpy, 1 thread, same set; the reference's own torch loop ran 17 k detections/s in the build container)"}
 
 
+def prep_bench(device):
+    """one training batch of decoded VOC-shaped photos (256 images, 500x375 / 375x500 / smaller) -> 352x352
+    normalised NCHW fp32.  Device leg: sources already in HBM.  CPU: the real Pillow resize + the ToTensor/Normalize tensor
+    ops (what collate_fn runs per image in the DataLoader workers), one thread, bounded sample."""
+    import numpy as np
+    from mobilenet_yolo_pytorch_amd import prep, synthetic
+    from oracle import prep_ref
+    r = np.random.RandomState(6)
+    shapes = [(375, 500), (500, 375), (333, 500), (500, 334), (281, 500), (375, 440)]
+    protos = synthetic.photos(shapes, seed=6)
+    imgs = [protos[i % len(protos)] for i in range(BATCH)]
+    mean, std = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+    bp = prep.BatchPrep([(SIZE, SIZE)], mean, std, device=device)
+    stage, desc, mh, mw = bp.pack(imgs)
+    src = stage.to(device)
+    desc_dev = torch.from_numpy(desc.view(np.uint8).copy()).to(device)
+    out = torch.empty(BATCH, 3, SIZE, SIZE, device=device)
+    bp.run_device(src, desc_dev, BATCH, mh, mw, (SIZE, SIZE), out=out)
+    torch.cuda.synchronize()
+    reps = 10
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        bp.run_device(src, desc_dev, BATCH, mh, mw, (SIZE, SIZE), out=out)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter()
+    for _ in range(3):
+        x = bp(imgs, (SIZE, SIZE))                    # pack into pinned memory + H2D + kernels
+    torch.cuda.synchronize()
+    dt_h = (time.perf_counter() - t0) / 3
+    k = len(protos)
+    try:
+        from PIL import Image
+        t0 = time.perf_counter()
+        n_cpu = 0
+        while time.perf_counter() - t0 < 3.0:
+            for im in protos:
+                rz = np.asarray(Image.fromarray(im).resize((SIZE, SIZE), Image.BILINEAR))
+                t = torch.from_numpy(rz.copy()).permute(2, 0, 1).contiguous().to(torch.float32).div(255)
+                t.sub_(torch.tensor(mean)[:, None, None]).div_(torch.tensor(std)[:, None, None])
+            n_cpu += k
+        cpu_dt = (time.perf_counter() - t0) / n_cpu
+        same = bool(torch.equal(out[k - 1].cpu(), t))
+        kind = "reference pieces (Pillow %s resize + torch ToTensor/Normalize ops, 1 thread, %d images)" % (getattr(Image, "__version__", "?"), n_cpu)
+    except ImportError:
+        t0 = time.perf_counter()
+        ref = prep_ref.collate(protos[:2], (SIZE, SIZE), mean, std)
+        cpu_dt = (time.perf_counter() - t0) / 2
+        same = bool(np.array_equal(out[:2].cpu().numpy(), ref))
+        kind = "port (oracle/prep_ref.py, numpy, 2 images)"
+    src_bytes = int(sum(im.size for im in imgs))
+    return {"workload": "%d decoded photos (%.0f MB uint8) -> %dx%d normalised NCHW fp32" % (BATCH, src_bytes / 1e6, SIZE, SIZE),
+            "images_per_s": round(BATCH / dt, 1), "ms": round(dt * 1e3, 3),
+            "hbm_gbs": round((src_bytes + 2 * BATCH * 420 * SIZE * 3 + BATCH * 3 * SIZE * SIZE * 4) / dt / 1e9, 1),
+            "with_pack_and_h2d_images_per_s": round(BATCH / dt_h, 1), "matches_cpu": same,
+            "cpu_images_per_s": round(1.0 / cpu_dt, 1), "cpu_kind": kind}
+
+
 def roofline_from(events, calls_by_list):
     """Aggregate HIP-event durations per entry point; pick the dominant one."""
     agg = {}
@@ -418,6 +476,7 @@ def main():
         if world == 1 and not a.no_nms:
             res["nms"] = nms_bench(device)
             res["map"] = map_bench(device)
+            res["prep"] = prep_bench(device)
             res["optimizer"] = optimizer_bench(model)
             res["pcie_inclusive"] = h2d_bench(step, x)
         print(json.dumps(res))
