@@ -611,8 +611,31 @@ static Nt2Plan nt2_plan(int64_t M, int K, int N, bool xf, int BF = 0) {
     if (want > kMaxParts) want = kMaxParts;
     int gx = pl.m_tiles < want ? pl.m_tiles : want;
     pl.tiles_per_block = (int)cdiv(pl.m_tiles, gx);
+    // Balance the CUs, not the slots: all blocks are resident at once and share their CU's matrix pipes, so a launch takes
+    // (blocks on the busiest CU) x (tiles per block).  Filling every slot (3/CU) with 5.04 tiles' worth of work each means 6
+    // rounds on CUs holding 3 blocks = 18 tile-times, where 2 blocks/CU x 8 tiles = 16.  Search tiles-per-block upwards from
+    // the one-wave minimum; ties -> more blocks (more waves to hide latency).
+    static const bool balance = getenv("MNY_NT_BALANCE") == nullptr || atoi(getenv("MNY_NT_BALANCE")) != 0;
+    static const double min_ai = getenv("MNY_NT_BALANCE_AI") ? atof(getenv("MNY_NT_BALANCE_AI")) : 100.0;
+    // ... for the matrix-pipe-bound shapes only (FLOP per byte of A + C rows): an HBM-bound layer wants every slot filled
+    // (memory-level parallelism), measured 5 % slower with fewer, longer blocks
+    const double ai = 2.0 * K * N / ((BF ? 2.0 : 4.0) * (K + N));
+    if (balance && ai >= min_ai) {
+        const int t_min = pl.tiles_per_block;
+        long best_cost = -1;
+        int best_t = t_min, best_b = 0;
+        for (int t = t_min; t <= 4 * t_min + 4 && t <= pl.m_tiles; ++t) {
+            const int g = (int)cdiv(pl.m_tiles, t);
+            const int nb = g * pl.n_tiles;                                     // real blocks (the grid's padding blocks exit at once)
+            if (nb < 256) break;                                               // never leave CUs without a block
+            const long cost = (long)cdiv(nb, 256) * t;
+            if (best_cost < 0 || cost < best_cost || (cost == best_cost && nb > best_b)) { best_cost = cost; best_t = t; best_b = nb; }
+        }
+        pl.tiles_per_block = best_t;
+    }
     pl.gx = (int)cdiv(pl.m_tiles, pl.tiles_per_block);
     pl.grid = (int)cdiv(pl.gx, 8) * 8 * pl.n_tiles;
+    if (getenv("MNY_PLAN_DEBUG")) fprintf(stderr, "nt2_plan M=%lld K=%d N=%d TN=%d bpc=%d m_tiles=%d n_tiles=%d t=%d gx=%d grid=%d\n", (long long)M, K, N, best, blocks_per_cu, pl.m_tiles, pl.n_tiles, pl.tiles_per_block, pl.gx, pl.grid);
     pl.lds = nt2_lds(best, K, xf, BF);
     return pl;
 }
