@@ -635,7 +635,8 @@ static Nt2Plan nt2_plan(int64_t M, int K, int N, bool xf, int BF = 0) {
     }
     pl.gx = (int)cdiv(pl.m_tiles, pl.tiles_per_block);
     pl.grid = (int)cdiv(pl.gx, 8) * 8 * pl.n_tiles;
-    if (getenv("MNY_PLAN_DEBUG")) fprintf(stderr, "nt2_plan M=%lld K=%d N=%d TN=%d bpc=%d m_tiles=%d n_tiles=%d t=%d gx=%d grid=%d\n", (long long)M, K, N, best, blocks_per_cu, pl.m_tiles, pl.n_tiles, pl.tiles_per_block, pl.gx, pl.grid);
+    static const bool plan_debug = getenv("MNY_PLAN_DEBUG") != nullptr;
+    if (plan_debug) fprintf(stderr, "nt2_plan M=%lld K=%d N=%d TN=%d bpc=%d m_tiles=%d n_tiles=%d t=%d gx=%d grid=%d\n", (long long)M, K, N, best, blocks_per_cu, pl.m_tiles, pl.n_tiles, pl.tiles_per_block, pl.gx, pl.grid);
     pl.lds = nt2_lds(best, K, xf, BF);
     return pl;
 }

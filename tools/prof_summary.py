@@ -67,6 +67,21 @@ def main():
                                                                                (2 * f_gb + w_gb) / ms * 1e3 if ms else 0))
         o.write("\nTotal per step: kernel time %.2f ms; FETCH_SIZE %.1f GB (x2 = %.1f GB), WRITE_SIZE %.1f GB -> %.2f TB/s average.\n" % (
             tms, tf, 2 * tf, tw, (2 * tf + tw) / tms))
+        # entry-point aggregate bench.py's roofline object must agree with: mny_pw_fwd = every NT GEMM kernel (forward + data gradient)
+        g = [(ms, n, f_gb, w_gb) for ms, k, n, f_gb, w_gb in rows if k.startswith("pw_gemm_nt")]
+        g_ms, g_n = sum(r[0] for r in g), sum(r[1] for r in g)
+        g_f, g_w = sum(r[2] for r in g), sum(r[3] for r in g)
+        o.write("\n`mny_pw_fwd` entry point (all `pw_gemm_nt*` kernels): %.0f launches/step, %.3f ms/step, avg %.1f us; HBM %.2f GB/step "
+                "(fetch x2 %.2f + write %.2f) = %.0f MB per launch.\n" % (g_n, g_ms, g_ms * 1e3 / max(g_n, 1), 2 * g_f + g_w, 2 * g_f, g_w,
+                                                                          (2 * g_f + g_w) * 1e3 / max(g_n, 1)))
+    import json
+    with open("profiles/%s_traffic_mny_pw_fwd.json" % tag, "w") as o:
+        json.dump({"entry_point": "mny_pw_fwd", "launches_per_step": g_n, "ms_per_step_rocprof": g_ms,
+                   "hbm_bytes_per_step": (2 * g_f + g_w) * 1e9, "hbm_bytes_per_launch": (2 * g_f + g_w) * 1e9 / max(g_n, 1),
+                   "fetch_size_x2_bytes_per_step": 2 * g_f * 1e9, "write_size_bytes_per_step": g_w * 1e9,
+                   "method": "rocprofv3 --kernel-trace --stats, --pmc FETCH_SIZE and --pmc WRITE_SIZE (three separate runs, tools/prof_round.sh) of "
+                             "`python3 bench.py --no-cpu-baseline --no-nms`; counter unit KiB; FETCH_SIZE x2 = gfx950 correction for wide coalesced "
+                             "streams (MI355X_MICROARCH.md, HBM section); WRITE_SIZE uncalibrated"}, o, indent=1)
     print(open("profiles/%s_kernels_time_and_hbm.md" % tag).read())
 
 
