@@ -390,7 +390,7 @@ def main():
     # timed region: K steps, barrier + sync on both sides; the dominant kernels are bracketed by HIP events
     inline = a.roofline_pass == "inline" or a.breakdown
     if inline:
-        plan.enable_timing(only=None if a.breakdown else MFMA_KERNELS)
+        plan.enable_timing(only=None if a.breakdown else MFMA_KERNELS, steps=a.steps)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -404,7 +404,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if not inline:                               # roofline leg: the same K steps again, MFMA kernels bracketed by HIP events
-        plan.enable_timing(only=MFMA_KERNELS)
+        plan.enable_timing(only=MFMA_KERNELS, steps=a.steps)
         for _ in range(a.steps):
             out = step()
         if reducer is not None:
