@@ -1243,7 +1243,8 @@ static WgPlan wg_plan(int64_t M, int K, int N, bool bf16 = false) {
         pl.TI = BI / 64; pl.TJ = BJ / 64;
         pl.gx = (int)cdiv(N, BI); pl.gy = (int)cdiv(K, BJ);
     }
-    int64_t splits = 1536 / ((int64_t)pl.gx * pl.gy);
+    static const int wg_blocks = getenv("MNY_WG_BLOCKS") ? atoi(getenv("MNY_WG_BLOCKS")) : 1536;
+    int64_t splits = wg_blocks / ((int64_t)pl.gx * pl.gy);
     if (splits < 1) splits = 1;
     const int64_t max_splits = cdiv(M, 4 * KC);
     if (splits > max_splits) splits = max_splits;
