@@ -83,8 +83,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     float4 s1 = f4zero(), s2 = f4zero();
     if (cvalid) {
         const float4 sc = ld4(scale + c), sh = ld4(shift + c), mu = ld4(mean + c), is = ld4(invstd + c);
-        for (int64_t m = (int64_t)blockIdx.x * ppb + pix; m < M; m += (int64_t)gridDim.x * ppb) {
-            const float4 gv = ld4(g + m * C + c), yv = ld4(y + m * C + c);
+        auto accum = [&](float4 gv, float4 yv) {
             float4 dz;
             dz.x = gv.x * act_bwd(fmaf(yv.x, sc.x, sh.x), act);
             dz.y = gv.y * act_bwd(fmaf(yv.y, sc.y, sh.y), act);
@@ -95,7 +94,22 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
             s2.y = fmaf(dz.y, (yv.y - mu.y) * is.y, s2.y);
             s2.z = fmaf(dz.z, (yv.z - mu.z) * is.z, s2.z);
             s2.w = fmaf(dz.w, (yv.w - mu.w) * is.w, s2.w);
+        };
+        const int64_t stride = (int64_t)gridDim.x * ppb;
+        int64_t m = (int64_t)blockIdx.x * ppb + pix;
+        // 16-bit storage: a lane's load is 8 bytes, so the loop is bound by loads in flight, not bytes — keep four rows' worth
+        // of loads outstanding (fp32 is already at the HBM ceiling with one)
+        constexpr int U = sizeof(T) == 2 ? 4 : 1;
+        if (U > 1) {
+            for (; m + (U - 1) * stride < M; m += U * stride) {
+                float4 gv[U], yv[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) { gv[u] = ld4(g + (m + u * stride) * C + c); yv[u] = ld4(y + (m + u * stride) * C + c); }
+#pragma unroll
+                for (int u = 0; u < U; ++u) accum(gv[u], yv[u]);
+            }
         }
+        for (; m < M; m += stride) accum(ld4(g + m * C + c), ld4(y + m * C + c));
     }
     red[tid * 2] = s1;
     red[tid * 2 + 1] = s2;
