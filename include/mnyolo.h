@@ -242,6 +242,20 @@ typedef struct mny_adamw_chunk {
 int mny_adamw_step(const mny_adamw_chunk* table_dev, int nchunks, double lr, double beta1, double beta2, double eps,
                    double weight_decay, int64_t step, void* stream);
 
+/* ---- data-gradient GEMM + BN-backward reduction of the unit it feeds ------------------------------------------
+ * dx[M,Nc] = dy[M,K] * W, with W^T given as [Nc][K] rows (mny_transpose of the conv weight) — the autograd
+ * data gradient of nn.Conv2d(Nc,K,1) (mobilenetv2.py:69,83) — when dx is the complete gradient of a
+ * conv+BN+act unit's output: the epilogue also forms that unit's BN-backward sums from the tile it just
+ * produced and the unit's raw output y[M,Nc]:  red[part][0][c] = sum dz, red[part][1][c] = sum dz*xhat,
+ * dz = dx * act'(scale*y+shift), xhat = (y-mean)*invstd — exactly what mny_bn_bwd_reduce(dx, y, ...) writes,
+ * in the same [parts][2][Nc] layout (parts = mny_pw_dgrad_bnred_parts(M,K,Nc)); feed it to mny_bn_bwd_finalize.
+ * Saves the reduce pass's read of dx.  fp32, K % 4 == 0, act in {NONE, RELU6, LEAKY, RELU}. */
+int mny_pw_dgrad_bnred_supported(int64_t M, int K, int Nc, int act);
+int mny_pw_dgrad_bnred_parts(int64_t M, int K, int Nc); /* partial rows it writes */
+int mny_pw_dgrad_bnred(const float* dy, const float* wT, float* dx, const float* y, const float* scale,
+                       const float* shift, int act, const float* mean, const float* invstd, float* red,
+                       int64_t M, int K, int Nc, void* stream);
+
 /* ---- evaluation consumer: VOC07 11-point mAP on the device -----------------------------
  * Replaces utils/eval_mAP.py:134-187 (calculate_mAP), :69-132 (eval_class_ap), :8-65
  * (eval_single_image_recall) and utils/iou.py:4-48 (find_jaccard_overlap) on a PACKED layout: the

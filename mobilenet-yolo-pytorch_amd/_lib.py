@@ -45,6 +45,9 @@ _SIGS = {
     "mny_pw_bnbwd_supported": (c_int, [c_int64, c_int, c_int]),
     "mny_pw_bnbwd_ws_floats": (c_size_t, [c_int64, c_int, c_int]),
     "mny_pw_bnbwd": (c_int, [P, P, P, P, c_int, P, P, P, P, P, P, c_int, P, P, P, P, P, P, P, c_int64, c_int, c_int, P]),
+    "mny_pw_dgrad_bnred_supported": (c_int, [c_int64, c_int, c_int, c_int]),
+    "mny_pw_dgrad_bnred_parts": (c_int, [c_int64, c_int, c_int]),
+    "mny_pw_dgrad_bnred": (c_int, [P, P, P, P, P, P, c_int, P, P, P, c_int64, c_int, c_int, P]),
     "mny_transpose": (c_int, [P, P, c_int, c_int, P]),
     "mny_transpose_pad": (c_int, [P, P, c_int, c_int, c_int, P]),
     "mny_pad_rows": (c_int, [P, P, P, c_int64, c_int, c_int, P]),

@@ -251,6 +251,9 @@ struct Gemm2Args {   // A / B / addend / C: float* (BF = 0) or bf16_t* (BF = 1)
     const void* B; const float* bias; const void* addend; void* C; float* stats;
     int64_t M; int K; int N;
     int m_tiles, tiles_per_block, gx, n_tiles;
+    // RED = 1 (data-gradient GEMM feeding a BN unit): C is that unit's dL/d(output); its BN-backward sums
+    // (sum dz, sum dz*xhat per column, dz = C * act'(r_scale*rY + r_shift)) leave through `stats` instead of the plain column sums
+    const float* rY; const float* r_scale; const float* r_shift; const float* r_mean; const float* r_invstd; int r_act;
 };
 
 // XF: 0 = A used as is, 1 = scale/shift + min(max(z, slope*z), hi) activation, 2 = scale/shift + hswish
@@ -260,7 +263,7 @@ struct Gemm2Args {   // A / B / addend / C: float* (BF = 0) or bf16_t* (BF = 1)
 //     main loop is 2 MFMAs per accumulator per stage instead of 16.
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 
-template <int TN, int XF, int BF>
+template <int TN, int XF, int BF, int RED = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void pw_gemm_nt_dma_kernel(Gemm2Args p) {
     using T = typename std::conditional<BF != 0, bf16_t, float>::type;
     constexpr int EPC = BF ? 8 : 4;                                           // elements per 16-B chunk
@@ -456,7 +459,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                     if (colq + 3 < p.N) bv.w = p.bias[colq + 3];
                 }
             }
-            if (p.stats) {                                        // column sums come from the un-transposed registers
+            if (RED) {                                            // BN-backward sums of the unit this gradient belongs to
+                const int col = n0 + u * 32 + lrow;
+                const bool ccol = col < p.N;
+                const int cc = ccol ? col : 0;
+                const float rsc = p.r_scale[cc], rsh = p.r_shift[cc], rmu = p.r_mean[cc], ris = p.r_invstd[cc];
+                const float rslope = act_slope(p.r_act), rhi = act_hi(p.r_act);
+                const int64_t rbase = m0 + wv * 32 + 4 * khalf;
+                const int rows_left = (int)max((int64_t)0, min((int64_t)64, p.M - rbase));   // rows rbase + 8*gq + j, 8*gq + j < rows_left, exist
+                const float* ybase = p.rY + (rows_left > 0 ? rbase : 0) * p.N + cc;
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {                  // four rows at a time: the loads of a group are all that is in flight
+                    float yv[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) yv[j] = ybase[(ccol && 8 * gq + j < rows_left ? 8 * gq + j : 0) * p.N];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float z = fmaf(yv[j], rsc, rsh);
+                        const float dz = acc[u][gq * 4 + j] * ((z > 0.f ? 1.f : rslope) * (z < rhi ? 1.f : 0.f));   // act_bwd(z), min/max family
+                        if (ccol && 8 * gq + j < rows_left) { s1[u] += dz; s2[u] = fmaf(dz, (yv[j] - rmu) * ris, s2[u]); }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else if (p.stats) {                                 // column sums come from the un-transposed registers
                 const bool ccol = n0 + u * 32 + lrow < p.N;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -593,11 +618,11 @@ static int nt2_blocks_per_cu(int TN, int XF, size_t lds, int BF = 0) {
     return nb;
 }
 
-static Nt2Plan nt2_plan(int64_t M, int K, int N, bool xf, int BF = 0) {
+static Nt2Plan nt2_plan(int64_t M, int K, int N, bool xf, int BF = 0, int tn_cap = 5) {
     Nt2Plan pl;
     int best = 1, best_pad = 1 << 30;
     static const int max_tn = getenv("MNY_NT_MAXTN") ? atoi(getenv("MNY_NT_MAXTN")) : 5;
-    for (int tn = max_tn; tn >= 1; --tn) {        // minimise the padded width; ties -> the wider tile (A read fewer times,
+    for (int tn = max_tn < tn_cap ? max_tn : tn_cap; tn >= 1; --tn) {        // minimise the padded width; ties -> the wider tile (A read fewer times,
         int pad = (int)cdiv(N, 32 * tn) * 32 * tn;   // longer contiguous output rows)
         if (pad < best_pad) { best_pad = pad; best = tn; }
     }
@@ -1874,13 +1899,47 @@ extern "C" int mny_pw_fwd(const float* x, const float* in_scale, const float* in
     if ((K & 3) == 0 && !force_v1) {                // LDS-DMA pipeline (v2): 16-B aligned input rows
         Nt2Plan p2 = nt2_plan(M, K, Nc, xf);
         MNY_REQUIRE(p2.lds <= 64 * 1024, "pw_fwd: K=%d too large for the LDS scale cache", K);
-        Gemm2Args g{x, in_scale, in_shift, in_act, w, bias, addend, y, stats, M, K, Nc, p2.m_tiles, p2.tiles_per_block, p2.gx, p2.n_tiles};
+        Gemm2Args g{x, in_scale, in_shift, in_act, w, bias, addend, y, stats, M, K, Nc, p2.m_tiles, p2.tiles_per_block, p2.gx, p2.n_tiles,
+                    nullptr, nullptr, nullptr, nullptr, nullptr, 0};
         dim3 grid2(p2.grid), block2(256);
         const int XF = !xf ? 0 : (in_act == MNY_ACT_HSWISH ? 2 : 1);
         hipLaunchKernelGGL(nt2_kernel(p2.TN, XF), grid2, block2, p2.lds, st, g);
         return check_launch("pw_gemm_nt_dma_kernel");
     }
     return pw_fwd_v1<float>(x, in_scale, in_shift, in_act, w, bias, addend, y, stats, M, K, Nc, st);
+}
+
+// data-gradient GEMM of a pointwise conv whose INPUT is the output of a conv+BN+act unit: dx = dy * W (W^T given, [K][Nc] rows = [Nc][K]
+// transposed -> NT), and in the same epilogue that unit's BN-backward reduction over (dx, its raw output y): the separate
+// mny_bn_bwd_reduce pass (one more read of dx and of y) disappears — only y is read, by the tile that just produced dx.
+// the reduction epilogue holds four more per-column constants and a group of loads: the 160-column tile (TN = 5) spills with it
+constexpr int kRedMaxTn = 4;
+static bool dgrad_bnred_ok(int64_t M, int K, int Nc, int act) {
+    if (K >= 512 && Nc >= 512) return false;      // matrix-pipe-bound: the reduce pass it would save is cheaper than the longer epilogue
+    return M > 0 && K > 0 && Nc > 0 && (K & 3) == 0 && (act == MNY_ACT_NONE || act == MNY_ACT_RELU6 || act == MNY_ACT_LEAKY || act == MNY_ACT_RELU) &&
+           getenv("MNY_GEMM_V1") == nullptr;
+}
+extern "C" int mny_pw_dgrad_bnred_supported(int64_t M, int K, int Nc, int act) { return dgrad_bnred_ok(M, K, Nc, act) ? 1 : 0; }
+extern "C" int mny_pw_dgrad_bnred_parts(int64_t M, int K, int Nc) {
+    if (M <= 0 || K <= 0 || Nc <= 0 || (K & 3)) return MNY_EINVAL;
+    return nt2_plan(M, K, Nc, false, 0, kRedMaxTn).gx;
+}
+extern "C" int mny_pw_dgrad_bnred(const float* dy, const float* wT, float* dx, const float* y, const float* scale, const float* shift, int act,
+                                  const float* mean, const float* invstd, float* red, int64_t M, int K, int Nc, void* stream) {
+    MNY_REQUIRE(dy && wT && dx && y && scale && shift && mean && invstd && red, "pw_dgrad_bnred: null pointer");
+    MNY_REQUIRE(dgrad_bnred_ok(M, K, Nc, act), "pw_dgrad_bnred: unsupported problem M=%lld K=%d N=%d act=%d (see mny_pw_dgrad_bnred_supported)", (long long)M, K, Nc, act);
+    Nt2Plan p2 = nt2_plan(M, K, Nc, false, 0, kRedMaxTn);
+    MNY_REQUIRE(p2.lds <= 64 * 1024, "pw_dgrad_bnred: K=%d too large", K);
+    Gemm2Args g{dy, nullptr, nullptr, MNY_ACT_NONE, wT, nullptr, nullptr, dx, red, M, K, Nc, p2.m_tiles, p2.tiles_per_block, p2.gx, p2.n_tiles,
+                y, scale, shift, mean, invstd, act};
+    Nt2Kernel k;
+    switch (p2.TN) {
+        case 1: k = (Nt2Kernel)pw_gemm_nt_dma_kernel<1, 0, 0, 1>; break; case 2: k = (Nt2Kernel)pw_gemm_nt_dma_kernel<2, 0, 0, 1>; break;
+        case 3: k = (Nt2Kernel)pw_gemm_nt_dma_kernel<3, 0, 0, 1>; break; case 4: k = (Nt2Kernel)pw_gemm_nt_dma_kernel<4, 0, 0, 1>; break;
+        default: k = (Nt2Kernel)pw_gemm_nt_dma_kernel<5, 0, 0, 1>; break;
+    }
+    hipLaunchKernelGGL(k, dim3(p2.grid), dim3(256), p2.lds, (hipStream_t)stream, g);
+    return check_launch("pw_gemm_nt_dma_kernel<RED>");
 }
 
 extern "C" int mny_pw_fwd_bf16(const void* x, const float* in_scale, const float* in_shift, int in_act, const void* w,
@@ -1895,7 +1954,8 @@ extern "C" int mny_pw_fwd_bf16(const void* x, const float* in_scale, const float
     if ((K & 7) == 0 && !force_v1) {                // LDS-DMA pipeline on the bf16 matrix cores (16-B aligned bf16 rows)
         Nt2Plan p2 = nt2_plan(M, K, Nc, xf, 1);
         MNY_REQUIRE(p2.lds <= 64 * 1024, "pw_fwd: K=%d too large for the LDS scale cache", K);
-        Gemm2Args g{x, in_scale, in_shift, in_act, w, bias, addend, y, stats, M, K, Nc, p2.m_tiles, p2.tiles_per_block, p2.gx, p2.n_tiles};
+        Gemm2Args g{x, in_scale, in_shift, in_act, w, bias, addend, y, stats, M, K, Nc, p2.m_tiles, p2.tiles_per_block, p2.gx, p2.n_tiles,
+                    nullptr, nullptr, nullptr, nullptr, nullptr, 0};
         const int XF = !xf ? 0 : (in_act == MNY_ACT_HSWISH ? 2 : 1);
         hipLaunchKernelGGL(nt2_kernel(p2.TN, XF, 1), dim3(p2.grid), dim3(256), p2.lds, st, g);
         return check_launch("pw_gemm_nt_dma_kernel<bf16>");

@@ -483,6 +483,13 @@ class NetPlan:
             else:
                 gs[o.id].buf = self.dheads[hi]
 
+        n_consumers = {v.id: 0 for v in g.values}
+        for nd in g.nodes:
+            for v in nd.ins:
+                n_consumers[v.id] += 1
+        for v in outs:
+            n_consumers[v.id] += 1
+        self.fused_red = {}      # value id -> (partial-sum buffer, rows) written by the data-gradient GEMM that produced the value's gradient
         for nd in order:
             o = nd.out
             shp = shape(o)
@@ -563,9 +570,12 @@ class NetPlan:
                     i = nd.ins[0]
                     ish = shape(i)
                     xv = view(i)
-                    bwd.add(K("mny_bn_bwd_reduce"), G, u.Y, u.scale, u.shift, o.act, u.mean, u.invstd, self.red_ws, M, o.C, self.stream,
-                            meta=dict(flops=0, bytes=2 * eb * M * o.C, shape="M%d C%d" % (M, o.C)))
-                    bwd.add("mny_bn_bwd_finalize", self.red_ws, parts, M, gam, u.mean, u.invstd, gv(nd.bn + ".weight"), gv(nd.bn + ".bias"),
+                    red_buf, red_parts = self.fused_red.get(o.id, (None, 0))
+                    if red_buf is None:
+                        red_buf, red_parts = self.red_ws, parts
+                        bwd.add(K("mny_bn_bwd_reduce"), G, u.Y, u.scale, u.shift, o.act, u.mean, u.invstd, self.red_ws, M, o.C, self.stream,
+                                meta=dict(flops=0, bytes=2 * eb * M * o.C, shape="M%d C%d" % (M, o.C)))
+                    bwd.add("mny_bn_bwd_finalize", red_buf, red_parts, M, gam, u.mean, u.invstd, gv(nd.bn + ".weight"), gv(nd.bn + ".bias"),
                             self.coef_ws, o.C, self.stream)
                     dwv = gv(nd.conv + ".weight")
                     wt = P[nd.conv + ".weight"]
@@ -622,9 +632,24 @@ class NetPlan:
                     bwd.add(K("mny_transpose_pad"), w, wT, o.C, i.C, oc, self.stream)
                 else:
                     bwd.add(K("mny_transpose"), w, wT, o.C, i.C, self.stream)
-                contribute_kernel(i, lambda out, addend, dY=dY, wT=wT, M=M, K=oc, Nc=i.C: bwd.add(
-                    self.K("mny_pw_fwd"), dY, None, None, ACT_NONE, wT, None, addend, out, None, M, K, Nc, self.stream,
-                    meta=dict(flops=2 * M * K * Nc, bytes=self.eb * (M * K + M * Nc) + 4 * K * Nc, shape="dgrad M%d K%d N%d" % (M, K, Nc))))
+                prod = i.node
+                if (not self.bf16 and os.environ.get("MNY_NO_REDFUSE") != "1" and prod is not None and prod.op == "dw" and gs[i.id].buf is None
+                        and n_consumers[i.id] == 1 and os.environ.get("MNY_NO_DWFUSE") != "1"
+                        and _lib.query("mny_dw_bnbwd_supported", prod.k, prod.stride) == 1 and prod.ins[0].act != _lib.ACT_HSIGMOID
+                        and _lib.query("mny_pw_dgrad_bnred_supported", M, oc, i.C, i.act) == 1):
+                    # this data gradient IS the complete dL/d(output) of a fused depthwise unit: its BN-backward sums are taken from
+                    # the GEMM's own output tile (+ the unit's raw output), the separate reduce pass is dropped
+                    pu = self.units[i.id]
+                    rparts = _lib.query("mny_pw_dgrad_bnred_parts", M, oc, i.C)
+                    rbuf = torch.empty(rparts * 2 * i.C, **f32)
+                    self.fused_red[i.id] = (rbuf, rparts)
+                    contribute_kernel(i, lambda out, addend, dY=dY, wT=wT, M=M, K=oc, Nc=i.C, pu=pu, rbuf=rbuf, act_=i.act: bwd.add(
+                        "mny_pw_dgrad_bnred", dY, wT, out, pu.Y, pu.scale, pu.shift, act_, pu.mean, pu.invstd, rbuf, M, K, Nc, self.stream,
+                        meta=dict(flops=2 * M * K * Nc, bytes=self.eb * (M * K + 2 * M * Nc) + 4 * K * Nc, shape="dgrad+red M%d K%d N%d" % (M, K, Nc))))
+                else:
+                    contribute_kernel(i, lambda out, addend, dY=dY, wT=wT, M=M, K=oc, Nc=i.C: bwd.add(
+                        self.K("mny_pw_fwd"), dY, None, None, ACT_NONE, wT, None, addend, out, None, M, K, Nc, self.stream,
+                        meta=dict(flops=2 * M * K * Nc, bytes=self.eb * (M * K + M * Nc) + 4 * K * Nc, shape="dgrad M%d K%d N%d" % (M, K, Nc))))
             flush_shared()
             bwd.marks[o.name] = len(bwd.calls)
 

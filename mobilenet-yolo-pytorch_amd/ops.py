@@ -140,6 +140,18 @@ def pw_bnbwd(g, y, scale, shift, act, mean, invstd, gamma, xview, w2d, addend=No
     return dx, dw, dgamma, dbeta
 
 
+def pw_dgrad_bnred(dy, wT, y_unit, scale, shift, act, mean, invstd):
+    """dx = dy @ W (wT = [Nc][K]) and the BN-backward partial sums of the unit whose output gradient dx is.
+    -> (dx [M,Nc], red [parts,2,Nc])"""
+    M, K = dy.numel() // dy.shape[-1], dy.shape[-1]
+    Nc = wT.shape[0]
+    parts = query("mny_pw_dgrad_bnred_parts", M, K, Nc)
+    dx = torch.empty(*dy.shape[:-1], Nc, device=dy.device, dtype=torch.float32)
+    red = torch.empty(parts, 2, Nc, device=dy.device, dtype=torch.float32)
+    call("mny_pw_dgrad_bnred", _p(dy), _p(wT), _p(dx), _p(y_unit), _p(scale), _p(shift), int(act), _p(mean), _p(invstd), _p(red), M, K, Nc, _st())
+    return dx, red
+
+
 def transpose(w2d, dtype=torch.float32):
     R, C = w2d.shape
     out = _new(C, R, like=w2d, dtype=dtype)

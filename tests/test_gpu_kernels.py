@@ -304,3 +304,26 @@ def test_dw_forward_lds_staged_variant(ops, N, H, W, C, s, act, monkeypatch):
     r1, r2 = stats_ref(y)
     check(s1, r1, 1e-4, 1e-3, "staged dw stats sum")
     check(s2, r2, 1e-4, 1e-3, "staged dw stats sumsq")
+
+
+@pytest.mark.parametrize("M,K,Nc,act", [(4 * 11 * 11, 16, 96, 1), (2 * 22 * 22 + 5, 24, 144, 1), (1000, 64, 384, 1), (777, 160, 960, 2),
+                                        (3 * 128 + 1, 96, 512, 0), (130, 32, 192, 1), (64, 320, 960, 1)])
+def test_dgrad_with_fused_bn_backward_reduction(ops, M, K, Nc, act):
+    """mny_pw_dgrad_bnred == mny_pw_fwd (data gradient) followed by mny_bn_bwd_reduce on its output."""
+    dy = rnd(M, K, seed=1).cuda()
+    w = (rnd(K, Nc, seed=2) / K ** 0.5)                      # conv weight [Cout=K][Cin=Nc]
+    y = (rnd(M, Nc, seed=3) * 2).cuda()                      # the fed unit's raw output
+    scale, shift = (1 + 0.3 * rnd(Nc, seed=4)).cuda(), (0.5 * rnd(Nc, seed=5)).cuda()
+    mean, invstd = (0.2 * rnd(Nc, seed=6)).cuda(), (1 + 0.2 * rnd(Nc, seed=7).abs()).cuda()
+    wT = ops.transpose(w.cuda())                              # [Nc][K]
+    dx, red = ops.pw_dgrad_bnred(dy, wT, y, scale, shift, act, mean, invstd)
+    ref_dx = dy.cpu().double() @ w.double()
+    check(dx, ref_dx, 2e-4, 2e-4, "dx")
+    z = y.cpu().double() * scale.cpu().double() + shift.cpu().double()
+    d = {0: torch.ones_like(z), 1: ((z > 0) & (z < 6)).double(), 2: torch.where(z > 0, 1.0, 0.1).double()}[act]
+    dz = dx.cpu().double() * d                                # from the kernel's own dx: isolates the reduction
+    xhat = (y.cpu().double() - mean.cpu().double()) * invstd.cpu().double()
+    s1, s2 = red[:, 0].double().sum(0).cpu(), red[:, 1].double().sum(0).cpu()
+    scale_ = dz.abs().sum(0).max().item()
+    assert (s1 - dz.sum(0)).abs().max().item() <= 2e-5 * scale_ + 1e-5
+    assert (s2 - (dz * xhat).sum(0)).abs().max().item() <= 2e-5 * (dz * xhat).abs().sum(0).max().item() + 1e-5
