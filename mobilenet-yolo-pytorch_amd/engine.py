@@ -490,6 +490,16 @@ class NetPlan:
         for v in outs:
             n_consumers[v.id] += 1
         self.fused_red = {}      # value id -> (partial-sum buffer, rows) written by the data-gradient GEMM that produced the value's gradient
+
+        def takes_own_sums(pn):
+            """True for the thin expand units handled by mny_pw_bnbwd (their stage 1 forms the BN sums itself)."""
+            if pn.op != "pw" or self.bf16 or os.environ.get("MNY_NO_BNFUSE") == "1":
+                return False
+            po, pi = pn.out, pn.ins[0]
+            if pi.act in (_lib.ACT_HSWISH, _lib.ACT_HSIGMOID) or po.act in (_lib.ACT_HSWISH, _lib.ACT_HSIGMOID):
+                return False
+            psh = shape(po)
+            return _lib.query("mny_pw_bnbwd_supported", psh[0] * psh[1] * psh[2], pi.C, po.C) == 1
         for nd in order:
             o = nd.out
             shp = shape(o)
@@ -587,9 +597,12 @@ class NetPlan:
                     bwd.marks[o.name] = len(bwd.calls)
                     continue
                 dY = G if not s.shared else alloc(o)
-                bwd.add(K("mny_bn_bwd_reduce"), G, u.Y, u.scale, u.shift, o.act, u.mean, u.invstd, self.red_ws, M, o.C, self.stream,
-                        meta=dict(flops=0, bytes=2 * eb * M * o.C, shape="M%d C%d" % (M, o.C)))
-                bwd.add("mny_bn_bwd_finalize", self.red_ws, parts, M, gam, u.mean, u.invstd, gv(nd.bn + ".weight"), gv(nd.bn + ".bias"),
+                red_buf, red_parts = self.fused_red.get(o.id, (None, 0))
+                if red_buf is None:
+                    red_buf, red_parts = self.red_ws, parts
+                    bwd.add(K("mny_bn_bwd_reduce"), G, u.Y, u.scale, u.shift, o.act, u.mean, u.invstd, self.red_ws, M, o.C, self.stream,
+                            meta=dict(flops=0, bytes=2 * eb * M * o.C, shape="M%d C%d" % (M, o.C)))
+                bwd.add("mny_bn_bwd_finalize", red_buf, red_parts, M, gam, u.mean, u.invstd, gv(nd.bn + ".weight"), gv(nd.bn + ".bias"),
                         self.coef_ws, o.C, self.stream)
                 bwd.add(K("mny_bn_bwd_apply"), G, u.Y, u.scale, u.shift, o.act, self.coef_ws, dY, M, o.C, self.stream,
                         meta=dict(flops=0, bytes=3 * eb * M * o.C, shape="M%d C%d" % (M, o.C)))
@@ -633,12 +646,11 @@ class NetPlan:
                 else:
                     bwd.add(K("mny_transpose"), w, wT, o.C, i.C, self.stream)
                 prod = i.node
-                if (not self.bf16 and os.environ.get("MNY_NO_REDFUSE") != "1" and prod is not None and prod.op == "dw" and gs[i.id].buf is None
-                        and n_consumers[i.id] == 1 and os.environ.get("MNY_NO_DWFUSE") != "1"
-                        and _lib.query("mny_dw_bnbwd_supported", prod.k, prod.stride) == 1 and prod.ins[0].act != _lib.ACT_HSIGMOID
+                if (not self.bf16 and os.environ.get("MNY_NO_REDFUSE") != "1" and prod is not None and prod.op in ("dw", "pw") and gs[i.id].buf is None
+                        and n_consumers[i.id] == 1 and not takes_own_sums(prod)
                         and _lib.query("mny_pw_dgrad_bnred_supported", M, oc, i.C, i.act) == 1):
-                    # this data gradient IS the complete dL/d(output) of a fused depthwise unit: its BN-backward sums are taken from
-                    # the GEMM's own output tile (+ the unit's raw output), the separate reduce pass is dropped
+                    # this data gradient IS the complete dL/d(output) of a conv+BN+act unit whose backward starts with a BN reduction:
+                    # the sums are taken from the GEMM's own output tile (+ the unit's raw output), the separate reduce pass is dropped
                     pu = self.units[i.id]
                     rparts = _lib.query("mny_pw_dgrad_bnred_parts", M, oc, i.C)
                     rbuf = torch.empty(rparts * 2 * i.C, **f32)
