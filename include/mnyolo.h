@@ -61,6 +61,15 @@ int mny_stem_wgrad(const float* x_nchw, const float* dy, float* dw, float* ws,
                    int N, int H, int W, int Cout, void* stream);
 int mny_stem_wgrad_parts(int N, int H, int W, int Cout);
 
+/* weight gradient of the stem conv straight from the stem unit's OUTPUT gradient g (what autograd hands to
+ * BatchNorm's backward, mobilenetv2.py:40-42): dY = ca*g*act'(scale*y+shift) + cb*y + cc is rebuilt on load from
+ * g and the raw conv output y (coef = mny_bn_bwd_finalize's [3][Cout]), so mny_bn_bwd_apply's dY tensor is
+ * neither written nor re-read.  ws as for mny_stem_wgrad.  Cout with 256 % (Cout/4) == 0. */
+int mny_stem_bnwgrad_supported(int Cout);
+int mny_stem_bnwgrad(const float* x_nchw, const float* g, const float* y, const float* scale,
+                     const float* shift, int act, const float* coef, float* dw, float* ws, int N, int H, int W,
+                     int Cout, void* stream);
+
 /* ---- depthwise KxK (K=3|5), stride 1|2, pad K/2, no bias ---------------------------------
  * replaces nn.Conv2d(C,C,3,s,1,groups=C) at models/mobilenetv2.py:65,79 and
  * models/mbv2_yolo.py:22 (BasicConv depthwise); K=5 for models/mobilenetv3.py:54.        */
@@ -362,6 +371,8 @@ int mny_dw_bnbwd_bf16(const void* g, const void* y, const float* scale, const fl
                       void* stream);
 int mny_pad_rows_bf16(const float* src, const float* alpha, void* dst, int64_t M, int C, int Cp, void* stream);
 int mny_transpose_pad_bf16(const float* src, void* dst, int R, int Cc, int Rp, void* stream);
+int mny_stem_bnwgrad_bf16(const float* x_nchw, const void* g, const void* y, const float* scale, const float* shift, int act,
+                          const float* coef, float* dw, float* ws, int N, int H, int W, int Cout, void* stream);
 int mny_axpy_bf16(const void* src, const float* alpha, void* dst, int accumulate, int64_t n, void* stream);
 /* element-wise storage conversion, n elements (RNE to bf16, exact widening back) */
 int mny_cvt_f32_bf16(const float* src, void* dst, int64_t n, void* stream);

@@ -107,9 +107,14 @@ constexpr int ST_TH = 8, ST_TW = 32, ST_IH = 2 * ST_TH + 1, ST_IW = 2 * ST_TW + 
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void stem_tile_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         T* __restrict__ y, const T* __restrict__ dy,
-                                                        float* __restrict__ parts, StemGeom g, int tiles_h, int tiles_w) {
+                                                        float* __restrict__ parts, StemGeom g, int tiles_h, int tiles_w,
+                                                        const T* __restrict__ yraw = nullptr, const float* __restrict__ scale = nullptr,
+                                                        const float* __restrict__ shift = nullptr, const float* __restrict__ coef = nullptr, int act = 0) {
+    // MODE 2 = MODE 1 with dY rebuilt on load from the unit's output gradient (`dy` argument) and its raw output `yraw`:
+    // dY = ca * G * act'(scale*y+shift) + cb * y + cc  (what mny_bn_bwd_apply would have written and this kernel re-read)
     __shared__ float tile[3 * ST_IH * ST_IWP];
     __shared__ float4 red[256 * 2];
+    __shared__ float4 cst[MODE == 2 ? 5 * 64 : 1];
     const int tid = threadIdx.x;
     const int cgn = g.cgb;                      // channel groups (divides 256)
     const int cgl = tid % cgn, c = cgl * 4;
@@ -121,6 +126,12 @@ __global__ __launch_bounds__(256) void stem_tile_kernel(const float* __restrict_
     } else {
 #pragma unroll
         for (int t = 0; t < 27; ++t) wv[t] = f4zero();     // accumulators in MODE 1
+    }
+    if (MODE == 2) {
+        if (tid < cgn) {
+            cst[tid] = ld4(scale + tid * 4); cst[64 + tid] = ld4(shift + tid * 4); cst[128 + tid] = ld4(coef + tid * 4);
+            cst[192 + tid] = ld4(coef + g.Cout + tid * 4); cst[256 + tid] = ld4(coef + 2 * g.Cout + tid * 4);
+        }
     }
     float4 s1 = f4zero(), s2 = f4zero();
     const int64_t plane = (int64_t)g.H * g.W;
@@ -161,7 +172,15 @@ __global__ __launch_bounds__(256) void stem_tile_kernel(const float* __restrict_
                 add4(s1, acc);
                 fma4(s2, acc, acc);
             } else {
-                const float4 d = ld4(dy + o);
+                float4 d = ld4(dy + o);
+                if (MODE == 2) {
+                    const float4 yv = ld4(yraw + o);
+                    const float4 sc = cst[cgl], sh = cst[64 + cgl], ca = cst[128 + cgl], cb = cst[192 + cgl], cc = cst[256 + cgl];
+                    d.x = fmaf(ca.x, d.x * act_bwd(fmaf(yv.x, sc.x, sh.x), act), fmaf(cb.x, yv.x, cc.x));
+                    d.y = fmaf(ca.y, d.y * act_bwd(fmaf(yv.y, sc.y, sh.y), act), fmaf(cb.y, yv.y, cc.y));
+                    d.z = fmaf(ca.z, d.z * act_bwd(fmaf(yv.z, sc.z, sh.z), act), fmaf(cb.z, yv.z, cc.z));
+                    d.w = fmaf(ca.w, d.w * act_bwd(fmaf(yv.w, sc.w, sh.w), act), fmaf(cb.w, yv.w, cc.w));
+                }
 #pragma unroll
                 for (int ci = 0; ci < 3; ++ci)
 #pragma unroll
@@ -265,6 +284,32 @@ static int stem_wgrad_impl(const float* x_nchw, const T* dy, float* dw, float* w
     if (rc) return rc;
     return launch_reduce_parts(ws, gx, Cout * 27, dw, (hipStream_t)stream);
 }
+// weight gradient of the stem conv straight from the unit's OUTPUT gradient: BN-backward-apply + activation backward are redone on
+// load (coef from mny_bn_bwd_finalize), so the dY tensor is neither written nor re-read
+extern "C" int mny_stem_bnwgrad_supported(int Cout) { return stem_tiled_ok(Cout) && Cout <= 256 ? 1 : 0; }
+template <typename T>
+static int stem_bnwgrad_impl(const float* x_nchw, const T* gout, const T* y, const float* scale, const float* shift, int act, const float* coef,
+                             float* dw, float* ws, int N, int H, int W, int Cout, void* stream) {
+    MNY_REQUIRE(x_nchw && gout && y && scale && shift && coef && dw && ws, "stem_bnwgrad: null pointer");
+    MNY_REQUIRE(mny_stem_bnwgrad_supported(Cout) == 1, "stem_bnwgrad: Cout=%d unsupported", Cout);
+    StemGeom g; int gx;
+    int rc = stem_geom(g, gx, N, H, W, Cout);
+    if (rc) return rc;
+    hipLaunchKernelGGL((stem_tile_kernel<T, 2>), dim3(gx), dim3(256), 0, (hipStream_t)stream, x_nchw, (const float*)nullptr, (T*)nullptr, gout, ws, g,
+                       (int)cdiv(g.Ho, ST_TH), (int)cdiv(g.Wo, ST_TW), y, scale, shift, coef, act);
+    rc = check_launch("stem_tile_kernel<bn-wgrad>");
+    if (rc) return rc;
+    return launch_reduce_parts(ws, gx, Cout * 27, dw, (hipStream_t)stream);
+}
+extern "C" int mny_stem_bnwgrad(const float* x_nchw, const float* g, const float* y, const float* scale, const float* shift, int act,
+                                const float* coef, float* dw, float* ws, int N, int H, int W, int Cout, void* stream) {
+    return stem_bnwgrad_impl<float>(x_nchw, g, y, scale, shift, act, coef, dw, ws, N, H, W, Cout, stream);
+}
+extern "C" int mny_stem_bnwgrad_bf16(const float* x_nchw, const void* g, const void* y, const float* scale, const float* shift, int act,
+                                     const float* coef, float* dw, float* ws, int N, int H, int W, int Cout, void* stream) {
+    return stem_bnwgrad_impl<bf16_t>(x_nchw, (const bf16_t*)g, (const bf16_t*)y, scale, shift, act, coef, dw, ws, N, H, W, Cout, stream);
+}
+
 extern "C" int mny_stem_wgrad(const float* x_nchw, const float* dy, float* dw, float* ws, int N, int H, int W, int Cout, void* stream) {
     return stem_wgrad_impl<float>(x_nchw, dy, dw, ws, N, H, W, Cout, stream);
 }

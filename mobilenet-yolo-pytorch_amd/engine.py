@@ -604,10 +604,16 @@ class NetPlan:
                             meta=dict(flops=0, bytes=2 * eb * M * o.C, shape="M%d C%d" % (M, o.C)))
                 bwd.add("mny_bn_bwd_finalize", red_buf, red_parts, M, gam, u.mean, u.invstd, gv(nd.bn + ".weight"), gv(nd.bn + ".bias"),
                         self.coef_ws, o.C, self.stream)
-                bwd.add(K("mny_bn_bwd_apply"), G, u.Y, u.scale, u.shift, o.act, self.coef_ws, dY, M, o.C, self.stream,
-                        meta=dict(flops=0, bytes=3 * eb * M * o.C, shape="M%d C%d" % (M, o.C)))
+                stem_fused = (nd.op == "stem" and os.environ.get("MNY_NO_STEMFUSE") != "1" and _lib.query("mny_stem_bnwgrad_supported", o.C) == 1)
+                if not stem_fused:
+                    bwd.add(K("mny_bn_bwd_apply"), G, u.Y, u.scale, u.shift, o.act, self.coef_ws, dY, M, o.C, self.stream,
+                            meta=dict(flops=0, bytes=3 * eb * M * o.C, shape="M%d C%d" % (M, o.C)))
             w = P[nd.conv + ".weight"]
-            if nd.op == "stem":
+            if nd.op == "stem" and stem_fused:
+                # the stem has no data gradient: its only consumer of dY is the weight gradient, which rebuilds dY from (G, Y) on load
+                bwd.add(K("mny_stem_bnwgrad"), self.x_ptr, G, u.Y, u.scale, u.shift, o.act, self.coef_ws, gv(nd.conv + ".weight"), self.ws,
+                        N, self.H, self.W, o.C, self.stream)
+            elif nd.op == "stem":
                 if self.side_on:
                     bwd.add_py(self._fork_side, "fork")
                 bwd.add(K("mny_stem_wgrad"), self.x_ptr, dY, gv(nd.conv + ".weight"), self.ws_side, N, self.H, self.W, o.C, self.stream_side)

@@ -58,6 +58,22 @@ def stem_wgrad(x_nchw, dy):
     return dw
 
 
+def stem_bnwgrad(x_nchw, g, y, scale, shift, act, gamma, mean, invstd):
+    """Stem weight gradient from the unit's output gradient g (BN-backward-apply redone on load). -> (dw, dgamma, dbeta)"""
+    N, _, H, W = x_nchw.shape
+    Co = y.shape[3]
+    M = y.numel() // Co
+    parts = query("mny_bn_bwd_parts", M, Co)
+    red = _new(parts, 2, Co, like=gamma)
+    call(_k("mny_bn_bwd_reduce", y), _p(g), _p(y), _p(scale), _p(shift), act, _p(mean), _p(invstd), _p(red), M, Co, _st())
+    dgamma, dbeta, coef = _new(Co, like=gamma), _new(Co, like=gamma), _new(3, Co, like=gamma)
+    call("mny_bn_bwd_finalize", _p(red), parts, M, _p(gamma), _p(mean), _p(invstd), _p(dgamma), _p(dbeta), _p(coef), Co, _st())
+    ws = _new(query("mny_stem_wgrad_parts", N, H, W, Co), Co * 27, like=gamma)
+    dw = _new(Co, 3, 3, 3, like=gamma)
+    call(_k("mny_stem_bnwgrad", y), _p(x_nchw), _p(g), _p(y), _p(scale), _p(shift), act, _p(coef), _p(dw), _p(ws), N, H, W, Co, _st())
+    return dw, dgamma, dbeta
+
+
 # ---- depthwise --------------------------------------------------------------------------------------
 def dw_fwd(view, w, stride, want_stats=True):
     x, sc, sh, act = view

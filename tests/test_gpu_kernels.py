@@ -327,3 +327,22 @@ def test_dgrad_with_fused_bn_backward_reduction(ops, M, K, Nc, act):
     scale_ = dz.abs().sum(0).max().item()
     assert (s1 - dz.sum(0)).abs().max().item() <= 2e-5 * scale_ + 1e-5
     assert (s2 - (dz * xhat).sum(0)).abs().max().item() <= 2e-5 * (dz * xhat).abs().sum(0).max().item() + 1e-5
+
+
+@pytest.mark.parametrize("N,H,W,Co,act,dtype", [(2, 32, 32, 32, 1, torch.float32), (3, 22, 18, 16, 2, torch.float32), (1, 130, 70, 32, 1, torch.float32),
+                                                 (2, 64, 64, 16, 1, torch.bfloat16)])
+def test_stem_weight_gradient_with_fused_bn_backward(ops, N, H, W, Co, act, dtype):
+    """mny_stem_bnwgrad(x, G, Y) == mny_bn_bwd_apply -> mny_stem_wgrad on the same inputs (and the same dgamma / dbeta)."""
+    x = rnd(N, 3, H, W, seed=1).cuda()
+    w = (rnd(Co, 3, 3, 3, seed=2) / 5).cuda()
+    y, st = ops.stem_fwd(x, w, dtype=dtype)
+    gamma, beta = (1 + 0.3 * rnd(Co, seed=4)).cuda(), (0.2 * rnd(Co, seed=5)).cuda()
+    M = y.numel() // Co
+    scale, shift, mean, invstd = ops.bn_finalize(st, M, gamma, beta)
+    g = rnd(*y.shape, seed=8).cuda().to(dtype)
+    dy, dgamma, dbeta = ops.bn_backward(g, y, scale, shift, act, gamma, mean, invstd)
+    ref = ops.stem_wgrad(x, dy)
+    got, dg2, db2 = ops.stem_bnwgrad(x, g, y, scale, shift, act, gamma, mean, invstd)
+    assert torch.equal(dg2, dgamma) and torch.equal(db2, dbeta)
+    tol = 2e-5 if dtype == torch.float32 else 1e-2              # bf16: the unfused path rounds dY to bf16, the fused one keeps it in fp32
+    assert (got - ref).abs().max().item() <= tol * ref.abs().max().item() + 1e-6
