@@ -373,6 +373,10 @@ int mny_pad_rows_bf16(const float* src, const float* alpha, void* dst, int64_t M
 int mny_transpose_pad_bf16(const float* src, void* dst, int R, int Cc, int Rp, void* stream);
 int mny_stem_bnwgrad_bf16(const float* x_nchw, const void* g, const void* y, const float* scale, const float* shift, int act,
                           const float* coef, float* dw, float* ws, int N, int H, int W, int Cout, void* stream);
+int mny_pw_dgrad_bnred_supported_bf16(int64_t M, int K, int Nc, int act);
+int mny_pw_dgrad_bnred_parts_bf16(int64_t M, int K, int Nc);
+int mny_pw_dgrad_bnred_bf16(const void* dy, const void* wT, void* dx, const void* y, const float* scale, const float* shift, int act,
+                            const float* mean, const float* invstd, float* red, int64_t M, int K, int Nc, void* stream);
 int mny_axpy_bf16(const void* src, const float* alpha, void* dst, int accumulate, int64_t n, void* stream);
 /* element-wise storage conversion, n elements (RNE to bf16, exact widening back) */
 int mny_cvt_f32_bf16(const float* src, void* dst, int64_t n, void* stream);

@@ -253,7 +253,7 @@ struct Gemm2Args {   // A / B / addend / C: float* (BF = 0) or bf16_t* (BF = 1)
     int m_tiles, tiles_per_block, gx, n_tiles;
     // RED = 1 (data-gradient GEMM feeding a BN unit): C is that unit's dL/d(output); its BN-backward sums
     // (sum dz, sum dz*xhat per column, dz = C * act'(r_scale*rY + r_shift)) leave through `stats` instead of the plain column sums
-    const float* rY; const float* r_scale; const float* r_shift; const float* r_mean; const float* r_invstd; int r_act;
+    const void* rY; const float* r_scale; const float* r_shift; const float* r_mean; const float* r_invstd; int r_act;
 };
 
 // XF: 0 = A used as is, 1 = scale/shift + min(max(z, slope*z), hi) activation, 2 = scale/shift + hswish
@@ -467,16 +467,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                 const float rslope = act_slope(p.r_act), rhi = act_hi(p.r_act);
                 const int64_t rbase = m0 + wv * 32 + 4 * khalf;
                 const int rows_left = (int)max((int64_t)0, min((int64_t)64, p.M - rbase));   // rows rbase + 8*gq + j, 8*gq + j < rows_left, exist
-                const float* ybase = p.rY + (rows_left > 0 ? rbase : 0) * p.N + cc;
+                const T* ybase = (const T*)p.rY + (rows_left > 0 ? rbase : 0) * p.N + cc;
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {                  // four rows at a time: the loads of a group are all that is in flight
                     float yv[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) yv[j] = ybase[(ccol && 8 * gq + j < rows_left ? 8 * gq + j : 0) * p.N];
+                    for (int j = 0; j < 4; ++j) yv[j] = ld1(ybase + (ccol && 8 * gq + j < rows_left ? 8 * gq + j : 0) * p.N);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float z = fmaf(yv[j], rsc, rsh);
-                        const float dz = acc[u][gq * 4 + j] * ((z > 0.f ? 1.f : rslope) * (z < rhi ? 1.f : 0.f));   // act_bwd(z), min/max family
+                        const float dz = stored<T>(acc[u][gq * 4 + j]) * ((z > 0.f ? 1.f : rslope) * (z < rhi ? 1.f : 0.f));   // act_bwd(z), min/max family
                         if (ccol && 8 * gq + j < rows_left) { s1[u] += dz; s2[u] = fmaf(dz, (yv[j] - rmu) * ris, s2[u]); }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -1924,22 +1924,37 @@ extern "C" int mny_pw_dgrad_bnred_parts(int64_t M, int K, int Nc) {
     if (M <= 0 || K <= 0 || Nc <= 0 || (K & 3)) return MNY_EINVAL;
     return nt2_plan(M, K, Nc, false, 0, kRedMaxTn).gx;
 }
-extern "C" int mny_pw_dgrad_bnred(const float* dy, const float* wT, float* dx, const float* y, const float* scale, const float* shift, int act,
-                                  const float* mean, const float* invstd, float* red, int64_t M, int K, int Nc, void* stream) {
+template <int BF>
+static int pw_dgrad_bnred_impl(const void* dy, const void* wT, void* dx, const void* y, const float* scale, const float* shift, int act,
+                               const float* mean, const float* invstd, float* red, int64_t M, int K, int Nc, void* stream) {
     MNY_REQUIRE(dy && wT && dx && y && scale && shift && mean && invstd && red, "pw_dgrad_bnred: null pointer");
-    MNY_REQUIRE(dgrad_bnred_ok(M, K, Nc, act), "pw_dgrad_bnred: unsupported problem M=%lld K=%d N=%d act=%d (see mny_pw_dgrad_bnred_supported)", (long long)M, K, Nc, act);
-    Nt2Plan p2 = nt2_plan(M, K, Nc, false, 0, kRedMaxTn);
+    MNY_REQUIRE(dgrad_bnred_ok(M, K, Nc, act) && (!BF || (K & 7) == 0), "pw_dgrad_bnred: unsupported problem M=%lld K=%d N=%d act=%d (see mny_pw_dgrad_bnred_supported)",
+                (long long)M, K, Nc, act);
+    Nt2Plan p2 = nt2_plan(M, K, Nc, false, BF, kRedMaxTn);
     MNY_REQUIRE(p2.lds <= 64 * 1024, "pw_dgrad_bnred: K=%d too large", K);
     Gemm2Args g{dy, nullptr, nullptr, MNY_ACT_NONE, wT, nullptr, nullptr, dx, red, M, K, Nc, p2.m_tiles, p2.tiles_per_block, p2.gx, p2.n_tiles,
                 y, scale, shift, mean, invstd, act};
     Nt2Kernel k;
     switch (p2.TN) {
-        case 1: k = (Nt2Kernel)pw_gemm_nt_dma_kernel<1, 0, 0, 1>; break; case 2: k = (Nt2Kernel)pw_gemm_nt_dma_kernel<2, 0, 0, 1>; break;
-        case 3: k = (Nt2Kernel)pw_gemm_nt_dma_kernel<3, 0, 0, 1>; break; case 4: k = (Nt2Kernel)pw_gemm_nt_dma_kernel<4, 0, 0, 1>; break;
-        default: k = (Nt2Kernel)pw_gemm_nt_dma_kernel<5, 0, 0, 1>; break;
+        case 1: k = (Nt2Kernel)pw_gemm_nt_dma_kernel<1, 0, BF, 1>; break; case 2: k = (Nt2Kernel)pw_gemm_nt_dma_kernel<2, 0, BF, 1>; break;
+        case 3: k = (Nt2Kernel)pw_gemm_nt_dma_kernel<3, 0, BF, 1>; break; default: k = (Nt2Kernel)pw_gemm_nt_dma_kernel<4, 0, BF, 1>; break;
     }
     hipLaunchKernelGGL(k, dim3(p2.grid), dim3(256), p2.lds, (hipStream_t)stream, g);
     return check_launch("pw_gemm_nt_dma_kernel<RED>");
+}
+extern "C" int mny_pw_dgrad_bnred(const float* dy, const float* wT, float* dx, const float* y, const float* scale, const float* shift, int act,
+                                  const float* mean, const float* invstd, float* red, int64_t M, int K, int Nc, void* stream) {
+    return pw_dgrad_bnred_impl<0>(dy, wT, dx, y, scale, shift, act, mean, invstd, red, M, K, Nc, stream);
+}
+// bf16 storage: dy, wT, dx, y are bf16; the sums are taken over the ROUNDED dx (what a separate reduce pass would read back)
+extern "C" int mny_pw_dgrad_bnred_supported_bf16(int64_t M, int K, int Nc, int act) { return dgrad_bnred_ok(M, K, Nc, act) && (K & 7) == 0 ? 1 : 0; }
+extern "C" int mny_pw_dgrad_bnred_parts_bf16(int64_t M, int K, int Nc) {
+    if (M <= 0 || K <= 0 || Nc <= 0 || (K & 7)) return MNY_EINVAL;
+    return nt2_plan(M, K, Nc, false, 1, kRedMaxTn).gx;
+}
+extern "C" int mny_pw_dgrad_bnred_bf16(const void* dy, const void* wT, void* dx, const void* y, const float* scale, const float* shift, int act,
+                                       const float* mean, const float* invstd, float* red, int64_t M, int K, int Nc, void* stream) {
+    return pw_dgrad_bnred_impl<1>(dy, wT, dx, y, scale, shift, act, mean, invstd, red, M, K, Nc, stream);
 }
 
 extern "C" int mny_pw_fwd_bf16(const void* x, const float* in_scale, const float* in_shift, int in_act, const void* w,

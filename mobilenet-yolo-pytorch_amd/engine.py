@@ -652,17 +652,17 @@ class NetPlan:
                 else:
                     bwd.add(K("mny_transpose"), w, wT, o.C, i.C, self.stream)
                 prod = i.node
-                if (not self.bf16 and os.environ.get("MNY_NO_REDFUSE") != "1" and prod is not None and prod.op in ("dw", "pw") and gs[i.id].buf is None
+                if (os.environ.get("MNY_NO_REDFUSE") != "1" and prod is not None and prod.op in ("dw", "pw") and gs[i.id].buf is None
                         and n_consumers[i.id] == 1 and not takes_own_sums(prod)
-                        and _lib.query("mny_pw_dgrad_bnred_supported", M, oc, i.C, i.act) == 1):
+                        and _lib.query(K("mny_pw_dgrad_bnred_supported"), M, oc, i.C, i.act) == 1):
                     # this data gradient IS the complete dL/d(output) of a conv+BN+act unit whose backward starts with a BN reduction:
                     # the sums are taken from the GEMM's own output tile (+ the unit's raw output), the separate reduce pass is dropped
                     pu = self.units[i.id]
-                    rparts = _lib.query("mny_pw_dgrad_bnred_parts", M, oc, i.C)
+                    rparts = _lib.query(K("mny_pw_dgrad_bnred_parts"), M, oc, i.C)
                     rbuf = torch.empty(rparts * 2 * i.C, **f32)
                     self.fused_red[i.id] = (rbuf, rparts)
                     contribute_kernel(i, lambda out, addend, dY=dY, wT=wT, M=M, K=oc, Nc=i.C, pu=pu, rbuf=rbuf, act_=i.act: bwd.add(
-                        "mny_pw_dgrad_bnred", dY, wT, out, pu.Y, pu.scale, pu.shift, act_, pu.mean, pu.invstd, rbuf, M, K, Nc, self.stream,
+                        self.K("mny_pw_dgrad_bnred"), dY, wT, out, pu.Y, pu.scale, pu.shift, act_, pu.mean, pu.invstd, rbuf, M, K, Nc, self.stream,
                         meta=dict(flops=2 * M * K * Nc, bytes=self.eb * (M * K + 2 * M * Nc) + 4 * K * Nc, shape="dgrad+red M%d K%d N%d" % (M, K, Nc))))
                 else:
                     contribute_kernel(i, lambda out, addend, dY=dY, wT=wT, M=M, K=oc, Nc=i.C: bwd.add(
