@@ -82,6 +82,20 @@ class CallList:
                 events.append((idx, name, a, b))
 
 
+class _TorchEvent:
+    """Fallback bracket event (see HipEvent._new)."""
+    __slots__ = ("e",)
+
+    def __init__(self):
+        self.e = torch.cuda.Event(enable_timing=True)
+
+    def record(self, stream):
+        self.e.record()
+
+    def elapsed_time(self, other):
+        return self.e.elapsed_time(other.e)
+
+
 class HipEvent:
     """Timing events straight on the HIP runtime (hipEventCreate / hipEventRecord / hipEventElapsedTime through ctypes), drawn from
     a pool that is filled BEFORE the timed region: a `torch.cuda.Event` is created lazily inside its first `record()`, which put
@@ -107,16 +121,27 @@ class HipEvent:
         self.h = h
 
     @classmethod
+    def _new(cls):
+        """A raw HIP event; if the runtime cannot be reached through ctypes (or is not the one torch runs on), a torch event."""
+        if cls._hip is not False:
+            try:
+                return cls()
+            except (OSError, AttributeError, MnyError) as e:
+                warnings.warn("raw HIP events unavailable (%s); timing brackets fall back to torch.cuda.Event" % (e,))
+                cls._hip = False
+        return _TorchEvent()
+
+    @classmethod
     def reserve(cls, n):
         """Rewind the pool and make sure it holds n events (call outside the timed region)."""
         cls._next = 0
         while len(cls._pool) < n:
-            cls._pool.append(cls())
+            cls._pool.append(cls._new())
 
     @classmethod
     def take(cls):
         if cls._next == len(cls._pool):
-            cls._pool.append(cls())
+            cls._pool.append(cls._new())
         cls._next += 1
         return cls._pool[cls._next - 1]
 
