@@ -261,6 +261,61 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2k3_kernel(const T* __restri
     }
 }
 
+// 5x5 stride-2 backward-data, the same idea: a thread owns the 2x2 input quad (2i..2i+1, 2j..2j+1) of 4 channels.  With pad 2,
+// dx[hi][wi] collects dy[ho][wo] * w[hi+2-2ho][wi+2-2wo]; even rows/columns take taps 4,2,0 from dy[i-1..i+1], odd ones taps 3,1 from
+// dy[i..i+1] -> 9 unconditional loads (clamped, zeroed by select), 25 statically chosen taps, no control flow.  (The generic
+// gather kernel above tested parity and bounds per tap: 0.4 TB/s.)
+template <typename T>
+__global__ __launch_bounds__(256) void dw_bwd_data_s2k5_kernel(const T* __restrict__ dy, const float* __restrict__ w,
+                                                               const T* __restrict__ addend, T* __restrict__ dx,
+                                                               int N, int H, int W, int C, int Ho, int Wo, int cgb, int cg_total) {
+    const int cgl = threadIdx.x % cgb, pix = threadIdx.x / cgb, ppb = blockDim.x / cgb;
+    const int cg = blockIdx.y * cgb + cgl;
+    if (cg >= cg_total) return;
+    const int c = cg * 4;
+    float4 wg[25];
+    load_weights<5>(w, c, false, wg);
+    const int Hq = (H + 1) / 2, Wq = (W + 1) / 2;
+    const int64_t nq = (int64_t)N * Hq * Wq;
+    for (int64_t q = (int64_t)blockIdx.x * ppb + pix; q < nq; q += (int64_t)gridDim.x * ppb) {
+        const int j = (int)(q % Wq), i = (int)((q / Wq) % Hq);
+        const int64_t n = q / ((int64_t)Wq * Hq);
+        const T* dn = dy + n * Ho * Wo * C + c;
+        float4 d[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const int r = i + a - 1, q2 = j + b - 1;
+                const float4 v = ld4(dn + ((int64_t)min(max(r, 0), Ho - 1) * Wo + min(max(q2, 0), Wo - 1)) * C);
+                d[a][b] = (r >= 0 && r < Ho && q2 >= 0 && q2 < Wo) ? v : f4zero();
+            }
+        float4 o00 = f4zero(), o01 = f4zero(), o10 = f4zero(), o11 = f4zero();
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                fma4(o00, d[a][b], wg[(4 - 2 * a) * 5 + (4 - 2 * b)]);                        // even row, even column: taps 4,2,0
+                if (b >= 1) fma4(o01, d[a][b], wg[(4 - 2 * a) * 5 + (5 - 2 * b)]);            // odd column: taps 3,1 from dy[j], dy[j+1]
+                if (a >= 1) fma4(o10, d[a][b], wg[(5 - 2 * a) * 5 + (4 - 2 * b)]);
+                if (a >= 1 && b >= 1) fma4(o11, d[a][b], wg[(5 - 2 * a) * 5 + (5 - 2 * b)]);
+            }
+        const int h0 = 2 * i, w0 = 2 * j;
+        const int64_t base = ((n * H + h0) * W + w0) * C + c;
+        const bool hv = h0 + 1 < H, wv2 = w0 + 1 < W;
+        if (addend) {
+            add4(o00, ld4(addend + base));
+            if (wv2) add4(o01, ld4(addend + base + C));
+            if (hv) add4(o10, ld4(addend + base + (int64_t)W * C));
+            if (hv && wv2) add4(o11, ld4(addend + base + (int64_t)W * C + C));
+        }
+        st4(dx + base, o00);
+        if (wv2) st4(dx + base + C, o01);
+        if (hv) st4(dx + base + (int64_t)W * C, o10);
+        if (hv && wv2) st4(dx + base + (int64_t)W * C + C, o11);
+    }
+}
+
 static int dw_geom(DwGeom& g, CgLayout& L, int& gx, int N, int H, int W, int C, int K, int stride) {
     MNY_REQUIRE(K == 3 || K == 5, "dw: kernel size %d unsupported (3 or 5)", K);
     MNY_REQUIRE(stride == 1 || stride == 2, "dw: stride %d unsupported", stride);
@@ -358,11 +413,13 @@ static int dw_bwd_data_impl(const T* dy, const float* w, const T* addend, T* dx,
     CgLayout L = make_stencil_layout(C);
     int64_t want = cdiv((int64_t)N * H * W, L.ppb);
     dim3 grid((unsigned)(want < 8192 ? want : 8192), L.chunks), block(L.threads);
-    if (K == 3) {
-        int64_t wq = cdiv((int64_t)N * ((H + 1) / 2) * ((W + 1) / 2), L.ppb);
-        dim3 gridq((unsigned)(wq < 8192 ? wq : 8192), L.chunks);
+    int64_t wq = cdiv((int64_t)N * ((H + 1) / 2) * ((W + 1) / 2), L.ppb);
+    dim3 gridq((unsigned)(wq < 8192 ? wq : 8192), L.chunks);
+    static const bool gather5 = getenv("MNY_DW_S2K5_GATHER") != nullptr;      // A/B: the generic parity-gather kernel
+    if (K == 3)
         hipLaunchKernelGGL((dw_bwd_data_s2k3_kernel<T>), gridq, block, 0, (hipStream_t)stream, dy, w, addend, dx, N, H, W, C, Ho, Wo, L.cgb, L.cg_total);
-    }
+    else if (!gather5)
+        hipLaunchKernelGGL((dw_bwd_data_s2k5_kernel<T>), gridq, block, 0, (hipStream_t)stream, dy, w, addend, dx, N, H, W, C, Ho, Wo, L.cgb, L.cg_total);
     else hipLaunchKernelGGL((dw_bwd_data_s2_kernel<T, 5>), grid, block, 0, (hipStream_t)stream, dy, w, addend, dx, N, H, W, C, Ho, Wo, L.cgb, L.cg_total);
     return check_launch("dw_bwd_data_s2_kernel");
 }
