@@ -45,7 +45,9 @@ class BatchPrep:
             desc[i] = (off, a.shape[0], a.shape[1])
             off += (a.size + 15) // 16 * 16
         if self._stage is None or self._stage.numel() < off:
-            self._stage = torch.empty(max(off, 1 << 20), dtype=torch.uint8).pin_memory()
+            self._stage = torch.empty(max(off, 1 << 20), dtype=torch.uint8)
+            if torch.cuda.is_available():
+                self._stage = self._stage.pin_memory()
         buf = self._stage.numpy()
         for d, a in zip(desc, arrs):
             buf[d["offset"]:d["offset"] + a.size] = a.reshape(-1)
