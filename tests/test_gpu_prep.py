@@ -97,3 +97,23 @@ def test_out_of_bounds_image_is_flagged_not_overrun(P):
     with pytest.raises(ValueError):
         bp([np.zeros((4, 4), np.uint8)])
     assert _lib.query("mny_prep_ws_bytes", 2, 64, 64, 32, 32) > 0
+
+
+def test_full_batch_properties(P):
+    """bs=256 at the headline size, through size-independent properties: an image already at the target size passes through
+    unresampled; a constant-colour image stays constant; every pixel is a valid normalised uint8 level."""
+    from mobilenet_yolo_pytorch_amd import synthetic
+    r = np.random.RandomState(0)
+    base = synthetic.photos([(352, 352), (375, 500), (500, 333)], seed=9)
+    flat = np.empty((281, 499, 3), np.uint8)
+    flat[...] = (17, 130, 250)
+    imgs = [base[i % 3] for i in range(254)] + [flat, base[0]]
+    out = P.BatchPrep([(352, 352)], MEAN, STD)(imgs).cpu().numpy()
+    assert out.shape == (256, 3, 352, 352)
+    m, s = np.asarray(MEAN, np.float32)[:, None, None], np.asarray(STD, np.float32)[:, None, None]
+    ident = (base[0].astype(np.float32).transpose(2, 0, 1) / np.float32(255) - m) / s
+    assert np.array_equal(out[0], ident) and np.array_equal(out[255], ident) and np.array_equal(out[3], out[0])
+    const = (np.array([17, 130, 250], np.float32)[:, None, None] / np.float32(255) - m) / s
+    assert np.array_equal(out[254], np.broadcast_to(const, (3, 352, 352)))
+    levels = np.rint((out * s + m) * 255)
+    assert np.abs((out * s + m) * 255 - levels).max() < 1e-3 and levels.min() >= 0 and levels.max() <= 255

@@ -164,3 +164,21 @@ def test_bdd_bf16_storage_trains():
     np.testing.assert_allclose(float(seg_out[0]), z["seg_out"][0], rtol=5e-2)
     g = dict(m.named_parameters())["seg_headS16.3.weight"].grad
     assert torch.isfinite(g).all() and g.abs().max() > 0
+
+
+def test_seg_loss_properties_at_full_size():
+    """bs=256 BDD-shaped seg head (26x26x2): loss is 0 with zero gradient when sigmoid(head) == truth; shifting every logit
+    up raises both monitoring means; the two selections partition the tensor."""
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(256, 2, 26, 26, generator=g)
+    t = torch.sigmoid(x).permute(0, 2, 3, 1).contiguous()
+    out3, dx = _seg_loss_gpu(x, t)
+    assert out3[0] < 1e-12 and np.abs(dx).max() < 1e-9
+    t2 = (torch.rand(256, 26, 26, 2, generator=g) > 0.5).float()
+    a, _ = _seg_loss_gpu(x, t2)
+    b, _ = _seg_loss_gpu(x + 1.0, t2)
+    assert b[1] > a[1] and b[2] > a[2]
+    s = torch.sigmoid(x).permute(0, 2, 3, 1)
+    n_obj = int((t2 >= 0.5).sum())
+    tot = (a[1] * n_obj + a[2] * (t2.numel() - n_obj)) / t2.numel()
+    assert abs(tot - float(s.mean())) < 1e-5
