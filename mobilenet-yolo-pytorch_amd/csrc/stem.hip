@@ -102,7 +102,9 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
 // LDS with loads that are contiguous along W (the NCHW fast axis), each thread keeps the 27 filter taps of its 4
 // output channels in registers and reads inputs as LDS broadcasts (the Cout/4 lanes of a pixel share an address).
 // Requires (Cout/4) to divide 256 (Cout = 16, 32, 64 ...).
-constexpr int ST_TH = 8, ST_TW = 32, ST_IH = 2 * ST_TH + 1, ST_IW = 2 * ST_TW + 1, ST_IWP = ST_IW + 1;
+// LDS row = 72 floats: the patch column `col` (0..64, image column 2*wo0 - 1 + col) sits at index col + 3, so that index 0 is image
+// column 64*tw - 4 — 16-byte aligned in the NCHW row — and a row is staged by 18 float4 loads when W % 4 == 0
+constexpr int ST_TH = 8, ST_TW = 32, ST_IH = 2 * ST_TH + 1, ST_IW = 2 * ST_TW + 1, ST_IWP = 72, ST_C0 = 3;
 
 template <typename T, int MODE>
 __global__ __launch_bounds__(256) void stem_tile_kernel(const float* __restrict__ x, const float* __restrict__ w,
@@ -142,11 +144,21 @@ __global__ __launch_bounds__(256) void stem_tile_kernel(const float* __restrict_
         const int ho0 = th * ST_TH, wo0 = tw * ST_TW;
         const int hi0 = 2 * ho0 - 1, wi0 = 2 * wo0 - 1;
         __syncthreads();                        // previous tile fully consumed
-        for (int i = tid; i < 3 * ST_IH * ST_IW; i += 256) {
-            const int col = i % ST_IW, row = (i / ST_IW) % ST_IH, ci = i / (ST_IW * ST_IH);
-            const int hi = hi0 + row, wi = wi0 + col;
-            tile[(ci * ST_IH + row) * ST_IWP + col] =
-                (hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) ? x[(n * 3 + ci) * plane + (int64_t)hi * g.W + wi] : 0.f;
+        if ((g.W & 3) == 0) {                   // 4x fewer, 4x wider loads: the staging loop, not the arithmetic, bounds this kernel
+            for (int i = tid; i < 3 * ST_IH * (ST_IWP / 4); i += 256) {
+                const int q4 = i % (ST_IWP / 4), row = (i / (ST_IWP / 4)) % ST_IH, ci = i / ((ST_IWP / 4) * ST_IH);
+                const int hi = hi0 + row, wi = wi0 - ST_C0 + 4 * q4;         // multiple of 4: a float4 is wholly inside or wholly outside the row
+                float4 v = f4zero();
+                if (hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) v = ld4(x + (n * 3 + ci) * plane + (int64_t)hi * g.W + wi);
+                *reinterpret_cast<float4*>(tile + (ci * ST_IH + row) * ST_IWP + 4 * q4) = v;
+            }
+        } else {
+            for (int i = tid; i < 3 * ST_IH * ST_IW; i += 256) {
+                const int col = i % ST_IW, row = (i / ST_IW) % ST_IH, ci = i / (ST_IW * ST_IH);
+                const int hi = hi0 + row, wi = wi0 + col;
+                tile[(ci * ST_IH + row) * ST_IWP + ST_C0 + col] =
+                    (hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) ? x[(n * 3 + ci) * plane + (int64_t)hi * g.W + wi] : 0.f;
+            }
         }
         __syncthreads();
         for (int pp = tid / cgn; pp < ST_TH * ST_TW; pp += ppi) {
@@ -154,7 +166,7 @@ __global__ __launch_bounds__(256) void stem_tile_kernel(const float* __restrict_
             const int ho = ho0 + pr, wo = wo0 + pc;
             if (ho >= g.Ho || wo >= g.Wo) continue;
             const int64_t o = ((n * g.Ho + ho) * g.Wo + wo) * g.Cout + c;
-            const float* tp = tile + (2 * pr) * ST_IWP + 2 * pc;
+            const float* tp = tile + (2 * pr) * ST_IWP + ST_C0 + 2 * pc;
             if (MODE == 0) {
                 float4 acc = f4zero();
 #pragma unroll
