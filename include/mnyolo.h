@@ -235,6 +235,17 @@ int mny_dw_bnbwd(const float* g, const float* y, const float* scale, const float
 int mny_pad_rows(const float* src, const float* alpha, float* dst, int64_t M, int C, int Cp, void* stream);
 int mny_transpose_pad(const float* src /*[R][Cc]*/, float* dst /*[Cc][Rp]*/, int R, int Cc, int Rp, void* stream);
 
+/* ---- all weight transposes of a backward pass in one launch ----------------------------------------------------
+ * The data-gradient GEMMs read W^T ([Cin][Cout] rows; mny_transpose / mny_transpose_pad per layer).  A static plan
+ * knows every (W, W^T) pair up front: jobs (DEVICE array) describe them, block_job (DEVICE int32[nblocks]) maps a
+ * 32x32-tile workgroup to its job (job.block0 = its first workgroup; a job has ceil(Cc/32)*ceil(Rp/32) of them). */
+typedef struct mny_transpose_job {
+    const float* src; /* [R][Cc] fp32 */
+    void* dst;        /* [Cc][Rp] fp32 (or bf16 for the _bf16 entry point), columns R..Rp-1 zeroed */
+    int32_t R, Cc, Rp, block0;
+} mny_transpose_job;
+int mny_transpose_batch(const mny_transpose_job* jobs, const int32_t* block_job, int nblocks, void* stream);
+
 /* ---- fused multi-tensor AdamW --------------------------------------------------------------
  * replaces optim.AdamW(...).step() at train.py:134,283 (torch semantics: decoupled weight decay, bias-corrected
  * moments, amsgrad off).  `table_dev` is a DEVICE array of chunks; one workgroup updates one chunk (callers split
@@ -377,6 +388,7 @@ int mny_pw_dgrad_bnred_supported_bf16(int64_t M, int K, int Nc, int act);
 int mny_pw_dgrad_bnred_parts_bf16(int64_t M, int K, int Nc);
 int mny_pw_dgrad_bnred_bf16(const void* dy, const void* wT, void* dx, const void* y, const float* scale, const float* shift, int act,
                             const float* mean, const float* invstd, float* red, int64_t M, int K, int Nc, void* stream);
+int mny_transpose_batch_bf16(const mny_transpose_job* jobs, const int32_t* block_job, int nblocks, void* stream);
 int mny_axpy_bf16(const void* src, const float* alpha, void* dst, int accumulate, int64_t n, void* stream);
 /* element-wise storage conversion, n elements (RNE to bf16, exact widening back) */
 int mny_cvt_f32_bf16(const float* src, void* dst, int64_t n, void* stream);

@@ -2052,6 +2052,36 @@ extern "C" int mny_pw_wgrad_bf16(const void* x, const float* in_scale, const flo
     return pw_wgrad_impl<bf16_t>((const bf16_t*)x, in_scale, in_shift, in_act, (const bf16_t*)dy, dw, dbias, ws, M, K, Nc, stream);
 }
 
+// every W^T of a backward pass in ONE launch: block b serves 32x32 tile (b - job.block0) of job block_job[b]
+template <typename T>
+__global__ void transpose_batch_kernel(const mny_transpose_job* __restrict__ jobs, const int32_t* __restrict__ block_job) {
+    __shared__ float tile[32][33];
+    const mny_transpose_job jb = jobs[block_job[blockIdx.x]];
+    const int local = (int)blockIdx.x - jb.block0, tx = (jb.Cc + 31) / 32;
+    const int bx = (local % tx) * 32, by = (local / tx) * 32;
+    const float* src = jb.src;
+    T* dst = (T*)jb.dst;
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        const int r = by + j, c = bx + threadIdx.x;
+        tile[j][threadIdx.x] = (r < jb.R && c < jb.Cc) ? src[(int64_t)r * jb.Cc + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += 8) {
+        const int c = bx + j, r = by + threadIdx.x;
+        if (r < jb.Rp && c < jb.Cc) st1(dst + (int64_t)c * jb.Rp + r, r < jb.R ? tile[threadIdx.x][j] : 0.f);
+    }
+}
+extern "C" int mny_transpose_batch(const mny_transpose_job* jobs, const int32_t* block_job, int nblocks, void* stream) {
+    MNY_REQUIRE(jobs && block_job && nblocks > 0, "transpose_batch: bad arguments");
+    hipLaunchKernelGGL((transpose_batch_kernel<float>), dim3((unsigned)nblocks), dim3(32, 8), 0, (hipStream_t)stream, jobs, block_job);
+    return check_launch("transpose_batch_kernel");
+}
+extern "C" int mny_transpose_batch_bf16(const mny_transpose_job* jobs, const int32_t* block_job, int nblocks, void* stream) {
+    MNY_REQUIRE(jobs && block_job && nblocks > 0, "transpose_batch: bad arguments");
+    hipLaunchKernelGGL((transpose_batch_kernel<bf16_t>), dim3((unsigned)nblocks), dim3(32, 8), 0, (hipStream_t)stream, jobs, block_job);
+    return check_launch("transpose_batch_kernel<bf16>");
+}
+
 extern "C" int mny_transpose(const float* src, float* dst, int R, int Cc, void* stream) {
     MNY_REQUIRE(src && dst && R > 0 && Cc > 0, "transpose: bad arguments");
     hipLaunchKernelGGL((transpose_kernel<float>), dim3((unsigned)cdiv(Cc, 32), (unsigned)cdiv(R, 32)), dim3(32, 8), 0, (hipStream_t)stream, src, dst, R, Cc, R);

@@ -525,6 +525,26 @@ class NetPlan:
                 return False
             psh = shape(po)
             return _lib.query("mny_pw_bnbwd_supported", psh[0] * psh[1] * psh[2], pi.C, po.C) == 1
+        # W^T of every generic pointwise unit, all in one launch at the head of the backward list (one per layer was 39 launches)
+        self.t_batch = os.environ.get("MNY_NO_TBATCH") != "1"
+        if self.t_batch:
+            import numpy as np
+            jobs, block_job = [], []
+            for nd in order:
+                if nd.op not in ("pw", "pwb") or takes_own_sums(nd) or nd.conv in self.wT:
+                    continue
+                w = P[nd.conv + ".weight"]
+                oc = self.head_cp.get(nd.out.id, nd.out.C)
+                wT = torch.empty(nd.ins[0].C, oc, **act)
+                self.wT[nd.conv] = wT
+                nb = ((nd.ins[0].C + 31) // 32) * ((oc + 31) // 32)
+                jobs.append((w.data_ptr(), wT.data_ptr(), nd.out.C, nd.ins[0].C, oc, len(block_job)))
+                block_job += [len(jobs) - 1] * nb
+            if jobs:
+                jt = np.array(jobs, dtype=np.dtype([("src", np.uint64), ("dst", np.uint64), ("R", np.int32), ("Cc", np.int32), ("Rp", np.int32), ("b0", np.int32)]))
+                self.t_jobs = torch.from_numpy(jt.view(np.uint8).copy()).to(dev)
+                self.t_blocks = torch.tensor(block_job, dtype=torch.int32, device=dev)
+                bwd.add(K("mny_transpose_batch"), self.t_jobs, self.t_blocks, len(block_job), self.stream)
         for nd in order:
             o = nd.out
             shp = shape(o)
@@ -670,12 +690,15 @@ class NetPlan:
                 bwd.add(K("mny_pw_wgrad"), xv[0], xv[1], xv[2], xv[3], dY, dwv_, db, self.ws_side if on_side else self.ws, M, i.C, oc,
                         self.stream_side if on_side else self.stream,
                         meta=dict(flops=2 * M * i.C * o.C, bytes=eb * (M * i.C + M * o.C) + 4 * i.C * o.C, shape="M%d K%d N%d" % (M, i.C, oc)))
-                wT = torch.empty(i.C, oc, **act)        # the data-gradient GEMM reads W^T in the activation storage type
-                self.wT[nd.conv] = wT
-                if oc != o.C:
-                    bwd.add(K("mny_transpose_pad"), w, wT, o.C, i.C, oc, self.stream)
+                if self.t_batch:
+                    wT = self.wT[nd.conv]               # filled by the batched transpose at the head of the list
                 else:
-                    bwd.add(K("mny_transpose"), w, wT, o.C, i.C, self.stream)
+                    wT = torch.empty(i.C, oc, **act)    # the data-gradient GEMM reads W^T in the activation storage type
+                    self.wT[nd.conv] = wT
+                    if oc != o.C:
+                        bwd.add(K("mny_transpose_pad"), w, wT, o.C, i.C, oc, self.stream)
+                    else:
+                        bwd.add(K("mny_transpose"), w, wT, o.C, i.C, self.stream)
                 prod = i.node
                 if (os.environ.get("MNY_NO_REDFUSE") != "1" and prod is not None and prod.op in ("dw", "pw") and gs[i.id].buf is None
                         and n_consumers[i.id] == 1 and not takes_own_sums(prod)

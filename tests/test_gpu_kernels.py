@@ -346,3 +346,27 @@ def test_stem_weight_gradient_with_fused_bn_backward(ops, N, H, W, Co, act, dtyp
     assert torch.equal(dg2, dgamma) and torch.equal(db2, dbeta)
     tol = 2e-5 if dtype == torch.float32 else 1e-2              # bf16: the unfused path rounds dY to bf16, the fused one keeps it in fp32
     assert (got - ref).abs().max().item() <= tol * ref.abs().max().item() + 1e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_batched_weight_transposes(dtype):
+    """mny_transpose_batch: every W^T of a backward pass in one launch (ragged shapes, padded rows for the heads)."""
+    import ctypes
+    from mobilenet_yolo_pytorch_amd import _lib
+    shapes = [(75, 512, 76), (16, 32, 16), (1280, 320, 1280), (33, 65, 40), (96, 16, 96)]       # (R = Cout, Cc = Cin, Rp)
+    srcs = [rnd(r, c, seed=i).cuda() for i, (r, c, _) in enumerate(shapes)]
+    dsts = [torch.full((c, rp), 7.0, device="cuda", dtype=dtype) for _, c, rp in shapes]
+    jobs, block_job = [], []
+    for i, ((r, c, rp), s, d) in enumerate(zip(shapes, srcs, dsts)):
+        jobs.append((s.data_ptr(), d.data_ptr(), r, c, rp, len(block_job)))
+        block_job += [i] * (((c + 31) // 32) * ((rp + 31) // 32))
+    jt = np.array(jobs, dtype=np.dtype([("src", np.uint64), ("dst", np.uint64), ("R", np.int32), ("Cc", np.int32), ("Rp", np.int32), ("b0", np.int32)]))
+    jd = torch.from_numpy(jt.view(np.uint8).copy()).cuda()
+    bj = torch.tensor(block_job, dtype=torch.int32, device="cuda")
+    name = "mny_transpose_batch" + ("_bf16" if dtype == torch.bfloat16 else "")
+    _lib.call(name, ctypes.c_void_p(jd.data_ptr()), ctypes.c_void_p(bj.data_ptr()), len(block_job), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    for (r, c, rp), s, d in zip(shapes, srcs, dsts):
+        want = torch.zeros(c, rp, device="cuda")
+        want[:, :r] = s.t()
+        assert torch.equal(d, want.to(dtype))
