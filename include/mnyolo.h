@@ -390,6 +390,14 @@ int mny_pw_dgrad_bnred_bf16(const void* dy, const void* wT, void* dx, const void
                             const float* mean, const float* invstd, float* red, int64_t M, int K, int Nc, void* stream);
 int mny_transpose_batch_bf16(const mny_transpose_job* jobs, const int32_t* block_job, int nblocks, void* stream);
 int mny_axpy_bf16(const void* src, const float* alpha, void* dst, int accumulate, int64_t n, void* stream);
+/* all bf16 weight shadows of a forward pass in one launch: block_job maps a workgroup (4096 elements) to its job */
+typedef struct mny_cvt_job {
+    const float* src;
+    void* dst; /* bf16 */
+    int64_t n;
+    int32_t block0, pad_;
+} mny_cvt_job;
+int mny_cvt_batch_f32_bf16(const mny_cvt_job* jobs, const int32_t* block_job, int nblocks, void* stream);
 /* element-wise storage conversion, n elements (RNE to bf16, exact widening back) */
 int mny_cvt_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
 int mny_cvt_bf16_f32(const void* src, float* dst, int64_t n, void* stream);

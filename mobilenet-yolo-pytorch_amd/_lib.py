@@ -91,6 +91,7 @@ for _n in BF16_TWINS:
     _SIGS[_n + "_bf16"] = _SIGS[_n]
 _SIGS["mny_transpose_bf16"] = _SIGS["mny_transpose"]
 _SIGS["mny_cvt_f32_bf16"] = (c_int, [P, P, c_int64, P])
+_SIGS["mny_cvt_batch_f32_bf16"] = (c_int, [P, P, c_int, P])
 _SIGS["mny_cvt_bf16_f32"] = (c_int, [P, P, c_int64, P])
 EXPORTS = tuple(_SIGS)
 

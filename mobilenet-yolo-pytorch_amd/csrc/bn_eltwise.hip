@@ -608,6 +608,24 @@ extern "C" int mny_cvt_f32_bf16(const float* src, void* dst, int64_t n, void* st
     return check_launch("cvt_kernel");
 }
 
+// every fp32 -> bf16 weight shadow of a forward pass in ONE launch: block b converts elements [4096*(b - job.block0), +4096) of
+// job block_job[b]
+__global__ __launch_bounds__(256) void cvt_batch_kernel(const mny_cvt_job* __restrict__ jobs, const int32_t* __restrict__ block_job) {
+    const mny_cvt_job jb = jobs[block_job[blockIdx.x]];
+    const int64_t base = (int64_t)((int)blockIdx.x - jb.block0) * 4096;
+    bf16_t* dst = (bf16_t*)jb.dst;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int64_t i = base + k * 256 + threadIdx.x;
+        if (i < jb.n) st1(dst + i, jb.src[i]);
+    }
+}
+extern "C" int mny_cvt_batch_f32_bf16(const mny_cvt_job* jobs, const int32_t* block_job, int nblocks, void* stream) {
+    MNY_REQUIRE(jobs && block_job && nblocks > 0, "cvt_batch: bad arguments");
+    hipLaunchKernelGGL(cvt_batch_kernel, dim3((unsigned)nblocks), dim3(256), 0, (hipStream_t)stream, jobs, block_job);
+    return check_launch("cvt_batch_kernel");
+}
+
 extern "C" int mny_cvt_bf16_f32(const void* src, float* dst, int64_t n, void* stream) {
     MNY_REQUIRE(src && dst && n > 0, "cvt_bf16_f32: bad arguments");
     int64_t blocks = cdiv(n / 4 > 0 ? n / 4 : 1, 256);

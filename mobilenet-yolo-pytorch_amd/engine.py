@@ -194,6 +194,8 @@ class NetPlan:
         self.eager_steps = 0
         self.x_static = None
         self.fwd = CallList()
+        self.cvt_batch = os.environ.get("MNY_NO_CBATCH") != "1"
+        self._cvt_jobs = []
         self.head32 = {}         # bf16 storage: value id -> fp32 copy of a detection head
         self.units = {}          # value id -> _Unit
         self.reals = {}          # value id -> tensor
@@ -291,6 +293,7 @@ class NetPlan:
             else:
                 raise AssertionError(nd.op)
 
+        self._flush_cvt_jobs()
         self.heads = [self.head32.get(o.id, self.reals[o.id]) for o in g.outputs]
         self.seg_head = self.head32.get(g.seg_out.id, self.reals[g.seg_out.id]) if g.seg_out is not None else None
         self.loss_outputs = list(g.outputs) + ([g.seg_out] if g.seg_out is not None else [])     # values a loss reads
@@ -726,8 +729,26 @@ class NetPlan:
         if not self.bf16:
             return w
         w16 = torch.empty(w.shape, device=self.dev, dtype=torch.bfloat16)
-        self.fwd.add("mny_cvt_f32_bf16", w, w16, w.numel(), self.stream)
+        if self.cvt_batch:
+            self._cvt_jobs.append((w, w16))          # one batched conversion at the head of the forward list (_flush_cvt_jobs)
+        else:
+            self.fwd.add("mny_cvt_f32_bf16", w, w16, w.numel(), self.stream)
         return w16
+
+    def _flush_cvt_jobs(self):
+        if not self._cvt_jobs:
+            return
+        import numpy as np
+        jobs, block_job = [], []
+        for w, w16 in self._cvt_jobs:
+            jobs.append((w.data_ptr(), w16.data_ptr(), w.numel(), len(block_job), 0))
+            block_job += [len(jobs) - 1] * ((w.numel() + 4095) // 4096)
+        jt = np.array(jobs, dtype=np.dtype([("src", np.uint64), ("dst", np.uint64), ("n", np.int64), ("b0", np.int32), ("pad", np.int32)]))
+        self.c_jobs = torch.from_numpy(jt.view(np.uint8).copy()).to(self.dev)
+        self.c_blocks = torch.tensor(block_job, dtype=torch.int32, device=self.dev)
+        self.fwd.add("mny_cvt_batch_f32_bf16", self.c_jobs, self.c_blocks, len(block_job), self.stream)
+        self.fwd.calls.insert(0, self.fwd.calls.pop())       # the shadows must exist before the first GEMM
+        self.fwd.keep += [t for pair in self._cvt_jobs for t in pair]
 
     def K(self, name):
         """Entry point for the plan's activation storage type."""
