@@ -133,6 +133,29 @@ def test_train_step_matches_oracle_bs8_352():
         assert abs(a - b) <= 2e-2 * b + 2e-5, (k, a, b)
 
 
+@pytest.mark.parametrize("size,bs", [(288, 3), (416, 2), (320, 5)])
+def test_multiscale_sizes_match_oracle(size, bs):
+    """The other entries of train_img_size (models/voc/config.yaml:4-9): every size builds its own static plan — other GEMM
+    tilings, other fused-reduction partial-row counts, ragged tile edges."""
+    ref = procedural.fill_state_dict_(net_ref.RefYolo(procedural.VOC_CONFIG)).train()
+    m = _model(train=True)
+    x = procedural.images(bs, size, size, seed=size)
+    tg = procedural.targets(bs, seed=size + 1, empty_every=0)
+    rr = ref(x, tg)
+    (rr[0][0] + rr[1][0]).backward()
+    res = m(x.cuda(), tg)
+    (res[0][0] + res[1][0]).backward()
+    for i in range(2):
+        np.testing.assert_allclose(float(res[i][0]), float(rr[i][0]), rtol=2e-3, atol=1e-5)
+    rp = dict(ref.named_parameters())
+    for k, p in m.named_parameters():
+        if rp[k].grad is None:
+            assert p.grad is None
+            continue
+        a, b = p.grad.double().norm().item(), rp[k].grad.double().norm().item()
+        assert abs(a - b) <= 2e-2 * b + 2e-5, (k, a, b)
+
+
 def test_second_step_and_grad_accumulation():
     m = _model(train=True, sync=False)
     x = procedural.images(4, 96, 96, seed=1).cuda()
