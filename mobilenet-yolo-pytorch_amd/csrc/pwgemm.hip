@@ -1360,6 +1360,7 @@ struct BnwArgs {
     const float* X; const float* xsc; const float* xsh; int xact;
     float* partial; unsigned long long* mask;   // mask[i*npairs + m/2]: bit (m&1)*32 + c%32 = [act'(z) is the "on" value]
     int64_t npairs; int64_t M; int K; int N; int64_t rows_per_block;
+    int tiles_total;    // ceil(N/32); blockIdx.y selects a slice of TI column tiles (wide units run as two slices: occupancy)
 };
 
 // partial layout per split: P1[N*K] | Gram[K*K] | s1[N] | s2[N] | s3[K]
@@ -1381,11 +1382,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     const float xslope = act_slope(p.xact), xhi = act_hi(p.xact);
     const float aslope = act_slope(p.act), ahi = act_hi(p.act);
     const int krow0 = wave * (KC / 4);
+    const int tile_off = blockIdx.y * TI, n_off = tile_off * 32;      // this block's column slice
+    const bool slice0 = blockIdx.y == 0;                              // Gram / colsum(X) are taken once
 
     float sc[TI], sh[TI], mu[TI], is[TI], s1[TI], s2[TI];
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
-        const int co = i * 32 + li;
+        const int co = n_off + i * 32 + li;
         const bool ok = co < p.N;
         sc[i] = ok ? p.sc[co] : 0.f; sh[i] = ok ? p.sh[co] : 0.f; mu[i] = ok ? p.mean[co] : 0.f; is[i] = ok ? p.invstd[co] : 0.f;
         s1[i] = 0.f; s2[i] = 0.f;
@@ -1408,8 +1411,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
         d_row[i] = q / W4;
         const int c = (q % W4) * 4;
         d_lds[i] = (d_kind[i] == 0 ? 0 : (d_kind[i] == 1 ? G_ST : 2 * G_ST)) + jj * 256;
-        d_ok[i] = c < (d_kind[i] == 2 ? p.K : p.N);
-        d_off[i] = c;
+        d_ok[i] = d_kind[i] == 2 ? c < p.K : n_off + c < p.N;
+        d_off[i] = d_kind[i] == 2 ? c : n_off + c;
     }
     auto issue = [&](int64_t m0, int slot) {
         float* stage = smem + slot * STAGE;
@@ -1454,7 +1457,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
                 const float z = fmaf(y, sc[i], sh[i]);
                 const bool on = z > 0.f && z < ahi;                                // act' = on ? 1 : slope
                 const unsigned long long bal = __ballot(on);
-                if (lane == 0 && m0 + krow0 + kp * 2 < m_end) p.mask[(int64_t)i * p.npairs + pair] = bal;
+                if (lane == 0 && m0 + krow0 + kp * 2 < m_end && tile_off + i < p.tiles_total) p.mask[(int64_t)(tile_off + i) * p.npairs + pair] = bal;
                 const float dz = on ? g : g * aslope;
                 s1[i] += dz;
                 s2[i] = fmaf(dz, (y - mu[i]) * is[i], s2[i]);
@@ -1462,7 +1465,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
             }
 #pragma unroll
             for (int i = 0; i < TI; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], b, acc[i], 0, 0, 0);
-            gram = __builtin_amdgcn_mfma_f32_32x32x2f32(b, b, gram, 0, 0, 0);
+            if (slice0) gram = __builtin_amdgcn_mfma_f32_32x32x2f32(b, b, gram, 0, 0, 0);
         }
     };
 
@@ -1504,8 +1507,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
         }
     };
 #pragma unroll
-    for (int i = 0; i < TI; ++i) reduce_tile(acc[i], dst, p.N, p.K, p.K, i * 32);
-    reduce_tile(gram, dst + (int64_t)p.N * p.K, p.K, p.K, p.K, 0);
+    for (int i = 0; i < TI; ++i) reduce_tile(acc[i], dst, p.N, p.K, p.K, n_off + i * 32);
+    if (slice0) reduce_tile(gram, dst + (int64_t)p.N * p.K, p.K, p.K, p.K, 0);
     // vectors: lanes l and l^32 hold the same channel
     __syncthreads();
     float* vred = smem;                        // [4][2*TI+1][32]
@@ -1524,9 +1527,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
         const int v = e / 32, l = e % 32;
         float a = 0.f;
         for (int w = 0; w < 4; ++w) a += vred[(w * (2 * TI + 1) + v) * 32 + l];
-        if (v < TI) { const int co = v * 32 + l; if (co < p.N) vdst[co] = a; }
-        else if (v < 2 * TI) { const int co = (v - TI) * 32 + l; if (co < p.N) vdst[p.N + co] = a; }
-        else if (l < p.K) vdst[2 * p.N + l] = a;
+        if (v < TI) { const int co = n_off + v * 32 + l; if (co < p.N) vdst[co] = a; }
+        else if (v < 2 * TI) { const int co = n_off + (v - TI) * 32 + l; if (co < p.N) vdst[p.N + co] = a; }
+        else if (l < p.K && slice0) vdst[2 * p.N + l] = a;
     }
 }
 
@@ -1816,7 +1819,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     }
 }
 
-struct BnwPlan { int TI, splits; int64_t rows_per_block; size_t lds1, lds2; int gx2, tiles_per_block, m_tiles; };
+struct BnwPlan { int TI, splits; int64_t rows_per_block; size_t lds1, lds2; int gx2, tiles_per_block, m_tiles; int TIs, nsl; };
 
 static bool bnw_supported(int64_t M, int K, int N) {
     return M >= 4096 && K <= 32 && K % 4 == 0 && N % 4 == 0 && N <= 192 && N > K;
@@ -1826,13 +1829,18 @@ static BnwPlan bnw_plan(int64_t M, int K, int N) {
     BnwPlan pl;
     pl.TI = (int)cdiv(N, 32);
     // whole waves of resident workgroups: TI <= 3 -> 168 VGPRs, 3 per CU (768); TI 4,5 -> 2 per CU (512); TI 6 -> 1 per CU
-    int64_t splits = pl.TI <= 3 ? 768 : 1024;
+    // stage 1 of a wide unit (5 or 6 column tiles: 225+ VGPRs, 1-2 workgroups per CU) runs as two column slices of <= 3 tiles
+    // (168 VGPRs, 3 per CU): each slice streams its half of G and Y and all of the thin X
+    static const bool slicing = getenv("MNY_BNW_NOSLICE") == nullptr;
+    pl.nsl = (slicing && pl.TI >= 5) ? 2 : 1;
+    pl.TIs = (int)cdiv(pl.TI, pl.nsl);
+    int64_t splits = (pl.TIs <= 3 ? 768 : 1024) / pl.nsl;
     const int64_t max_splits = cdiv(M, 64);
     if (splits > max_splits) splits = max_splits;
     pl.rows_per_block = cdiv(cdiv(M, splits), 16) * 16;
     pl.splits = (int)cdiv(M, pl.rows_per_block);
-    pl.lds1 = (size_t)3 * 16 * (2 * 32 * pl.TI + 32) * sizeof(float);
-    const size_t need = (size_t)4 * (2 * pl.TI + 1) * 32 * sizeof(float);
+    pl.lds1 = (size_t)3 * 16 * (2 * 32 * pl.TIs + 32) * sizeof(float);
+    const size_t need = (size_t)4 * (2 * pl.TIs + 1) * 32 * sizeof(float);
     if (pl.lds1 < need) pl.lds1 = need;
     if (pl.lds1 < 3 * 16 * 64 * sizeof(float)) pl.lds1 = 3 * 16 * 64 * sizeof(float);
     pl.lds2 = (size_t)3 * (64 * 32 + 32 * 32) * sizeof(float) + 64 * sizeof(float) + 2 * 16 * 64 * sizeof(float);
@@ -2135,8 +2143,8 @@ extern "C" int mny_pw_bnbwd(const float* g, const float* y, const float* scale, 
     moff = (moff + 15) / 16 * 16;                                      // 64-byte aligned mask words
     unsigned long long* mask = reinterpret_cast<unsigned long long*>(ws + moff);
     const int64_t npairs = (M / 2 + 66) / 2 * 2;                      // even (16-B aligned rows of words) + a tile of slack
-    BnwArgs a{g, y, scale, shift, act, mean, invstd, x, in_scale, in_shift, in_act, ws, mask, npairs, M, K, Nc, pl.rows_per_block};
-    dim3 grid(pl.splits), block(256);
+    BnwArgs a{g, y, scale, shift, act, mean, invstd, x, in_scale, in_shift, in_act, ws, mask, npairs, M, K, Nc, pl.rows_per_block, pl.TI};
+    dim3 grid(pl.splits, pl.nsl), block(256);
     static bool attr1 = false;
     if (!attr1) {                                   // TI >= 5 needs more than 64 KB of dynamic LDS
         if (hipFuncSetAttribute((const void*)pw_bnbwd_stage1_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ||
@@ -2145,7 +2153,7 @@ extern "C" int mny_pw_bnbwd(const float* g, const float* y, const float* scale, 
         }
         attr1 = true;
     }
-    switch (pl.TI) {
+    switch (pl.TIs) {
         case 1: hipLaunchKernelGGL((pw_bnbwd_stage1_kernel<1>), grid, block, pl.lds1, st, a); break;
         case 2: hipLaunchKernelGGL((pw_bnbwd_stage1_kernel<2>), grid, block, pl.lds1, st, a); break;
         case 3: hipLaunchKernelGGL((pw_bnbwd_stage1_kernel<3>), grid, block, pl.lds1, st, a); break;
