@@ -1260,9 +1260,17 @@ static WgPlan wg_plan(int64_t M, int K, int N, bool bf16 = false) {
     WgPlan pl;
     const int nco = (int)cdiv(N, 32), nci = (int)cdiv(K, 32);
     int BI, BJ, KC;
+    static const bool slice96 = getenv("MNY_WG_NOSLICE96") == nullptr;
     if (nco * nci <= 6) {
         pl.mode = 1; pl.TI = nco; pl.TJ = nci; BI = 32 * nco; BJ = 32 * nci; KC = bf16 ? 64 : 32;
         pl.gx = pl.gy = 1;
+    } else if (slice96 && !bf16 && ((K == 96 && N >= 192) || (N == 96 && K >= 192))) {
+        // a 96-wide side is 1.5 of the 64-wide units of the 2x2-wave tiles (25-33 % of the MFMAs multiply padding): slice the
+        // other side instead and give every workgroup exact 96 x 64 tiles in the all-waves-share-the-tile mode
+        pl.mode = 1; KC = 32;
+        if (K == 96) { pl.TJ = 3; pl.TI = 2; } else { pl.TI = 3; pl.TJ = 2; }
+        BI = 32 * pl.TI; BJ = 32 * pl.TJ;
+        pl.gx = (int)cdiv(N, BI); pl.gy = (int)cdiv(K, BJ);
     } else {
         pl.mode = 0; BI = pick_block(N); BJ = pick_block(K); KC = 16;
         pl.TI = BI / 64; pl.TJ = BJ / 64;
