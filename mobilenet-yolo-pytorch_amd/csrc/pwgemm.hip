@@ -1299,13 +1299,16 @@ __global__ __launch_bounds__(256) void reduce_parts_kernel(const float* __restri
     __shared__ double red[8][32];
     const int ol = threadIdx.x & 31, slice = threadIdx.x >> 5;
     const int64_t i = (int64_t)blockIdx.x * 32 + ol;
-    double s0 = 0.0, s1 = 0.0;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     if (i < n) {
-        int pidx = slice;
-        for (; pidx + 8 < nparts; pidx += 16) { s0 += (double)parts[(int64_t)pidx * n + i]; s1 += (double)parts[(int64_t)(pidx + 8) * n + i]; }
-        if (pidx < nparts) s0 += (double)parts[(int64_t)pidx * n + i];
+        int pidx = slice;                              // four partial rows in flight per thread: the loop is pure load latency otherwise
+        for (; pidx + 24 < nparts; pidx += 32) {
+            s0 += (double)parts[(int64_t)pidx * n + i];        s1 += (double)parts[(int64_t)(pidx + 8) * n + i];
+            s2 += (double)parts[(int64_t)(pidx + 16) * n + i]; s3 += (double)parts[(int64_t)(pidx + 24) * n + i];
+        }
+        for (; pidx < nparts; pidx += 8) s0 += (double)parts[(int64_t)pidx * n + i];
     }
-    red[slice][ol] = s0 + s1;
+    red[slice][ol] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (slice == 0 && i < n) {
         double s = 0.0;
