@@ -455,11 +455,11 @@ def main():
                 "algorithmic_hbm_gbs": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1)}
         # HBM bytes per launch of the dominant entry point from the PMC counters: bench.py cannot run rocprofv3 on itself, so this is
         # the committed result of the prescribed separate --pmc passes over this very command (profiles/README.md), headline config only
-        side = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01g_traffic_mny_pw_fwd.json")
+        side = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01h_traffic_mny_pw_fwd.json")
         if (a.arch, a.size, a.batch, a.dtype, world) == ("mbv2", SIZE, BATCH, "f32", 1) and dom == "mny_pw_fwd" and os.path.exists(side):
             tj = json.load(open(side))
             roof["traffic"] = round(tj["hbm_bytes_per_launch"])
-            roof["traffic_source"] = "profiles/r01g_traffic_mny_pw_fwd.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + --pmc WRITE_SIZE, separate passes"
+            roof["traffic_source"] = "profiles/r01h_traffic_mny_pw_fwd.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + --pmc WRITE_SIZE, separate passes"
         res = {
             "metric": "images/sec MobileNetV2-YOLO 352x352 fwd+bwd @ bs256" if (a.arch, a.size, a.batch, a.dtype) == ("mbv2", SIZE, BATCH, "f32")
             else "images/sec %s-YOLO %dx%d fwd+bwd @ bs%d (NOT the headline config)" % (a.arch, a.size, a.size, a.batch), "value": round(world * a.batch * a.steps / dt, 2),
