@@ -269,7 +269,7 @@ int mny_adamw_step(const mny_adamw_chunk* table_dev, int nchunks, double lr, dou
  * produced and the unit's raw output y[M,Nc]:  red[part][0][c] = sum dz, red[part][1][c] = sum dz*xhat,
  * dz = dx * act'(scale*y+shift), xhat = (y-mean)*invstd — exactly what mny_bn_bwd_reduce(dx, y, ...) writes,
  * in the same [parts][2][Nc] layout (parts = mny_pw_dgrad_bnred_parts(M,K,Nc)); feed it to mny_bn_bwd_finalize.
- * Saves the reduce pass's read of dx.  fp32, K % 4 == 0, act in {NONE, RELU6, LEAKY, RELU}. */
+ * Saves the reduce pass's read of dx.  K % 4 == 0 (K % 8 for the bf16 twin), any activation. */
 int mny_pw_dgrad_bnred_supported(int64_t M, int K, int Nc, int act);
 int mny_pw_dgrad_bnred_parts(int64_t M, int K, int Nc); /* partial rows it writes */
 int mny_pw_dgrad_bnred(const float* dy, const float* wT, float* dx, const float* y, const float* scale,

@@ -476,7 +476,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float z = fmaf(yv[j], rsc, rsh);
-                        const float dz = stored<T>(acc[u][gq * 4 + j]) * ((z > 0.f ? 1.f : rslope) * (z < rhi ? 1.f : 0.f));   // act_bwd(z), min/max family
+                        const float dact = p.r_act >= MNY_ACT_HSWISH ? act_bwd(z, p.r_act) : (z > 0.f ? 1.f : rslope) * (z < rhi ? 1.f : 0.f);
+                        const float dz = stored<T>(acc[u][gq * 4 + j]) * dact;
                         if (ccol && 8 * gq + j < rows_left) { s1[u] += dz; s2[u] = fmaf(dz, (yv[j] - rmu) * ris, s2[u]); }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -1935,8 +1936,7 @@ extern "C" int mny_pw_fwd(const float* x, const float* in_scale, const float* in
 constexpr int kRedMaxTn = 4;
 static bool dgrad_bnred_ok(int64_t M, int K, int Nc, int act) {
     if (K >= 512 && Nc >= 512) return false;      // matrix-pipe-bound: the reduce pass it would save is cheaper than the longer epilogue
-    return M > 0 && K > 0 && Nc > 0 && (K & 3) == 0 && (act == MNY_ACT_NONE || act == MNY_ACT_RELU6 || act == MNY_ACT_LEAKY || act == MNY_ACT_RELU) &&
-           getenv("MNY_GEMM_V1") == nullptr;
+    return M > 0 && K > 0 && Nc > 0 && (K & 3) == 0 && act >= MNY_ACT_NONE && act <= MNY_ACT_HSIGMOID && getenv("MNY_GEMM_V1") == nullptr;
 }
 extern "C" int mny_pw_dgrad_bnred_supported(int64_t M, int K, int Nc, int act) { return dgrad_bnred_ok(M, K, Nc, act) ? 1 : 0; }
 extern "C" int mny_pw_dgrad_bnred_parts(int64_t M, int K, int Nc) {

@@ -703,7 +703,10 @@ class NetPlan:
                     else:
                         bwd.add(K("mny_transpose"), w, wT, o.C, i.C, self.stream)
                 prod = i.node
-                if (os.environ.get("MNY_NO_REDFUSE") != "1" and prod is not None and prod.op in ("dw", "pw") and gs[i.id].buf is None
+                # (fp32 plans only: with bf16 storage the epilogue's 2-byte loads of the unit's output cost what the saved pass did —
+                # same-box A/B 3 281 vs 3 293 img/s on MobileNetV3 512 — MNY_REDFUSE_BF16=1 turns it on for measurements)
+                if (os.environ.get("MNY_NO_REDFUSE") != "1" and (not self.bf16 or os.environ.get("MNY_REDFUSE_BF16") == "1")
+                        and prod is not None and prod.op in ("dw", "pw") and gs[i.id].buf is None
                         and n_consumers[i.id] == 1 and not takes_own_sums(prod)
                         and _lib.query(K("mny_pw_dgrad_bnred_supported"), M, oc, i.C, i.act) == 1):
                     # this data gradient IS the complete dL/d(output) of a conv+BN+act unit whose backward starts with a BN reduction:

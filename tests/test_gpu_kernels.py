@@ -307,7 +307,7 @@ def test_dw_forward_lds_staged_variant(ops, N, H, W, C, s, act, monkeypatch):
 
 
 @pytest.mark.parametrize("M,K,Nc,act", [(4 * 11 * 11, 16, 96, 1), (2 * 22 * 22 + 5, 24, 144, 1), (1000, 64, 384, 1), (777, 160, 960, 2),
-                                        (3 * 128 + 1, 96, 512, 0), (130, 32, 192, 1), (64, 320, 960, 1)])
+                                        (3 * 128 + 1, 96, 512, 0), (130, 32, 192, 1), (64, 320, 960, 1), (900, 40, 120, 4), (500, 112, 672, 3)])
 def test_dgrad_with_fused_bn_backward_reduction(ops, M, K, Nc, act):
     """mny_pw_dgrad_bnred == mny_pw_fwd (data gradient) followed by mny_bn_bwd_reduce on its output."""
     dy = rnd(M, K, seed=1).cuda()
@@ -320,7 +320,8 @@ def test_dgrad_with_fused_bn_backward_reduction(ops, M, K, Nc, act):
     ref_dx = dy.cpu().double() @ w.double()
     check(dx, ref_dx, 2e-4, 2e-4, "dx")
     z = y.cpu().double() * scale.cpu().double() + shift.cpu().double()
-    d = {0: torch.ones_like(z), 1: ((z > 0) & (z < 6)).double(), 2: torch.where(z > 0, 1.0, 0.1).double()}[act]
+    d = {0: torch.ones_like(z), 1: ((z > 0) & (z < 6)).double(), 2: torch.where(z > 0, 1.0, 0.1).double(), 3: (z > 0).double(),
+         4: torch.where(z <= -3, 0.0, torch.where(z >= 3, 1.0, (2 * z + 3) / 6)).double()}[act]      # 3: relu, 4: h-swish
     dz = dx.cpu().double() * d                                # from the kernel's own dx: isolates the reduction
     xhat = (y.cpu().double() - mean.cpu().double()) * invstd.cpu().double()
     s1, s2 = red[:, 0].double().sum(0).cpu(), red[:, 1].double().sum(0).cpu()
@@ -370,3 +371,32 @@ def test_batched_weight_transposes(dtype):
         want = torch.zeros(c, rp, device="cuda")
         want[:, :r] = s.t()
         assert torch.equal(d, want.to(dtype))
+
+
+def test_dgrad_with_fused_bn_backward_reduction_bf16(ops):
+    """bf16 twin: sums are taken over the ROUNDED dx (what a separate reduce pass would read back), y is bf16."""
+    import ctypes
+    from mobilenet_yolo_pytorch_amd import _lib
+    M, K, Nc, act = 777, 96, 384, 1
+    bf = torch.bfloat16
+    dy = rnd(M, K, seed=1).cuda().to(bf)
+    w = (rnd(K, Nc, seed=2) / K ** 0.5)
+    y = (rnd(M, Nc, seed=3) * 2).cuda().to(bf)
+    scale, shift = (1 + 0.3 * rnd(Nc, seed=4)).cuda(), (0.5 * rnd(Nc, seed=5)).cuda()
+    mean, invstd = (0.2 * rnd(Nc, seed=6)).cuda(), (1 + 0.2 * rnd(Nc, seed=7).abs()).cuda()
+    wT = ops.transpose(w.cuda(), dtype=bf)
+    parts = _lib.query("mny_pw_dgrad_bnred_parts_bf16", M, K, Nc)
+    dx = torch.empty(M, Nc, device="cuda", dtype=bf)
+    red = torch.empty(parts, 2, Nc, device="cuda")
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    _lib.call("mny_pw_dgrad_bnred_bf16", p(dy), p(wT), p(dx), p(y), p(scale), p(shift), act, p(mean), p(invstd), p(red), M, K, Nc,
+              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    ref_dx = dy.float().cpu().double() @ w.to(bf).float().double()
+    assert (dx.float().cpu().double() - ref_dx).abs().max().item() <= 2 ** -7 * ref_dx.abs().max().item()
+    z = y.float().cpu().double() * scale.cpu().double() + shift.cpu().double()
+    dz = dx.float().cpu().double() * ((z > 0) & (z < 6)).double()
+    xhat = (y.float().cpu().double() - mean.cpu().double()) * invstd.cpu().double()
+    s1, s2 = red[:, 0].double().sum(0).cpu(), red[:, 1].double().sum(0).cpu()
+    assert (s1 - dz.sum(0)).abs().max().item() <= 2e-5 * dz.abs().sum(0).max().item() + 1e-5
+    assert (s2 - (dz * xhat).sum(0)).abs().max().item() <= 2e-5 * (dz * xhat).abs().sum(0).max().item() + 1e-5
