@@ -101,6 +101,7 @@ class HipEvent:
     a pool that is filled BEFORE the timed region: a `torch.cuda.Event` is created lazily inside its first `record()`, which put
     ~10 us of host work per bracket into the measured step (invisible at bs=256, 15 % of the step at bs=64)."""
     _hip = None
+    _checked = False
     _pool = []
     _next = 0
     __slots__ = ("h",)
@@ -108,7 +109,16 @@ class HipEvent:
     @classmethod
     def _rt(cls):
         if cls._hip is None:
-            cls._hip = ctypes.CDLL("libamdhip64.so")
+            path = "libamdhip64.so"
+            try:                                   # the copy of the runtime this process (torch) already runs on, not whatever the loader finds first
+                with open("/proc/self/maps") as f:
+                    for line in f:
+                        if "libamdhip64.so" in line:
+                            path = line.split()[-1]
+                            break
+            except OSError:
+                pass
+            cls._hip = ctypes.CDLL(path)
             cls._hip.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
             cls._hip.hipEventRecord.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
             cls._hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
@@ -125,8 +135,16 @@ class HipEvent:
         """A raw HIP event; if the runtime cannot be reached through ctypes (or is not the one torch runs on), a torch event."""
         if cls._hip is not False:
             try:
-                return cls()
-            except (OSError, AttributeError, MnyError) as e:
+                ev = cls()
+                if not cls._checked:               # one record / elapsed round trip on torch's stream before trusting the handle
+                    ev2 = cls()
+                    st = _vp(torch.cuda.current_stream().cuda_stream)
+                    ev.record(st); ev2.record(st)
+                    torch.cuda.current_stream().synchronize()
+                    ev.elapsed_time(ev2)
+                    cls._checked = True
+                return ev
+            except (OSError, AttributeError, MnyError, RuntimeError) as e:
                 warnings.warn("raw HIP events unavailable (%s); timing brackets fall back to torch.cuda.Event" % (e,))
                 cls._hip = False
         return _TorchEvent()
