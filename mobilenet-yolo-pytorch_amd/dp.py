@@ -42,10 +42,13 @@ class BucketedAllReduce:
         self.flat, self.buckets, self.group = flat, buckets, group
         self.world = dist.get_world_size(group)
         self.pending = []
-        try:
-            self.avg = dist.ReduceOp.AVG if flat.is_cuda else None
-        except AttributeError:
-            self.avg = None
+        # the reduction op follows the BACKEND, not the tensor's device: RCCL ("nccl") averages in the collective; gloo has no
+        # AVG (SUM, then scale) and — the way two ranks share the one GPU of a test box — is fed through a host staging copy
+        self.backend = str(dist.get_backend(group)).lower()
+        self.avg = getattr(dist.ReduceOp, "AVG", None) if self.backend == "nccl" else None
+        self.stage_host = self.avg is None and flat.is_cuda
+        if self.stage_host:
+            self.host = torch.empty(max(e - b for b, e, _ in buckets), dtype=flat.dtype).pin_memory()
 
     def launch(self, k):
         b, e, _ = self.buckets[k]
@@ -53,7 +56,15 @@ class BucketedAllReduce:
         if self.avg is not None:
             w = dist.all_reduce(view, op=self.avg, group=self.group, async_op=True)
             self.pending.append((w, None))
-        else:                       # gloo (CPU tests): SUM then scale
+        elif self.stage_host:       # gloo over device memory (tests): stream-ordered copy out, blocking reduce, copy back
+            h = self.host[:e - b]
+            h.copy_(view)           # D2H on the current stream: ordered behind the backward calls that produced the bucket
+            torch.cuda.current_stream(self.flat.device).synchronize()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            h.mul_(1.0 / self.world)
+            view.copy_(h)
+            torch.cuda.current_stream(self.flat.device).synchronize()      # `host` is reused by the next bucket
+        else:                       # gloo on CPU tensors: SUM then scale
             w = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self.pending.append((w, view))
 
@@ -70,12 +81,24 @@ class PlanReducer:
     segments and enqueues each bucket's all-reduce right after the segment that completes it."""
 
     def __init__(self, plan, group=None, n_buckets=4):
-        names = plan.grad_params
-        sizes = [(plan.grad_slots[n][1] + 3) // 4 * 4 for n in names]
+        sizes = self.slot_extents(plan)
         ready = self._ready_calls(plan)
         self.plan = plan
         self.buckets = plan_buckets(sizes, ready, n_buckets)
+        if self.buckets[0][0] != 0 or self.buckets[-1][1] != plan.gflat.numel():
+            raise RuntimeError("gradient buckets [%d, %d) do not cover the arena of %d floats" % (
+                self.buckets[0][0], self.buckets[-1][1], plan.gflat.numel()))
         self.ar = BucketedAllReduce(plan.gflat, self.buckets, group)
+
+    @staticmethod
+    def slot_extents(plan):
+        """Floats each gradient slot occupies in the arena, in arena order, taken from the REAL layout: next slot's offset
+        minus this slot's, the arena's end closing the last one.  (The engine pads slots to 16 bytes and reserves slack behind
+        the padded detection-head gradients — engine._build_backward — so sizes recomputed from numel() fall short.)"""
+        offs = [plan.grad_slots[n][0] for n in plan.grad_params]
+        assert offs == sorted(offs) and (not offs or offs[0] == 0), "arena slots must be laid out in grad_params order"
+        ends = offs[1:] + [plan.gflat.numel()]
+        return [e - b for b, e in zip(offs, ends)]
 
     @staticmethod
     def _ready_calls(plan):

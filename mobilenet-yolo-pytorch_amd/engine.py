@@ -180,8 +180,15 @@ class _Unit:
 
 
 class NetPlan:
-    def __init__(self, net, N, H, W, training, act_dtype=torch.float32):
+    def __init__(self, net, N, H, W, training, act_dtype=torch.float32, bn_batch=None):
+        """training: build the loss calls (else decode + NMS).  bn_batch (default = training): BatchNorm on batch statistics
+        with the running-statistics update, and the backward list; False with training=True is the "validation loss" plan
+        (running statistics, buffers untouched, forward only)."""
         self.net, self.N, self.H, self.W, self.training = net, N, H, W, training
+        bn_batch = training if bn_batch is None else (bn_batch and training)
+        self.bn_batch = bn_batch
+        self.fwd_gen = 0
+        self.resident_bytes = 0
         dev = net.device
         self.dev = dev
         # storage type of activations / activation gradients.  bf16 selects the `*_bf16` twins of the entry points
@@ -250,7 +257,7 @@ class NetPlan:
                 u.act, u.C, u.M, u.shape = o.act, o.C, M, shp
                 self.units[o.id] = u
                 w = P[nd.conv + ".weight"]
-                stats = self.stats_ws if training else None
+                stats = self.stats_ws if bn_batch else None
                 if nd.op == "stem":
                     parts = _lib.query("mny_stem_stat_parts", N, H, W, o.C)
                     self.fwd.add(K("mny_stem_fwd"), self.x_ptr, w, u.Y, stats, N, H, W, o.C, self.stream,
@@ -271,7 +278,7 @@ class NetPlan:
                                  meta=dict(flops=2 * M * i.C * o.C, bytes=eb * (M * i.C + M * o.C) + 4 * i.C * o.C, shape="M%d K%d N%d" % (M, i.C, o.C)))
                 gam, bet = P[nd.bn + ".weight"], P[nd.bn + ".bias"]
                 rm, rv = P[nd.bn + ".running_mean"], P[nd.bn + ".running_var"]
-                if training:
+                if bn_batch:
                     self.fwd.add("mny_bn_finalize", self.stats_ws, parts, M, gam, bet, BN_EPS, BN_MOMENTUM, rm, rv,
                                  u.scale, u.shift, u.mean, u.invstd, o.C, self.stream)
                 else:
@@ -316,7 +323,7 @@ class NetPlan:
         self.seg_head = self.head32.get(g.seg_out.id, self.reals[g.seg_out.id]) if g.seg_out is not None else None
         self.loss_outputs = list(g.outputs) + ([g.seg_out] if g.seg_out is not None else [])     # values a loss reads
         self._build_detection()
-        if training:
+        if training and bn_batch:
             self._build_backward()
 
     # ------------------------------------------------------------------------------------------
@@ -851,6 +858,7 @@ class NetPlan:
             self.seg_maps.copy_(seg_maps, non_blocking=True)                    # seg_loss.py:53 (clone().to(device))
         self._replay("fwd", self.fwd)
         self.saved_x = x
+        self.fwd_gen += 1
         return self.out14
 
     def backward(self, g_losses):

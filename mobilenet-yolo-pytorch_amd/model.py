@@ -63,7 +63,7 @@ class _TrainStep(torch.autograd.Function):
     def forward(ctx, x, anchor, model, plan, targets, seg_maps=None):
         out14 = plan.forward_train(x, targets, seg_maps)
         res = out14.clone()
-        ctx.model, ctx.plan = model, plan
+        ctx.model, ctx.plan, ctx.gen = model, plan, plan.fwd_gen
         losses, metrics = res[:, 0].contiguous(), res[:, 1:].contiguous()
         if plan.seg_head is not None:             # third loss: SegLoss (mbv2_yolo.py:167-170); its two means ride along
             seg3 = plan.seg_out3.clone()
@@ -74,6 +74,9 @@ class _TrainStep(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_losses, _g_metrics):
+        if ctx.plan.fwd_gen != ctx.gen:           # the plan's resident activations belong to a later forward
+            raise RuntimeError("backward() of a step whose plan has run another forward since (static plans keep ONE set of saved "
+                               "activations per (batch, height, width)): call backward before the next forward of the same shape")
         ctx.model._run_backward(ctx.plan, g_losses.contiguous())
         return None, None, None, None, None, None
 
@@ -144,8 +147,50 @@ class yolo(nn.Module):
     def param_tensors(self):
         return {k: (v.data if isinstance(v, nn.Parameter) else v) for k, v in self.state_dict(keep_vars=True).items()}
 
+    def load_pretrained_backbone(self, checkpoint, strict_shapes=True):
+        """The ImageNet-backbone loader of `mobilenetv2(pretrained)` (models/mobilenetv2.py:161-181, called from
+        mbv2_yolo.py:116-117), from a LOCAL state dict or file — never a download.
+
+        Same key rule as the reference: a checkpoint key (with `module.` removed) is matched against every backbone key after
+        renaming `features2.{0..3}.` to `features.{14..17}.` (the reference splits torchvision-style `features` into
+        `features` [0..13] and `features2` [0..3]); matches are copied, everything else (the checkpoint's classifier, backbone
+        keys the checkpoint lacks) is left alone; when several checkpoint keys collapse onto one name the last one wins, as in
+        the reference's nested loop.  Returns the list of backbone keys that were loaded."""
+        if self.ARCH != "mbv2":
+            raise ValueError("load_pretrained_backbone is the MobileNetV2 loader (models/mobilenetv2.py:161); "
+                             "the MobileNetV3 reference has none (mbv3_yolo.py:104)")
+        if isinstance(checkpoint, (str, bytes)) or hasattr(checkpoint, "__fspath__"):
+            path = str(checkpoint)
+            if "://" in path:
+                raise ValueError("pass a local file or a state dict: this build never downloads")
+            checkpoint = torch.load(path, map_location="cpu")
+        own = self.backbone.state_dict()
+        alias = {}
+        for k2 in own:
+            n2 = k2
+            for i in range(4):                                                  # mobilenetv2.py:173-176
+                n2 = n2.replace("features2.%d." % i, "features.%d." % (14 + i))
+            alias[n2] = k2
+        picked = {}
+        for k1, v1 in checkpoint.items():
+            k2 = alias.get(k1.replace("module.", ""))
+            if k2 is not None:
+                picked[k2] = v1
+        for k2, v in picked.items():
+            if tuple(v.shape) != tuple(own[k2].shape):
+                if strict_shapes:                                               # what load_state_dict (:180) raises on
+                    raise RuntimeError("size mismatch for %s: checkpoint %s vs model %s" % (k2, tuple(v.shape), tuple(own[k2].shape)))
+                continue
+            with torch.no_grad():
+                own[k2].copy_(v)                                                # state_dict tensors alias the live parameters
+        return sorted(picked)
+
     # ---- plans --------------------------------------------------------------------------------
+    PLAN_BUDGET_FRAC = 0.6        # share of the device's HBM the cached plans may keep resident
+
     def _plan(self, N, H, W, training):
+        """`training`: True (loss + backward, batch statistics), False (decode + NMS, running statistics) or "evalloss"
+        (loss on running statistics, no statistics update, no backward: `model.eval()(images, targets)`)."""
         key = (N, H, W, training) if self.act_dtype == torch.float32 else (N, H, W, training, "bf16")
         p = self._plans.get(key)
         if p is None or p.stale():
@@ -153,10 +198,18 @@ class yolo(nn.Module):
                 raise _lib.MnyError("yolo runs only on an MI355X (HIP) device: move the module and inputs to cuda; "
                                     "there is no CPU fallback")
             _lib.load()
-            p = NetPlan(self, N, H, W, training, self.act_dtype)
+            self._plans.pop(key, None)
+            before = torch.cuda.memory_allocated(self.device)
+            p = NetPlan(self, N, H, W, bool(training), self.act_dtype, bn_batch=(training is True))
+            p.resident_bytes = max(torch.cuda.memory_allocated(self.device) - before, 0)
             self._plans[key] = p
-            if len(self._plans) > 8:                                            # multi-scale training: bound resident plans
+            # multi-scale training keeps one plan per size: bound them by resident BYTES (a bs=256/352x352 training plan holds
+            # ~40 GB), oldest first, never the one just built
+            budget = self.PLAN_BUDGET_FRAC * torch.cuda.get_device_properties(self.device).total_memory
+            while len(self._plans) > 1 and (len(self._plans) > 8 or sum(q.resident_bytes for q in self._plans.values()) > budget):
                 self._plans.pop(next(iter(self._plans)))
+        else:
+            self._plans[key] = self._plans.pop(key)                             # most recently used last
         return p
 
     def _check_input(self, x):
@@ -174,15 +227,26 @@ class yolo(nn.Module):
             hs.img_size = [H, W]                                                # mbv2_yolo.py:139-140
         if targets is None:
             return self._forward_eval(x)
-        plan = self._plan(N, H, W, True)
-        if self._anchor is None or self._anchor.device != x.device:
-            self._anchor = torch.zeros((), device=x.device, requires_grad=True)
-        if self.training:
-            nbt = [b for k, b in self.named_buffers() if k.endswith("num_batches_tracked")]
-            torch._foreach_add_(nbt, 1)
         if self.has_seg and seg_maps is not None:
             seg_maps = seg_maps.to(device=x.device, dtype=torch.float32)
-        losses, metrics = _TrainStep.apply(x, self._anchor, self, plan, targets, seg_maps if self.has_seg else None)
+        if self.training:
+            plan = self._plan(N, H, W, True)
+            if self._anchor is None or self._anchor.device != x.device:
+                self._anchor = torch.zeros((), device=x.device, requires_grad=True)
+            nbt = [b for k, b in self.named_buffers() if k.endswith("num_batches_tracked")]
+            torch._foreach_add_(nbt, 1)
+            losses, metrics = _TrainStep.apply(x, self._anchor, self, plan, targets, seg_maps if self.has_seg else None)
+        else:
+            # model.eval()(images, targets) — a validation loss: nn.BatchNorm2d normalises with the running statistics and leaves
+            # them untouched (mobilenetv2.py:41-84 in eval mode).  Forward only: the result carries no autograd graph.
+            plan = self._plan(N, H, W, "evalloss")
+            with torch.no_grad():
+                res = plan.forward_train(x, targets, seg_maps if self.has_seg else None).clone()
+                losses, metrics = res[:, 0].contiguous(), res[:, 1:].contiguous()
+                if plan.seg_head is not None:
+                    seg3 = plan.seg_out3.clone()
+                    losses = torch.cat((losses, seg3[:1]))
+                    metrics = torch.cat((metrics.reshape(-1), seg3[1:]))
         seg_metrics = None
         if self.has_seg:
             seg_metrics, metrics = metrics[12:], metrics[:12].view(2, 6)
@@ -205,12 +269,16 @@ class yolo(nn.Module):
         # gradient accumulation (backward twice without zero_grad(set_to_none=True)): keep the old arena
         first = P[plan.grad_params[0]]
         prev = None
-        if first.grad is not None and first.grad.data_ptr() == plan.gviews[plan.grad_params[0]].data_ptr():
-            prev = plan.gflat.clone()
         red = getattr(self, "dp_reducer", None)
         plan.reducer = red.for_plan(plan) if red is not None else None
+        if first.grad is not None and first.grad.data_ptr() == plan.gviews[plan.grad_params[0]].data_ptr():
+            if plan.reducer is not None:
+                plan.reducer.wait()               # the previous step's last buckets may still be in flight on the arena
+            prev = plan.gflat.clone()
         plan.backward(g_losses)
         if prev is not None:
+            if plan.reducer is not None:
+                plan.reducer.wait()               # accumulate into AVERAGED gradients, never under a running all-reduce
             plan.gflat.add_(prev)
         for nm in plan.grad_params:
             p = P[nm]

@@ -94,3 +94,28 @@ def photos(sizes, seed=0):
         img += r.randn(h, w, 3) * 12
         out.append(np.clip(img, 0, 255).astype(np.uint8))
     return out
+
+
+def dli14_mobilenetv2_keys(width=1.0):
+    """(key, shape) list with the layout of the ImageNet MobileNetV2 checkpoint the reference downloads (d-li14
+    `mobilenetv2-c5e733a8.pth`, mbv2_yolo.py:116): ONE `features` Sequential of 18 modules (stem + 17 inverted-residual
+    blocks), the 1x1 `conv` to 1280 and a `classifier` — the input side of `yolo.load_pretrained_backbone`.
+    Written from the architecture table (t, c, n, s); used by tests and tools to build local stand-in checkpoints."""
+    def bn(prefix, c):
+        return [(prefix + ".weight", (c,)), (prefix + ".bias", (c,)), (prefix + ".running_mean", (c,)),
+                (prefix + ".running_var", (c,)), (prefix + ".num_batches_tracked", ())]
+    out = [("features.0.0.weight", (32, 3, 3, 3))] + bn("features.0.1", 32)
+    cin, idx = 32, 1
+    for t, c, n, _s in [(1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2), (6, 96, 3, 1), (6, 160, 3, 2), (6, 320, 1, 1)]:
+        for _ in range(n):
+            p = "features.%d.conv" % idx
+            hid, j = cin * t, 0
+            if t != 1:
+                out += [(p + ".0.weight", (hid, cin, 1, 1))] + bn(p + ".1", hid)
+                j = 3
+            out += [(p + ".%d.weight" % j, (hid, 1, 3, 3))] + bn(p + ".%d" % (j + 1), hid)
+            out += [(p + ".%d.weight" % (j + 3), (c, hid, 1, 1))] + bn(p + ".%d" % (j + 4), c)
+            cin, idx = c, idx + 1
+    out += [("conv.0.weight", (1280, cin, 1, 1))] + bn("conv.1", 1280)
+    out += [("classifier.weight", (1000, 1280)), ("classifier.bias", (1000,))]
+    return out

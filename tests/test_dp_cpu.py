@@ -26,6 +26,15 @@ def test_plan_buckets_contiguous_and_cut_at_call_boundaries():
     assert one == [(0, 5, 1)]
 
 
+def test_slot_extents_follow_the_real_arena_layout():
+    """bucket ranges must come from slot offsets, not from numel() — the padded heads leave slack."""
+    plan = FakePlan(0, [75 * 8, 75, 32, 5], slack={0: 76 * 8, 1: 76})
+    ext = dp.PlanReducer.slot_extents(plan)
+    assert ext == [608, 76, 32, 8] and sum(ext) == plan.gflat.numel()
+    naive = [(plan.grad_slots[n][1] + 3) // 4 * 4 for n in plan.grad_params]
+    assert sum(naive) < plan.gflat.numel()              # what round 1 computed: stops short of the arena's end
+
+
 class _V:
     def __init__(self, v):
         self.value = v
@@ -39,13 +48,14 @@ class _Calls:
 class FakePlan:
     """Mimics engine.NetPlan for dp.PlanReducer: call i 'computes' slot i of the gradient arena."""
 
-    def __init__(self, rank, sizes):
+    def __init__(self, rank, sizes, slack=None):
         self.rank = rank
         self.grad_params = ["p%d" % i for i in range(len(sizes))]
         self.grad_slots, off = {}, 0
-        for n, s in zip(self.grad_params, sizes):
+        slack = slack or {}
+        for i, (n, s) in enumerate(zip(self.grad_params, sizes)):
             self.grad_slots[n] = (off, s)
-            off += (s + 3) // 4 * 4
+            off += (max(s, slack.get(i, 0)) + 3) // 4 * 4       # engine._build_backward: padded detection heads reserve slack
         self.gflat = torch.zeros(off)
         self.gviews = {n: self.gflat[o:o + s] for n, (o, s) in self.grad_slots.items()}
         # two calls per slot: a no-op and the producing call (so ready indices are not trivially i+1)
@@ -67,8 +77,10 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         sizes = [7, 64, 3, 1000, 12, 5, 256, 33]
-        plan = FakePlan(rank, sizes)
+        plan = FakePlan(rank, sizes, slack={0: 40, 3: 1100})   # slots longer than their parameter, like the 75->76 channel heads
         red = dp.PlanReducer(plan, n_buckets=3)
+        assert red.buckets[0][0] == 0 and red.buckets[-1][1] == plan.gflat.numel()
+        assert red.ar.backend == "gloo" and red.ar.avg is None and not red.ar.stage_host
         for step in range(2):                       # second step exercises the wait-before-rewrite path
             red.run_backward()
             red.wait()

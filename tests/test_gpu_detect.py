@@ -188,3 +188,31 @@ def test_nms_bucket_overflow_is_reported(ops):
     beg, cnt = torch.tensor([0], dtype=torch.int32).cuda(), torch.tensor([9000], dtype=torch.int32).cuda()
     _, counts, _, _, status = ops.nms_per_class(rows.cuda(), beg, cnt, 1, 0.45)
     assert int(status.cpu()) == 9000 and int(counts.cpu()[0]) == 0
+
+
+def _config5_rows(n=100000, C=20, seed=2):
+    """BASELINE configs[4] / SURVEY §8d C5(ii): one image of n rows, cls~U{0..C-1}, centres U(0,1)^2, sizes U(0.02,0.3)."""
+    r = np.random.RandomState(seed)
+    ctr = r.rand(n, 2).astype(np.float32)
+    wh = (0.02 + 0.28 * r.rand(n, 2)).astype(np.float32)
+    return torch.from_numpy(np.concatenate((ctr - wh / 2, ctr + wh / 2, r.rand(n, 2).astype(np.float32),
+                                            r.randint(0, C, (n, 1)).astype(np.float32)), 1).astype(np.float32))
+
+
+def test_nms_config5_100k_boxes_20_classes_indices_equal_cpu(ops):
+    """The full-size configs[4] case (the rows bench.py times): kept indices identical to oracle/nms_ref.c, order included."""
+    n, C = 100000, 20
+    rows = _config5_rows(n, C)
+    ref_rows, ref_idx = nms_ref.nms_rows(rows, C, 0.45)
+    beg, cnt = torch.tensor([0], dtype=torch.int32).cuda(), torch.tensor([n], dtype=torch.int32).cuda()
+    out_idx, out_counts, out_rows, prefix, status = ops.nms_per_class(rows.cuda(), beg, cnt, C, 0.45)
+    kept = int(out_counts.cpu()[0])
+    assert int(status.cpu()) == 0 and kept == len(ref_idx)
+    assert np.array_equal(out_idx[:kept].cpu().numpy(), ref_idx.numpy())
+    assert np.array_equal(out_rows[:kept].cpu().numpy(), ref_rows.numpy())
+    # size-independent properties (SURVEY §8c): per class, kept boxes are pairwise IoU <= thr and score-descending
+    k = out_rows[:kept].cpu()
+    for c in range(C):
+        kc = k[k[:, 6] == c]
+        s = kc[:, 4] * kc[:, 5]
+        assert bool((s[:-1] >= s[1:]).all())

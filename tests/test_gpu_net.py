@@ -176,3 +176,39 @@ def test_second_step_and_grad_accumulation():
     (r3[0][0] + r3[1][0]).backward()                                       # no zero_grad -> accumulates
     torch.testing.assert_close(w.grad, 2 * g1, rtol=1e-5, atol=1e-7)
     assert torch.is_tensor(r3[0][1]) and r3[0][1].is_cuda                  # sync_metrics=False keeps metrics on device
+
+
+def test_eval_mode_loss_uses_running_statistics_and_leaves_them_alone():
+    """`model.eval()(images, targets)` — a validation loss.  nn.BatchNorm2d in eval mode normalises with the running
+    statistics and does not update them (models/mobilenetv2.py:41-84 under .eval()); the oracle in eval mode is the reference."""
+    ref = procedural.fill_state_dict_(net_ref.RefYolo(procedural.VOC_CONFIG)).eval()
+    m = _model(train=False)
+    x = procedural.images(4, 128, 128, seed=31)
+    tg = procedural.targets(4, seed=32, empty_every=4)
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        rr = ref(x, tg)
+    res = m(x.cuda(), tg)
+    for i in range(2):
+        np.testing.assert_allclose(np.array([float(v) for v in res[i]]), np.array([float(v) for v in rr[i]]), rtol=2e-3, atol=1e-5)
+    assert not res[0][0].requires_grad                       # forward only
+    for k, v in m.state_dict().items():                      # running_mean / running_var / num_batches_tracked untouched
+        assert torch.equal(v, before[k]), k
+    # and it differs from the batch-statistics loss of train mode (the bug was silently returning that one)
+    m.train()
+    tr = m(x.cuda(), tg)
+    assert abs(float(tr[0][0]) - float(res[0][0])) > 1e-3 * abs(float(res[0][0]))
+    # detections in eval mode still work next to the loss plan
+    m.eval()
+    assert len(m(x.cuda())) == 4
+
+
+def test_backward_after_a_second_forward_of_the_same_plan_is_refused():
+    m = _model(train=True)
+    x = procedural.images(2, 96, 96, seed=33).cuda()
+    tg = procedural.targets(2, seed=34, empty_every=0)
+    a = m(x, tg)
+    b = m(x, tg)                                             # overwrites the plan's saved activations
+    with pytest.raises(RuntimeError, match="another forward"):
+        (a[0][0] + a[1][0]).backward()
+    (b[0][0] + b[1][0]).backward()                           # the latest one is fine

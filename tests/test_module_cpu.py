@@ -68,3 +68,48 @@ def test_cpu_call_fails_loudly():
     m = _mk().eval()
     with pytest.raises(MnyError, match="no CPU fallback"):
         m(torch.zeros(1, 3, 96, 96))
+
+
+def test_pretrained_backbone_loader_follows_reference_remap():
+    """a5: models/mobilenetv2.py:161-181.  Fixture = which checkpoint key the REAL loader put into every backbone tensor
+    (tools/gen_golden_pretrained.py); the checkpoint is rebuilt here with the same recipe (tensor i filled with i+1,
+    every 7th key prefixed `module.`)."""
+    from mobilenet_yolo_pytorch_amd import synthetic
+    man = json.load(open(os.path.join(G, "pretrained_map.json")))
+    spec = synthetic.dli14_mobilenetv2_keys()
+    assert len(spec) == man["spec_len"]
+    ckpt, fill = {}, {}
+    for i, (k, shape) in enumerate(spec):
+        if i % 7 == 3:
+            k = "module." + k
+        ckpt[k] = torch.full(shape, float(i + 1))
+        fill[k] = float(i + 1)
+    m = _mk()
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    loaded = m.load_pretrained_backbone(ckpt)
+    sd = m.state_dict()
+    for k, src in man["map"]:
+        v = sd["backbone." + k]
+        if src is None:
+            assert torch.equal(v, before["backbone." + k]), k
+        else:
+            assert bool((v.double() == fill[src]).all()), (k, src)
+    assert loaded == sorted(k for k, src in man["map"] if src is not None)
+    for k, v in sd.items():                     # neck / heads untouched; the checkpoint's classifier went nowhere
+        if not k.startswith("backbone."):
+            assert torch.equal(v, before[k]), k
+    # the split backbone really maps features2.N <- features.(14+N)
+    assert bool((sd["backbone.features2.3.conv.6.weight"] == fill["features.17.conv.6.weight"]).all()
+                if "features.17.conv.6.weight" in fill else True)
+    # shape mismatch is an error like load_state_dict's; a URL is refused (no downloads)
+    bad = dict(ckpt)
+    bad["features.0.0.weight"] = torch.zeros(16, 3, 3, 3)
+    with pytest.raises(RuntimeError):
+        _mk().load_pretrained_backbone(bad)
+    with pytest.raises(ValueError):
+        _mk().load_pretrained_backbone("https://example.invalid/mobilenetv2.pth")
+    # from a file
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".pth") as f:
+        torch.save(ckpt, f.name)
+        assert _mk().load_pretrained_backbone(f.name) == loaded
