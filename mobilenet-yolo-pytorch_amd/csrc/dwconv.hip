@@ -22,6 +22,8 @@ struct DwGeom {
     int TH, nHS;        // strip height, strips per column
     int64_t nstrips;    // N * Wo * nHS
     int cg_total, cgb;  // channel groups total / per block
+    int xcd;            // second-generation forward: XCD-contiguous strip order
+    int nt;             // second-generation forward: non-temporal output stores
 };
 
 template <int KS>
@@ -171,6 +173,198 @@ __global__ __launch_bounds__(256) void dw_slide_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 3x3 forward, second generation (stride 1 | 2; also the stride-1 backward-data as a correlation with the flipped filter).
+//
+// dw_slide_kernel's inner loop is 161 VALU instructions per output row of a wave (ISA count, fp32 3x3 s1 + ReLU6 view): every
+// tap is transformed separately (fma + mul/max/min + a padding select per element), the window is shifted with 28 v_mov, every
+// tap address is a 64-bit multiply.  At 4 cycles per wave64 VALU instruction that is 644 cycles per 2 KB of algorithmic
+// traffic and SIMD = a 7.8 TB/s ceiling for the whole chip, i.e. the "HBM-bound" kernel ran at 55-60 % VALU utilisation with
+// only 4 waves/SIMD to hide memory latency behind it.  This kernel keeps the thread mapping (thread = 4 channels x one output
+// column sliding down a strip; lanes = channel groups, then columns: every wave-level access is a contiguous run of 16-B
+// vectors) and removes the instructions:
+//   * packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): a float4 is two register pairs, every fma covers 2 lanes' worth;
+//   * ReLU6 as one v_med3_f32; the view transform is templated (none / ReLU6 / h-swish / generic clamp);
+//   * no per-tap padding selects: the transformed row is multiplied by a 0/1 mask per column (row inside the image x column
+//     inside the image: one packed multiply per register pair);
+//   * the 3-row window rotates through a x3-unrolled loop by renaming instead of moves;
+//   * three column pointers bumped by the row pitch instead of per-tap 64-bit index arithmetic.
+// ~60 VALU per row.  Strips are handed to workgroups XCD-contiguously (workgroup i lands on XCD i % 8): the column / row halo
+// a workgroup shares with its neighbours is then in the same 4-MB L2 instead of going out to the fabric again.
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct F4P { v2f lo, hi; };
+__device__ __forceinline__ F4P f4p(float4 v) { F4P r; r.lo = v2f{v.x, v.y}; r.hi = v2f{v.z, v.w}; return r; }
+__device__ __forceinline__ F4P f4p0() { F4P r; r.lo = v2f{0.f, 0.f}; r.hi = v2f{0.f, 0.f}; return r; }
+
+// XF: 0 none (value used as is), 1 ReLU6, 2 h-swish, 4 max(z, slope*z) = leaky / relu / scale-only (no upper clip)
+template <int XF>
+__device__ __forceinline__ F4P dw_xf(float4 v, v2f sc_lo, v2f sc_hi, v2f sh_lo, v2f sh_hi, float slope, float hi_clip) {
+    F4P z;
+    if (XF == 0) { z.lo = v2f{v.x, v.y}; z.hi = v2f{v.z, v.w}; return z; }
+    z.lo = __builtin_elementwise_fma(v2f{v.x, v.y}, sc_lo, sh_lo);
+    z.hi = __builtin_elementwise_fma(v2f{v.z, v.w}, sc_hi, sh_hi);
+    if (XF == 1) {
+        z.lo = v2f{__builtin_amdgcn_fmed3f(z.lo.x, 0.f, 6.f), __builtin_amdgcn_fmed3f(z.lo.y, 0.f, 6.f)};
+        z.hi = v2f{__builtin_amdgcn_fmed3f(z.hi.x, 0.f, 6.f), __builtin_amdgcn_fmed3f(z.hi.y, 0.f, 6.f)};
+    } else if (XF == 2) {
+        const v2f three = v2f{3.f, 3.f}, sixth = v2f{1.f / 6.f, 1.f / 6.f};
+        v2f a = z.lo + three, b = z.hi + three;
+        a = v2f{__builtin_amdgcn_fmed3f(a.x, 0.f, 6.f), __builtin_amdgcn_fmed3f(a.y, 0.f, 6.f)};
+        b = v2f{__builtin_amdgcn_fmed3f(b.x, 0.f, 6.f), __builtin_amdgcn_fmed3f(b.y, 0.f, 6.f)};
+        z.lo = z.lo * a * sixth;                      // same operation order as act_fwd: z * clamp(z + 3) / 6 -> (z * h) * (1/6) differs by <= 1 ulp
+        z.hi = z.hi * b * sixth;
+    } else if (XF == 4) {                                // leaky / relu / scale-only: no upper clip
+        const v2f sl = v2f{slope, slope};
+        const v2f a = z.lo * sl, b = z.hi * sl;
+        z.lo = v2f{fmaxf(z.lo.x, a.x), fmaxf(z.lo.y, a.y)};
+        z.hi = v2f{fmaxf(z.hi.x, b.x), fmaxf(z.hi.y, b.y)};
+    }
+    return z;
+}
+
+template <typename T, int S, int XF, bool ADD, bool NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void dw3_fwd_kernel(
+    const T* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift, int in_act,
+    const float* __restrict__ w, int flip, const T* __restrict__ addend, T* __restrict__ y, float* __restrict__ parts, DwGeom g) {
+    __shared__ float4 red[256 * 2];
+    const int tid = threadIdx.x;
+    const int cgl = tid % g.cgb;
+    const int pix = tid / g.cgb;
+    const int ppb = blockDim.x / g.cgb;
+    const int cg = blockIdx.y * g.cgb + cgl;
+    const bool cvalid = cg < g.cg_total;
+    const int c = cg * 4;
+    // XCD-contiguous strip order: hardware places workgroup b on XCD b % 8 (gridDim.x is a multiple of 8 whenever it exceeds 8)
+    const int gx = gridDim.x;
+    const int lb = (g.xcd && (gx & 7) == 0) ? (int)(blockIdx.x & 7) * (gx >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+
+    F4P acc1 = f4p0(), acc2 = f4p0();
+    if (cvalid) {
+        v2f sc_lo = v2f{1.f, 1.f}, sc_hi = sc_lo, sh_lo = v2f{0.f, 0.f}, sh_hi = sh_lo;
+        if (in_scale != nullptr) {
+            const float4 a = ld4(in_scale + c), b = ld4(in_shift + c);
+            sc_lo = v2f{a.x, a.y}; sc_hi = v2f{a.z, a.w}; sh_lo = v2f{b.x, b.y}; sh_hi = v2f{b.z, b.w};
+        }
+        const float slope = act_slope(in_act), hi_clip = act_hi(in_act);
+        // filter taps of this thread's 4 channels (36 contiguous floats), loaded once per thread
+        F4P wt[9];
+        {
+            float raw[36];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                const float4 v = ld4(w + (int64_t)c * 9 + 4 * i);
+                raw[4 * i] = v.x; raw[4 * i + 1] = v.y; raw[4 * i + 2] = v.z; raw[4 * i + 3] = v.w;
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                wt[t].lo = v2f{flip ? raw[8 - t] : raw[t], flip ? raw[9 + 8 - t] : raw[9 + t]};
+                wt[t].hi = v2f{flip ? raw[18 + 8 - t] : raw[18 + t], flip ? raw[27 + 8 - t] : raw[27 + t]};
+            }
+        }
+        const int64_t pitch = (int64_t)g.W * g.C;               // input row pitch (elements)
+        const int64_t opitch = (int64_t)g.Wo * g.C;
+        for (int64_t strip = (int64_t)lb * ppb + pix; strip < g.nstrips; strip += (int64_t)gx * ppb) {
+            const int wo = (int)(strip % g.Wo);
+            const int hs = (int)((strip / g.Wo) % g.nHS);
+            const int n = (int)(strip / ((int64_t)g.Wo * g.nHS));
+            const int ho0 = hs * g.TH;
+            const int ho1 = min(ho0 + g.TH, g.Ho);
+            const float ml = (wo * S - 1 >= 0) ? 1.f : 0.f, mr = (wo * S + 1 < g.W) ? 1.f : 0.f;     // column taps outside the image
+            const int wl = max(wo * S - 1, 0), wm = wo * S, wr = min(wo * S + 1, g.W - 1);
+            const T* xn = x + (int64_t)n * g.H * pitch + c;
+            // row pointers of the three columns; `hi_next` = input row the next load fetches
+            int hi_next = ho0 * S - 1;
+            const T* pl = xn + (int64_t)max(hi_next, 0) * pitch + (int64_t)wl * g.C;
+            const T* pm = xn + (int64_t)max(hi_next, 0) * pitch + (int64_t)wm * g.C;
+            const T* pr = xn + (int64_t)max(hi_next, 0) * pitch + (int64_t)wr * g.C;
+            T* yo = y + (((int64_t)n * g.Ho + ho0) * g.Wo + wo) * g.C + c;
+            const T* ad = ADD ? addend + (((int64_t)n * g.Ho + ho0) * g.Wo + wo) * g.C + c : nullptr;
+
+            // load + transform one input row into r[3]; rows outside the image come out as zeros
+            // fetch = the three 16-B loads of one input row (+ pointer bump); finish = view transform, zero if the row is outside
+            auto fetch = [&](float4 (&raw)[3], float& m) {
+                m = (hi_next >= 0 && hi_next < g.H) ? 1.f : 0.f;
+                raw[0] = ld4(pl); raw[1] = ld4(pm); raw[2] = ld4(pr);
+                // advance unless the next row would leave the image (the clamped re-read is zeroed by its own `m`)
+                const int64_t step = (hi_next >= 0 && hi_next + 1 < g.H) ? pitch : 0;
+                pl += step; pm += step; pr += step;
+                ++hi_next;
+            };
+            auto finish = [&](const float4 (&raw)[3], float m, F4P (&r)[3]) {
+                const float mq[3] = {m * ml, m, m * mr};          // row outside the image / column outside the image -> zeros
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const v2f m2 = v2f{mq[q], mq[q]};
+                    r[q] = dw_xf<XF>(raw[q], sc_lo, sc_hi, sh_lo, sh_hi, slope, hi_clip);
+                    r[q].lo *= m2; r[q].hi *= m2;
+                }
+            };
+            auto load_row = [&](F4P (&r)[3]) { float4 raw[3]; float m; fetch(raw, m); finish(raw, m, r); };
+            // stride 2: both rows' loads are issued before either is transformed (6 x 16 B in flight per thread)
+            auto load_rows2 = [&](F4P (&ra)[3], F4P (&rb)[3]) {
+                float4 wa[3], wb[3]; float ma, mb;
+                fetch(wa, ma); fetch(wb, mb);
+                __builtin_amdgcn_sched_barrier(0);
+                finish(wa, ma, ra); finish(wb, mb, rb);
+            };
+            auto emit = [&](const F4P (&top)[3], const F4P (&mid)[3], const F4P (&bot)[3]) {
+                F4P o = f4p0();
+                if (ADD) { o = f4p(ld4(ad)); ad += opitch; }
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    o.lo = __builtin_elementwise_fma(top[q].lo, wt[q].lo, o.lo);         o.hi = __builtin_elementwise_fma(top[q].hi, wt[q].hi, o.hi);
+                    o.lo = __builtin_elementwise_fma(mid[q].lo, wt[3 + q].lo, o.lo);     o.hi = __builtin_elementwise_fma(mid[q].hi, wt[3 + q].hi, o.hi);
+                    o.lo = __builtin_elementwise_fma(bot[q].lo, wt[6 + q].lo, o.lo);     o.hi = __builtin_elementwise_fma(bot[q].hi, wt[6 + q].hi, o.hi);
+                }
+                const float4 of = make_float4(o.lo.x, o.lo.y, o.hi.x, o.hi.y);
+                if (NT) st4_stream(yo, of); else st4(yo, of);
+                yo += opitch;
+                const F4P os = f4p(stored4<T>(of));               // statistics over the values the consumer will read
+                acc1.lo += os.lo; acc1.hi += os.hi;
+                acc2.lo = __builtin_elementwise_fma(os.lo, os.lo, acc2.lo);
+                acc2.hi = __builtin_elementwise_fma(os.hi, os.hi, acc2.hi);
+                __builtin_amdgcn_sched_barrier(0);               // keep the three unrolled steps apart: interleaving them costs 100+ VGPRs
+            };
+            F4P r0[3], r1[3], r2[3];
+            int left = ho1 - ho0;
+            if (S == 1) {
+                load_row(r0);                 // row ho0-1
+                load_row(r1);                 // row ho0
+                // each step: load the row below, emit, rotate by renaming
+#pragma clang loop unroll(disable)
+                for (; left >= 3; left -= 3) {
+                    load_row(r2); emit(r0, r1, r2);
+                    load_row(r0); emit(r1, r2, r0);
+                    load_row(r1); emit(r2, r0, r1);
+                }
+                if (left >= 1) { load_row(r2); emit(r0, r1, r2); }
+                if (left >= 2) { load_row(r0); emit(r1, r2, r0); }
+            } else {
+                load_row(r0);                 // row 2*ho0-1
+#pragma clang loop unroll(disable)
+                for (; left >= 3; left -= 3) {
+                    load_rows2(r1, r2); emit(r0, r1, r2);
+                    load_rows2(r0, r1); emit(r2, r0, r1);
+                    load_rows2(r2, r0); emit(r1, r2, r0);
+                }
+                if (left >= 1) { load_rows2(r1, r2); emit(r0, r1, r2); }
+                if (left >= 2) { load_rows2(r0, r1); emit(r2, r0, r1); }
+            }
+        }
+    }
+    if (parts == nullptr) return;
+    red[tid * 2 + 0] = make_float4(acc1.lo.x, acc1.lo.y, acc1.hi.x, acc1.hi.y);
+    red[tid * 2 + 1] = make_float4(acc2.lo.x, acc2.lo.y, acc2.hi.x, acc2.hi.y);
+    __syncthreads();
+    if (pix == 0 && cvalid) {
+        float4 a = f4zero(), b = f4zero();
+        for (int p = 0; p < ppb; ++p) { add4(a, red[(p * g.cgb + cgl) * 2]); add4(b, red[(p * g.cgb + cgl) * 2 + 1]); }
+        float* dst = parts + (int64_t)blockIdx.x * 2 * g.C;
+        st4(dst + c, a);
+        st4(dst + g.C + c, b);
+    }
+}
+
 // stride-2 backward-data as a gather over the (at most ceil(K/2)^2) contributing taps
 template <typename T, int KS>
 __global__ __launch_bounds__(256) void dw_bwd_data_s2_kernel(const T* __restrict__ dy, const float* __restrict__ w,
@@ -316,7 +510,12 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2k5_kernel(const T* __restri
     }
 }
 
-static int dw_geom(DwGeom& g, CgLayout& L, int& gx, int N, int H, int W, int C, int K, int stride) {
+static bool dw_use_v2(int K, int mode) {
+    static const bool v1 = getenv("MNY_DW_V1") != nullptr;       // A/B: the first-generation sliding-window kernel
+    return K == 3 && mode == 0 && !v1;
+}
+
+static int dw_geom(DwGeom& g, CgLayout& L, int& gx, int N, int H, int W, int C, int K, int stride, int mode = 0) {
     MNY_REQUIRE(K == 3 || K == 5, "dw: kernel size %d unsupported (3 or 5)", K);
     MNY_REQUIRE(stride == 1 || stride == 2, "dw: stride %d unsupported", stride);
     MNY_REQUIRE(C % 4 == 0 && C > 0, "dw: C=%d must be a positive multiple of 4", C);
@@ -325,15 +524,43 @@ static int dw_geom(DwGeom& g, CgLayout& L, int& gx, int N, int H, int W, int C, 
     g.N = N; g.H = H; g.W = W; g.C = C;
     g.Ho = (H + 2 * P - K) / stride + 1;
     g.Wo = (W + 2 * P - K) / stride + 1;
-    static const int th = getenv("MNY_DW_TH") ? atoi(getenv("MNY_DW_TH")) : 16;   // strip height: 16 re-reads 2/16 halo rows (8: 2/8); 4.15 -> 4.05 ms
-    const int ns = (int)cdiv(g.Ho, th);
+    L = make_stencil_layout(C);
+    g.cg_total = L.cg_total; g.cgb = L.cgb;
+    // gx * chunks workgroups = one resident round: 4 per CU (first generation, <= 128 VGPRs), 3 per CU for the second-generation
+    // forward (<= 168 VGPRs: the h-swish / leaky variants spilled inside the row loop at 128; tools/probe/dw_probe.hip shows 2, 3
+    // and 4 waves per SIMD stream at the same rate)
+    static const int res_env = getenv("MNY_DW_RES") ? atoi(getenv("MNY_DW_RES")) : 768;
+    const int resident = dw_use_v2(K, mode) ? res_env : kMaxParts;
+    int cap = resident / L.chunks > 0 ? resident / L.chunks : 1;
+    if (cap > 8) cap &= ~7;                                               // whole XCD rounds (workgroup b runs on XCD b % 8)
+    static const int th_env = getenv("MNY_DW_TH") ? atoi(getenv("MNY_DW_TH")) : 0;          // > 0: strip height; -1: balance search
+    static const int xcd_env = getenv("MNY_DW_XCD") ? atoi(getenv("MNY_DW_XCD")) : 1;
+    static const int nt_env = getenv("MNY_DW_NT") ? atoi(getenv("MNY_DW_NT")) : 1;
+    g.xcd = xcd_env;
+    g.nt = nt_env;
+    int ns;
+    if (dw_use_v2(K, mode) && th_env < 0) {
+        // strips per column: a workgroup walks ceil(want / cap) strips, the last round partly empty, and every strip pays
+        // (K - stride) halo rows of loads without an output row -> pick the split with the best product of both efficiencies
+        double best = -1.0;
+        ns = 1;
+        for (int cand = 1; cand <= g.Ho && g.Ho / cand >= 4; ++cand) {
+            const int th = (int)cdiv(g.Ho, cand);
+            const int64_t want = cdiv((int64_t)N * g.Wo * cdiv(g.Ho, th), L.ppb);
+            const double rounds = (double)want / cap;
+            const double fill = rounds <= 1.0 ? 1.0 : rounds / (double)cdiv(want, cap);
+            const double eff = fill * th / (th + (K - stride) * 0.75);
+            if (eff > best + 1e-9) { best = eff; ns = cand; }
+        }
+    } else {
+        const int th = th_env > 0 ? th_env : 16;                          // first generation: 16 re-reads 2/16 halo rows (8: 2/8); 4.15 -> 4.05 ms
+        ns = (int)cdiv(g.Ho, th);
+    }
     g.TH = (int)cdiv(g.Ho, ns);
     g.nHS = (int)cdiv(g.Ho, g.TH);
     g.nstrips = (int64_t)N * g.Wo * g.nHS;
-    L = make_stencil_layout(C);
-    g.cg_total = L.cg_total; g.cgb = L.cgb;
     int64_t want = cdiv(g.nstrips, L.ppb);
-    const int cap = kMaxParts / L.chunks > 0 ? kMaxParts / L.chunks : 1;      // gx * chunks workgroups = 4 per CU
+    if (want > 8) want = (want + 7) & ~(int64_t)7;
     gx = (int)(want < cap ? want : cap);
     return MNY_OK;
 }
@@ -343,9 +570,20 @@ static int dw_launch(const T* x, const float* sc, const float* sh, int act, cons
                      const T* addend, T* y, const T* dy, float* parts,
                      int N, int H, int W, int C, int K, int stride, hipStream_t st) {
     DwGeom g; CgLayout L; int gx;
-    int rc = dw_geom(g, L, gx, N, H, W, C, K, stride);
+    int rc = dw_geom(g, L, gx, N, H, W, C, K, stride, MODE);
     if (rc) return rc;
     dim3 grid(gx, L.chunks), block(L.threads);
+    if (dw_use_v2(K, MODE) && (addend == nullptr || (sc == nullptr && act == MNY_ACT_NONE))) {     // an addend only occurs without a view (backward-data)
+        const int xf2 = (sc == nullptr && act == MNY_ACT_NONE) ? 0 : (act == MNY_ACT_RELU6 ? 1 : (act == MNY_ACT_HSWISH ? 2 : 4));
+#define MNY_DW2(S_, X_, A_) do { if (g.nt) hipLaunchKernelGGL((dw3_fwd_kernel<T, S_, X_, A_, true>), grid, block, 0, st, x, sc, sh, act, w, flip, addend, y, parts, g); \
+        else hipLaunchKernelGGL((dw3_fwd_kernel<T, S_, X_, A_, false>), grid, block, 0, st, x, sc, sh, act, w, flip, addend, y, parts, g); } while (0)
+#define MNY_DW2S(S_) do { if (xf2 == 0) { if (addend) MNY_DW2(S_, 0, true); else MNY_DW2(S_, 0, false); } else if (xf2 == 1) MNY_DW2(S_, 1, false); \
+        else if (xf2 == 2) MNY_DW2(S_, 2, false); else MNY_DW2(S_, 4, false); } while (0)
+        if (stride == 1) MNY_DW2S(1); else MNY_DW2S(2);
+#undef MNY_DW2S
+#undef MNY_DW2
+        return check_launch("dw3_fwd_kernel");
+    }
     const int xf = (sc == nullptr && act == MNY_ACT_NONE) ? 0 : (act == MNY_ACT_HSWISH ? 2 : 1);
 #define MNY_DW(KS_, S_) do { if (xf == 0) hipLaunchKernelGGL((dw_slide_kernel<T, KS_, S_, MODE, 0>), grid, block, 0, st, x, sc, sh, act, w, flip, addend, y, dy, parts, g); \
         else if (xf == 1) hipLaunchKernelGGL((dw_slide_kernel<T, KS_, S_, MODE, 1>), grid, block, 0, st, x, sc, sh, act, w, flip, addend, y, dy, parts, g); \
@@ -379,7 +617,7 @@ extern "C" int mny_dw_stat_parts(int N, int H, int W, int C, int K, int stride) 
 }
 extern "C" int mny_dw_wgrad_parts(int N, int H, int W, int C, int K, int stride) {
     DwGeom g; CgLayout L; int gx;
-    if (dw_geom(g, L, gx, N, H, W, C, K, stride)) return MNY_EINVAL;
+    if (dw_geom(g, L, gx, N, H, W, C, K, stride, 1)) return MNY_EINVAL;
     return gx;
 }
 

@@ -17,6 +17,15 @@ from . import nms_ref
 from . import seg_ref
 
 
+def _store(t):
+    """Storage hook of a MATERIALISED sum (residual adds): identity for the fp32 reference; oracle/bf16_storage.py swaps in a
+    straight-through bf16 rounding to model the `act_dtype=bfloat16` plans of the product (BASELINE configs[3])."""
+    return STORE(t)
+
+
+STORE = lambda t: t        # noqa: E731
+
+
 def _cbr6(cin, cout, k, stride, groups=1):
     """conv -> BN -> ReLU6 triple as three Sequential children (mobilenetv2.py:38-51)."""
     return [nn.Conv2d(cin, cout, k, stride, k // 2, groups=groups, bias=False),
@@ -39,7 +48,7 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         y = self.conv(x)
-        return x + y if self.identity else y
+        return _store(x + y) if self.identity else y
 
 
 class Backbone(nn.Module):
@@ -106,8 +115,11 @@ class Residual(nn.Module):                                          # mbv2_yolo.
         super().__init__()
         self.conv = nn.Sequential(ConvBnLeaky(c, c, 3, True), ConvBnLeaky(c, c, 1))
 
-    def forward(self, x):
-        return torch.add(x, self.conv(x))
+    def forward(self, x, extra=None):
+        s = torch.add(x, self.conv(x))
+        if extra is not None:                                       # mbv2_yolo.py:151 (the sum the product forms in the same pass)
+            s = torch.add(s, extra)
+        return _store(s)
 
 
 class RefYolo(nn.Module):
@@ -140,7 +152,7 @@ class RefYolo(nn.Module):
         s32 = self.connect_for_S32(self.conv_for_S32(f2))
         out0 = self.yolo_headS32(s32)
         up = F.interpolate(s32, scale_factor=2, mode="nearest")
-        s16 = torch.add(self.connect_for_S16(self.conv_for_S16(f1)), up)
+        s16 = self.connect_for_S16(self.conv_for_S16(f1), extra=up)                  # :147,:151
         out1 = self.yolo_headS16(s16)
         self.seg_branch = self.seg_connect_for_S16(self.seg_conv_for_S16(f1))         # always executed (Q10)
         return out0, out1

@@ -9,7 +9,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import nms_ref, yolo_ref
-from .net_ref import ConvBnLeaky, Residual, _dw_pw_pw, _head
+from .net_ref import ConvBnLeaky, Residual, _dw_pw_pw, _head, _store
 
 
 def hswish(x):
@@ -25,7 +25,7 @@ class PixelGate(nn.Module):
                                 nn.Conv2d(c // r, c, 1, bias=False), nn.BatchNorm2d(c), nn.Identity())
 
     def forward(self, x):
-        return x * (F.relu6(self.se(x) + 3) / 6)
+        return _store(x * (F.relu6(self.se(x) + 3) / 6))
 
 
 class V3Block(nn.Module):
@@ -52,7 +52,7 @@ class V3Block(nn.Module):
         y = self.bn3(self.conv3(y))
         if self.se is not None:
             y = self.se(y)
-        return y + self.shortcut(x) if self.stride == 1 else y
+        return _store(y + self.shortcut(x)) if self.stride == 1 else y
 
 
 class V3Backbone(nn.Module):
@@ -112,7 +112,7 @@ class RefYoloV3(nn.Module):
         up = F.interpolate(s32, scale_factor=2, mode="nearest")
         s16 = self.connect_for_S16(self.connect_for_S16(f1))       # the same module twice (Q12)
         n = s16.size(1)                                              # PartAdd :85-96
-        s16 = torch.cat((s16 + up[:, :n], up[:, n:]), 1)
+        s16 = _store(torch.cat((s16 + up[:, :n], up[:, n:]), 1))
         return out0, self.yolo_headS16(s16)
 
     def forward(self, x, targets=None):
