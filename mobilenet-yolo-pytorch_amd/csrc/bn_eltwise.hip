@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
         o.y = fmaf(ca.y, gv.y * act_bwd(fmaf(yv.y, sc.y, sh.y), act), fmaf(cb.y, yv.y, cc.y));
         o.z = fmaf(ca.z, gv.z * act_bwd(fmaf(yv.z, sc.z, sh.z), act), fmaf(cb.z, yv.z, cc.z));
         o.w = fmaf(ca.w, gv.w * act_bwd(fmaf(yv.w, sc.w, sh.w), act), fmaf(cb.w, yv.w, cc.w));
-        st4(dy + m * C + c, o);
+        st4_stream(dy + m * C + c, o);
     }
 }
 
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void add_views_kernel(const T* __restrict__ a,
             const int64_t n = m / ((int64_t)W * H);
             add4(o, ld4(up + ((n * (H / 2) + hi / 2) * (W / 2) + wi / 2) * C + c));
         }
-        st4(out + m * C + c, o);
+        st4_stream(out + m * C + c, o);
     }
 }
 

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void dw_bnbwd_s1k3_kernel(
                     const int64_t o = img + ((int64_t)(r - 1) * gm.W + wo) * gm.C;
                     float4 out = P0;
                     if (addend) add4(out, ld4(addend + o));
-                    st4(dx + o, out);
+                    st4_stream(dx + o, out);
                 }
                 P0 = P1; P1 = P2;
                 // weight gradient: input row r-1 against the centre dY of rows r, r-1, r-2 (only rows this strip owns)

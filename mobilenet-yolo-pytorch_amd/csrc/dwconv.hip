@@ -448,10 +448,10 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2k3_kernel(const T* __restri
             if (hv) add4(o10, ld4(addend + base + (int64_t)W * C));
             if (hv && wv2) add4(o11, ld4(addend + base + (int64_t)W * C + C));
         }
-        st4(dx + base, o00);
-        if (wv2) st4(dx + base + C, o01);
-        if (hv) st4(dx + base + (int64_t)W * C, o10);
-        if (hv && wv2) st4(dx + base + (int64_t)W * C + C, o11);
+        st4_stream(dx + base, o00);
+        if (wv2) st4_stream(dx + base + C, o01);
+        if (hv) st4_stream(dx + base + (int64_t)W * C, o10);
+        if (hv && wv2) st4_stream(dx + base + (int64_t)W * C + C, o11);
     }
 }
 
@@ -503,10 +503,10 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2k5_kernel(const T* __restri
             if (hv) add4(o10, ld4(addend + base + (int64_t)W * C));
             if (hv && wv2) add4(o11, ld4(addend + base + (int64_t)W * C + C));
         }
-        st4(dx + base, o00);
-        if (wv2) st4(dx + base + C, o01);
-        if (hv) st4(dx + base + (int64_t)W * C, o10);
-        if (hv && wv2) st4(dx + base + (int64_t)W * C + C, o11);
+        st4_stream(dx + base, o00);
+        if (wv2) st4_stream(dx + base + C, o01);
+        if (hv) st4_stream(dx + base + (int64_t)W * C, o10);
+        if (hv && wv2) st4_stream(dx + base + (int64_t)W * C + C, o11);
     }
 }
 

@@ -513,7 +513,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                     float4 v = make_float4(r0 + bv.x, r1 + bv.y, r2 + bv.z, r3 + bv.w);
                     if (nvec) {
                         if (pAdd) add4(v, ld4(pAdd + row * p.N + colq));
-                        st4(pC + row * p.N + colq, v);
+                        st4_stream(pC + row * p.N + colq, v);
                     } else {
                         // ragged width (75-channel heads, 10-channel gate): rows are not 16-B aligned -> up to four element stores
                         // off ONE address (the transposed layout keeps this cheap: one row, consecutive columns)
@@ -1763,7 +1763,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                 float4 o = make_float4(r0 + bv.x, r1 + bv.y, r2 + bv.z, r3 + bv.w);
                 if (p.addend) { o.x += ad.x; o.y += ad.y; o.z += ad.z; o.w += ad.w; }
                 const int64_t row = m0 + wm * 32 + 8 * gq + 4 * khalf + jq;
-                if (cok && row < p.M) st4(p.C + row * p.Kc + colq, o);
+                if (cok && row < p.M) st4_stream(p.C + row * p.Kc + colq, o);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

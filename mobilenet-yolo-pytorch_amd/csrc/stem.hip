@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
                 o.x = fmaf(in[t], wv.x, o.x); o.y = fmaf(in[t], wv.y, o.y);
                 o.z = fmaf(in[t], wv.z, o.z); o.w = fmaf(in[t], wv.w, o.w);
             }
-            st4(y + p * g.Cout + c, o);
+            st4_stream(y + p * g.Cout + c, o);
             o = stored4<T>(o);
             add4(s1, o);
             fma4(s2, o, o);
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void stem_tile_kernel(const float* __restrict_
                             const float4 ww = wv[ci * 9 + kh * 3 + kw];
                             acc.x = fmaf(v, ww.x, acc.x); acc.y = fmaf(v, ww.y, acc.y); acc.z = fmaf(v, ww.z, acc.z); acc.w = fmaf(v, ww.w, acc.w);
                         }
-                st4(y + o, acc);
+                st4_stream(y + o, acc);
                 acc = stored4<T>(acc);
                 add4(s1, acc);
                 fma4(s2, acc, acc);
