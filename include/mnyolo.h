@@ -202,8 +202,10 @@ int mny_yolo_decode(const float* head, const float* anchors_all, const int32_t* 
  * out_rows (optional): the kept rows gathered densely, segment after segment.
  * thr is a double and the float IoU is promoted before the strict `>` compare, like torchvision.
  * max_seg_rows: caller's upper bound on rows in any one segment (sizes the LDS sort buffer;
- * 0 = use `capacity`).  A (segment,class) bucket larger than 8192 rows cannot be sorted in LDS:
- * it keeps nothing and the int32 at ws+mny_nms_status_offset() receives the offending size (0 = ok).
+ * 0 = use `capacity`).  No bucket-size limit (utils/box.py:20-29 has none): a (segment,class)
+ * bucket beyond the 8192-row LDS image is sorted and resolved through global scratch.  Only a
+ * WRONG bound (a real segment larger than max_seg_rows) is an error: such a bucket keeps nothing
+ * and the int32 at ws+mny_nms_status_offset() receives its size (0 = ok).
  * The int32[S+1] exclusive prefix of out_counts is left at ws+mny_nms_prefix_offset().
  * ws: mny_nms_ws_bytes() bytes. */
 int mny_nms_per_class(const float* rows, const int32_t* seg_begin, const int32_t* seg_count, int S,

@@ -439,8 +439,8 @@ __global__ __launch_bounds__(1024) void nms_bucket_kernel(const float* __restric
     const int n = s_n;
     const int bbase = r0 + s_lower;
     if (threadIdx.x == 0) bucket_base[s * num_classes + c] = bbase;
-    if (n > cap) {                                                       // does not fit: report, keep nothing
-        if (threadIdx.x == 0) { kept_count[s * num_classes + c] = 0; atomicMax(status, n); }
+    if (n > cap) {                                                       // does not fit the LDS image: leave it to nms_big_bucket_kernel
+        if (threadIdx.x == 0) kept_count[s * num_classes + c] = -n;       // (marker: negative size)
         return;
     }
     if (n == 0) { if (threadIdx.x == 0) kept_count[s * num_classes + c] = 0; return; }
@@ -562,7 +562,7 @@ __global__ __launch_bounds__(512) void nms_mask_kernel(const float4* __restrict_
                                                        const int32_t* __restrict__ bucket_n, double thr, int NT,
                                                        unsigned long long* __restrict__ mask) {
     const int b = blockIdx.y;
-    const int n = bucket_n[b], bbase = bucket_base[b];
+    const int n = max(bucket_n[b], 0), bbase = bucket_base[b];            // negative = oversized bucket (nms_big_bucket_kernel's)
     const int ntiles = (n + 63) >> 6;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // row tile blockIdx.x and its mirror ntiles-1-blockIdx.x: (ntiles - it) + (it + 1) column tiles per workgroup — the
@@ -611,6 +611,7 @@ __global__ __launch_bounds__(256) void nms_resolve_kernel(const unsigned long lo
     __shared__ int s_K;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = bucket_n_kept[b], bbase = bucket_base[b];
+    if (n < 0) return;                                                    // oversized bucket: keep the marker for nms_big_bucket_kernel
     if (tid == 0) s_K = 0;
     __syncthreads();
     const int ntiles = (n + 63) >> 6;
@@ -661,18 +662,166 @@ __global__ __launch_bounds__(256) void nms_resolve_kernel(const unsigned long lo
     if (tid == 0) bucket_n_kept[b] = s_K;
 }
 
+// ---- buckets beyond the LDS image (more than NMS_CAP boxes of one class in one image) --------------------------------------------
+// utils/box.py:20-29 has no size limit.  Such a bucket is rare (the reference's own eval path produces at most 1 815 candidates
+// per image), so it gets the simple treatment: ONE workgroup of 1024 threads with its sort keys and row indices in global
+// scratch — a second scan of the segment to collect the bucket (stable), a bitonic sort over global memory (same key = score
+// descending, original position ascending, so the order is the one the LDS sort produces), then the same 64-candidates-at-a-time
+// greedy loop as nms_bucket_kernel (kept boxes re-read from kbox).  grid (S, C); every bucket that fitted exits at once.
+//   gkeys  [2 * capacity] u64: bucket at 2 * bbase (padded to a power of two < 2n: regions of different buckets stay disjoint)
+//   growidx[capacity]      i32: bucket at bbase
+__global__ __launch_bounds__(1024) void nms_big_bucket_kernel(const float* __restrict__ rows, const int32_t* __restrict__ seg_begin,
+                                                              const int32_t* __restrict__ seg_count, int num_classes, double thr,
+                                                              int32_t* __restrict__ tmp, float4* kbox, const int32_t* __restrict__ bucket_base,
+                                                              int32_t* __restrict__ kept_count, unsigned long long* __restrict__ gkeys,
+                                                              int32_t* __restrict__ growidx) {
+    const int s = blockIdx.x, c = blockIdx.y, b = s * num_classes + c;
+    const int marker = kept_count[b];
+    if (marker >= 0) return;
+    const int n = -marker, bbase = bucket_base[b];
+    const int BT = blockDim.x, NWV = BT >> 6;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = seg_begin[s], r1 = r0 + seg_count[s];
+    const float cf = (float)c;
+    unsigned long long* keys = gkeys + 2 * (int64_t)bbase;
+    int32_t* rowidx = growidx + bbase;
+    __shared__ int32_t s_wsum[16];
+    __shared__ int32_t s_n, s_kept;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    // 1. stable fill
+    for (int c0 = r0; c0 < r1; c0 += BT) {
+        const int i = c0 + threadIdx.x;
+        bool mine = false;
+        float score = 0.f;
+        if (i < r1) {
+            const float* r = rows + (int64_t)i * 7;
+            mine = (r[6] == cf);
+            if (mine) score = r[5] * r[4];                               // utils/box.py:27
+        }
+        const unsigned long long bm = __ballot(mine);
+        if (lane == 0) s_wsum[wave] = __popcll(bm);
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; ++w) woff += s_wsum[w];
+        const int base = s_n;
+        if (mine) {
+            const int pos = base + woff + __popcll(bm & ((1ull << lane) - 1ull));
+            keys[pos] = ((unsigned long long)desc_key(score) << 32) | (unsigned)pos;
+            rowidx[pos] = i;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { int a = 0; for (int w = 0; w < NWV; ++w) a += s_wsum[w]; s_n = base + a; }
+        __syncthreads();
+    }
+    int n2 = 1; while (n2 < n) n2 <<= 1;
+    for (int i = n + threadIdx.x; i < n2; i += BT) keys[i] = ~0ull;
+    __syncthreads();
+    // 2. bitonic sort in global memory (one workgroup: __syncthreads orders its own global accesses)
+    for (int k = 2; k <= n2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < n2; i += BT) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const unsigned long long a = keys[i], bb = keys[l];
+                    const bool up = (i & k) == 0;
+                    if ((a > bb) == up) { keys[i] = bb; keys[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    // 3. greedy suppression, 64 candidates at a time (see nms_bucket_kernel): 16 waves split the kept list
+    __shared__ float4 tbox[64];
+    __shared__ unsigned long long tmask[64];
+    __shared__ int tsup[64];
+    __shared__ unsigned long long s_keepbits;
+    if (threadIdx.x == 0) s_kept = 0;
+    __syncthreads();
+    const int cnd = lane, part = wave;
+    for (int tile0 = 0; tile0 < n; tile0 += 64) {
+        const int j = tile0 + cnd;
+        const bool valid = j < n;
+        int ri = 0;
+        float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) {
+            ri = rowidx[(unsigned)(keys[j] & 0xFFFFFFFFull)];
+            const float* bp = rows + (int64_t)ri * 7;
+            bx = make_float4(bp[0], bp[1], bp[2], bp[3]);
+        }
+        const float aj = (bx.z - bx.x) * (bx.w - bx.y);
+        if (part == 0) { tbox[cnd] = bx; tsup[cnd] = valid ? 0 : 1; tmask[cnd] = 0ull; }
+        __syncthreads();
+        const int K = s_kept;
+        bool sup = false;
+        for (int k = part; k < K; k += NWV) {
+            const float4 kb = kbox[bbase + k];
+            const float ia = (kb.z - kb.x) * (kb.w - kb.y);
+            const float xx1 = kb.x > bx.x ? kb.x : bx.x, yy1 = kb.y > bx.y ? kb.y : bx.y;
+            const float xx2 = kb.z < bx.z ? kb.z : bx.z, yy2 = kb.w < bx.w ? kb.w : bx.w;
+            float w = xx2 - xx1; if (!(w > 0.f)) w = 0.f;
+            float h = yy2 - yy1; if (!(h > 0.f)) h = 0.f;
+            const float inter = w * h;
+            const float ovr = inter / (ia + aj - inter);
+            if ((double)ovr > thr) sup = true;
+        }
+        if (sup && valid) tsup[cnd] = 1;                           // benign race: only ever set to 1
+        unsigned long long bits = 0ull;                            // which of candidates part*4..+3 would `cnd` suppress
+        for (int q = 0; q < 64 / 16; ++q) {
+            const int o = part * (64 / 16) + q;
+            if (part >= 16 || o <= cnd || tile0 + o >= n) continue;
+            const float4 ob = tbox[o];
+            const float ao = (ob.z - ob.x) * (ob.w - ob.y);
+            const float xx1 = bx.x > ob.x ? bx.x : ob.x, yy1 = bx.y > ob.y ? bx.y : ob.y;
+            const float xx2 = bx.z < ob.z ? bx.z : ob.z, yy2 = bx.w < ob.w ? bx.w : ob.w;
+            float w = xx2 - xx1; if (!(w > 0.f)) w = 0.f;
+            float h = yy2 - yy1; if (!(h > 0.f)) h = 0.f;
+            const float inter = w * h;
+            const float ovr = inter / (aj + ao - inter);
+            if ((double)ovr > thr) bits |= 1ull << o;
+        }
+        if (bits) atomicOr(&tmask[cnd], bits);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned long long removed = 0ull, keep = 0ull;
+            const int lim = min(64, n - tile0);
+            for (int i = 0; i < lim; ++i) {
+                if (tsup[i] || ((removed >> i) & 1ull)) continue;
+                keep |= 1ull << i;
+                removed |= tmask[i];
+            }
+            s_keepbits = keep;
+        }
+        __syncthreads();
+        const unsigned long long keep = s_keepbits;
+        if (part == 0 && ((keep >> cnd) & 1ull)) {
+            const int r = K + __popcll(keep & ((1ull << cnd) - 1ull));
+            tmp[bbase + r] = ri;
+            kbox[bbase + r] = bx;
+        }
+        __syncthreads();                                           // kept boxes visible to the whole workgroup
+        if (threadIdx.x == 0) s_kept = K + __popcll(keep);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) kept_count[b] = s_kept;
+}
+
 // grid (S, slices): concatenate the kept lists of a segment in class order (every block walks the class offsets, copies its
 // slice of each class)
 __global__ __launch_bounds__(256) void nms_compact_kernel(const int32_t* __restrict__ seg_begin, int num_classes,
                                                           const int32_t* __restrict__ tmp, const int32_t* __restrict__ bucket_base,
                                                           const int32_t* __restrict__ kept_count, int32_t* __restrict__ out_idx,
-                                                          int32_t* __restrict__ out_counts) {
+                                                          int32_t* __restrict__ out_counts, int32_t* __restrict__ status) {
     const int s = blockIdx.x;
     const int begin = seg_begin[s];
     const int t0 = blockIdx.y * 256 + threadIdx.x, tstride = gridDim.y * 256;
     int off = begin;
     for (int c = 0; c < num_classes; ++c) {
-        const int k = kept_count[s * num_classes + c], b = bucket_base[s * num_classes + c];
+        int k = kept_count[s * num_classes + c];
+        const int b = bucket_base[s * num_classes + c];
+        if (k < 0) {                     // an oversized bucket nobody processed: the caller's max_seg_rows was smaller than a real segment
+            if (t0 == 0) atomicMax(status, -k);
+            k = 0;
+        }
         for (int i = t0; i < k; i += tstride) out_idx[off + i] = tmp[b + i];
         off += k;
     }
@@ -769,6 +918,7 @@ extern "C" size_t mny_nms_ws_bytes(int S, int capacity, int num_classes) {
     size_t bytes = align256((size_t)(capacity > 0 ? capacity : 1) * 4) + 2 * align256((size_t)S * num_classes * 4) + align256((size_t)(S + 1) * 4) + 256 +
                    align256((size_t)(capacity > 0 ? capacity : 1) * 16);
     if (nms_large(S, capacity)) bytes += align256((size_t)capacity * (nms_cap_for(capacity) / 64) * 8);
+    if (capacity > NMS_CAP) bytes += align256((size_t)capacity * 16) + align256((size_t)capacity * 4);     // oversized buckets: global sort keys + row indices
     return bytes;
 }
 
@@ -803,6 +953,11 @@ extern "C" int mny_nms_per_class(const float* rows, const int32_t* seg_begin, co
         attr_set = true;
     }
     if (hipMemsetAsync(status, 0, 4, st) != hipSuccess) { set_error("nms: memset failed"); return MNY_EHIP; }
+    char* after = (char*)kbox + align256((size_t)(capacity > 0 ? capacity : 1) * 16);
+    if (nms_large(S, capacity)) after += align256((size_t)capacity * (nms_cap_for(capacity) / 64) * 8);
+    unsigned long long* gkeys = (unsigned long long*)after;               // only laid out when capacity > NMS_CAP (mny_nms_ws_bytes)
+    int32_t* growidx = (int32_t*)(after + align256((size_t)capacity * 16));
+    const int seg_bound = max_seg_rows > 0 && max_seg_rows < capacity ? max_seg_rows : capacity;       // no bucket is larger than its segment
     if (nms_large(S, capacity)) {
         unsigned long long* mask = (unsigned long long*)((char*)kbox + align256((size_t)(capacity > 0 ? capacity : 1) * 16));
         const int NT = cap / 64;
@@ -813,8 +968,11 @@ extern "C" int mny_nms_per_class(const float* rows, const int32_t* seg_begin, co
     } else
     hipLaunchKernelGGL(nms_bucket_kernel<false>, dim3(S, num_classes), dim3(256), lds, st, rows, seg_begin, seg_count, num_classes, thr, cap, tmp,
                        kbox, bucket_base, kept, status);
+    if (seg_bound > NMS_CAP)                                               // a bucket may exceed the LDS image: those (marked) go through global scratch
+        hipLaunchKernelGGL(nms_big_bucket_kernel, dim3(S, num_classes), dim3(1024), 0, st, rows, seg_begin, seg_count, num_classes, thr, tmp, kbox,
+                           bucket_base, kept, gkeys, growidx);
     const int slices = nms_large(S, capacity) ? 64 : 1;                    // few huge segments: spread the copies over more blocks
-    hipLaunchKernelGGL(nms_compact_kernel, dim3(S, slices), dim3(256), 0, st, seg_begin, num_classes, tmp, bucket_base, kept, out_idx, out_counts);
+    hipLaunchKernelGGL(nms_compact_kernel, dim3(S, slices), dim3(256), 0, st, seg_begin, num_classes, tmp, bucket_base, kept, out_idx, out_counts, status);
     hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(256), 0, st, out_counts, S, prefix);
     if (out_rows)
         hipLaunchKernelGGL(nms_gather_kernel, dim3(S, slices), dim3(256), 0, st, rows, seg_begin, out_idx, out_counts, prefix, out_rows);

@@ -299,7 +299,7 @@ class yolo(nn.Module):
             plan.forward_eval(x, [float(h.val_conf) for h in self.yolo_losses])
             counts = plan.out_counts.tolist()                                   # the one host sync of the eval path
             if int(plan.nms_status.item()) != 0:
-                raise _lib.MnyError("NMS: a class bucket of %d boxes exceeds the 8192-box LDS limit" % int(plan.nms_status.item()))
+                raise _lib.MnyError("NMS: a bucket of %d boxes exceeded the plan's per-image candidate bound" % int(plan.nms_status.item()))
             total = sum(counts)
             dets = plan.out_rows[:total].clone()
         dets = list(torch.split(dets, counts))                                  # list of [k_i,7] (mbv2_yolo.py:159-166)

@@ -183,10 +183,44 @@ def test_nms_reference_driver_fixture(ops):
     assert np.array_equal(out_rows[:int(prefix[-1])].cpu().numpy(), zn["rows"])
 
 
-def test_nms_bucket_overflow_is_reported(ops):
+def test_nms_buckets_beyond_the_lds_image(ops):
+    """utils/box.py:20-29 has no bucket-size limit: one class with 9 000 / 50 000 boxes (more than the 8 192-row LDS image) goes
+    through the global-scratch path, mixed with ordinary buckets, on both driver paths — indices identical to the CPU kernel."""
+    for n, C, seed, dense in ((9000, 1, 5, False), (50000, 1, 6, True), (30000, 3, 7, False)):
+        r = np.random.RandomState(seed)
+        if dense:                                   # heavy overlap: long kept list re-scans
+            ctr = 0.5 + 0.15 * r.randn(n, 2).astype(np.float32)
+            wh = (0.05 + 0.1 * r.rand(n, 2)).astype(np.float32)
+            cls = np.zeros((n, 1), np.float32)
+        else:
+            ctr = r.rand(n, 2).astype(np.float32)
+            wh = (0.02 + 0.1 * r.rand(n, 2)).astype(np.float32)
+            cls = np.zeros((n, 1), np.float32) if C == 1 else np.where(r.rand(n, 1) < 0.8, 1.0, r.randint(0, C, (n, 1))).astype(np.float32)   # class 1 oversized
+        rows = torch.from_numpy(np.concatenate((ctr - wh / 2, ctr + wh / 2, r.rand(n, 2).astype(np.float32), cls), 1).astype(np.float32))
+        ref_rows, ref_idx = nms_ref.nms_rows(rows, C, 0.45)
+        for segs in ((n,), (n // 3, n - n // 3)):   # one segment (large-bucket driver) and two (still oversized buckets)
+            off = np.concatenate(([0], np.cumsum(segs))).astype(np.int32)
+            beg, cnt = torch.from_numpy(off[:-1].copy()).cuda(), torch.tensor(segs, dtype=torch.int32).cuda()
+            out_idx, out_counts, out_rows, prefix, status = ops.nms_per_class(rows.cuda(), beg, cnt, C, 0.45, max_seg_rows=max(segs))
+            assert int(status.cpu()) == 0
+            oc = out_counts.cpu().numpy()
+            if len(segs) == 1:
+                assert oc[0] == len(ref_idx)
+                assert np.array_equal(out_idx[:oc[0]].cpu().numpy(), ref_idx.numpy())
+                assert np.array_equal(out_rows[:oc[0]].cpu().numpy(), ref_rows.numpy())
+            else:
+                for si in range(len(segs)):
+                    seg = rows[off[si]:off[si + 1]]
+                    rr, ri = nms_ref.nms_rows(seg, C, 0.45)
+                    got = out_idx[off[si]:off[si] + oc[si]].cpu().numpy() - off[si]
+                    assert oc[si] == len(ri) and np.array_equal(got, ri.numpy()), (n, C, si)
+
+
+def test_nms_wrong_segment_bound_is_reported(ops):
+    """A caller's max_seg_rows smaller than a real segment is the one remaining error: reported through the status word."""
     rows = _rand_rows(9000, 1, seed=5)
     beg, cnt = torch.tensor([0], dtype=torch.int32).cuda(), torch.tensor([9000], dtype=torch.int32).cuda()
-    _, counts, _, _, status = ops.nms_per_class(rows.cuda(), beg, cnt, 1, 0.45)
+    _, counts, _, _, status = ops.nms_per_class(rows.cuda(), beg, cnt, 1, 0.45, max_seg_rows=4000)
     assert int(status.cpu()) == 9000 and int(counts.cpu()[0]) == 0
 
 
