@@ -31,7 +31,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
+PROFILE_TAG = "r02"               # profiles/<tag>_traffic_*.json: PMC passes of this round (tools/prof_round.sh + tools/prof_summary.py)
 BATCH = 256
 SIZE = 352
 
@@ -41,6 +43,10 @@ SIZE = 352
 # reduction in the epilogue: MFMA work plus an HBM-bound read of that unit's output) is a different entry point with its own,
 # distinct kernel instantiations (pw_gemm_nt_dma_kernel<..., RED = 1>) — it is not priced against the MFMA peak
 MFMA_KERNELS = {"mny_pw_fwd", "mny_pw_fwd_bf16"}
+# priced in a SECOND, untimed pass of K event-bracketed steps (brackets cost the GPU its back-to-back dispatch, so they stay out
+# of the timed region): the depthwise forward against HBM (north-star target >= 60 %), the other two GEMM entry points against MFMA
+SECOND_PASS = {"mny_dw_fwd": "hbm", "mny_pw_wgrad": "mfma", "mny_pw_dgrad_bnred": "mfma",
+               "mny_dw_fwd_bf16": "hbm", "mny_pw_wgrad_bf16": "mfma", "mny_pw_dgrad_bnred_bf16": "mfma"}
 
 
 def parse():
@@ -361,6 +367,94 @@ def roofline_from(events, calls_by_list):
     return agg
 
 
+def plan_signature(plan, entry):
+    """Stable fingerprint of the launches of one entry point in a plan (shapes in launch order): the committed PMC traffic
+    figure is only valid for exactly this launch list."""
+    import hashlib
+    items = []
+    for calls in (plan.fwd.calls, plan.bwd.calls):
+        for _fn, _args, name, meta in calls:
+            if name == entry:
+                items.append((meta or {}).get("shape", "?"))
+    return len(items), hashlib.sha256("|".join(items).encode()).hexdigest()[:16]
+
+
+def committed_traffic(plan, entry, headline):
+    """HBM bytes per launch of `entry` from the PMC counters.  bench.py cannot run rocprofv3 on itself, so this is the committed
+    result of the prescribed separate --pmc passes over this very command (profiles/README.md) — accepted only while the plan
+    still launches exactly the kernels that were profiled; otherwise null and a loud note."""
+    path = os.path.join(HERE, "profiles", "%s_traffic_%s.json" % (PROFILE_TAG, entry))
+    if not headline or not os.path.exists(path):
+        return None, None
+    tj = json.load(open(path))
+    n, sig = plan_signature(plan, entry)
+    if tj.get("launches_per_step") != n or tj.get("plan_signature") != sig:
+        print("bench: %s is STALE (profiled %s launches / signature %s, plan now has %d / %s): roofline.traffic left null — "
+              "re-run tools/prof_round.sh" % (os.path.basename(path), tj.get("launches_per_step"), tj.get("plan_signature"), n, sig), file=sys.stderr)
+        return None, "stale: " + os.path.basename(path)
+    return round(tj["hbm_bytes_per_launch"]), "profiles/%s: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + --pmc WRITE_SIZE, separate passes" % os.path.basename(path)
+
+
+def roofline_object(name, d, steps, bound, bf16, measured):
+    secs = d["ms"] * 1e-3
+    o = {"kernel": name, "bound": bound, "launches_per_step": d["n"] // steps, "ms_per_step": round(d["ms"] / steps, 3),
+         "algorithmic_bytes_per_launch": round(d["bytes"] / max(d["n"], 1)), "measured": measured}
+    if bound == "mfma":
+        peak = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
+        ach = d["flops"] / secs / 1e12
+        o.update(achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4),
+                 algorithmic_gflop_per_step=round(d["flops"] / steps / 1e9, 2), algorithmic_hbm_gbs=round(d["bytes"] / secs / 1e9, 1))
+    else:
+        ach = d["bytes"] / secs / 1e9
+        o.update(achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4),
+                 algorithmic_gb_per_step=round(d["bytes"] / steps / 1e9, 3))
+    o["traffic"] = None
+    return o
+
+
+def config3_leg(device, steps=12, warmup=4):
+    """BASELINE configs[3]: MobileNetV3-YOLO 512x512, bf16 activation storage, bs=64 — one extra leg of the default run so the
+    driver's own `python bench.py` carries it.  HBM-bound almost everywhere (SURVEY §8d C4 note: machine balance at bf16 is
+    312 FLOP/B, one layer of 82 exceeds it), so the honest roofline is algorithmic bytes / time against 8 TB/s."""
+    from mobilenet_yolo_pytorch_amd import mbv3, synthetic
+    torch.manual_seed(0)
+    model = mbv3.yolo(synthetic.VOC_CONFIG, act_dtype=torch.bfloat16).to(device).train()
+    bs, size = 64, 512
+    x = synthetic.images(bs, size, size, seed=0).to(device)
+    tg = synthetic.targets(bs, seed=1, empty_every=16)
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        out = model(x, tg)
+        (out[0][0] + out[1][0]).backward()
+        return out
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    plan = model._plans[(bs, size, size, True, "bf16")]
+    by, fl = 0, 0
+    for calls in (plan.fwd.calls, plan.bwd.calls):
+        for c in calls:
+            by += (c[3] or {}).get("bytes", 0)
+            fl += (c[3] or {}).get("flops", 0)
+    res = {"workload": "MobileNetV3-YOLO 512x512 bs=64 fwd+loss+bwd, bf16 activation storage (BASELINE configs[3])",
+           "value": round(bs / dt, 1), "unit": "images/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps, "warmup": warmup, "dtype": "bf16",
+           "loss": round(float(out[0][0].detach()) + float(out[1][0].detach()), 5),
+           "roofline": {"bound": "hbm", "achieved": round(by / dt / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(by / dt / 1e9 / PEAK_HBM_GBS, 4),
+                        "traffic": None, "algorithmic_gb_per_step": round(by / 1e9, 3), "algorithmic_tflop_per_step": round(fl / 1e12, 3),
+                        "launches_per_step": len(plan.fwd.calls) + len(plan.bwd.calls),
+                        "note": "whole step: sum of the algorithmic bytes of every conv / BN / elementwise call of the plan over the step time"}}
+    del model, plan
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -433,6 +527,16 @@ def main():
         torch.cuda.synchronize()
     timing = plan.disable_timing()
     loss = float(out[0][0].detach()) + float(out[1][0].detach())
+    second = None
+    if world == 1 and not a.breakdown:                # untimed second pass (single GPU only): the other priced entry points, bracketed
+        k2 = max(3, min(a.steps, 10))
+        plan.enable_timing(only=set(SECOND_PASS), steps=k2)
+        for _ in range(k2):
+            step()
+        if reducer is not None:
+            reducer.wait()
+        torch.cuda.synchronize()
+        second = (plan.disable_timing(), k2)
 
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -462,22 +566,26 @@ def main():
                 print("%s %-18s %-28s %8.3f ms  %7.1f TF/s %7.1f GB/s" % (which, name, meta.get("shape", ""), ms,
                       meta.get("flops", 0) / ms / 1e9 if ms else 0, meta.get("bytes", 0) / ms / 1e6 if ms else 0), file=sys.stderr)
         dom = max((n for n in agg if n in MFMA_KERNELS), key=lambda n: agg[n]["ms"])
-        d = agg[dom]
-        achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
-        roof = {"kernel": dom, "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
-                "algorithmic_bytes_per_launch": round(d["bytes"] / max(d["n"], 1)),
-                "launches_per_step": d["n"] // a.steps, "measured": ("HIP events inside the timed steps" if inline else
-                "HIP events over %d further steps run right after the timed (hipGraph-replayed) steps" % a.steps), "ms_per_step": round(d["ms"] / a.steps, 3),
-                "algorithmic_gflop_per_step": round(d["flops"] / a.steps / 1e9, 2),
-                "algorithmic_hbm_gbs": round(d["bytes"] / (d["ms"] * 1e-3) / 1e9, 1)}
-        # HBM bytes per launch of the dominant entry point from the PMC counters: bench.py cannot run rocprofv3 on itself, so this is
-        # the committed result of the prescribed separate --pmc passes over this very command (profiles/README.md), headline config only
-        side = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01h_traffic_mny_pw_fwd.json")
-        if (a.arch, a.size, a.batch, a.dtype, world) == ("mbv2", SIZE, BATCH, "f32", 1) and dom == "mny_pw_fwd" and os.path.exists(side):
-            tj = json.load(open(side))
-            roof["traffic"] = round(tj["hbm_bytes_per_launch"])
-            roof["traffic_source"] = "profiles/r01h_traffic_mny_pw_fwd.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + --pmc WRITE_SIZE, separate passes"
+        headline = (a.arch, a.size, a.batch, a.dtype, world) == ("mbv2", SIZE, BATCH, "f32", 1)
+        bf16 = a.dtype == "bf16"
+        roof = roofline_object(dom, agg[dom], a.steps, "mfma", bf16, "HIP events inside the timed steps" if inline else
+                               "HIP events over %d further steps run right after the timed (hipGraph-replayed) steps" % a.steps)
+        roof["traffic"], src = committed_traffic(plan, dom, headline)
+        if src:
+            roof["traffic_source"] = src
+        if bf16:                                       # bf16 storage: the GEMMs are HBM-bound — say so on the line
+            roof["note"] = "priced against the dense bf16 MFMA peak; this configuration is HBM-bound: see algorithmic_hbm_gbs / %d GB/s" % int(PEAK_HBM_GBS)
+        others = []
+        if second is not None:
+            t2, k2 = second
+            agg2 = roofline_from({"fwd": t2["fwd"], "bwd": t2["bwd"]}, {"fwd": plan.fwd.calls, "bwd": plan.bwd.calls})
+            for name in sorted(agg2, key=lambda n: -agg2[n]["ms"]):
+                o = roofline_object(name, agg2[name], k2, SECOND_PASS[name], bf16,
+                                    "HIP events over %d further steps run right after the timed region (untimed pass)" % k2)
+                o["traffic"], src = committed_traffic(plan, name, headline)
+                if src:
+                    o["traffic_source"] = src
+                others.append(o)
         res = {
             "metric": "images/sec MobileNetV2-YOLO 352x352 fwd+bwd @ bs256" if (a.arch, a.size, a.batch, a.dtype) == ("mbv2", SIZE, BATCH, "f32")
             else "images/sec %s-YOLO %dx%d fwd+bwd @ bs%d (NOT the headline config)" % (a.arch, a.size, a.size, a.batch), "value": round(world * a.batch * a.steps / dt, 2),
@@ -492,8 +600,17 @@ def main():
                        "loss": round(loss, 5)},
             "roofline": roof,
         }
+        res["plan_signatures"] = {e: list(plan_signature(plan, e)) for e in [dom] + sorted(SECOND_PASS) if plan_signature(plan, e)[0]}
+        hb = [o for o in others if o["bound"] == "hbm"]
+        if hb:
+            res["roofline_hbm"] = hb[0]               # the bandwidth-bound depthwise forward (north-star target: frac >= 0.6)
+        if others:
+            res["roofline_more"] = [o for o in others if o["bound"] != "hbm"]
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
+        if world == 1 and not a.no_nms and headline:
+            del out
+            res["config3"] = config3_leg(device)
         if world == 1 and not a.no_nms:
             res["nms"] = nms_bench(device)
             res["map"] = map_bench(device)

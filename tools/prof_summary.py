@@ -76,13 +76,35 @@ def main():
                 "(fetch x2 %.2f + write %.2f) = %.0f MB per launch.\n" % (g_n, g_ms, g_ms * 1e3 / max(g_n, 1), 2 * g_f + g_w, 2 * g_f, g_w,
                                                                           (2 * g_f + g_w) * 1e3 / max(g_n, 1)))
     import json
-    with open("profiles/%s_traffic_mny_pw_fwd.json" % tag, "w") as o:
-        json.dump({"entry_point": "mny_pw_fwd", "launches_per_step": g_n, "ms_per_step_rocprof": g_ms,
-                   "hbm_bytes_per_step": (2 * g_f + g_w) * 1e9, "hbm_bytes_per_launch": (2 * g_f + g_w) * 1e9 / max(g_n, 1),
-                   "fetch_size_x2_bytes_per_step": 2 * g_f * 1e9, "write_size_bytes_per_step": g_w * 1e9,
-                   "method": "rocprofv3 --kernel-trace --stats, --pmc FETCH_SIZE and --pmc WRITE_SIZE (three separate runs, tools/prof_round.sh) of "
-                             "`python3 bench.py --no-cpu-baseline --no-nms`; counter unit KiB; FETCH_SIZE x2 = gfx950 correction for wide coalesced "
-                             "streams (MI355X_MICROARCH.md, HBM section); WRITE_SIZE uncalibrated"}, o, indent=1)
+    # per entry point: HBM bytes per launch from the counters + the launch-list fingerprint bench.py printed in the SAME stats run
+    # (bench.py refuses the figure when its plan no longer launches exactly these kernels)
+    sigs = {}
+    try:
+        line = [ln for ln in open(stats_dir + "/../prof_stats.json") if ln.startswith("{")][-1]
+        sigs = json.loads(line).get("plan_signatures", {})
+    except (OSError, IndexError, ValueError):
+        print("warning: no bench JSON line next to the stats directory: traffic files carry no plan signature")
+    groups = {
+        "mny_pw_fwd": lambda k: k.startswith("pw_gemm_nt") and not re.search(r", 1>$", k),
+        "mny_pw_dgrad_bnred": lambda k: k.startswith("pw_gemm_nt") and bool(re.search(r", 1>$", k)),
+        "mny_pw_wgrad": lambda k: k.startswith("pw_wgrad"),
+        "mny_dw_fwd": lambda k: k.startswith("dw3_fwd_kernel") or bool(re.match(r"dw_slide_kernel<f32, \d, \d, 0,", k)),
+    }
+    for entry, pred in groups.items():
+        g = [(ms, n, f_gb, w_gb) for ms, k, n, f_gb, w_gb in rows if pred(k)]
+        g_ms, g_n = sum(r[0] for r in g), sum(r[1] for r in g)
+        g_f, g_w = sum(r[2] for r in g), sum(r[3] for r in g)
+        sig = sigs.get(entry, [None, None])
+        if sig[0] is not None and abs(sig[0] - g_n) > 0.01:
+            print("warning: %s: %s kernel launches/step in the trace vs %s calls in the plan (helper kernels or a wrong name filter)" % (entry, g_n, sig[0]))
+        with open("profiles/%s_traffic_%s.json" % (tag, entry), "w") as o:
+            json.dump({"entry_point": entry, "launches_per_step": sig[0] if sig[0] is not None else g_n, "plan_signature": sig[1],
+                       "kernel_launches_per_step_rocprof": g_n, "ms_per_step_rocprof": g_ms,
+                       "hbm_bytes_per_step": (2 * g_f + g_w) * 1e9, "hbm_bytes_per_launch": (2 * g_f + g_w) * 1e9 / max(sig[0] or g_n, 1),
+                       "fetch_size_x2_bytes_per_step": 2 * g_f * 1e9, "write_size_bytes_per_step": g_w * 1e9,
+                       "method": "rocprofv3 --kernel-trace --stats, --pmc FETCH_SIZE and --pmc WRITE_SIZE (three separate runs, tools/prof_round.sh) of "
+                                 "`python3 bench.py --no-cpu-baseline --no-nms`; counter unit KiB; FETCH_SIZE x2 = gfx950 correction for wide coalesced "
+                                 "streams (MI355X_MICROARCH.md, HBM section); WRITE_SIZE uncalibrated"}, o, indent=1)
     print(open("profiles/%s_kernels_time_and_hbm.md" % tag).read())
 
 
