@@ -441,15 +441,16 @@ def config3_leg(device, steps=12, warmup=4):
     by, fl = 0, 0
     for calls in (plan.fwd.calls, plan.bwd.calls):
         for c in calls:
-            by += (c[3] or {}).get("bytes", 0)
-            fl += (c[3] or {}).get("flops", 0)
+            if (c[3] or {}).get("flops", 0) > 0:       # convolution work only (forward, data / weight gradient); the separate BN passes
+                by += c[3].get("bytes", 0)             # of the un-fused units are overhead, not algorithmic traffic
+                fl += c[3]["flops"]
     res = {"workload": "MobileNetV3-YOLO 512x512 bs=64 fwd+loss+bwd, bf16 activation storage (BASELINE configs[3])",
            "value": round(bs / dt, 1), "unit": "images/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps, "warmup": warmup, "dtype": "bf16",
            "loss": round(float(out[0][0].detach()) + float(out[1][0].detach()), 5),
            "roofline": {"bound": "hbm", "achieved": round(by / dt / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(by / dt / 1e9 / PEAK_HBM_GBS, 4),
                         "traffic": None, "algorithmic_gb_per_step": round(by / 1e9, 3), "algorithmic_tflop_per_step": round(fl / 1e12, 3),
                         "launches_per_step": len(plan.fwd.calls) + len(plan.bwd.calls),
-                        "note": "whole step: sum of the algorithmic bytes of every conv / BN / elementwise call of the plan over the step time"}}
+                        "note": "whole step: algorithmic bytes of every convolution call of the plan (forward + data gradient + weight gradient; BN / elementwise passes not counted) over the step time"}}
     del model, plan
     torch.cuda.empty_cache()
     return res
