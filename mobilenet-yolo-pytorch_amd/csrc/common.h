@@ -107,6 +107,18 @@ __device__ __forceinline__ void fma4(float4& acc, float4 a, float4 b) {
 }
 __device__ __forceinline__ void add4(float4& acc, float4 a) { acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w; }
 
+// packed fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): a float4 as two register pairs — the stencil kernels are VALU-heavy
+// enough (3x3 taps x 4 channels, BN-apply / activation per tap) that halving the fma / mul count shows up in step time
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct F4P { v2f lo, hi; };
+__device__ __forceinline__ F4P f4p(float4 v) { F4P r; r.lo = v2f{v.x, v.y}; r.hi = v2f{v.z, v.w}; return r; }
+__device__ __forceinline__ F4P f4p0() { F4P r; r.lo = v2f{0.f, 0.f}; r.hi = v2f{0.f, 0.f}; return r; }
+__device__ __forceinline__ float4 f4u(F4P v) { return make_float4(v.lo.x, v.lo.y, v.hi.x, v.hi.y); }
+__device__ __forceinline__ void pfma(F4P& acc, F4P a, F4P b) {
+    acc.lo = __builtin_elementwise_fma(a.lo, b.lo, acc.lo);
+    acc.hi = __builtin_elementwise_fma(a.hi, b.hi, acc.hi);
+}
+
 // ---- LDS reads the compiler cannot see ------------------------------------------------------------------------------
 // hipcc treats every LDS read after a `global_load_lds` as possibly aliasing the DMA's LDS write and puts `s_waitcnt vmcnt(0)`
 // in front of it (SIInsertWaitcnts; no alias-scope information survives from HIP source).  In a multi-stage ring that wait
@@ -173,12 +185,6 @@ inline CgLayout make_stencil_layout(int C, int max_cgb = 64) {
     L.threads = L.cgb * L.ppb;
     return L;
 }
-
-// LDS-DMA staged depthwise forward (dwstage.hip): eligibility, partial-row count and launch
-bool dws_supported(int N, int H, int W, int C, int K, int stride);
-int dws_parts(int N, int H, int W, int C, int stride);
-int dws_launch(const float* x, const float* sc, const float* sh, int act, const float* w, float* y, float* parts, int N, int H, int W,
-               int C, int stride, hipStream_t st);
 
 // partial rows [parts][n] -> out[n]: 32 outputs x 8 part-slices per block, fp64 combine, fixed order
 __global__ void reduce_parts_f64_kernel(const float* __restrict__ parts, int nparts, int n, float* __restrict__ out);

@@ -26,12 +26,13 @@ struct DwbGeom {
     int TH, nHS;
     int64_t nstrips;
     int cg_total, cgb;
+    int xcd;            // XCD-contiguous strip order (workgroup b runs on XCD b % 8): column / row halos shared with the neighbours hit the same L2
 };
 
 // AM: activation of THIS unit: 0 = none (act' = 1), 1 = min(max(z, slope z), hi) family, 2 = hswish
-// XF: view of the input: 0 = as is, 1 = scale/shift + clamp family, 2 = scale/shift + hswish
+// XF: view of the input: 0 = as is, 1 = scale/shift + ReLU6, 2 = scale/shift + hswish, 3 = scale/shift + max(z, slope z) (leaky / relu / none)
 template <typename T, int AM, int XF>
-__global__ __launch_bounds__(256) void dw_bnbwd_s1k3_kernel(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void dw_bnbwd_s1k3_kernel(
     const T* __restrict__ g, const T* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift, int act,
     const float* __restrict__ coef, const T* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
     int in_act, const float* __restrict__ w, const T* __restrict__ addend, T* __restrict__ dx, float* __restrict__ parts, DwbGeom gm) {
@@ -64,21 +65,37 @@ __global__ __launch_bounds__(256) void dw_bnbwd_s1k3_kernel(
     if (cvalid) {
 #define WG(t) my[(t) * gm.cgb]
         const float slope = act_slope(act), hi = act_hi(act);
-        const float xslope = act_slope(in_act), xhi = act_hi(in_act);
+        const float xslope = act_slope(in_act);
 
-        auto dy1 = [&](float gv, float yv, float s, float h, float a, float b, float cterm) {
-            float d = gv;
-            if (AM == 1) { const float z = fmaf(yv, s, h); d = gv * ((z > 0.f ? 1.f : slope) * (z < hi ? 1.f : 0.f)); }
-            if (AM == 2) { const float z = fmaf(yv, s, h); d = gv * (z <= -3.f ? 0.f : (z >= 3.f ? 1.f : (2.f * z + 3.f) / 6.f)); }
-            return fmaf(a, d, fmaf(b, yv, cterm));
+        // dY = ca * G * act'(sc*Y + sh) + cb * Y + cc on one register pair (packed fma; the activation derivative is a select)
+        // act'(z) as selects between constants (v_cndmask; a select between computed values turned into branches)
+        auto dact = [&](float z) {
+            if (AM == 2) return z <= -3.f ? 0.f : (z >= 3.f ? 1.f : (2.f * z + 3.f) / 6.f);
+            return (z > 0.f ? 1.f : slope) * (z < hi ? 1.f : 0.f);
         };
-        auto xf1 = [&](float v, float s, float h) {
+        auto dy2 = [&](v2f gv, v2f yv, v2f s, v2f h, v2f a, v2f b, v2f cterm) {
+            v2f d = gv;
+            if (AM != 0) { const v2f z = __builtin_elementwise_fma(yv, s, h); d = gv * v2f{dact(z.x), dact(z.y)}; }
+            return __builtin_elementwise_fma(a, d, __builtin_elementwise_fma(b, yv, cterm));
+        };
+        auto xf2 = [&](v2f v, v2f s, v2f h) {
             if (XF == 0) return v;
-            const float z = fmaf(v, s, h);
-            return XF == 1 ? fminf(fmaxf(z, xslope * z), xhi) : z * fminf(fmaxf(z + 3.f, 0.f), 6.f) / 6.f;
+            const v2f z = __builtin_elementwise_fma(v, s, h);
+            if (XF == 1) return v2f{__builtin_amdgcn_fmed3f(z.x, 0.f, 6.f), __builtin_amdgcn_fmed3f(z.y, 0.f, 6.f)};      // ReLU6
+            if (XF == 3) {                                                   // leaky / relu / scale-only: max(z, slope z), no upper clip
+                const v2f t = z * v2f{xslope, xslope};
+                return v2f{fmaxf(z.x, t.x), fmaxf(z.y, t.y)};
+            }
+            const v2f t = z + v2f{3.f, 3.f};
+            return z * v2f{__builtin_amdgcn_fmed3f(t.x, 0.f, 6.f), __builtin_amdgcn_fmed3f(t.y, 0.f, 6.f)} * v2f{1.f / 6.f, 1.f / 6.f};
         };
 
-        for (int64_t strip = (int64_t)blockIdx.x * ppb + pix; strip < gm.nstrips; strip += (int64_t)gridDim.x * ppb) {
+        const int gxd = gridDim.x;
+        const int lb = (gm.xcd && (gxd & 7) == 0) ? (int)(blockIdx.x & 7) * (gxd >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+        F4P wp[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wp[t] = f4p(wacc[t]);
+        for (int64_t strip = (int64_t)lb * ppb + pix; strip < gm.nstrips; strip += (int64_t)gxd * ppb) {
             const int wo = (int)(strip % gm.W);
             const int hs = (int)((strip / gm.W) % gm.nHS);
             const int n = (int)(strip / ((int64_t)gm.W * gm.nHS));
@@ -86,19 +103,19 @@ __global__ __launch_bounds__(256) void dw_bnbwd_s1k3_kernel(
             const int h1 = min(h0 + gm.TH, gm.H);
             const int64_t img = (int64_t)n * gm.H * gm.W * gm.C + c;
             int col[3];
-            bool cok[3];
+            float cokf[3];
 #pragma unroll
-            for (int q = 0; q < 3; ++q) { const int wi = wo - 1 + q; cok[q] = wi >= 0 && wi < gm.W; col[q] = min(max(wi, 0), gm.W - 1); }
+            for (int q = 0; q < 3; ++q) { const int wi = wo - 1 + q; cokf[q] = (wi >= 0 && wi < gm.W) ? 1.f : 0.f; col[q] = min(max(wi, 0), gm.W - 1); }
 
-            float4 P0 = f4zero(), P1 = f4zero();
-            float4 aprev[3] = {f4zero(), f4zero(), f4zero()};
-            float4 dc1 = f4zero(), dc2 = f4zero();
+            F4P P0 = f4p0(), P1 = f4p0();
+            F4P aprev[3] = {f4p0(), f4p0(), f4p0()};
+            F4P dc1 = f4p0(), dc2 = f4p0();
             for (int r = h0 - 1; r <= h1; ++r) {
                 int lo = cgl;
                 asm volatile("" : "+v"(lo));                       // opaque per iteration: keeps the LDS constant reads IN the loop
                 const float4* my = cst + lo;                      // (hoisted, they are 64 VGPRs live across it)
                 const int rc = min(max(r, 0), gm.H - 1);
-                const bool rok = r >= 0 && r < gm.H;
+                const float rokf = (r >= 0 && r < gm.H) ? 1.f : 0.f;
                 const int64_t rowoff = img + (int64_t)rc * gm.W * gm.C;
                 float4 gv[3], yv[3], xv[3];
 #pragma unroll
@@ -106,42 +123,43 @@ __global__ __launch_bounds__(256) void dw_bnbwd_s1k3_kernel(
                     const int64_t o = rowoff + (int64_t)col[q] * gm.C;
                     gv[q] = ld4(g + o); yv[q] = ld4(y + o); xv[q] = ld4(x + o);
                 }
-                float4 dyr[3], ar[3];
-                const float4 sc = my[9 * gm.cgb], sh = my[10 * gm.cgb], ca = my[11 * gm.cgb], cb = my[12 * gm.cgb], cc = my[13 * gm.cgb];
-                const float4 xsc = my[14 * gm.cgb], xsh = my[15 * gm.cgb];
+                F4P dyr[3], ar[3];
+                const F4P sc = f4p(my[9 * gm.cgb]), sh = f4p(my[10 * gm.cgb]), ca = f4p(my[11 * gm.cgb]), cb = f4p(my[12 * gm.cgb]), cc = f4p(my[13 * gm.cgb]);
+                const F4P xsc = f4p(my[14 * gm.cgb]), xsh = f4p(my[15 * gm.cgb]);
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
-                    float4 d, a;
-                    d.x = dy1(gv[q].x, yv[q].x, sc.x, sh.x, ca.x, cb.x, cc.x); d.y = dy1(gv[q].y, yv[q].y, sc.y, sh.y, ca.y, cb.y, cc.y);
-                    d.z = dy1(gv[q].z, yv[q].z, sc.z, sh.z, ca.z, cb.z, cc.z); d.w = dy1(gv[q].w, yv[q].w, sc.w, sh.w, ca.w, cb.w, cc.w);
-                    a.x = xf1(xv[q].x, xsc.x, xsh.x); a.y = xf1(xv[q].y, xsc.y, xsh.y);
-                    a.z = xf1(xv[q].z, xsc.z, xsh.z); a.w = xf1(xv[q].w, xsc.w, xsh.w);
-                    const bool ok = rok && cok[q];                 // dY and the activated input are 0 outside the image
-                    dyr[q] = ok ? d : f4zero();
-                    ar[q] = ok ? a : f4zero();
+                    const float m = rokf * cokf[q];                // dY and the activated input are 0 outside the image
+                    const v2f m2 = v2f{m, m};
+                    const F4P G4 = f4p(gv[q]), Y4 = f4p(yv[q]), X4 = f4p(xv[q]);
+                    dyr[q].lo = dy2(G4.lo, Y4.lo, sc.lo, sh.lo, ca.lo, cb.lo, cc.lo) * m2;
+                    dyr[q].hi = dy2(G4.hi, Y4.hi, sc.hi, sh.hi, ca.hi, cb.hi, cc.hi) * m2;
+                    ar[q].lo = xf2(X4.lo, xsc.lo, xsh.lo) * m2;
+                    ar[q].hi = xf2(X4.hi, xsc.hi, xsh.hi) * m2;
                 }
                 // data gradient: dX[i][w] += sum_kq dY[r][w+1-kq] * wt[i-r+1][kq]  (dyr[q] sits at column w-1+q -> q = 2-kq)
-                float4 P2 = f4zero();
+                F4P P2 = f4p0();
 #pragma unroll
                 for (int kq = 0; kq < 3; ++kq) {
-                    fma4(P0, dyr[2 - kq], WG(0 + kq));
-                    fma4(P1, dyr[2 - kq], WG(3 + kq));
-                    fma4(P2, dyr[2 - kq], WG(6 + kq));
+                    pfma(P0, dyr[2 - kq], f4p(WG(0 + kq)));
+                    pfma(P1, dyr[2 - kq], f4p(WG(3 + kq)));
+                    pfma(P2, dyr[2 - kq], f4p(WG(6 + kq)));
                 }
                 if (r - 1 >= h0) {                                  // row r-1 is complete (r-1 < h1 by the loop bound)
                     const int64_t o = img + ((int64_t)(r - 1) * gm.W + wo) * gm.C;
-                    float4 out = P0;
+                    float4 out = f4u(P0);
                     if (addend) add4(out, ld4(addend + o));
                     st4_stream(dx + o, out);
                 }
                 P0 = P1; P1 = P2;
                 // weight gradient: input row r-1 against the centre dY of rows r, r-1, r-2 (only rows this strip owns)
-                const float4 dc0 = (r >= h0 && r < h1) ? dyr[1] : f4zero();
+                const float own = (r >= h0 && r < h1) ? 1.f : 0.f;
+                F4P dc0;
+                dc0.lo = dyr[1].lo * v2f{own, own}; dc0.hi = dyr[1].hi * v2f{own, own};
 #pragma unroll
                 for (int kq = 0; kq < 3; ++kq) {
-                    fma4(wacc[0 + kq], aprev[kq], dc0);
-                    fma4(wacc[3 + kq], aprev[kq], dc1);
-                    fma4(wacc[6 + kq], aprev[kq], dc2);
+                    pfma(wp[0 + kq], aprev[kq], dc0);
+                    pfma(wp[3 + kq], aprev[kq], dc1);
+                    pfma(wp[6 + kq], aprev[kq], dc2);
                 }
                 dc2 = dc1; dc1 = dc0;
 #pragma unroll
@@ -149,8 +167,10 @@ __global__ __launch_bounds__(256) void dw_bnbwd_s1k3_kernel(
             }
             // tail: input row h1 meets the centre dY of row h1-1 (kr = 2)
 #pragma unroll
-            for (int kq = 0; kq < 3; ++kq) fma4(wacc[6 + kq], aprev[kq], dc2);
+            for (int kq = 0; kq < 3; ++kq) pfma(wp[6 + kq], aprev[kq], dc2);
         }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wacc[t] = f4u(wp[t]);
 #undef WG
     }
 
@@ -182,7 +202,11 @@ static int dwb_geom(DwbGeom& g, CgLayout& L, int& gx, int N, int H, int W, int C
     L = make_stencil_layout(C);                            // <= 64 channel groups per block: >= 4 columns, <= 16 KB of LDS constants
     g.cg_total = L.cg_total; g.cgb = L.cgb;
     int64_t want = cdiv(g.nstrips, L.ppb);
-    const int cap = 768 / L.chunks > 0 ? 768 / L.chunks : 1;   // 3 resident workgroups per CU (<= 168 VGPRs): one full wave of blocks
+    int cap = 768 / L.chunks > 0 ? 768 / L.chunks : 1;         // 3 resident workgroups per CU (<= 168 VGPRs): one full wave of blocks
+    static const int xcd_env = getenv("MNY_DWB_XCD") ? atoi(getenv("MNY_DWB_XCD")) : 1;
+    g.xcd = xcd_env;
+    if (cap > 8) cap &= ~7;
+    if (want > 8) want = (want + 7) & ~(int64_t)7;
     gx = (int)(want < cap ? want : cap);
     return MNY_OK;
 }
@@ -200,14 +224,14 @@ static int dw_bnbwd_impl(const T* g, const T* y, const float* scale, const float
     dim3 grid(gx, L.chunks), block(L.threads);
     hipStream_t st = (hipStream_t)stream;
     const int am = act == MNY_ACT_NONE ? 0 : (act == MNY_ACT_HSWISH ? 2 : 1);
-    const int xf = (in_scale == nullptr && in_act == MNY_ACT_NONE) ? 0 : (in_act == MNY_ACT_HSWISH ? 2 : 1);
+    const int xf = (in_scale == nullptr && in_act == MNY_ACT_NONE) ? 0 : (in_act == MNY_ACT_HSWISH ? 2 : (in_act == MNY_ACT_RELU6 ? 1 : 3));
     const size_t lds = (size_t)16 * L.cgb * sizeof(float4);
 #define MNY_L(A_, X_) hipLaunchKernelGGL((dw_bnbwd_s1k3_kernel<T, A_, X_>), grid, block, lds, st, g, y, scale, shift, act, coef, x, in_scale, in_shift, \
                                          in_act, w, addend, dx, ws, gm)
-    switch (am * 3 + xf) {
-        case 0: MNY_L(0, 0); break; case 1: MNY_L(0, 1); break; case 2: MNY_L(0, 2); break;
-        case 3: MNY_L(1, 0); break; case 4: MNY_L(1, 1); break; case 5: MNY_L(1, 2); break;
-        case 6: MNY_L(2, 0); break; case 7: MNY_L(2, 1); break; default: MNY_L(2, 2); break;
+    switch (am * 4 + xf) {
+        case 0: MNY_L(0, 0); break; case 1: MNY_L(0, 1); break; case 2: MNY_L(0, 2); break; case 3: MNY_L(0, 3); break;
+        case 4: MNY_L(1, 0); break; case 5: MNY_L(1, 1); break; case 6: MNY_L(1, 2); break; case 7: MNY_L(1, 3); break;
+        case 8: MNY_L(2, 0); break; case 9: MNY_L(2, 1); break; case 10: MNY_L(2, 2); break; default: MNY_L(2, 3); break;
     }
 #undef MNY_L
     rc = check_launch("dw_bnbwd_s1k3_kernel");

@@ -191,10 +191,6 @@ __global__ __launch_bounds__(256) void dw_slide_kernel(
 //   * three column pointers bumped by the row pitch instead of per-tap 64-bit index arithmetic.
 // ~60 VALU per row.  Strips are handed to workgroups XCD-contiguously (workgroup i lands on XCD i % 8): the column / row halo
 // a workgroup shares with its neighbours is then in the same 4-MB L2 instead of going out to the fabric again.
-typedef float v2f __attribute__((ext_vector_type(2)));
-struct F4P { v2f lo, hi; };
-__device__ __forceinline__ F4P f4p(float4 v) { F4P r; r.lo = v2f{v.x, v.y}; r.hi = v2f{v.z, v.w}; return r; }
-__device__ __forceinline__ F4P f4p0() { F4P r; r.lo = v2f{0.f, 0.f}; r.hi = v2f{0.f, 0.f}; return r; }
 
 // XF: 0 none (value used as is), 1 ReLU6, 2 h-swish, 4 max(z, slope*z) = leaky / relu / scale-only (no upper clip)
 template <int XF>
@@ -600,19 +596,9 @@ static int dw_launch(const T* x, const float* sc, const float* sh, int act, cons
 
 using namespace mny;
 
-// The LDS-DMA staged forward (dwstage.hip) is opt-in (MNY_DW_STAGED=1, read per call).  Same-box A/B at bs=256: 4.34 vs 3.95
-// ms/step for the 24 depthwise forwards — equal where the block geometry is equal (C = 32, 96, 192), slower where the
-// channel chunking gives narrow per-pixel runs (C = 144: 18 groups = 288 B) — both kernels already sit at ~6 TB/s at the
-// L2->fabric counters, so staging has no latency left to hide.
-static bool use_staged(int N, int H, int W, int C, int K, int stride) {
-    const char* e = getenv("MNY_DW_STAGED");
-    return e && atoi(e) == 1 && dws_supported(N, H, W, C, K, stride);
-}
-
 extern "C" int mny_dw_stat_parts(int N, int H, int W, int C, int K, int stride) {
     DwGeom g; CgLayout L; int gx;
     if (dw_geom(g, L, gx, N, H, W, C, K, stride)) return MNY_EINVAL;
-    if (use_staged(N, H, W, C, K, stride)) return dws_parts(N, H, W, C, stride);
     return gx;
 }
 extern "C" int mny_dw_wgrad_parts(int N, int H, int W, int C, int K, int stride) {
@@ -630,8 +616,6 @@ static int dw_fwd_impl(const T* x, const float* in_scale, const float* in_shift,
 extern "C" int mny_dw_fwd(const float* x, const float* in_scale, const float* in_shift, int in_act, const float* w,
                           float* y, float* stats, int N, int H, int W, int C, int K, int stride, void* stream) {
     MNY_REQUIRE(x && w && y, "dw_fwd: null pointer");
-    if (use_staged(N, H, W, C, K, stride))                 // fp32 3x3: input rows staged through LDS by DMA (dwstage.hip)
-        return dws_launch(x, in_scale, in_shift, in_act, w, y, stats, N, H, W, C, stride, (hipStream_t)stream);
     return dw_fwd_impl<float>(x, in_scale, in_shift, in_act, w, y, stats, N, H, W, C, K, stride, stream);
 }
 extern "C" int mny_dw_fwd_bf16(const void* x, const float* in_scale, const float* in_shift, int in_act, const float* w,

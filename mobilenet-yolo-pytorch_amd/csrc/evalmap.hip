@@ -3,7 +3,8 @@
 // O(classes x images x detections) Python loop of 1xn IoU calls; here
 //   match  : thread per detection — best ground truth of its image & class (first maximum, fp32 IoU), the object's first
 //            claimant by atomicMin over the (stored-order) detection index  = the reference's sequential "already detected" flag
-//   flags  : TP / FP per detection + a 40-bit sort key (class | descending score); radix sort (rocPRIM, stable)
+//   flags  : TP / FP per detection + a 40-bit sort key (class | descending score); own bitonic sort of (key, stored index) pairs —
+//            the index breaks score ties, which is exactly what a stable sort of the stored order yields
 //   ap     : workgroup per class — n_easy, its key segment by binary search, block scan of TP/FP over the sorted run,
 //            11 running maxima of precision where recall >= t
 // Compiled with -ffp-contract=off: the IoU must round like the CPU tensor ops it replaces.
@@ -11,13 +12,10 @@
 
 #include <cstring>
 
-#include <rocprim/device/device_radix_sort.hpp>
-
 namespace mny {
 namespace {
 
 constexpr int kApThreads = 1024;
-constexpr int kKeyBits = 40;             // 8 class bits above 32 score bits
 constexpr uint32_t kNoClass = 255;
 
 struct thresholds { float t[11]; };
@@ -84,6 +82,69 @@ __global__ void map_flag_kernel(const float* __restrict__ det_labels, const floa
     const uint32_t asc = sb ^ ((sb >> 31) ? 0xFFFFFFFFu : 0x80000000u);        // order-preserving map of a float
     keys[d] = ((uint64_t)(c ? c : kNoClass) << 32) | (uint32_t)~asc;            // descending score inside the class
     vals[d] = ((uint32_t)d << 2) | (tp << 1) | fp;
+}
+
+// ---- sort of (key, value) pairs, ascending in (key, value) ----------------------------------------------------------------
+// value = stored detection index << 2 | flags, so the pair order is total and equals the stable order by key.  Bitonic network
+// over n2 = 2^m >= D padded pairs: every run of steps with partner distance < kSortChunk happens inside LDS (one workgroup per
+// 4096-pair chunk), the few steps with a longer distance are one global compare-exchange pass each (6 MB for VOC07-test).
+constexpr int kSortChunk = 4096;
+
+__device__ __forceinline__ bool pair_gt(uint64_t ka, uint32_t va, uint64_t kb, uint32_t vb) { return ka > kb || (ka == kb && va > vb); }
+
+__global__ void map_sort_pad_kernel(uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, int D, int n2) {
+    const int i = D + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n2) { keys[i] = ~0ull; vals[i] = ~0u; }
+}
+
+// steps j = j_first, j_first/2, ..., 1 of stage k (or, with k_first > 0, ALL stages k = 2 .. k_first) on one chunk
+__global__ __launch_bounds__(1024) void map_sort_local_kernel(uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, int k_first, int k, int j_first) {
+    __shared__ uint64_t sk[kSortChunk];
+    __shared__ uint32_t sv[kSortChunk];
+    const int base = blockIdx.x * kSortChunk;
+    for (int i = threadIdx.x; i < kSortChunk; i += blockDim.x) { sk[i] = keys[base + i]; sv[i] = vals[base + i]; }
+    __syncthreads();
+    auto steps = [&](int kk, int jf) {
+        for (int j = jf; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < kSortChunk; i += blockDim.x) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const bool up = ((base + i) & kk) == 0;
+                    const uint64_t a = sk[i], b = sk[l];
+                    const uint32_t x = sv[i], y = sv[l];
+                    if (pair_gt(a, x, b, y) == up) { sk[i] = b; sk[l] = a; sv[i] = y; sv[l] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    };
+    if (k_first > 0) { for (int kk = 2; kk <= k_first; kk <<= 1) steps(kk, kk >> 1); }
+    else steps(k, j_first);
+    for (int i = threadIdx.x; i < kSortChunk; i += blockDim.x) { keys[base + i] = sk[i]; vals[base + i] = sv[i]; }
+}
+
+__global__ void map_sort_global_kernel(uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, int n2, int k, int j) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int l = i ^ j;
+    if (i >= n2 || l <= i) return;
+    const bool up = (i & k) == 0;
+    const uint64_t a = keys[i], b = keys[l];
+    const uint32_t x = vals[i], y = vals[l];
+    if (pair_gt(a, x, b, y) == up) { keys[i] = b; keys[l] = a; vals[i] = y; vals[l] = x; }
+}
+
+inline int sort_size(int64_t D) { int n2 = kSortChunk; while (n2 < D) n2 <<= 1; return n2; }
+
+int sort_pairs(uint64_t* keys, uint32_t* vals, int D, hipStream_t st) {
+    const int n2 = sort_size(D);
+    if (n2 > D) map_sort_pad_kernel<<<(int)cdiv(n2 - D, 256), 256, 0, st>>>(keys, vals, D, n2);
+    const int chunks = n2 / kSortChunk;
+    map_sort_local_kernel<<<chunks, 1024, 0, st>>>(keys, vals, kSortChunk, 0, 0);
+    for (int k = 2 * kSortChunk; k <= n2; k <<= 1) {
+        for (int j = k >> 1; j >= kSortChunk; j >>= 1) map_sort_global_kernel<<<(int)cdiv(n2, 256), 256, 0, st>>>(keys, vals, n2, k, j);
+        map_sort_local_kernel<<<chunks, 1024, 0, st>>>(keys, vals, 0, k, kSortChunk >> 1);
+    }
+    return check_launch("mny_map sort");
 }
 
 __device__ __forceinline__ int lower_bound_key(const uint64_t* keys, int n, uint64_t k) {
@@ -199,7 +260,7 @@ __global__ void eval_pack_kernel(const float* __restrict__ rows, int D, const fl
 }
 
 struct map_ws_layout {
-    size_t keys_in, keys_out, vals_in, vals_out, match, first, sort_tmp, sort_bytes, total;
+    size_t keys, vals, match, first, total;
 };
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -207,19 +268,11 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 int map_layout(int64_t D, int64_t T, map_ws_layout& L) {
     size_t o = 0;
     const size_t d = (size_t)(D > 0 ? D : 1), t = (size_t)(T > 0 ? T : 1);
-    L.keys_in = o;  o = align256(o + d * 8);
-    L.keys_out = o; o = align256(o + d * 8);
-    L.vals_in = o;  o = align256(o + d * 4);
-    L.vals_out = o; o = align256(o + d * 4);
-    L.match = o;    o = align256(o + d * 4);
-    L.first = o;    o = align256(o + t * 4);
-    L.sort_bytes = 0;
-    if (D > 0) {
-        const hipError_t e = rocprim::radix_sort_pairs(nullptr, L.sort_bytes, (const uint64_t*)nullptr, (uint64_t*)nullptr, (const uint32_t*)nullptr,
-                                                       (uint32_t*)nullptr, (size_t)D, 0, kKeyBits, (hipStream_t)0);
-        if (e != hipSuccess) { set_error("mny_map: radix sort workspace query failed: %s", hipGetErrorString(e)); return MNY_EHIP; }
-    }
-    L.sort_tmp = o; o = align256(o + L.sort_bytes);
+    const size_t n2 = (size_t)sort_size(D);                    // the sort runs in place over the padded power of two
+    L.keys = o;  o = align256(o + n2 * 8);
+    L.vals = o;  o = align256(o + n2 * 4);
+    L.match = o; o = align256(o + d * 4);
+    L.first = o; o = align256(o + t * 4);
     L.total = o;
     return 0;
 }
@@ -249,22 +302,20 @@ extern "C" int mny_map_eval(const float* det_boxes, const float* det_labels, con
     map_ws_layout L;
     if (int rc = map_layout(D, T, L)) return rc;
     char* w = (char*)ws;
-    uint64_t *kin = (uint64_t*)(w + L.keys_in), *kout = (uint64_t*)(w + L.keys_out);
-    uint32_t *vin = (uint32_t*)(w + L.vals_in), *vout = (uint32_t*)(w + L.vals_out);
+    uint64_t* keys = (uint64_t*)(w + L.keys);
+    uint32_t* vals = (uint32_t*)(w + L.vals);
     int *match = (int*)(w + L.match), *first = (int*)(w + L.first);
     if (D > 0) {
         if (T > 0 && hipMemsetAsync(first, 0x7f, (size_t)T * 4, st) != hipSuccess) { set_error("mny_map_eval: memset failed"); return MNY_EHIP; }
         const int blocks = (int)cdiv(D, 256);
         map_match_kernel<<<blocks, 256, 0, st>>>(det_boxes, det_labels, det_off, true_boxes, true_labels, true_diff, true_off, n_images, (int)D, n_classes,
                                                  match, first);
-        map_flag_kernel<<<blocks, 256, 0, st>>>(det_labels, det_scores, match, first, (int)D, n_classes, kin, vin);
-        size_t bytes = L.sort_bytes;
-        const hipError_t e = rocprim::radix_sort_pairs(w + L.sort_tmp, bytes, (const uint64_t*)kin, kout, (const uint32_t*)vin, vout, (size_t)D, 0, kKeyBits, st);
-        if (e != hipSuccess) { set_error("mny_map_eval: radix sort failed: %s", hipGetErrorString(e)); return MNY_EHIP; }
+        map_flag_kernel<<<blocks, 256, 0, st>>>(det_labels, det_scores, match, first, (int)D, n_classes, keys, vals);
+        if (int rc = sort_pairs(keys, vals, (int)D, st)) return rc;
     }
     thresholds thr;
     for (int i = 0; i < 11; ++i) thr.t[i] = (float)(0.1 * (double)i);             // torch.arange(0, 1.1, .1): double start + i*step, rounded to fp32
-    map_ap_kernel<<<n_classes - 1, kApThreads, 0, st>>>(kout, vout, (int)D, true_labels, true_diff, (int)T, thr, ap, tp_sum, fp_sum, prec11);
+    map_ap_kernel<<<n_classes - 1, kApThreads, 0, st>>>(keys, vals, (int)D, true_labels, true_diff, (int)T, thr, ap, tp_sum, fp_sum, prec11);
     map_mean_kernel<<<1, 1, 0, st>>>(ap, n_classes - 1, mean_ap);
     return check_launch("mny_map_eval");
 }

@@ -110,14 +110,25 @@ class HipEvent:
     def _rt(cls):
         if cls._hip is None:
             path = "libamdhip64.so"
-            try:                                   # the copy of the runtime this process (torch) already runs on, not whatever the loader finds first
+            try:                                   # the copy of the runtime TORCH runs on: a handle from another mapped copy crashes instead of failing
+                tlib = os.path.join(os.path.dirname(os.path.abspath(torch.__file__)), "lib")
+                cands = []
                 with open("/proc/self/maps") as f:
                     for line in f:
                         if "libamdhip64.so" in line:
-                            path = line.split()[-1]
-                            break
-            except OSError:
-                pass
+                            cands.append(line.split()[-1])
+                mine = [c for c in cands if os.path.dirname(os.path.abspath(c)) == tlib]
+                uniq = sorted(set(cands))
+                if mine:
+                    path = mine[0]                 # torch's bundled runtime
+                elif len(uniq) == 1:
+                    path = uniq[0]                 # one runtime in the process (system ROCm): unambiguous
+                elif uniq:
+                    raise OSError("several HIP runtimes mapped (%s), none of them torch's" % ", ".join(uniq))
+            except OSError as e:
+                warnings.warn("raw HIP events unavailable (%s); timing brackets use torch.cuda.Event" % (e,))
+                cls._hip = False
+                raise MnyError("no unambiguous HIP runtime")
             cls._hip = ctypes.CDLL(path)
             cls._hip.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
             cls._hip.hipEventRecord.argtypes = [ctypes.c_void_p, ctypes.c_void_p]

@@ -26,8 +26,7 @@ class AdamW(torch.optim.Optimizer):
         if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
             raise ValueError("invalid AdamW hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False))
-        self._tables = {}           # group index -> (signature, device table, nchunks, ids of the covered parameters)
-        self._t = {}                # group index -> current step count (per-parameter `step` tensors are synced lazily)
+        self._tables = {}           # group index -> (signature, [one chunk table per distinct step count: table, nchunks, t, params])
 
     def _ensure_state(self, group):
         new = [p for p in group["params"] if p.grad is not None and len(self.state[p]) == 0]
@@ -49,43 +48,47 @@ class AdamW(torch.optim.Optimizer):
             off += (n + 3) // 4 * 4
 
     def _table(self, gi, group):
-        """Device chunk table of group `gi`, rebuilt only when a parameter / gradient pointer changes (a step costs one pass
-        over the parameters reading two pointers each — the moments only move through load_state_dict, which drops the cache)."""
+        """Device chunk tables of group `gi`, rebuilt only when a parameter / gradient pointer changes (a step costs one pass
+        over the parameters reading two pointers each — the moments only move through load_state_dict, which drops the cache).
+        One table (= one launch) per distinct step count: torch keeps the step per parameter, and parameters that first receive
+        a gradient later (a branch enabled or unfrozen mid-run, a torch checkpoint with mixed counts) carry their own."""
         live = [p for p in group["params"] if p.grad is not None]
         sig = tuple((p.data_ptr(), p.grad.data_ptr()) for p in live)
         cached = self._tables.get(gi)
         if cached is not None and cached[0] == sig:
-            return cached[1], cached[2], live
-        self._sync_steps(gi)                                      # counters of the parameters the old table covered
-        steps = {float(self.state[p]["step"]) for p in live}
-        if len(steps) != 1:
-            raise _lib.MnyError("fused AdamW: parameters of one group must share the step count (got %s)" % sorted(steps))
-        rows = []
+            return cached[1], live
+        self._sync_steps(gi)                                      # counters of the parameters the old tables covered
+        by_step = {}
         for p, (pp, gp) in zip(live, sig):
             g, st = p.grad, self.state[p]
             if not (g.is_cuda and g.dtype == torch.float32 and g.is_contiguous()):
                 raise _lib.MnyError("fused AdamW needs contiguous fp32 CUDA(HIP) gradients")
             mp, vp = st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr()
             n = p.numel()
+            sub = by_step.setdefault(int(float(st["step"])), {"rows": [], "ids": set(), "params": []})
+            sub["ids"].add(id(p))
+            sub["params"].append(p)
             for o in range(0, n, CHUNK):
                 c = min(CHUNK, n - o)
                 ptrs = (pp + 4 * o, gp + 4 * o, mp + 4 * o, vp + 4 * o)
-                rows.append(ptrs + (c, int(all(q % 16 == 0 for q in ptrs))))
-        host = np.array(rows, dtype=_CHUNK_DT)
-        table = torch.from_numpy(host.view(np.uint8).reshape(-1)).to(live[0].device)
-        self._tables[gi] = (sig, table, len(rows), {id(p) for p in live})
-        self._t[gi] = int(steps.pop())
-        return table, len(rows), live
+                sub["rows"].append(ptrs + (c, int(all(q % 16 == 0 for q in ptrs))))
+        subs = []
+        for t in sorted(by_step):
+            sub = by_step[t]
+            host = np.array(sub["rows"], dtype=_CHUNK_DT)
+            subs.append({"table": torch.from_numpy(host.view(np.uint8).reshape(-1)).to(live[0].device), "nchunks": len(sub["rows"]), "t": t,
+                         "ids": sub["ids"], "params": sub["params"]})
+        self._tables[gi] = (sig, subs)
+        return subs, live
 
     def _sync_steps(self, only=None):
-        """write the group step counters back into the per-parameter `step` tensors (torch's state layout)"""
-        for gi, group in enumerate(self.param_groups):
-            c = self._tables.get(gi)
-            if c is None or (only is not None and gi != only):
+        """write the step counters back into the per-parameter `step` tensors (torch's state layout)"""
+        for gi in list(self._tables):
+            if only is not None and gi != only:
                 continue
-            for p in group["params"]:
-                if id(p) in c[3]:
-                    self.state[p]["step"].fill_(float(self._t[gi]))
+            for sub in self._tables[gi][1]:
+                for p in sub["params"]:
+                    self.state[p]["step"].fill_(float(sub["t"]))
 
     def state_dict(self):
         self._sync_steps()
@@ -94,7 +97,6 @@ class AdamW(torch.optim.Optimizer):
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
         self._tables.clear()
-        self._t.clear()
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -106,10 +108,11 @@ class AdamW(torch.optim.Optimizer):
             self._ensure_state(group)
             if not any(p.grad is not None for p in group["params"]):
                 continue
-            table, nchunks, live = self._table(gi, group)
-            t = self._t[gi] + 1
+            subs, live = self._table(gi, group)
             b1, b2 = group["betas"]
-            _lib.call("mny_adamw_step", ctypes.c_void_p(table.data_ptr()), nchunks, float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                      float(group["weight_decay"]), t, ctypes.c_void_p(torch.cuda.current_stream(live[0].device).cuda_stream))
-            self._t[gi] = t
+            st = ctypes.c_void_p(torch.cuda.current_stream(live[0].device).cuda_stream)
+            for sub in subs:                                      # normally one; one launch per distinct step count otherwise
+                sub["t"] += 1
+                _lib.call("mny_adamw_step", ctypes.c_void_p(sub["table"].data_ptr()), sub["nchunks"], float(group["lr"]), float(b1), float(b2),
+                          float(group["eps"]), float(group["weight_decay"]), sub["t"], st)
         return loss

@@ -7,7 +7,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-ACTS = {0: lambda z: z, 1: lambda z: torch.clamp(z, 0, 6), 2: lambda z: F.leaky_relu(z, 0.1)}
+ACTS = {0: lambda z: z, 1: lambda z: torch.clamp(z, 0, 6), 2: lambda z: F.leaky_relu(z, 0.1), 3: F.relu, 4: lambda z: z * F.relu6(z + 3) / 6}
 
 
 @pytest.fixture(scope="module")
@@ -290,20 +290,22 @@ def test_fused_dw_unit_backward(ops, N, H, W, C, act, xact, dtype):
 
 
 @pytest.mark.parametrize("N,H,W,C,s,act", [(1, 44, 44, 192, 2, 0), (2, 22, 22, 96, 2, 1), (1, 44, 44, 384, 1, 1), (4, 88, 88, 144, 2, 1),
-                                           (2, 11, 11, 960, 1, 1), (3, 33, 17, 32, 1, 2), (1, 7, 50, 200, 2, 0)])
-def test_dw_forward_lds_staged_variant(ops, N, H, W, C, s, act, monkeypatch):
-    """The opt-in LDS-DMA staged depthwise forward (MNY_DW_STAGED=1): same outputs and BN partial sums as torch, 1e-4."""
-    monkeypatch.setenv("MNY_DW_STAGED", "1")
+                                           (2, 11, 11, 960, 1, 1), (3, 33, 17, 32, 1, 2), (1, 7, 50, 200, 2, 0), (2, 37, 5, 64, 1, 4), (2, 3, 3, 32, 2, 3),
+                                           (1, 1, 9, 16, 1, 1), (2, 9, 1, 16, 2, 2)])
+def test_dw_forward_odd_shapes_and_views(ops, N, H, W, C, s, act, monkeypatch):
+    """Both generations of the 3x3 depthwise forward (MNY_DW_V1=1 selects the sliding-window kernel the 5x5 layers still use; the
+    switch is read once per process, so this checks whichever one the process started with, on shapes with odd sizes, one-pixel
+    images and every view activation): same outputs and BN partial sums as torch, 1e-4."""
     x = rnd(N, C, H, W, seed=1)
     w = rnd(C, 1, 3, 3, seed=2, scale=0.4)
     sc, sh = 1 + 0.2 * rnd(C, seed=3), 0.3 * rnd(C, seed=4)
     y = F.conv2d(view_ref(x, sc, sh, act), w, None, s, 1, 1, C)
     got, st = ops.dw_fwd((nhwc(x), sc.cuda(), sh.cuda(), act), w.cuda().contiguous(), s)
-    check(nchw(got), y, 1e-4, 1e-5, "staged dw fwd")
+    check(nchw(got), y, 1e-4, 1e-5, "dw fwd")
     s1, s2 = stats_got(st)
     r1, r2 = stats_ref(y)
-    check(s1, r1, 1e-4, 1e-3, "staged dw stats sum")
-    check(s2, r2, 1e-4, 1e-3, "staged dw stats sumsq")
+    check(s1, r1, 1e-4, 1e-3, "dw stats sum")
+    check(s2, r2, 1e-4, 1e-3, "dw stats sumsq")
 
 
 @pytest.mark.parametrize("M,K,Nc,act", [(4 * 11 * 11, 16, 96, 1), (2 * 22 * 22 + 5, 24, 144, 1), (1000, 64, 384, 1), (777, 160, 960, 2),
