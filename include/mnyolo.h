@@ -227,6 +227,15 @@ int mny_dw_bnbwd(const float* g, const float* y, const float* scale, const float
                  const float* x, const float* in_scale, const float* in_shift, int in_act, const float* w,
                  const float* addend, float* dx, float* dw, float* ws, int N, int H, int W, int C, int K, int stride,
                  void* stream);
+/* mny_dw_bnbwd + the BN-backward sums of the unit that PRODUCED the input: when `x` is the raw output of a conv+BN+act unit
+ * (in_scale/in_shift/in_act = its view, in_mean/in_invstd = its batch statistics) whose only consumer is this depthwise unit,
+ * the dX written here is that unit's complete output gradient, and the kernel also leaves its sums (sum dz, sum dz*xhat per
+ * channel) as partial rows in_red[mny_dw_bnbwd_parts()][2][C] — the input of mny_bn_bwd_finalize that a separate
+ * mny_bn_bwd_reduce pass over (dX, x) would have produced (autograd of BatchNorm2d + ReLU6 at models/mobilenetv2.py:69-71). */
+int mny_dw_bnbwd_red(const float* g, const float* y, const float* scale, const float* shift, int act, const float* coef,
+                     const float* x, const float* in_scale, const float* in_shift, int in_act, const float* in_mean,
+                     const float* in_invstd, const float* w, const float* addend, float* dx, float* dw, float* ws, float* in_red,
+                     int N, int H, int W, int C, int K, int stride, void* stream);
 
 /* ---- row padding for the detection heads' backward ---------------------------------------------------------
  * The head gradient dL/dhead is [M][75] (yolo_loss.py:84 channel layout): rows are neither 16-B aligned nor a multiple
@@ -382,6 +391,10 @@ int mny_dw_bnbwd_bf16(const void* g, const void* y, const float* scale, const fl
                       const void* x, const float* in_scale, const float* in_shift, int in_act, const float* w,
                       const void* addend, void* dx, float* dw, float* ws, int N, int H, int W, int C, int K, int stride,
                       void* stream);
+int mny_dw_bnbwd_red_bf16(const void* g, const void* y, const float* scale, const float* shift, int act, const float* coef,
+                          const void* x, const float* in_scale, const float* in_shift, int in_act, const float* in_mean,
+                          const float* in_invstd, const float* w, const void* addend, void* dx, float* dw, float* ws, float* in_red,
+                          int N, int H, int W, int C, int K, int stride, void* stream);
 int mny_pad_rows_bf16(const float* src, const float* alpha, void* dst, int64_t M, int C, int Cp, void* stream);
 int mny_transpose_pad_bf16(const float* src, void* dst, int R, int Cc, int Rp, void* stream);
 int mny_stem_bnwgrad_bf16(const float* x_nchw, const void* g, const void* y, const float* scale, const float* shift, int act,

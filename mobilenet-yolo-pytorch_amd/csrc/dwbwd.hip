@@ -31,15 +31,22 @@ struct DwbGeom {
 
 // AM: activation of THIS unit: 0 = none (act' = 1), 1 = min(max(z, slope z), hi) family, 2 = hswish
 // XF: view of the input: 0 = as is, 1 = scale/shift + ReLU6, 2 = scale/shift + hswish, 3 = scale/shift + max(z, slope z) (leaky / relu / none)
-template <typename T, int AM, int XF>
+// RED: the input X is itself the raw output of a conv+BN+act unit P whose ONLY consumer is this depthwise unit, so the dX
+// written here is P's complete output gradient: the kernel also leaves P's BN-backward sums (sum dz, sum dz * xhat per channel,
+// dz = dX * act_P'(in_scale * x + in_shift), xhat = (x - in_mean) * in_invstd) as per-block partial rows [gridDim.x][2][C] —
+// what a separate mny_bn_bwd_reduce pass over (dX, X) would produce, without re-reading either.  The accumulators and the
+// parked raw centre input live in LDS (the kernel sits at the 168-VGPR limit of 3 waves per SIMD).
+template <typename T, int AM, int XF, bool RED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void dw_bnbwd_s1k3_kernel(
     const T* __restrict__ g, const T* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift, int act,
     const float* __restrict__ coef, const T* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
-    int in_act, const float* __restrict__ w, const T* __restrict__ addend, T* __restrict__ dx, float* __restrict__ parts, DwbGeom gm) {
+    int in_act, const float* __restrict__ w, const T* __restrict__ addend, T* __restrict__ dx, float* __restrict__ parts,
+    const float* __restrict__ in_mean, const float* __restrict__ in_invstd, float* __restrict__ in_red, DwbGeom gm) {
     __shared__ float4 red[256];
-    // per-channel constants (9 filter taps + 7 coefficient vectors) live in LDS, [16][cgb] float4, read where used: keeping
-    // them in registers put the kernel at ~200 VGPRs = 2 waves/SIMD, too few loads in flight for an HBM-bound stream
+    // per-channel constants (9 filter taps + 7 coefficient vectors [+ mean, invstd of the input's unit]) live in LDS,
+    // [18][cgb] float4, read where used: keeping them in registers put the kernel at ~200 VGPRs = 2 waves/SIMD
     extern __shared__ __attribute__((aligned(16))) float4 cst[];
+    float4* xcs = cst + 18 * gm.cgb;                     // RED: [256] raw centre input of the previous row, [256] s1, [256] s2
     const int tid = threadIdx.x;
     const int cgl = tid % gm.cgb, pix = tid / gm.cgb, ppb = blockDim.x / gm.cgb;
     const int cg = blockIdx.y * gm.cgb + cgl;
@@ -60,7 +67,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         cst[13 * gm.cgb + cgl] = ld4(coef + 2 * gm.C + c);
         cst[14 * gm.cgb + cgl] = (XF != 0 && in_scale) ? ld4(in_scale + c) : f4one();
         cst[15 * gm.cgb + cgl] = (XF != 0 && in_scale) ? ld4(in_shift + c) : f4zero();
+        if (RED) { cst[16 * gm.cgb + cgl] = ld4(in_mean + c); cst[17 * gm.cgb + cgl] = ld4(in_invstd + c); }
     }
+    if (RED) { xcs[256 + tid] = f4zero(); xcs[512 + tid] = f4zero(); }
     __syncthreads();
     if (cvalid) {
 #define WG(t) my[(t) * gm.cgb]
@@ -149,7 +158,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                     float4 out = f4u(P0);
                     if (addend) add4(out, ld4(addend + o));
                     st4_stream(dx + o, out);
+                    if (RED) {                                      // BN-backward sums of the unit that produced X (raw x of row r-1 was parked below)
+                        const float4 xc = xcs[tid], mu = my[16 * gm.cgb], is = my[17 * gm.cgb];
+                        const float4 gq = stored4<T>(out);
+                        auto pact = [&](float xv1, float s, float h) {
+                            const float z = fmaf(xv1, s, h);
+                            if (XF == 1) return (z > 0.f ? 1.f : 0.f) * (z < 6.f ? 1.f : 0.f);
+                            if (XF == 2) return z <= -3.f ? 0.f : (z >= 3.f ? 1.f : (2.f * z + 3.f) / 6.f);
+                            return z > 0.f ? 1.f : xslope;
+                        };
+                        float4 dz;
+                        dz.x = gq.x * pact(xc.x, xsc.lo.x, xsh.lo.x); dz.y = gq.y * pact(xc.y, xsc.lo.y, xsh.lo.y);
+                        dz.z = gq.z * pact(xc.z, xsc.hi.x, xsh.hi.x); dz.w = gq.w * pact(xc.w, xsc.hi.y, xsh.hi.y);
+                        float4 a1 = xcs[256 + tid], a2 = xcs[512 + tid];
+                        add4(a1, dz);
+                        fma4(a2, dz, make_float4((xc.x - mu.x) * is.x, (xc.y - mu.y) * is.y, (xc.z - mu.z) * is.z, (xc.w - mu.w) * is.w));
+                        xcs[256 + tid] = a1; xcs[512 + tid] = a2;
+                    }
                 }
+                if (RED) xcs[tid] = xv[1];                          // raw centre input of row r, for the store of the next iteration
                 P0 = P1; P1 = P2;
                 // weight gradient: input row r-1 against the centre dY of rows r, r-1, r-2 (only rows this strip owns)
                 const float own = (r >= h0 && r < h1) ? 1.f : 0.f;
@@ -188,6 +215,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
             dst[(c + 2) * 9 + t] = a.z; dst[(c + 3) * 9 + t] = a.w;
         }
     }
+    if (RED) {                                           // per-block partial row of the producer unit's BN-backward sums, fixed order
+        __syncthreads();
+        if (pix == 0 && cvalid) {
+            float4 a = f4zero(), b = f4zero();
+            for (int p = 0; p < ppb; ++p) { add4(a, xcs[256 + p * gm.cgb + cgl]); add4(b, xcs[512 + p * gm.cgb + cgl]); }
+            float* dst = in_red + (int64_t)blockIdx.x * 2 * gm.C;
+            st4(dst + c, a);
+            st4(dst + gm.C + c, b);
+        }
+    }
 }
 
 static int dwb_geom(DwbGeom& g, CgLayout& L, int& gx, int N, int H, int W, int C) {
@@ -214,8 +251,10 @@ static int dwb_geom(DwbGeom& g, CgLayout& L, int& gx, int N, int H, int W, int C
 template <typename T>
 static int dw_bnbwd_impl(const T* g, const T* y, const float* scale, const float* shift, int act, const float* coef,
                          const T* x, const float* in_scale, const float* in_shift, int in_act, const float* w,
-                         const T* addend, T* dx, float* dw, float* ws, int N, int H, int W, int C, int K, int stride, void* stream) {
+                         const T* addend, T* dx, float* dw, float* ws, int N, int H, int W, int C, int K, int stride, void* stream,
+                         const float* in_mean = nullptr, const float* in_invstd = nullptr, float* in_red = nullptr) {
     MNY_REQUIRE(g && y && scale && shift && coef && x && w && dx && dw && ws, "dw_bnbwd: null pointer");
+    MNY_REQUIRE(!in_red || (in_mean && in_invstd && in_scale && in_shift), "dw_bnbwd_red: the input must be a BN unit's raw output (scale, shift, mean, invstd)");
     MNY_REQUIRE(K == 3 && stride == 1, "dw_bnbwd: only 3x3 stride 1 is fused (got K=%d stride=%d); use bn_bwd_apply + dw_bwd_*", K, stride);
     MNY_REQUIRE(act != MNY_ACT_HSIGMOID && in_act != MNY_ACT_HSIGMOID, "dw_bnbwd: h-sigmoid views are not supported");
     DwbGeom gm; CgLayout L; int gx;
@@ -225,9 +264,11 @@ static int dw_bnbwd_impl(const T* g, const T* y, const float* scale, const float
     hipStream_t st = (hipStream_t)stream;
     const int am = act == MNY_ACT_NONE ? 0 : (act == MNY_ACT_HSWISH ? 2 : 1);
     const int xf = (in_scale == nullptr && in_act == MNY_ACT_NONE) ? 0 : (in_act == MNY_ACT_HSWISH ? 2 : (in_act == MNY_ACT_RELU6 ? 1 : 3));
-    const size_t lds = (size_t)16 * L.cgb * sizeof(float4);
-#define MNY_L(A_, X_) hipLaunchKernelGGL((dw_bnbwd_s1k3_kernel<T, A_, X_>), grid, block, lds, st, g, y, scale, shift, act, coef, x, in_scale, in_shift, \
-                                         in_act, w, addend, dx, ws, gm)
+    const size_t lds = (size_t)(18 * L.cgb + (in_red ? 3 * 256 : 0)) * sizeof(float4);
+#define MNY_L(A_, X_) do { if (in_red) hipLaunchKernelGGL((dw_bnbwd_s1k3_kernel<T, A_, X_, true>), grid, block, lds, st, g, y, scale, shift, act, coef, x, in_scale, in_shift, \
+                                         in_act, w, addend, dx, ws, in_mean, in_invstd, in_red, gm); \
+        else hipLaunchKernelGGL((dw_bnbwd_s1k3_kernel<T, A_, X_, false>), grid, block, lds, st, g, y, scale, shift, act, coef, x, in_scale, in_shift, \
+                                         in_act, w, addend, dx, ws, in_mean, in_invstd, in_red, gm); } while (0)
     switch (am * 4 + xf) {
         case 0: MNY_L(0, 0); break; case 1: MNY_L(0, 1); break; case 2: MNY_L(0, 2); break; case 3: MNY_L(0, 3); break;
         case 4: MNY_L(1, 0); break; case 5: MNY_L(1, 1); break; case 6: MNY_L(1, 2); break; case 7: MNY_L(1, 3); break;
@@ -256,6 +297,24 @@ extern "C" int mny_dw_bnbwd(const float* g, const float* y, const float* scale, 
                             const float* addend, float* dx, float* dw, float* ws, int N, int H, int W, int C, int K, int stride,
                             void* stream) {
     return dw_bnbwd_impl<float>(g, y, scale, shift, act, coef, x, in_scale, in_shift, in_act, w, addend, dx, dw, ws, N, H, W, C, K, stride, stream);
+}
+
+extern "C" int mny_dw_bnbwd_red(const float* g, const float* y, const float* scale, const float* shift, int act, const float* coef,
+                                const float* x, const float* in_scale, const float* in_shift, int in_act, const float* in_mean, const float* in_invstd,
+                                const float* w, const float* addend, float* dx, float* dw, float* ws, float* in_red, int N, int H, int W, int C,
+                                int K, int stride, void* stream) {
+    MNY_REQUIRE(in_red && in_mean && in_invstd, "dw_bnbwd_red: null pointer");
+    return dw_bnbwd_impl<float>(g, y, scale, shift, act, coef, x, in_scale, in_shift, in_act, w, addend, dx, dw, ws, N, H, W, C, K, stride, stream,
+                                in_mean, in_invstd, in_red);
+}
+
+extern "C" int mny_dw_bnbwd_red_bf16(const void* g, const void* y, const float* scale, const float* shift, int act, const float* coef,
+                                     const void* x, const float* in_scale, const float* in_shift, int in_act, const float* in_mean,
+                                     const float* in_invstd, const float* w, const void* addend, void* dx, float* dw, float* ws, float* in_red,
+                                     int N, int H, int W, int C, int K, int stride, void* stream) {
+    MNY_REQUIRE(in_red && in_mean && in_invstd, "dw_bnbwd_red: null pointer");
+    return dw_bnbwd_impl<bf16_t>((const bf16_t*)g, (const bf16_t*)y, scale, shift, act, coef, (const bf16_t*)x, in_scale, in_shift, in_act, w,
+                                 (const bf16_t*)addend, (bf16_t*)dx, dw, ws, N, H, W, C, K, stride, stream, in_mean, in_invstd, in_red);
 }
 
 extern "C" int mny_dw_bnbwd_bf16(const void* g, const void* y, const float* scale, const float* shift, int act, const float* coef,

@@ -1935,7 +1935,8 @@ extern "C" int mny_pw_fwd(const float* x, const float* in_scale, const float* in
 // the reduction epilogue holds four more per-column constants and a group of loads: the 160-column tile (TN = 5) spills with it
 constexpr int kRedMaxTn = 4;
 static bool dgrad_bnred_ok(int64_t M, int K, int Nc, int act) {
-    if (K >= 512 && Nc >= 512) return false;      // matrix-pipe-bound: the reduce pass it would save is cheaper than the longer epilogue
+    static const bool red512 = getenv("MNY_RED512") != nullptr && atoi(getenv("MNY_RED512")) != 0;
+    if (K >= 512 && Nc >= 512 && !red512) return false;      // matrix-pipe-bound: the reduce pass it would save is cheaper than the longer epilogue (MNY_RED512=1: A/B)
     return M > 0 && K > 0 && Nc > 0 && (K & 3) == 0 && act >= MNY_ACT_NONE && act <= MNY_ACT_HSIGMOID && getenv("MNY_GEMM_V1") == nullptr;
 }
 extern "C" int mny_pw_dgrad_bnred_supported(int64_t M, int K, int Nc, int act) { return dgrad_bnred_ok(M, K, Nc, act) ? 1 : 0; }

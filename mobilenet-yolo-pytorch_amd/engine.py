@@ -673,10 +673,26 @@ class NetPlan:
                             self.coef_ws, o.C, self.stream)
                     dwv = gv(nd.conv + ".weight")
                     wt = P[nd.conv + ".weight"]
-                    contribute_kernel(i, lambda out, addend, G=G, u=u, xv=xv, wt=wt, dwv=dwv, ish=ish, C=o.C, act=o.act, M=M: bwd.add(
-                        self.K("mny_dw_bnbwd"), G, u.Y, u.scale, u.shift, act, self.coef_ws, xv[0], xv[1], xv[2], xv[3], wt, addend, out, dwv, self.ws,
-                        N, ish[1], ish[2], C, 3, 1, self.stream,
-                        meta=dict(flops=4 * M * C * 9, bytes=self.eb * 4 * M * C, shape="C%d H%d" % (C, ish[1]))))
+                    prod = i.node
+                    # the input is the raw output of a conv+BN+act unit consumed ONLY here: this kernel's dX is that unit's complete
+                    # output gradient, so it also leaves the unit's BN-backward sums (mny_dw_bnbwd_red) and the unit's separate
+                    # bn_bwd_reduce pass — a re-read of dX and X — disappears (wide expand units, the stem, the neck's pointwise units)
+                    if (os.environ.get("MNY_NO_DWRED") != "1" and i.kind == "unit" and prod is not None and prod.op in ("pw", "stem")
+                            and gs[i.id].buf is None and n_consumers[i.id] == 1 and not takes_own_sums(prod) and xv[1] is not None
+                            and i.act not in (_lib.ACT_HSIGMOID,)):
+                        pu = self.units[i.id]
+                        rparts = _lib.query("mny_dw_bnbwd_parts", N, ish[1], ish[2], o.C)
+                        rbuf = torch.empty(rparts * 2 * i.C, **f32)
+                        self.fused_red[i.id] = (rbuf, rparts)
+                        contribute_kernel(i, lambda out, addend, G=G, u=u, xv=xv, wt=wt, dwv=dwv, ish=ish, C=o.C, act=o.act, M=M, pu=pu, rbuf=rbuf: bwd.add(
+                            self.K("mny_dw_bnbwd_red"), G, u.Y, u.scale, u.shift, act, self.coef_ws, xv[0], xv[1], xv[2], xv[3], pu.mean, pu.invstd, wt, addend,
+                            out, dwv, self.ws, rbuf, N, ish[1], ish[2], C, 3, 1, self.stream,
+                            meta=dict(flops=4 * M * C * 9, bytes=self.eb * 4 * M * C, shape="C%d H%d +red" % (C, ish[1]))))
+                    else:
+                        contribute_kernel(i, lambda out, addend, G=G, u=u, xv=xv, wt=wt, dwv=dwv, ish=ish, C=o.C, act=o.act, M=M: bwd.add(
+                            self.K("mny_dw_bnbwd"), G, u.Y, u.scale, u.shift, act, self.coef_ws, xv[0], xv[1], xv[2], xv[3], wt, addend, out, dwv, self.ws,
+                            N, ish[1], ish[2], C, 3, 1, self.stream,
+                            meta=dict(flops=4 * M * C * 9, bytes=self.eb * 4 * M * C, shape="C%d H%d" % (C, ish[1]))))
                     flush_shared()
                     bwd.marks[o.name] = len(bwd.calls)
                     continue

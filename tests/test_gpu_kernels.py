@@ -289,6 +289,37 @@ def test_fused_dw_unit_backward(ops, N, H, W, C, act, xact, dtype):
     check(dbeta, br.grad, 5e-4, 5e-4 * max(1.0, br.grad.abs().max().item()), "dbeta")
 
 
+@pytest.mark.parametrize("N,H,W,C,act,xact,dtype", [(2, 11, 11, 32, 1, 1, "f32"), (3, 22, 19, 96, 2, 2, "f32"), (2, 37, 8, 144, 1, 3, "f32"),
+                                                    (1, 5, 5, 960, 0, 1, "f32"), (2, 20, 20, 120, 4, 4, "f32"), (2, 33, 17, 64, 1, 1, "bf16"),
+                                                    (2, 40, 40, 384, 1, 1, "f32")])
+def test_fused_dw_unit_backward_with_producer_bn_sums(ops, N, H, W, C, act, xact, dtype):
+    """mny_dw_bnbwd_red == mny_dw_bnbwd (same dX, dW) and its extra output == mny_bn_bwd_reduce run on that dX and the raw input:
+    the BN-backward sums of the unit that produced the input, without the separate pass."""
+    import ctypes
+    from mobilenet_yolo_pytorch_amd import _lib
+    bf = dtype == "bf16"
+    q = (lambda t: t.to(torch.bfloat16).float()) if bf else (lambda t: t)
+    dev = (lambda t: nhwc(t).to(torch.bfloat16)) if bf else nhwc
+    x, y, g, add = (dev(q(rnd(N, C, H, W, seed=s))) for s in (1, 2, 3, 4))
+    w = rnd(C, 1, 3, 3, seed=5, scale=0.4).cuda().contiguous()
+    mk = lambda seed, a, b: (a + b * rnd(C, seed=seed)).cuda()          # noqa: E731
+    scale, shift, coef = mk(6, 1.0, 0.2), mk(7, 0.0, 0.3), torch.stack((mk(8, 1.0, 0.2), mk(9, 0.0, 0.05), mk(10, 0.0, 0.05))).contiguous()
+    xs, xh, xmean, xinv = mk(11, 1.0, 0.2), mk(12, 0.0, 0.3), mk(13, 0.0, 0.2), mk(14, 1.0, 0.1).abs()
+    dx0, dw0 = ops.dw_bnbwd(g, y, scale, shift, act, coef, (x, xs, xh, xact), w, addend=add)
+    dx1, dw1, red = ops.dw_bnbwd(g, y, scale, shift, act, coef, (x, xs, xh, xact), w, addend=add, in_stats=(xmean, xinv))
+    assert torch.equal(dx0, dx1) and torch.equal(dw0, dw1)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())                          # noqa: E731
+    M = N * H * W
+    parts = _lib.query("mny_bn_bwd_parts", M, C)
+    ref = torch.empty(parts, 2, C, device="cuda")
+    _lib.call("mny_bn_bwd_reduce" + ("_bf16" if bf else ""), p(dx1), p(x), p(xs), p(xh), xact, p(xmean), p(xinv), p(ref), M, C,
+              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    got, want = red.double().sum(0).cpu(), ref.double().sum(0).cpu()
+    for k in range(2):
+        tol = 2e-5 * want[k].abs().max().item() + 1e-4
+        assert (got[k] - want[k]).abs().max().item() <= tol, (k, (got[k] - want[k]).abs().max().item(), tol)
+
+
 @pytest.mark.parametrize("N,H,W,C,s,act", [(1, 44, 44, 192, 2, 0), (2, 22, 22, 96, 2, 1), (1, 44, 44, 384, 1, 1), (4, 88, 88, 144, 2, 1),
                                            (2, 11, 11, 960, 1, 1), (3, 33, 17, 32, 1, 2), (1, 7, 50, 200, 2, 0), (2, 37, 5, 64, 1, 4), (2, 3, 3, 32, 2, 3),
                                            (1, 1, 9, 16, 1, 1), (2, 9, 1, 16, 2, 2)])
