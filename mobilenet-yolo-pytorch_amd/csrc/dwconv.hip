@@ -361,6 +361,135 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 5x5 forward (stride 1 | 2) and stride-1 backward-data (flipped filter) — MobileNetV3's depthwise layers.
+//
+// The sliding-window kernel keeps a 5x5 register window (100 VGPRs) next to the 25 taps (100 VGPRs): 250-266 VGPRs, two waves
+// per SIMD with half of them spilling, 0.6-1.5 TB/s on the bf16 configuration.  Here the window is gone: every INPUT row (five
+// columns, transformed once) is scattered into the partial sums of the output rows it belongs to — stride 1: rows hi-2..hi+2
+// (five accumulators), stride 2: an even row feeds three outputs (taps 4, 2, 0), an odd row two (taps 3, 1) — and an output row
+// is stored as soon as its last input row has passed.  Per thread (4 channels x one output column): 25 taps + 3-5 accumulators
+// + one row, ~170 VGPRs, no spills, two resident workgroups per CU (512 blocks).  Same lane mapping, XCD-contiguous strip order,
+// masks and streaming stores as dw3_fwd_kernel.
+template <typename T, int S, int XF, bool ADD, bool NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) void dw5_fwd_kernel(
+    const T* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift, int in_act,
+    const float* __restrict__ w, int flip, const T* __restrict__ addend, T* __restrict__ y, float* __restrict__ parts, DwGeom g) {
+    __shared__ float4 red[256 * 2];
+    const int tid = threadIdx.x;
+    const int cgl = tid % g.cgb;
+    const int pix = tid / g.cgb;
+    const int ppb = blockDim.x / g.cgb;
+    const int cg = blockIdx.y * g.cgb + cgl;
+    const bool cvalid = cg < g.cg_total;
+    const int c = cg * 4;
+    const int gx = gridDim.x;
+    const int lb = (g.xcd && (gx & 7) == 0) ? (int)(blockIdx.x & 7) * (gx >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+
+    F4P acc1 = f4p0(), acc2 = f4p0();
+    if (cvalid) {
+        v2f sc_lo = v2f{1.f, 1.f}, sc_hi = sc_lo, sh_lo = v2f{0.f, 0.f}, sh_hi = sh_lo;
+        if (in_scale != nullptr) {
+            const float4 a = ld4(in_scale + c), b = ld4(in_shift + c);
+            sc_lo = v2f{a.x, a.y}; sc_hi = v2f{a.z, a.w}; sh_lo = v2f{b.x, b.y}; sh_hi = v2f{b.z, b.w};
+        }
+        const float slope = act_slope(in_act), hi_clip = act_hi(in_act);
+        F4P wt[25];                                                // taps of this thread's 4 channels (100 contiguous floats)
+        {
+            const float* wp = w + (int64_t)c * 25;
+#pragma unroll
+            for (int t = 0; t < 25; ++t) {
+                const int s = flip ? 24 - t : t;
+                wt[t].lo = v2f{wp[s], wp[25 + s]};
+                wt[t].hi = v2f{wp[50 + s], wp[75 + s]};
+            }
+        }
+        const int64_t pitch = (int64_t)g.W * g.C, opitch = (int64_t)g.Wo * g.C;
+        for (int64_t strip = (int64_t)lb * ppb + pix; strip < g.nstrips; strip += (int64_t)gx * ppb) {
+            const int wo = (int)(strip % g.Wo);
+            const int hs = (int)((strip / g.Wo) % g.nHS);
+            const int n = (int)(strip / ((int64_t)g.Wo * g.nHS));
+            const int ho0 = hs * g.TH;
+            const int ho1 = min(ho0 + g.TH, g.Ho);
+            int coff[5];
+            float cm[5];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const int wi = wo * S - 2 + q;
+                cm[q] = (wi >= 0 && wi < g.W) ? 1.f : 0.f;
+                coff[q] = min(max(wi, 0), g.W - 1) * g.C;
+            }
+            const T* xn = x + (int64_t)n * g.H * pitch + c;
+            T* yo = y + (((int64_t)n * g.Ho + ho0) * g.Wo + wo) * g.C + c;
+            const T* ad = ADD ? addend + (((int64_t)n * g.Ho + ho0) * g.Wo + wo) * g.C + c : nullptr;
+
+            auto load_row = [&](int hi, F4P (&r)[5]) {             // five columns of input row hi, transformed; zeros outside the image
+                const float rm = (hi >= 0 && hi < g.H) ? 1.f : 0.f;
+                const T* p = xn + (int64_t)min(max(hi, 0), g.H - 1) * pitch;
+                float4 raw[5];
+#pragma unroll
+                for (int q = 0; q < 5; ++q) raw[q] = ld4(p + coff[q]);
+#pragma unroll
+                for (int q = 0; q < 5; ++q) {
+                    const float m = rm * cm[q];
+                    const v2f m2 = v2f{m, m};
+                    r[q] = dw_xf<XF>(raw[q], sc_lo, sc_hi, sh_lo, sh_hi, slope, hi_clip);
+                    r[q].lo *= m2; r[q].hi *= m2;
+                }
+            };
+            auto tap_row = [&](F4P& acc, const F4P (&r)[5], int kr) {
+#pragma unroll
+                for (int q = 0; q < 5; ++q) pfma(acc, r[q], wt[kr * 5 + q]);
+            };
+            auto emit = [&](F4P o) {
+                if (ADD) { const F4P a = f4p(ld4(ad)); o.lo += a.lo; o.hi += a.hi; ad += opitch; }
+                const float4 of = f4u(o);
+                if (NT) st4_stream(yo, of); else st4(yo, of);
+                yo += opitch;
+                const F4P os = f4p(stored4<T>(of));
+                acc1.lo += os.lo; acc1.hi += os.hi;
+                acc2.lo = __builtin_elementwise_fma(os.lo, os.lo, acc2.lo);
+                acc2.hi = __builtin_elementwise_fma(os.hi, os.hi, acc2.hi);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            F4P r[5];
+            if (S == 1) {
+                // accumulator j holds output row (hi - 2 + j) while input row hi is being scattered: kr = 4 - j
+                F4P P0 = f4p0(), P1 = f4p0(), P2 = f4p0(), P3 = f4p0(), P4 = f4p0();
+                for (int hi = ho0 - 2; hi <= ho1 + 1; ++hi) {
+                    load_row(hi, r);
+                    tap_row(P0, r, 4); tap_row(P1, r, 3); tap_row(P2, r, 2); tap_row(P3, r, 1); tap_row(P4, r, 0);
+                    if (hi - 2 >= ho0) emit(P0);                    // output row hi-2 has seen its last input row (hi-2 < ho1 by the loop bound)
+                    P0 = P1; P1 = P2; P2 = P3; P3 = P4; P4 = f4p0();
+                }
+            } else {
+                // output row t collects input rows 2t-2 .. 2t+2: an even row 2t feeds outputs t-1, t, t+1 with taps 4, 2, 0, an odd
+                // row 2t+1 feeds t, t+1 with taps 3, 1; output t-1 is complete after row 2t
+                F4P P0 = f4p0(), P1 = f4p0(), P2 = f4p0();
+                for (int t = ho0 - 1; t <= ho1; ++t) {
+                    load_row(2 * t, r);
+                    tap_row(P0, r, 4); tap_row(P1, r, 2); tap_row(P2, r, 0);
+                    if (t - 1 >= ho0) emit(P0);                     // (t-1 < ho1 by the loop bound)
+                    load_row(2 * t + 1, r);
+                    tap_row(P1, r, 3); tap_row(P2, r, 1);
+                    P0 = P1; P1 = P2; P2 = f4p0();
+                }
+            }
+        }
+    }
+    if (parts == nullptr) return;
+    red[tid * 2 + 0] = f4u(acc1);
+    red[tid * 2 + 1] = f4u(acc2);
+    __syncthreads();
+    if (pix == 0 && cvalid) {
+        float4 a = f4zero(), b = f4zero();
+        for (int p = 0; p < ppb; ++p) { add4(a, red[(p * g.cgb + cgl) * 2]); add4(b, red[(p * g.cgb + cgl) * 2 + 1]); }
+        float* dst = parts + (int64_t)blockIdx.x * 2 * g.C;
+        st4(dst + c, a);
+        st4(dst + g.C + c, b);
+    }
+}
+
 // stride-2 backward-data as a gather over the (at most ceil(K/2)^2) contributing taps
 template <typename T, int KS>
 __global__ __launch_bounds__(256) void dw_bwd_data_s2_kernel(const T* __restrict__ dy, const float* __restrict__ w,
@@ -508,7 +637,7 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2k5_kernel(const T* __restri
 
 static bool dw_use_v2(int K, int mode) {
     static const bool v1 = getenv("MNY_DW_V1") != nullptr;       // A/B: the first-generation sliding-window kernel
-    return K == 3 && mode == 0 && !v1;
+    return (K == 3 || K == 5) && mode == 0 && !v1;
 }
 
 static int dw_geom(DwGeom& g, CgLayout& L, int& gx, int N, int H, int W, int C, int K, int stride, int mode = 0) {
@@ -526,7 +655,7 @@ static int dw_geom(DwGeom& g, CgLayout& L, int& gx, int N, int H, int W, int C, 
     // forward (<= 168 VGPRs: the h-swish / leaky variants spilled inside the row loop at 128; tools/probe/dw_probe.hip shows 2, 3
     // and 4 waves per SIMD stream at the same rate)
     static const int res_env = getenv("MNY_DW_RES") ? atoi(getenv("MNY_DW_RES")) : 768;
-    const int resident = dw_use_v2(K, mode) ? res_env : kMaxParts;
+    const int resident = dw_use_v2(K, mode) ? (K == 5 ? 512 : res_env) : kMaxParts;          // 5x5: ~170 VGPRs, two workgroups per CU
     int cap = resident / L.chunks > 0 ? resident / L.chunks : 1;
     if (cap > 8) cap &= ~7;                                               // whole XCD rounds (workgroup b runs on XCD b % 8)
     static const int th_env = getenv("MNY_DW_TH") ? atoi(getenv("MNY_DW_TH")) : 0;          // > 0: strip height; -1: balance search
@@ -575,10 +704,14 @@ static int dw_launch(const T* x, const float* sc, const float* sh, int act, cons
         else hipLaunchKernelGGL((dw3_fwd_kernel<T, S_, X_, A_, false>), grid, block, 0, st, x, sc, sh, act, w, flip, addend, y, parts, g); } while (0)
 #define MNY_DW2S(S_) do { if (xf2 == 0) { if (addend) MNY_DW2(S_, 0, true); else MNY_DW2(S_, 0, false); } else if (xf2 == 1) MNY_DW2(S_, 1, false); \
         else if (xf2 == 2) MNY_DW2(S_, 2, false); else MNY_DW2(S_, 4, false); } while (0)
-        if (stride == 1) MNY_DW2S(1); else MNY_DW2S(2);
+        if (K == 3) { if (stride == 1) MNY_DW2S(1); else MNY_DW2S(2); }
+#undef MNY_DW2
+#define MNY_DW2(S_, X_, A_) do { if (g.nt) hipLaunchKernelGGL((dw5_fwd_kernel<T, S_, X_, A_, true>), grid, block, 0, st, x, sc, sh, act, w, flip, addend, y, parts, g); \
+        else hipLaunchKernelGGL((dw5_fwd_kernel<T, S_, X_, A_, false>), grid, block, 0, st, x, sc, sh, act, w, flip, addend, y, parts, g); } while (0)
+        if (K == 5) { if (stride == 1) MNY_DW2S(1); else MNY_DW2S(2); }
 #undef MNY_DW2S
 #undef MNY_DW2
-        return check_launch("dw3_fwd_kernel");
+        return check_launch(K == 3 ? "dw3_fwd_kernel" : "dw5_fwd_kernel");
     }
     const int xf = (sc == nullptr && act == MNY_ACT_NONE) ? 0 : (act == MNY_ACT_HSWISH ? 2 : 1);
 #define MNY_DW(KS_, S_) do { if (xf == 0) hipLaunchKernelGGL((dw_slide_kernel<T, KS_, S_, MODE, 0>), grid, block, 0, st, x, sc, sh, act, w, flip, addend, y, dy, parts, g); \

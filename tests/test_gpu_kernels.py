@@ -53,7 +53,8 @@ def stats_got(st):
 
 @pytest.mark.parametrize("N,H,W,C,K,s,act", [
     (2, 11, 11, 32, 3, 1, 1), (3, 22, 22, 96, 3, 2, 1), (2, 13, 9, 144, 3, 1, 2), (1, 44, 44, 192, 3, 2, 0),
-    (2, 11, 11, 960, 3, 1, 1), (2, 15, 11, 32, 3, 2, 1), (2, 16, 16, 72, 5, 2, 1), (1, 9, 12, 120, 5, 1, 2), (5, 7, 7, 1280, 3, 1, 1)])
+    (2, 11, 11, 960, 3, 1, 1), (2, 15, 11, 32, 3, 2, 1), (2, 16, 16, 72, 5, 2, 1), (1, 9, 12, 120, 5, 1, 2), (5, 7, 7, 1280, 3, 1, 1),
+    (2, 33, 19, 672, 5, 1, 1), (3, 17, 23, 40, 5, 2, 0), (2, 3, 4, 16, 5, 1, 2), (1, 2, 2, 8, 5, 2, 1), (2, 40, 40, 960, 5, 1, 0)])
 def test_dw_forward_backward(ops, N, H, W, C, K, s, act):
     x = rnd(N, C, H, W, seed=1)
     w = rnd(C, 1, K, K, seed=2, scale=0.4)
