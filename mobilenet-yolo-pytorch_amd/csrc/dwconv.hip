@@ -490,6 +490,115 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     }
 }
 
+// 5x5 weight gradient, the dual of dw5_fwd_kernel: dW[kr][q] = sum over outputs of dY[ho][wo] * a[S*ho - 2 + kr][S*wo - 2 + q].
+// The thread (4 channels x one output column) walks the INPUT rows of its strip once; input row hi meets the centre-column dY
+// of the output rows it belongs to (stride 1: hi-2..hi+2, kept as a 5-entry history; stride 2: t-1, t, t+1 for an even row 2t,
+// t, t+1 for the odd one) — 25 accumulators + one input row + the dY history, no 5x5 window (the sliding-window kernel needed
+// 250+ VGPRs and spilled).  A strip owns its OUTPUT rows: dY of other strips' rows enters as zero.
+template <typename T, int S, int XF>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) void dw5_wgrad_kernel(
+    const T* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift, int in_act,
+    const T* __restrict__ dy, float* __restrict__ parts, DwGeom g) {
+    __shared__ float4 red[256];
+    const int tid = threadIdx.x;
+    const int cgl = tid % g.cgb;
+    const int pix = tid / g.cgb;
+    const int ppb = blockDim.x / g.cgb;
+    const int cg = blockIdx.y * g.cgb + cgl;
+    const bool cvalid = cg < g.cg_total;
+    const int c = cg * 4;
+    const int gx = gridDim.x;
+    const int lb = (g.xcd && (gx & 7) == 0) ? (int)(blockIdx.x & 7) * (gx >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    F4P acc[25];
+#pragma unroll
+    for (int t = 0; t < 25; ++t) acc[t] = f4p0();
+    if (cvalid) {
+        v2f sc_lo = v2f{1.f, 1.f}, sc_hi = sc_lo, sh_lo = v2f{0.f, 0.f}, sh_hi = sh_lo;
+        if (in_scale != nullptr) {
+            const float4 a = ld4(in_scale + c), b = ld4(in_shift + c);
+            sc_lo = v2f{a.x, a.y}; sc_hi = v2f{a.z, a.w}; sh_lo = v2f{b.x, b.y}; sh_hi = v2f{b.z, b.w};
+        }
+        const float slope = act_slope(in_act), hi_clip = act_hi(in_act);
+        const int64_t pitch = (int64_t)g.W * g.C, opitch = (int64_t)g.Wo * g.C;
+        for (int64_t strip = (int64_t)lb * ppb + pix; strip < g.nstrips; strip += (int64_t)gx * ppb) {
+            const int wo = (int)(strip % g.Wo);
+            const int hs = (int)((strip / g.Wo) % g.nHS);
+            const int n = (int)(strip / ((int64_t)g.Wo * g.nHS));
+            const int ho0 = hs * g.TH;
+            const int ho1 = min(ho0 + g.TH, g.Ho);
+            int coff[5];
+            float cm[5];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const int wi = wo * S - 2 + q;
+                cm[q] = (wi >= 0 && wi < g.W) ? 1.f : 0.f;
+                coff[q] = min(max(wi, 0), g.W - 1) * g.C;
+            }
+            const T* xn = x + (int64_t)n * g.H * pitch + c;
+            const T* dn = dy + ((int64_t)n * g.Ho * g.Wo + wo) * g.C + c;
+            auto load_row = [&](int hi, F4P (&r)[5]) {
+                const float rm = (hi >= 0 && hi < g.H) ? 1.f : 0.f;
+                const T* p = xn + (int64_t)min(max(hi, 0), g.H - 1) * pitch;
+                float4 raw[5];
+#pragma unroll
+                for (int q = 0; q < 5; ++q) raw[q] = ld4(p + coff[q]);
+#pragma unroll
+                for (int q = 0; q < 5; ++q) {
+                    const float m = rm * cm[q];
+                    const v2f m2 = v2f{m, m};
+                    r[q] = dw_xf<XF>(raw[q], sc_lo, sc_hi, sh_lo, sh_hi, slope, hi_clip);
+                    r[q].lo *= m2; r[q].hi *= m2;
+                }
+            };
+            auto load_dy = [&](int ho) {                            // centre-column dY of output row ho; zero outside this strip's rows
+                const float m = (ho >= ho0 && ho < ho1) ? 1.f : 0.f;
+                F4P d = f4p(ld4(dn + (int64_t)min(max(ho, 0), g.Ho - 1) * opitch));
+                d.lo *= v2f{m, m}; d.hi *= v2f{m, m};
+                return d;
+            };
+            auto tap_row = [&](const F4P (&r)[5], F4P d, int kr) {
+#pragma unroll
+                for (int q = 0; q < 5; ++q) pfma(acc[kr * 5 + q], r[q], d);
+            };
+            F4P r[5];
+            if (S == 1) {
+                // d[j] = dY of output row hi - 2 + j while input row hi is processed (kr = 4 - j)
+                F4P d0 = f4p0(), d1 = f4p0(), d2 = load_dy(ho0 - 2), d3 = load_dy(ho0 - 1), d4 = load_dy(ho0);
+                for (int hi = ho0 - 2; hi <= ho1 + 1; ++hi) {
+                    load_row(hi, r);
+                    tap_row(r, d0, 4); tap_row(r, d1, 3); tap_row(r, d2, 2); tap_row(r, d3, 1); tap_row(r, d4, 0);
+                    d0 = d1; d1 = d2; d2 = d3; d3 = d4; d4 = load_dy(hi + 3);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                F4P dm = f4p0(), dc = load_dy(ho0 - 1), dp = load_dy(ho0);      // outputs t-1, t, t+1 for t = ho0 - 1
+                for (int t = ho0 - 1; t <= ho1; ++t) {
+                    load_row(2 * t, r);
+                    tap_row(r, dm, 4); tap_row(r, dc, 2); tap_row(r, dp, 0);
+                    load_row(2 * t + 1, r);
+                    tap_row(r, dc, 3); tap_row(r, dp, 1);
+                    dm = dc; dc = dp; dp = load_dy(t + 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+    // deterministic block reduction over the pixel slots, one tap at a time
+#pragma unroll
+    for (int t = 0; t < 25; ++t) {
+        __syncthreads();
+        red[tid] = f4u(acc[t]);
+        __syncthreads();
+        if (pix == 0 && cvalid) {
+            float4 a = f4zero();
+            for (int p = 0; p < ppb; ++p) add4(a, red[p * g.cgb + cgl]);
+            float* dst = parts + (int64_t)blockIdx.x * g.C * 25;
+            dst[(c + 0) * 25 + t] = a.x; dst[(c + 1) * 25 + t] = a.y;
+            dst[(c + 2) * 25 + t] = a.z; dst[(c + 3) * 25 + t] = a.w;
+        }
+    }
+}
+
 // stride-2 backward-data as a gather over the (at most ceil(K/2)^2) contributing taps
 template <typename T, int KS>
 __global__ __launch_bounds__(256) void dw_bwd_data_s2_kernel(const T* __restrict__ dy, const float* __restrict__ w,
@@ -637,7 +746,7 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2k5_kernel(const T* __restri
 
 static bool dw_use_v2(int K, int mode) {
     static const bool v1 = getenv("MNY_DW_V1") != nullptr;       // A/B: the first-generation sliding-window kernel
-    return (K == 3 || K == 5) && mode == 0 && !v1;
+    return ((K == 3 || K == 5) && mode == 0 && !v1) || (K == 5 && mode == 1 && !v1);      // 5x5 weight gradient: dw5_wgrad_kernel
 }
 
 static int dw_geom(DwGeom& g, CgLayout& L, int& gx, int N, int H, int W, int C, int K, int stride, int mode = 0) {
@@ -698,7 +807,16 @@ static int dw_launch(const T* x, const float* sc, const float* sh, int act, cons
     int rc = dw_geom(g, L, gx, N, H, W, C, K, stride, MODE);
     if (rc) return rc;
     dim3 grid(gx, L.chunks), block(L.threads);
-    if (dw_use_v2(K, MODE) && (addend == nullptr || (sc == nullptr && act == MNY_ACT_NONE))) {     // an addend only occurs without a view (backward-data)
+    if (MODE == 1 && dw_use_v2(K, MODE)) {
+        const int xf5 = (sc == nullptr && act == MNY_ACT_NONE) ? 0 : (act == MNY_ACT_RELU6 ? 1 : (act == MNY_ACT_HSWISH ? 2 : 4));
+#define MNY_W5(S_, X_) hipLaunchKernelGGL((dw5_wgrad_kernel<T, S_, X_>), grid, block, 0, st, x, sc, sh, act, dy, parts, g)
+#define MNY_W5S(S_) do { if (xf5 == 0) MNY_W5(S_, 0); else if (xf5 == 1) MNY_W5(S_, 1); else if (xf5 == 2) MNY_W5(S_, 2); else MNY_W5(S_, 4); } while (0)
+        if (stride == 1) MNY_W5S(1); else MNY_W5S(2);
+#undef MNY_W5S
+#undef MNY_W5
+        return check_launch("dw5_wgrad_kernel");
+    }
+    if (MODE == 0 && dw_use_v2(K, MODE) && (addend == nullptr || (sc == nullptr && act == MNY_ACT_NONE))) {     // an addend only occurs without a view (backward-data)
         const int xf2 = (sc == nullptr && act == MNY_ACT_NONE) ? 0 : (act == MNY_ACT_RELU6 ? 1 : (act == MNY_ACT_HSWISH ? 2 : 4));
 #define MNY_DW2(S_, X_, A_) do { if (g.nt) hipLaunchKernelGGL((dw3_fwd_kernel<T, S_, X_, A_, true>), grid, block, 0, st, x, sc, sh, act, w, flip, addend, y, parts, g); \
         else hipLaunchKernelGGL((dw3_fwd_kernel<T, S_, X_, A_, false>), grid, block, 0, st, x, sc, sh, act, w, flip, addend, y, parts, g); } while (0)
