@@ -250,6 +250,21 @@ int mny_transpose_pad(const float* src /*[R][Cc]*/, float* dst /*[Cc][Rp]*/, int
  * The data-gradient GEMMs read W^T ([Cin][Cout] rows; mny_transpose / mny_transpose_pad per layer).  A static plan
  * knows every (W, W^T) pair up front: jobs (DEVICE array) describe them, block_job (DEVICE int32[nblocks]) maps a
  * 32x32-tile workgroup to its job (job.block0 = its first workgroup; a job has ceil(Cc/32)*ceil(Rp/32) of them). */
+/* Deferred partial combines.  Every weight-gradient entry point (mny_pw_wgrad, mny_dw_bwd_weight, mny_dw_bnbwd[_red],
+ * mny_stem_wgrad, mny_stem_bnwgrad and their _bf16 twins) writes per-workgroup partial sums [nparts][n] to `ws` and then
+ * combines them (fp64, fixed order) into dW.  Called with dw == NULL it stops after the partials (mny_pw_wgrad: only without
+ * dbias); a static plan gives each layer its own `ws` and combines a whole backward segment in ONE launch: jobs (DEVICE
+ * array) name the partials, block_job (DEVICE int32[nblocks]) maps a workgroup (32 outputs) to its job (job.block0 = its first
+ * workgroup, ceil(n/32) of them).  Same arithmetic and order as the per-layer combine. */
+typedef struct mny_reduce_job {
+    const float* parts; /* [nparts][n] */
+    float* out;         /* [n] */
+    int64_t n;
+    int32_t nparts, block0;
+} mny_reduce_job;
+int mny_reduce_batch(const mny_reduce_job* jobs, const int32_t* block_job, int nblocks, void* stream);
+int mny_pw_wgrad_splits(int64_t M, int K, int Nc);      /* nparts of mny_pw_wgrad's partials (n = Nc * K) */
+
 typedef struct mny_transpose_job {
     const float* src; /* [R][Cc] fp32 */
     void* dst;        /* [Cc][Rp] fp32 (or bf16 for the _bf16 entry point), columns R..Rp-1 zeroed */
@@ -404,6 +419,7 @@ int mny_pw_dgrad_bnred_parts_bf16(int64_t M, int K, int Nc);
 int mny_pw_dgrad_bnred_bf16(const void* dy, const void* wT, void* dx, const void* y, const float* scale, const float* shift, int act,
                             const float* mean, const float* invstd, float* red, int64_t M, int K, int Nc, void* stream);
 int mny_transpose_batch_bf16(const mny_transpose_job* jobs, const int32_t* block_job, int nblocks, void* stream);
+int mny_pw_wgrad_splits_bf16(int64_t M, int K, int Nc);
 int mny_axpy_bf16(const void* src, const float* alpha, void* dst, int accumulate, int64_t n, void* stream);
 /* all bf16 weight shadows of a forward pass in one launch: block_job maps a workgroup (4096 elements) to its job */
 typedef struct mny_cvt_job {

@@ -253,7 +253,7 @@ static int dw_bnbwd_impl(const T* g, const T* y, const float* scale, const float
                          const T* x, const float* in_scale, const float* in_shift, int in_act, const float* w,
                          const T* addend, T* dx, float* dw, float* ws, int N, int H, int W, int C, int K, int stride, void* stream,
                          const float* in_mean = nullptr, const float* in_invstd = nullptr, float* in_red = nullptr) {
-    MNY_REQUIRE(g && y && scale && shift && coef && x && w && dx && dw && ws, "dw_bnbwd: null pointer");
+    MNY_REQUIRE(g && y && scale && shift && coef && x && w && dx && ws, "dw_bnbwd: null pointer");
     MNY_REQUIRE(!in_red || (in_mean && in_invstd && in_scale && in_shift), "dw_bnbwd_red: the input must be a BN unit's raw output (scale, shift, mean, invstd)");
     MNY_REQUIRE(K == 3 && stride == 1, "dw_bnbwd: only 3x3 stride 1 is fused (got K=%d stride=%d); use bn_bwd_apply + dw_bwd_*", K, stride);
     MNY_REQUIRE(act != MNY_ACT_HSIGMOID && in_act != MNY_ACT_HSIGMOID, "dw_bnbwd: h-sigmoid views are not supported");
@@ -276,7 +276,7 @@ static int dw_bnbwd_impl(const T* g, const T* y, const float* scale, const float
     }
 #undef MNY_L
     rc = check_launch("dw_bnbwd_s1k3_kernel");
-    if (rc) return rc;
+    if (rc || !dw) return rc;                       // dw == NULL: partials only (combined later by mny_reduce_batch)
     return launch_reduce_parts(ws, gx, C * 9, dw, st);
 }
 

@@ -908,9 +908,9 @@ extern "C" int mny_dw_bwd_data_bf16(const void* dy, const float* w, const void* 
 template <typename T>
 static int dw_bwd_weight_impl(const T* x, const float* in_scale, const float* in_shift, int in_act, const T* dy,
                               float* dw, float* ws, int N, int H, int W, int C, int K, int stride, void* stream) {
-    MNY_REQUIRE(x && dy && dw && ws, "dw_bwd_weight: null pointer");
+    MNY_REQUIRE(x && dy && ws, "dw_bwd_weight: null pointer");
     int rc = dw_launch<1, T>(x, in_scale, in_shift, in_act, nullptr, 0, nullptr, nullptr, dy, ws, N, H, W, C, K, stride, (hipStream_t)stream);
-    if (rc) return rc;
+    if (rc || !dw) return rc;                       // dw == NULL: partials only (combined later by mny_reduce_batch)
     const int parts = mny_dw_wgrad_parts(N, H, W, C, K, stride);
     return launch_reduce_parts(ws, parts, C * K * K, dw, (hipStream_t)stream);
 }

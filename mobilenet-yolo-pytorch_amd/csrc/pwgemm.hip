@@ -2005,10 +2005,14 @@ extern "C" size_t mny_pw_wgrad_ws_floats(int64_t M, int K, int Nc) {
     return (size_t)pl.splits * Nc * K + (size_t)colsum_parts(M) * Nc;
 }
 
+extern "C" int mny_pw_wgrad_splits(int64_t M, int K, int Nc) { return (M <= 0 || K <= 0 || Nc <= 0) ? MNY_EINVAL : wg_plan(M, K, Nc, false).splits; }
+extern "C" int mny_pw_wgrad_splits_bf16(int64_t M, int K, int Nc) { return (M <= 0 || K <= 0 || Nc <= 0) ? MNY_EINVAL : wg_plan(M, K, Nc, true).splits; }
+
 template <typename T>
 static int pw_wgrad_impl(const T* x, const float* in_scale, const float* in_shift, int in_act, const T* dy,
                          float* dw, float* dbias, float* ws, int64_t M, int K, int Nc, void* stream) {
-    MNY_REQUIRE(x && dy && dw && ws, "pw_wgrad: null pointer");
+    MNY_REQUIRE(x && dy && ws, "pw_wgrad: null pointer");
+    MNY_REQUIRE(dw || !dbias, "pw_wgrad: a deferred combine (dw == NULL) cannot carry a bias gradient");
     MNY_REQUIRE(M > 0 && K > 0 && Nc > 0, "pw_wgrad: empty problem");
     constexpr bool is_f32 = sizeof(T) == 4;
     WgPlan pl = wg_plan(M, K, Nc, !is_f32);
@@ -2049,6 +2053,7 @@ static int pw_wgrad_impl(const T* x, const float* in_scale, const float* in_shif
 #undef MNY_WG
     int rc = check_launch("pw_wgrad_kernel");
     if (rc) return rc;
+    if (!dw) return MNY_OK;                         // partials only: the caller combines them (mny_reduce_batch)
     const int64_t n = (int64_t)Nc * K;
     hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(n, 32)), dim3(256), 0, st, ws, pl.splits, n, dw);
     rc = check_launch("reduce_parts_kernel");

@@ -283,7 +283,7 @@ extern "C" int mny_stem_fwd_bf16(const float* x_nchw, const float* w, void* y, f
 
 template <typename T>
 static int stem_wgrad_impl(const float* x_nchw, const T* dy, float* dw, float* ws, int N, int H, int W, int Cout, void* stream) {
-    MNY_REQUIRE(x_nchw && dy && dw && ws, "stem_wgrad: null pointer");
+    MNY_REQUIRE(x_nchw && dy && ws, "stem_wgrad: null pointer");
     StemGeom g; int gx;
     int rc = stem_geom(g, gx, N, H, W, Cout);
     if (rc) return rc;
@@ -293,7 +293,7 @@ static int stem_wgrad_impl(const float* x_nchw, const T* dy, float* dw, float* w
     else
         hipLaunchKernelGGL((stem_kernel<T, 1>), dim3(gx), dim3(g.cgb * g.ppb), 0, (hipStream_t)stream, x_nchw, (const float*)nullptr, (T*)nullptr, dy, ws, g);
     rc = check_launch("stem_kernel<wgrad>");
-    if (rc) return rc;
+    if (rc || !dw) return rc;                       // dw == NULL: partials only (combined later by mny_reduce_batch)
     return launch_reduce_parts(ws, gx, Cout * 27, dw, (hipStream_t)stream);
 }
 // weight gradient of the stem conv straight from the unit's OUTPUT gradient: BN-backward-apply + activation backward are redone on
@@ -302,7 +302,7 @@ extern "C" int mny_stem_bnwgrad_supported(int Cout) { return stem_tiled_ok(Cout)
 template <typename T>
 static int stem_bnwgrad_impl(const float* x_nchw, const T* gout, const T* y, const float* scale, const float* shift, int act, const float* coef,
                              float* dw, float* ws, int N, int H, int W, int Cout, void* stream) {
-    MNY_REQUIRE(x_nchw && gout && y && scale && shift && coef && dw && ws, "stem_bnwgrad: null pointer");
+    MNY_REQUIRE(x_nchw && gout && y && scale && shift && coef && ws, "stem_bnwgrad: null pointer");
     MNY_REQUIRE(mny_stem_bnwgrad_supported(Cout) == 1, "stem_bnwgrad: Cout=%d unsupported", Cout);
     StemGeom g; int gx;
     int rc = stem_geom(g, gx, N, H, W, Cout);
@@ -310,7 +310,7 @@ static int stem_bnwgrad_impl(const float* x_nchw, const T* gout, const T* y, con
     hipLaunchKernelGGL((stem_tile_kernel<T, 2>), dim3(gx), dim3(256), 0, (hipStream_t)stream, x_nchw, (const float*)nullptr, (T*)nullptr, gout, ws, g,
                        (int)cdiv(g.Ho, ST_TH), (int)cdiv(g.Wo, ST_TW), y, scale, shift, coef, act);
     rc = check_launch("stem_tile_kernel<bn-wgrad>");
-    if (rc) return rc;
+    if (rc || !dw) return rc;
     return launch_reduce_parts(ws, gx, Cout * 27, dw, (hipStream_t)stream);
 }
 extern "C" int mny_stem_bnwgrad(const float* x_nchw, const float* g, const float* y, const float* scale, const float* shift, int act,

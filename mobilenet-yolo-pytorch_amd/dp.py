@@ -105,9 +105,9 @@ class PlanReducer:
         """For every gradient slot: index (exclusive end) of the backward call that writes it last."""
         ptr_to_slot = {plan.gviews[n].data_ptr(): i for i, n in enumerate(plan.grad_params)}
         ready = [0] * len(plan.grad_params)
-        for ci, (_fn, args, _name, _meta) in enumerate(plan.bwd.calls):
-            for a in args:
-                v = getattr(a, "value", None)
+        for ci, (_fn, args, _name, meta) in enumerate(plan.bwd.calls):
+            written = [getattr(a, "value", None) for a in args] + list((meta or {}).get("writes", ()))   # `writes`: destinations named inside a device job table (mny_reduce_batch)
+            for v in written:
                 if v in ptr_to_slot:
                     ready[ptr_to_slot[v]] = ci + 1
         # arena order == production order, but make the sequence monotone for safety

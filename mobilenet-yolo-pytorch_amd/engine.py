@@ -472,6 +472,40 @@ class NetPlan:
                 tmp, dst = self.shared_tmp.pop()
                 bwd.add("mny_axpy", tmp, None, dst, 1, tmp.numel(), self.stream)
 
+        # Deferred partial combines: every weight-gradient call leaves per-workgroup partial sums; instead of one small combine
+        # launch per layer (70 launches of 8-10 us at bs=256, 0.66 ms/step) the layer gets its OWN partial buffer, is called with
+        # dw = NULL, and a whole run of layers is combined by one mny_reduce_batch launch (flush_reduce: every `defer_every` jobs, so
+        # the data-parallel buckets still complete early).  MNY_NO_DEFER=1: the per-layer combines.
+        self.defer = os.environ.get("MNY_NO_DEFER") != "1" and not self.side_on
+        defer_every = int(os.environ.get("MNY_DEFER_EVERY", "16"))
+        self._red_jobs, self._red_keep = [], []
+        uses = {}
+        for nd in order:                                          # a module applied twice (mbv3_yolo.py:133-134) adds a second contribution right
+            if nd.conv:                                            # after its producing call: its combines stay inline
+                uses[nd.conv] = uses.get(nd.conv, 0) + 1
+        single = lambda nd: uses.get(nd.conv, 0) == 1             # noqa: E731
+
+        def defer_job(n_floats, dest, nparts, n):
+            """-> private partial buffer of a deferred combine writing `dest` (an arena view)."""
+            wsl = torch.empty(max(int(n_floats), 1), **f32)
+            self._red_jobs.append((wsl, dest, int(nparts), int(n)))
+            return wsl
+
+        def flush_reduce(force=False):
+            if not self._red_jobs or (not force and len(self._red_jobs) < defer_every):
+                return
+            import numpy as np
+            jobs, block_job = [], []
+            for wsl, dest, nparts, n in self._red_jobs:
+                jobs.append((wsl.data_ptr(), dest.data_ptr(), n, nparts, len(block_job)))
+                block_job += [len(jobs) - 1] * ((n + 31) // 32)
+            jt = np.array(jobs, dtype=np.dtype([("parts", np.uint64), ("out", np.uint64), ("n", np.int64), ("nparts", np.int32), ("b0", np.int32)]))
+            jdev = torch.from_numpy(jt.view(np.uint8).copy()).to(dev)
+            bdev = torch.tensor(block_job, dtype=torch.int32, device=dev)
+            self._red_keep += [t for job in self._red_jobs for t in job[:2]]
+            bwd.add("mny_reduce_batch", jdev, bdev, len(block_job), self.stream, meta=dict(writes=[job[1].data_ptr() for job in self._red_jobs]))
+            self._red_jobs = []
+
         # workspaces shared by all layers (single stream => sequential use)
         ws_floats = 1
         max_parts = _lib.query("mny_max_parts")
@@ -671,8 +705,13 @@ class NetPlan:
                                 meta=dict(flops=0, bytes=2 * eb * M * o.C, shape="M%d C%d" % (M, o.C)))
                     bwd.add("mny_bn_bwd_finalize", red_buf, red_parts, M, gam, u.mean, u.invstd, gv(nd.bn + ".weight"), gv(nd.bn + ".bias"),
                             self.coef_ws, o.C, self.stream)
+                    n_sh = len(self.shared_tmp)
                     dwv = gv(nd.conv + ".weight")
                     wt = P[nd.conv + ".weight"]
+                    dwv_k, ws_k = dwv, self.ws
+                    if self.defer and single(nd):
+                        dparts = _lib.query("mny_dw_bnbwd_parts", N, ish[1], ish[2], o.C)
+                        dwv_k, ws_k = None, defer_job(dparts * o.C * 9, dwv, dparts, o.C * 9)
                     prod = i.node
                     # the input is the raw output of a conv+BN+act unit consumed ONLY here: this kernel's dX is that unit's complete
                     # output gradient, so it also leaves the unit's BN-backward sums (mny_dw_bnbwd_red) and the unit's separate
@@ -684,16 +723,17 @@ class NetPlan:
                         rparts = _lib.query("mny_dw_bnbwd_parts", N, ish[1], ish[2], o.C)
                         rbuf = torch.empty(rparts * 2 * i.C, **f32)
                         self.fused_red[i.id] = (rbuf, rparts)
-                        contribute_kernel(i, lambda out, addend, G=G, u=u, xv=xv, wt=wt, dwv=dwv, ish=ish, C=o.C, act=o.act, M=M, pu=pu, rbuf=rbuf: bwd.add(
+                        contribute_kernel(i, lambda out, addend, G=G, u=u, xv=xv, wt=wt, dwv=dwv_k, wsl=ws_k, ish=ish, C=o.C, act=o.act, M=M, pu=pu, rbuf=rbuf: bwd.add(
                             self.K("mny_dw_bnbwd_red"), G, u.Y, u.scale, u.shift, act, self.coef_ws, xv[0], xv[1], xv[2], xv[3], pu.mean, pu.invstd, wt, addend,
-                            out, dwv, self.ws, rbuf, N, ish[1], ish[2], C, 3, 1, self.stream,
+                            out, dwv, wsl, rbuf, N, ish[1], ish[2], C, 3, 1, self.stream,
                             meta=dict(flops=4 * M * C * 9, bytes=self.eb * 4 * M * C, shape="C%d H%d +red" % (C, ish[1]))))
                     else:
-                        contribute_kernel(i, lambda out, addend, G=G, u=u, xv=xv, wt=wt, dwv=dwv, ish=ish, C=o.C, act=o.act, M=M: bwd.add(
-                            self.K("mny_dw_bnbwd"), G, u.Y, u.scale, u.shift, act, self.coef_ws, xv[0], xv[1], xv[2], xv[3], wt, addend, out, dwv, self.ws,
+                        contribute_kernel(i, lambda out, addend, G=G, u=u, xv=xv, wt=wt, dwv=dwv_k, wsl=ws_k, ish=ish, C=o.C, act=o.act, M=M: bwd.add(
+                            self.K("mny_dw_bnbwd"), G, u.Y, u.scale, u.shift, act, self.coef_ws, xv[0], xv[1], xv[2], xv[3], wt, addend, out, dwv, wsl,
                             N, ish[1], ish[2], C, 3, 1, self.stream,
                             meta=dict(flops=4 * M * C * 9, bytes=self.eb * 4 * M * C, shape="C%d H%d" % (C, ish[1]))))
                     flush_shared()
+                    flush_reduce()
                     bwd.marks[o.name] = len(bwd.calls)
                     continue
                 dY = G if not s.shared else alloc(o)
@@ -711,7 +751,11 @@ class NetPlan:
             w = P[nd.conv + ".weight"]
             if nd.op == "stem" and stem_fused:
                 # the stem has no data gradient: its only consumer of dY is the weight gradient, which rebuilds dY from (G, Y) on load
-                bwd.add(K("mny_stem_bnwgrad"), self.x_ptr, G, u.Y, u.scale, u.shift, o.act, self.coef_ws, gv(nd.conv + ".weight"), self.ws,
+                sdw, sws = gv(nd.conv + ".weight"), self.ws
+                if self.defer and single(nd):
+                    sparts = _lib.query("mny_stem_wgrad_parts", N, self.H, self.W, o.C)
+                    sdw, sws = None, defer_job(sparts * o.C * 27, sdw, sparts, o.C * 27)
+                bwd.add(K("mny_stem_bnwgrad"), self.x_ptr, G, u.Y, u.scale, u.shift, o.act, self.coef_ws, sdw, sws,
                         N, self.H, self.W, o.C, self.stream)
             elif nd.op == "stem":
                 if self.side_on:
@@ -727,7 +771,11 @@ class NetPlan:
                 on_side = self.side_on and len(self.shared_tmp) == n_sh
                 if on_side:
                     bwd.add_py(self._fork_side, "fork")
-                bwd.add(K("mny_dw_bwd_weight"), xv[0], xv[1], xv[2], xv[3], dY, dwv_, self.ws_side if on_side else self.ws, N, ish[1], ish[2], o.C,
+                dws_ = self.ws_side if on_side else self.ws
+                if self.defer and single(nd):
+                    wparts = _lib.query("mny_dw_wgrad_parts", N, ish[1], ish[2], o.C, nd.k, nd.stride)
+                    dws_, dwv_ = defer_job(wparts * o.C * nd.k * nd.k, dwv_, wparts, o.C * nd.k * nd.k), None
+                bwd.add(K("mny_dw_bwd_weight"), xv[0], xv[1], xv[2], xv[3], dY, dwv_, dws_, N, ish[1], ish[2], o.C,
                         nd.k, nd.stride, self.stream_side if on_side else self.stream, meta=dict(flops=2 * M * o.C * nd.k * nd.k, bytes=dwb, shape="C%d H%d s%d" % (o.C, ish[1], nd.stride)))
                 contribute_kernel(i, lambda out, addend, dY=dY, w=w, ish=ish, nd=nd, C=o.C, M=M, dwb=dwb: bwd.add(
                     K("mny_dw_bwd_data"), dY, w, addend, out, N, ish[1], ish[2], C, nd.k, nd.stride, self.stream,
@@ -742,7 +790,11 @@ class NetPlan:
                 oc = self.head_cp.get(o.id, o.C)        # channel count of dY as the GEMMs see it (padded for the heads)
                 if on_side:
                     bwd.add_py(self._fork_side, "fork")
-                bwd.add(K("mny_pw_wgrad"), xv[0], xv[1], xv[2], xv[3], dY, dwv_, db, self.ws_side if on_side else self.ws, M, i.C, oc,
+                pws_ = self.ws_side if on_side else self.ws
+                if self.defer and db is None and single(nd):
+                    psplits = _lib.query(K("mny_pw_wgrad_splits"), M, i.C, oc)
+                    pws_, dwv_ = defer_job(max(_lib.query("mny_pw_wgrad_ws_floats", M, i.C, oc), psplits * oc * i.C), dwv_, psplits, oc * i.C), None
+                bwd.add(K("mny_pw_wgrad"), xv[0], xv[1], xv[2], xv[3], dY, dwv_, db, pws_, M, i.C, oc,
                         self.stream_side if on_side else self.stream,
                         meta=dict(flops=2 * M * i.C * o.C, bytes=eb * (M * i.C + M * o.C) + 4 * i.C * o.C, shape="M%d K%d N%d" % (M, i.C, oc)))
                 if self.t_batch:
@@ -775,7 +827,9 @@ class NetPlan:
                         self.K("mny_pw_fwd"), dY, None, None, ACT_NONE, wT, None, addend, out, None, M, K, Nc, self.stream,
                         meta=dict(flops=2 * M * K * Nc, bytes=self.eb * (M * K + M * Nc) + 4 * K * Nc, shape="dgrad M%d K%d N%d" % (M, K, Nc))))
             flush_shared()
+            flush_reduce()
             bwd.marks[o.name] = len(bwd.calls)
+        flush_reduce(force=True)
 
     # ------------------------------------------------------------------------------------------
     def _gemm_weight(self, w):
