@@ -227,6 +227,13 @@ int mny_dw_bnbwd(const float* g, const float* y, const float* scale, const float
                  const float* x, const float* in_scale, const float* in_shift, int in_act, const float* w,
                  const float* addend, float* dx, float* dw, float* ws, int N, int H, int W, int C, int K, int stride,
                  void* stream);
+/* The same fusion for a 3x3 STRIDE-2 depthwise unit (x is [N,H,W,C], g / y are [N,Ho,Wo,C] with Ho = (H-1)/2+1): replaces
+ * mny_bn_bwd_apply + mny_dw_bwd_weight + mny_dw_bwd_data of the four down-sampling units (models/mobilenetv2.py:65-67 at
+ * stride 2).  ws: [mny_dw_bnbwd_s2_parts()][C*9] floats; dw == NULL leaves the partials to mny_reduce_batch. */
+int mny_dw_bnbwd_s2_parts(int N, int H, int W, int C);
+int mny_dw_bnbwd_s2(const float* g, const float* y, const float* scale, const float* shift, int act, const float* coef,
+                    const float* x, const float* in_scale, const float* in_shift, int in_act, const float* w,
+                    const float* addend, float* dx, float* dw, float* ws, int N, int H, int W, int C, void* stream);
 /* mny_dw_bnbwd + the BN-backward sums of the unit that PRODUCED the input: when `x` is the raw output of a conv+BN+act unit
  * (in_scale/in_shift/in_act = its view, in_mean/in_invstd = its batch statistics) whose only consumer is this depthwise unit,
  * the dX written here is that unit's complete output gradient, and the kernel also leaves its sums (sum dz, sum dz*xhat per
@@ -406,6 +413,9 @@ int mny_dw_bnbwd_bf16(const void* g, const void* y, const float* scale, const fl
                       const void* x, const float* in_scale, const float* in_shift, int in_act, const float* w,
                       const void* addend, void* dx, float* dw, float* ws, int N, int H, int W, int C, int K, int stride,
                       void* stream);
+int mny_dw_bnbwd_s2_bf16(const void* g, const void* y, const float* scale, const float* shift, int act, const float* coef,
+                         const void* x, const float* in_scale, const float* in_shift, int in_act, const float* w,
+                         const void* addend, void* dx, float* dw, float* ws, int N, int H, int W, int C, void* stream);
 int mny_dw_bnbwd_red_bf16(const void* g, const void* y, const float* scale, const float* shift, int act, const float* coef,
                           const void* x, const float* in_scale, const float* in_shift, int in_act, const float* in_mean,
                           const float* in_invstd, const float* w, const void* addend, void* dx, float* dw, float* ws, float* in_red,

@@ -227,6 +227,218 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused backward of a depthwise 3x3 STRIDE-2 conv+BN+activation unit (the four down-sampling units of MobileNetV2).
+// Unfused: bn_bwd_apply (read G, Y; write dY) + dw_bwd_weight (read X at 4x the size, dY) + dw_bwd_data (read dY, write dX at
+// 4x the size) = 13 output-sized passes; here G, Y and X are read once and dX written once (10), in one launch instead of three.
+// Thread = 4 channels x one input-quad column j (input columns 2j, 2j+1 = output column j), walking down quad rows i:
+//   dY[i+1][j], dY[i+1][j+1] are rebuilt from (G, Y) each step, row i is carried over from the previous one;
+//   dX of the 2x2 input quad from dY[i..i+1][j..j+1] with statically known taps (see dw_bwd_data_s2k3_kernel);
+//   dW += dY[i][j] * a[2i-1..2i+1][2j-1..2j+1]: input rows 2i, 2i+1 are loaded (three columns), row 2i-1 is carried over.
+// Same LDS-resident per-channel constants, masks instead of selects and XCD-contiguous strips as the stride-1 kernel.
+template <typename T, int AM, int XF>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void dw_bnbwd_s2k3_kernel(
+    const T* __restrict__ g, const T* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift, int act,
+    const float* __restrict__ coef, const T* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+    int in_act, const float* __restrict__ w, const T* __restrict__ addend, T* __restrict__ dx, float* __restrict__ parts, DwbGeom gm) {
+    __shared__ float4 red[256];
+    extern __shared__ __attribute__((aligned(16))) float4 cst[];
+    const int tid = threadIdx.x;
+    const int cgl = tid % gm.cgb, pix = tid / gm.cgb, ppb = blockDim.x / gm.cgb;
+    const int cg = blockIdx.y * gm.cgb + cgl;
+    const bool cvalid = cg < gm.cg_total;
+    const int c = cg * 4;
+    const int Ho = (gm.H - 1) / 2 + 1, Wo = (gm.W - 1) / 2 + 1;        // = quad rows / columns
+
+    F4P wp[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wp[t] = f4p0();
+    if (pix == 0 && cvalid) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) cst[t * gm.cgb + cgl] = make_float4(w[(c + 0) * 9 + t], w[(c + 1) * 9 + t], w[(c + 2) * 9 + t], w[(c + 3) * 9 + t]);
+        cst[9 * gm.cgb + cgl] = ld4(scale + c);
+        cst[10 * gm.cgb + cgl] = ld4(shift + c);
+        cst[11 * gm.cgb + cgl] = ld4(coef + c);
+        cst[12 * gm.cgb + cgl] = ld4(coef + gm.C + c);
+        cst[13 * gm.cgb + cgl] = ld4(coef + 2 * gm.C + c);
+        cst[14 * gm.cgb + cgl] = (XF != 0 && in_scale) ? ld4(in_scale + c) : f4one();
+        cst[15 * gm.cgb + cgl] = (XF != 0 && in_scale) ? ld4(in_shift + c) : f4zero();
+    }
+    __syncthreads();
+    if (cvalid) {
+#define WG(t) f4p(my[(t) * gm.cgb])
+        const float slope = act_slope(act), hi = act_hi(act);
+        const float xslope = act_slope(in_act);
+        auto dact = [&](float z) {
+            if (AM == 2) return z <= -3.f ? 0.f : (z >= 3.f ? 1.f : (2.f * z + 3.f) / 6.f);
+            return (z > 0.f ? 1.f : slope) * (z < hi ? 1.f : 0.f);
+        };
+        auto dy2 = [&](v2f gv, v2f yv, v2f s, v2f h, v2f a, v2f b, v2f cterm) {
+            v2f d = gv;
+            if (AM != 0) { const v2f z = __builtin_elementwise_fma(yv, s, h); d = gv * v2f{dact(z.x), dact(z.y)}; }
+            return __builtin_elementwise_fma(a, d, __builtin_elementwise_fma(b, yv, cterm));
+        };
+        auto xf2 = [&](v2f v, v2f s, v2f h) {
+            if (XF == 0) return v;
+            const v2f z = __builtin_elementwise_fma(v, s, h);
+            if (XF == 1) return v2f{__builtin_amdgcn_fmed3f(z.x, 0.f, 6.f), __builtin_amdgcn_fmed3f(z.y, 0.f, 6.f)};
+            if (XF == 3) { const v2f t = z * v2f{xslope, xslope}; return v2f{fmaxf(z.x, t.x), fmaxf(z.y, t.y)}; }
+            const v2f t = z + v2f{3.f, 3.f};
+            return z * v2f{__builtin_amdgcn_fmed3f(t.x, 0.f, 6.f), __builtin_amdgcn_fmed3f(t.y, 0.f, 6.f)} * v2f{1.f / 6.f, 1.f / 6.f};
+        };
+        const int gxd = gridDim.x;
+        const int lb = (gm.xcd && (gxd & 7) == 0) ? (int)(blockIdx.x & 7) * (gxd >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+        const int64_t pitch = (int64_t)gm.W * gm.C, opitch = (int64_t)Wo * gm.C;
+        for (int64_t strip = (int64_t)lb * ppb + pix; strip < gm.nstrips; strip += (int64_t)gxd * ppb) {
+            const int j = (int)(strip % Wo);
+            const int hs = (int)((strip / Wo) % gm.nHS);
+            const int n = (int)(strip / ((int64_t)Wo * gm.nHS));
+            const int i0 = hs * gm.TH, i1 = min(i0 + gm.TH, Ho);
+            const T* xn = x + (int64_t)n * gm.H * pitch + c;
+            const int64_t on = (int64_t)n * Ho * opitch + c;
+            int xoff[3];
+            float xm[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { const int wi = 2 * j - 1 + q; xm[q] = (wi >= 0 && wi < gm.W) ? 1.f : 0.f; xoff[q] = min(max(wi, 0), gm.W - 1) * gm.C; }
+            const float jm1 = (j + 1 < Wo) ? 1.f : 0.f;
+            const int joff0 = j * gm.C, joff1 = min(j + 1, Wo - 1) * gm.C;
+
+            // dY at output row `ho`, columns j and j+1 (zero outside the output)
+            auto dy_row = [&](int ho, const float4* my, F4P& d0, F4P& d1) {
+                const float rm = (ho < Ho) ? 1.f : 0.f;
+                const int64_t ro = on + (int64_t)min(ho, Ho - 1) * opitch;
+                const float4 g0 = ld4(g + ro + joff0), y0 = ld4(y + ro + joff0), g1 = ld4(g + ro + joff1), y1 = ld4(y + ro + joff1);
+                const F4P sc = f4p(my[9 * gm.cgb]), sh = f4p(my[10 * gm.cgb]), ca = f4p(my[11 * gm.cgb]), cb = f4p(my[12 * gm.cgb]), cc = f4p(my[13 * gm.cgb]);
+                const F4P G0 = f4p(g0), Y0 = f4p(y0), G1 = f4p(g1), Y1 = f4p(y1);
+                const v2f m0 = v2f{rm, rm}, m1 = v2f{rm * jm1, rm * jm1};
+                d0.lo = dy2(G0.lo, Y0.lo, sc.lo, sh.lo, ca.lo, cb.lo, cc.lo) * m0; d0.hi = dy2(G0.hi, Y0.hi, sc.hi, sh.hi, ca.hi, cb.hi, cc.hi) * m0;
+                d1.lo = dy2(G1.lo, Y1.lo, sc.lo, sh.lo, ca.lo, cb.lo, cc.lo) * m1; d1.hi = dy2(G1.hi, Y1.hi, sc.hi, sh.hi, ca.hi, cb.hi, cc.hi) * m1;
+            };
+            // activated input row hi, columns 2j-1, 2j, 2j+1 (zero outside the image)
+            auto x_row = [&](int hi, const float4* my, F4P (&a)[3]) {
+                const float rm = (hi >= 0 && hi < gm.H) ? 1.f : 0.f;
+                const T* p = xn + (int64_t)min(max(hi, 0), gm.H - 1) * pitch;
+                float4 raw[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) raw[q] = ld4(p + xoff[q]);
+                const F4P xsc = f4p(my[14 * gm.cgb]), xsh = f4p(my[15 * gm.cgb]);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const float m = rm * xm[q];
+                    const F4P X4 = f4p(raw[q]);
+                    a[q].lo = xf2(X4.lo, xsc.lo, xsh.lo) * v2f{m, m};
+                    a[q].hi = xf2(X4.hi, xsc.hi, xsh.hi) * v2f{m, m};
+                }
+            };
+            F4P d00, d01, atop[3];
+            {
+                int lo = cgl;
+                asm volatile("" : "+v"(lo));
+                const float4* my = cst + lo;
+                dy_row(i0, my, d00, d01);
+                x_row(2 * i0 - 1, my, atop);
+            }
+            for (int i = i0; i < i1; ++i) {
+                int lo = cgl;
+                asm volatile("" : "+v"(lo));                       // keeps the LDS constant reads inside the loop (see the stride-1 kernel)
+                const float4* my = cst + lo;
+                F4P d10, d11, amid[3], abot[3];
+                dy_row(i + 1, my, d10, d11);
+                x_row(2 * i, my, amid);
+                x_row(2 * i + 1, my, abot);
+                // weight gradient: dY[i][j] against the 3x3 input patch around (2i, 2j)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { pfma(wp[q], atop[q], d00); pfma(wp[3 + q], amid[q], d00); pfma(wp[6 + q], abot[q], d00); }
+                // data gradient of the quad (2i..2i+1, 2j..2j+1): taps as in dw_bwd_data_s2k3_kernel
+                F4P o00 = f4p0(), o01 = f4p0(), o10 = f4p0(), o11 = f4p0();
+                pfma(o00, d00, WG(4));
+                pfma(o01, d00, WG(5)); pfma(o01, d01, WG(3));
+                pfma(o10, d00, WG(7)); pfma(o10, d10, WG(1));
+                pfma(o11, d00, WG(8)); pfma(o11, d01, WG(6)); pfma(o11, d10, WG(2)); pfma(o11, d11, WG(0));
+                const int h0 = 2 * i, w0 = 2 * j;
+                const int64_t base = (int64_t)n * gm.H * pitch + (int64_t)h0 * pitch + (int64_t)w0 * gm.C + c;
+                const bool hv = h0 + 1 < gm.H, wv2 = w0 + 1 < gm.W;
+                float4 f00 = f4u(o00), f01 = f4u(o01), f10 = f4u(o10), f11 = f4u(o11);
+                if (addend) {
+                    add4(f00, ld4(addend + base));
+                    if (wv2) add4(f01, ld4(addend + base + gm.C));
+                    if (hv) add4(f10, ld4(addend + base + pitch));
+                    if (hv && wv2) add4(f11, ld4(addend + base + pitch + gm.C));
+                }
+                st4_stream(dx + base, f00);
+                if (wv2) st4_stream(dx + base + gm.C, f01);
+                if (hv) st4_stream(dx + base + pitch, f10);
+                if (hv && wv2) st4_stream(dx + base + pitch + gm.C, f11);
+                d00 = d10; d01 = d11;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) atop[q] = abot[q];
+            }
+        }
+#undef WG
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        __syncthreads();
+        red[tid] = f4u(wp[t]);
+        __syncthreads();
+        if (pix == 0 && cvalid) {
+            float4 a = f4zero();
+            for (int p = 0; p < ppb; ++p) add4(a, red[p * gm.cgb + cgl]);
+            float* dst = parts + (int64_t)blockIdx.x * gm.C * 9;
+            dst[(c + 0) * 9 + t] = a.x; dst[(c + 1) * 9 + t] = a.y;
+            dst[(c + 2) * 9 + t] = a.z; dst[(c + 3) * 9 + t] = a.w;
+        }
+    }
+}
+
+// geometry of the stride-2 kernel: strips of TH quad rows over (N, quad columns)
+static int dwb2_geom(DwbGeom& g, CgLayout& L, int& gx, int N, int H, int W, int C) {
+    MNY_REQUIRE(C % 4 == 0 && C > 0, "dw_bnbwd_s2: C=%d must be a positive multiple of 4", C);
+    MNY_REQUIRE(N > 0 && H > 0 && W > 0, "dw_bnbwd_s2: empty tensor");
+    g.N = N; g.H = H; g.W = W; g.C = C;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const int ns = (int)cdiv(Ho, 16);
+    g.TH = (int)cdiv(Ho, ns);
+    g.nHS = (int)cdiv(Ho, g.TH);
+    g.nstrips = (int64_t)N * Wo * g.nHS;
+    L = make_stencil_layout(C);
+    g.cg_total = L.cg_total; g.cgb = L.cgb;
+    int64_t want = cdiv(g.nstrips, L.ppb);
+    int cap = 768 / L.chunks > 0 ? 768 / L.chunks : 1;
+    g.xcd = 1;
+    if (cap > 8) cap &= ~7;
+    if (want > 8) want = (want + 7) & ~(int64_t)7;
+    gx = (int)(want < cap ? want : cap);
+    return MNY_OK;
+}
+
+template <typename T>
+static int dw_bnbwd_s2_impl(const T* g, const T* y, const float* scale, const float* shift, int act, const float* coef,
+                            const T* x, const float* in_scale, const float* in_shift, int in_act, const float* w,
+                            const T* addend, T* dx, float* dw, float* ws, int N, int H, int W, int C, void* stream) {
+    MNY_REQUIRE(g && y && scale && shift && coef && x && w && dx && ws, "dw_bnbwd_s2: null pointer");
+    MNY_REQUIRE(act != MNY_ACT_HSIGMOID && in_act != MNY_ACT_HSIGMOID, "dw_bnbwd_s2: h-sigmoid views are not supported");
+    DwbGeom gm; CgLayout L; int gx;
+    int rc = dwb2_geom(gm, L, gx, N, H, W, C);
+    if (rc) return rc;
+    dim3 grid(gx, L.chunks), block(L.threads);
+    hipStream_t st = (hipStream_t)stream;
+    const int am = act == MNY_ACT_NONE ? 0 : (act == MNY_ACT_HSWISH ? 2 : 1);
+    const int xf = (in_scale == nullptr && in_act == MNY_ACT_NONE) ? 0 : (in_act == MNY_ACT_HSWISH ? 2 : (in_act == MNY_ACT_RELU6 ? 1 : 3));
+    const size_t lds = (size_t)16 * L.cgb * sizeof(float4);
+#define MNY_L2(A_, X_) hipLaunchKernelGGL((dw_bnbwd_s2k3_kernel<T, A_, X_>), grid, block, lds, st, g, y, scale, shift, act, coef, x, in_scale, in_shift, \
+                                          in_act, w, addend, dx, ws, gm)
+    switch (am * 4 + xf) {
+        case 0: MNY_L2(0, 0); break; case 1: MNY_L2(0, 1); break; case 2: MNY_L2(0, 2); break; case 3: MNY_L2(0, 3); break;
+        case 4: MNY_L2(1, 0); break; case 5: MNY_L2(1, 1); break; case 6: MNY_L2(1, 2); break; case 7: MNY_L2(1, 3); break;
+        case 8: MNY_L2(2, 0); break; case 9: MNY_L2(2, 1); break; case 10: MNY_L2(2, 2); break; default: MNY_L2(2, 3); break;
+    }
+#undef MNY_L2
+    rc = check_launch("dw_bnbwd_s2k3_kernel");
+    if (rc || !dw) return rc;
+    return launch_reduce_parts(ws, gx, C * 9, dw, st);
+}
+
 static int dwb_geom(DwbGeom& g, CgLayout& L, int& gx, int N, int H, int W, int C) {
     MNY_REQUIRE(C % 4 == 0 && C > 0, "dw_bnbwd: C=%d must be a positive multiple of 4", C);
     MNY_REQUIRE(N > 0 && H > 0 && W > 0, "dw_bnbwd: empty tensor");
@@ -285,6 +497,23 @@ static int dw_bnbwd_impl(const T* g, const T* y, const float* scale, const float
 using namespace mny;
 
 extern "C" int mny_dw_bnbwd_supported(int K, int stride) { return (K == 3 && stride == 1) ? 1 : 0; }
+
+extern "C" int mny_dw_bnbwd_s2_parts(int N, int H, int W, int C) {
+    DwbGeom g; CgLayout L; int gx;
+    if (dwb2_geom(g, L, gx, N, H, W, C)) return MNY_EINVAL;
+    return gx;
+}
+extern "C" int mny_dw_bnbwd_s2(const float* g, const float* y, const float* scale, const float* shift, int act, const float* coef,
+                               const float* x, const float* in_scale, const float* in_shift, int in_act, const float* w,
+                               const float* addend, float* dx, float* dw, float* ws, int N, int H, int W, int C, void* stream) {
+    return dw_bnbwd_s2_impl<float>(g, y, scale, shift, act, coef, x, in_scale, in_shift, in_act, w, addend, dx, dw, ws, N, H, W, C, stream);
+}
+extern "C" int mny_dw_bnbwd_s2_bf16(const void* g, const void* y, const float* scale, const float* shift, int act, const float* coef,
+                                    const void* x, const float* in_scale, const float* in_shift, int in_act, const float* w,
+                                    const void* addend, void* dx, float* dw, float* ws, int N, int H, int W, int C, void* stream) {
+    return dw_bnbwd_s2_impl<bf16_t>((const bf16_t*)g, (const bf16_t*)y, scale, shift, act, coef, (const bf16_t*)x, in_scale, in_shift, in_act, w,
+                                    (const bf16_t*)addend, (bf16_t*)dx, dw, ws, N, H, W, C, stream);
+}
 
 extern "C" int mny_dw_bnbwd_parts(int N, int H, int W, int C) {
     DwbGeom g; CgLayout L; int gx;

@@ -517,7 +517,7 @@ class NetPlan:
                 ws_floats = max(ws_floats, _lib.query("mny_pw_wgrad_ws_floats", M, nd.ins[0].C, self.head_cp.get(o.id, o.C)),
                                 _lib.query("mny_pw_bnbwd_ws_floats", M, nd.ins[0].C, o.C))
             elif nd.op == "dw":
-                ws_floats = max(ws_floats, max_parts * o.C * nd.k * nd.k)
+                ws_floats = max(ws_floats, max_parts * o.C * nd.k * nd.k)     # (max_parts = 1024 >= the 768-row grids of the fused kernels)
             elif nd.op == "stem":
                 ws_floats = max(ws_floats, max_parts * o.C * 27)
         self.ws = torch.empty(ws_floats, **f32)
@@ -732,6 +732,33 @@ class NetPlan:
                             self.K("mny_dw_bnbwd"), G, u.Y, u.scale, u.shift, act, self.coef_ws, xv[0], xv[1], xv[2], xv[3], wt, addend, out, dwv, wsl,
                             N, ish[1], ish[2], C, 3, 1, self.stream,
                             meta=dict(flops=4 * M * C * 9, bytes=self.eb * 4 * M * C, shape="C%d H%d" % (C, ish[1]))))
+                    flush_shared()
+                    flush_reduce()
+                    bwd.marks[o.name] = len(bwd.calls)
+                    continue
+                if (nd.op == "dw" and nd.k == 3 and nd.stride == 2 and os.environ.get("MNY_NO_DWFUSE2") != "1"
+                        and o.act != _lib.ACT_HSIGMOID and nd.ins[0].act != _lib.ACT_HSIGMOID):
+                    # 3x3 stride-2 depthwise unit: the same fusion (mny_dw_bnbwd_s2): no dY tensor, one launch instead of three
+                    i = nd.ins[0]
+                    ish = shape(i)
+                    xv = view(i)
+                    red_buf, red_parts = self.fused_red.get(o.id, (None, 0))
+                    if red_buf is None:
+                        red_buf, red_parts = self.red_ws, parts
+                        bwd.add(K("mny_bn_bwd_reduce"), G, u.Y, u.scale, u.shift, o.act, u.mean, u.invstd, self.red_ws, M, o.C, self.stream,
+                                meta=dict(flops=0, bytes=2 * eb * M * o.C, shape="M%d C%d" % (M, o.C)))
+                    bwd.add("mny_bn_bwd_finalize", red_buf, red_parts, M, gam, u.mean, u.invstd, gv(nd.bn + ".weight"), gv(nd.bn + ".bias"),
+                            self.coef_ws, o.C, self.stream)
+                    dwv = gv(nd.conv + ".weight")
+                    wt = P[nd.conv + ".weight"]
+                    dwv_k, ws_k = dwv, self.ws
+                    if self.defer and single(nd):
+                        dparts = _lib.query("mny_dw_bnbwd_s2_parts", N, ish[1], ish[2], o.C)
+                        dwv_k, ws_k = None, defer_job(dparts * o.C * 9, dwv, dparts, o.C * 9)
+                    contribute_kernel(i, lambda out, addend, G=G, u=u, xv=xv, wt=wt, dwv=dwv_k, wsl=ws_k, ish=ish, C=o.C, act=o.act, M=M: bwd.add(
+                        self.K("mny_dw_bnbwd_s2"), G, u.Y, u.scale, u.shift, act, self.coef_ws, xv[0], xv[1], xv[2], xv[3], wt, addend, out, dwv, wsl,
+                        N, ish[1], ish[2], C, self.stream,
+                        meta=dict(flops=4 * M * C * 9, bytes=self.eb * (2 * M * C + 2 * N * ish[1] * ish[2] * C), shape="C%d H%d s2" % (C, ish[1]))))
                     flush_shared()
                     flush_reduce()
                     bwd.marks[o.name] = len(bwd.calls)

@@ -123,6 +123,18 @@ def dw_bnbwd(g, y, scale, shift, act, coef, xview, w, addend=None, in_stats=None
     return dx, dw, red
 
 
+def dw_bnbwd_s2(g, y, scale, shift, act, coef, xview, w, addend=None):
+    """Fused BN-backward-apply + weight / data gradient of a 3x3 STRIDE-2 depthwise unit -> (dx, dw)."""
+    x, xs, xh, xact = xview
+    N, H, W, C = x.shape
+    ws = _new(query("mny_dw_bnbwd_s2_parts", N, H, W, C), C * 9, like=x)
+    dx = torch.empty_like(x)
+    dw = _new(C, 1, 3, 3, like=x)
+    call(_k("mny_dw_bnbwd_s2", x), _p(g), _p(y), _p(scale), _p(shift), act, _p(coef), _p(x), _p(xs), _p(xh), xact, _p(w), _p(addend), _p(dx),
+         _p(dw), _p(ws), N, H, W, C, _st())
+    return dx, dw
+
+
 # ---- pointwise --------------------------------------------------------------------------------------
 def pw_fwd(view, w2d, bias=None, addend=None, want_stats=True, out=None):
     """bf16 activations take bf16 weights (mny_pw_fwd_bf16)."""

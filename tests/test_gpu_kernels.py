@@ -290,6 +290,38 @@ def test_fused_dw_unit_backward(ops, N, H, W, C, act, xact, dtype):
     check(dbeta, br.grad, 5e-4, 5e-4 * max(1.0, br.grad.abs().max().item()), "dbeta")
 
 
+@pytest.mark.parametrize("N,H,W,C,act,xact,dtype", [(2, 16, 16, 32, 1, 1, "f32"), (3, 22, 19, 96, 2, 3, "f32"), (2, 37, 9, 144, 1, 1, "f32"),
+                                                    (1, 5, 5, 576, 0, 1, "f32"), (2, 20, 21, 120, 4, 4, "f32"), (2, 33, 17, 64, 1, 1, "bf16"),
+                                                    (2, 1, 7, 16, 1, 0, "f32"), (4, 44, 44, 192, 1, 1, "f32")])
+def test_fused_dw_stride2_unit_backward(ops, N, H, W, C, act, xact, dtype):
+    """mny_dw_bnbwd_s2 == mny_bn_bwd_apply -> mny_dw_bwd_weight + mny_dw_bwd_data (the three launches it replaces), same inputs:
+    fp32 2e-4 relative; bf16 storage: dX within one rounding of the unfused path (which rounds dY to bf16 in between)."""
+    import ctypes
+    from mobilenet_yolo_pytorch_amd import _lib
+    bf = dtype == "bf16"
+    q = (lambda t: t.to(torch.bfloat16).float()) if bf else (lambda t: t)
+    dev = (lambda t: nhwc(t).to(torch.bfloat16)) if bf else nhwc
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    x, add = dev(q(rnd(N, C, H, W, seed=1))), dev(q(rnd(N, C, H, W, seed=4)))
+    y, g = dev(q(rnd(N, C, Ho, Wo, seed=2))), dev(q(rnd(N, C, Ho, Wo, seed=3)))
+    w = rnd(C, 1, 3, 3, seed=5, scale=0.4).cuda().contiguous()
+    mk = lambda seed, a, b: (a + b * rnd(C, seed=seed)).cuda()          # noqa: E731
+    scale, shift, coef = mk(6, 1.0, 0.2), mk(7, 0.0, 0.3), torch.stack((mk(8, 1.0, 0.2), mk(9, 0.0, 0.05), mk(10, 0.0, 0.05))).contiguous()
+    xs, xh = (mk(11, 1.0, 0.2), mk(12, 0.0, 0.3)) if xact else (None, None)
+    dx, dw = ops.dw_bnbwd_s2(g, y, scale, shift, act, coef, (x, xs, xh, xact), w, addend=add)
+    # the unfused chain
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
+    dy = torch.empty_like(g)
+    _lib.call("mny_bn_bwd_apply" + ("_bf16" if bf else ""), p(g), p(y), p(scale), p(shift), act, p(coef), p(dy), N * Ho * Wo, C,
+              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    dx_ref = ops.dw_bwd_data(dy, w, (H, W), 2, addend=add)
+    dw_ref = ops.dw_bwd_weight((x, xs, xh, xact), dy, 3, 2)
+    rt, at = (2.0 ** -6, 2e-2) if bf else (2e-4, 2e-5)
+    check(dx.float(), dx_ref.float(), rt, at * max(1.0, dx_ref.float().abs().max().item()), "fused s2 dw: dX")
+    tw = 5e-3 if bf else 3e-4
+    check(dw, dw_ref, tw, tw * dw_ref.abs().max().item(), "fused s2 dw: dW")
+
+
 @pytest.mark.parametrize("N,H,W,C,act,xact,dtype", [(2, 11, 11, 32, 1, 1, "f32"), (3, 22, 19, 96, 2, 2, "f32"), (2, 37, 8, 144, 1, 3, "f32"),
                                                     (1, 5, 5, 960, 0, 1, "f32"), (2, 20, 20, 120, 4, 4, "f32"), (2, 33, 17, 64, 1, 1, "bf16"),
                                                     (2, 40, 40, 384, 1, 1, "f32")])
