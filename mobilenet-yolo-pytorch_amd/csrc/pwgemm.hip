@@ -484,11 +484,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                 }
             } else if (p.stats) {                                 // column sums come from the un-transposed registers
                 const bool ccol = n0 + u * 32 + lrow < p.N;
+                if (m0 + BM <= p.M) {                             // whole tile inside M (all but the last one): packed pairs, no row tests
+                    v2f a1 = v2f{0.f, 0.f}, a2 = v2f{0.f, 0.f};
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t row = m0 + wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                    const float q = stored<T>(acc[u][r]);
-                    if (ccol && row < p.M) { s1[u] += q; s2[u] = fmaf(q, q, s2[u]); }
+                    for (int r = 0; r < 16; r += 2) {
+                        const v2f q = v2f{stored<T>(acc[u][r]), stored<T>(acc[u][r + 1])};
+                        a1 += q;
+                        a2 = __builtin_elementwise_fma(q, q, a2);
+                    }
+                    if (ccol) { s1[u] += a1.x + a1.y; s2[u] += a2.x + a2.y; }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int64_t row = m0 + wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                        const float q = stored<T>(acc[u][r]);
+                        if (ccol && row < p.M) { s1[u] += q; s2[u] = fmaf(q, q, s2[u]); }
+                    }
                 }
             }
 #pragma unroll
@@ -510,7 +521,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                 }
                 const int64_t row = m0 + wv * 32 + 8 * gq + 4 * khalf + jq;
                 if (cok && row < p.M) {
-                    float4 v = make_float4(r0 + bv.x, r1 + bv.y, r2 + bv.z, r3 + bv.w);
+                    float4 v = make_float4(r0, r1, r2, r3);
+                    if (p.bias) { v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }        // wave-uniform: only the two head convs carry a bias
                     if (nvec) {
                         if (pAdd) add4(v, ld4(pAdd + row * p.N + colq));
                         st4_stream(pC + row * p.N + colq, v);
