@@ -219,10 +219,14 @@ class NetPlan:
         # occupancy query) the call lists are captured once per segment and replayed.  Measured on MI355X: no gain
         # (68.1 vs 67.7 ms/step) — the eager list already keeps the GPU queue full — so it is off by default.
         self.use_graphs = training and os.environ.get("MNY_HIPGRAPH", "0") == "1"
-        # weight-gradient kernels on a side stream (MNY_SIDE_STREAM=1): they feed nothing downstream in the backward pass, so
-        # the MFMA-bound ones can overlap the HBM-bound BN / depthwise kernels of the following layers.  Fork = the side
-        # stream waits for what the main stream has enqueued (dY ready); join at the end of every replayed segment.
-        self.side_on = training and not self.use_graphs and os.environ.get("MNY_SIDE_STREAM", "0") == "1"
+        # weight-gradient kernels on a side stream: they feed nothing downstream in the backward pass, so they can overlap the
+        # kernels of the following layers.  Fork = the side stream waits for what the main stream has enqueued (dY ready); join
+        # before every batched combine and at the end of every replayed segment.  Measured (same-box A/B): no gain at
+        # bs=256/352x352, where every kernel fills the chip (49.4 vs 49.5-49.8 ms), +3 % on MobileNetV3 512x512 bs=64 bf16, whose
+        # 10-100 us kernels leave CUs idle (17.7 -> 17.2 ms) -> on by default for plans below 24 M input pixels; MNY_SIDE_STREAM=0/1 forces.
+        env_side = os.environ.get("MNY_SIDE_STREAM")
+        auto_side = N * H * W <= 24 * 1000 * 1000
+        self.side_on = training and not self.use_graphs and (env_side == "1" or (env_side is None and auto_side))
         self.stream_side = _vp(0)
         self._side_stream = torch.cuda.Stream(dev) if self.side_on else None
         self._side_used = False
@@ -476,7 +480,7 @@ class NetPlan:
         # launch per layer (70 launches of 8-10 us at bs=256, 0.66 ms/step) the layer gets its OWN partial buffer, is called with
         # dw = NULL, and a whole run of layers is combined by one mny_reduce_batch launch (flush_reduce: every `defer_every` jobs, so
         # the data-parallel buckets still complete early).  MNY_NO_DEFER=1: the per-layer combines.
-        self.defer = os.environ.get("MNY_NO_DEFER") != "1" and not self.side_on
+        self.defer = os.environ.get("MNY_NO_DEFER") != "1"
         defer_every = int(os.environ.get("MNY_DEFER_EVERY", "16"))
         self._red_jobs, self._red_keep = [], []
         uses = {}
@@ -503,6 +507,8 @@ class NetPlan:
             jdev = torch.from_numpy(jt.view(np.uint8).copy()).to(dev)
             bdev = torch.tensor(block_job, dtype=torch.int32, device=dev)
             self._red_keep += [t for job in self._red_jobs for t in job[:2]]
+            if self.side_on:
+                bwd.add_py(self._join_side, "join")               # the partials of side-stream weight gradients must have landed
             bwd.add("mny_reduce_batch", jdev, bdev, len(block_job), self.stream, meta=dict(writes=[job[1].data_ptr() for job in self._red_jobs]))
             self._red_jobs = []
 
@@ -795,7 +801,7 @@ class NetPlan:
                 dwb = eb * (N * ish[1] * ish[2] * o.C + M * o.C)
                 n_sh = len(self.shared_tmp)
                 dwv_ = gv(nd.conv + ".weight")
-                on_side = self.side_on and len(self.shared_tmp) == n_sh
+                on_side = self.side_on and single(nd)          # (both contributions of a module applied twice stay in order on the main stream)
                 if on_side:
                     bwd.add_py(self._fork_side, "fork")
                 dws_ = self.ws_side if on_side else self.ws
@@ -813,7 +819,7 @@ class NetPlan:
                 n_sh = len(self.shared_tmp)
                 db = gv(nd.conv + ".bias") if nd.bias else None
                 dwv_ = gv(nd.conv + ".weight")
-                on_side = self.side_on and len(self.shared_tmp) == n_sh
+                on_side = self.side_on and single(nd)          # (both contributions of a module applied twice stay in order on the main stream)
                 oc = self.head_cp.get(o.id, o.C)        # channel count of dY as the GEMMs see it (padded for the heads)
                 if on_side:
                     bwd.add_py(self._fork_side, "fork")
@@ -988,13 +994,16 @@ class NetPlan:
             self._side_stream.wait_event(ev)
             self._side_used = True
 
-    def run_bwd_segment(self, begin, end):
-        self._replay("bwd", self.bwd, begin, end)
-        if self._side_used:                                  # join: gradients of this segment are complete on the main stream
+    def _join_side(self):
+        if self._side_used:
             ev = torch.cuda.Event()
             ev.record(self._side_stream)
             torch.cuda.current_stream(self.dev).wait_event(ev)
             self._side_used = False
+
+    def run_bwd_segment(self, begin, end):
+        self._replay("bwd", self.bwd, begin, end)
+        self._join_side()                                    # gradients of this segment are complete on the main stream
 
     def enable_timing(self, only=None, steps=1):
         """Bracket calls with HIP events (bench.py roofline leg); disable with disable_timing().  `steps`: how many steps will
