@@ -308,6 +308,13 @@ int mny_pw_dgrad_bnred_parts(int64_t M, int K, int Nc); /* partial rows it write
 int mny_pw_dgrad_bnred(const float* dy, const float* wT, float* dx, const float* y, const float* scale,
                        const float* shift, int act, const float* mean, const float* invstd, float* red,
                        int64_t M, int K, int Nc, void* stream);
+/* ... with an addend: dx = dy * W + addend is the LAST contribution to that unit's output gradient (the others — a residual
+ * branch — were accumulated into `addend`), and the sums are taken over the complete dx (torch.add at mobilenetv2.py:89 followed
+ * by the BatchNorm backward of the block's project conv). */
+int mny_pw_dgrad_bnred_add_supported(int64_t M, int K, int Nc, int act);
+int mny_pw_dgrad_bnred_add(const float* dy, const float* wT, const float* addend, float* dx, const float* y, const float* scale,
+                           const float* shift, int act, const float* mean, const float* invstd, float* red, int64_t M, int K, int Nc,
+                           void* stream);
 
 /* ---- evaluation consumer: VOC07 11-point mAP on the device -----------------------------
  * Replaces utils/eval_mAP.py:134-187 (calculate_mAP), :69-132 (eval_class_ap), :8-65
@@ -428,6 +435,10 @@ int mny_pw_dgrad_bnred_supported_bf16(int64_t M, int K, int Nc, int act);
 int mny_pw_dgrad_bnred_parts_bf16(int64_t M, int K, int Nc);
 int mny_pw_dgrad_bnred_bf16(const void* dy, const void* wT, void* dx, const void* y, const float* scale, const float* shift, int act,
                             const float* mean, const float* invstd, float* red, int64_t M, int K, int Nc, void* stream);
+int mny_pw_dgrad_bnred_add_supported_bf16(int64_t M, int K, int Nc, int act);
+int mny_pw_dgrad_bnred_add_bf16(const void* dy, const void* wT, const void* addend, void* dx, const void* y, const float* scale,
+                                const float* shift, int act, const float* mean, const float* invstd, float* red, int64_t M, int K,
+                                int Nc, void* stream);
 int mny_transpose_batch_bf16(const mny_transpose_job* jobs, const int32_t* block_job, int nblocks, void* stream);
 int mny_pw_wgrad_splits_bf16(int64_t M, int K, int Nc);
 int mny_axpy_bf16(const void* src, const float* alpha, void* dst, int accumulate, int64_t n, void* stream);

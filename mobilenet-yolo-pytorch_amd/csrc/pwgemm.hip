@@ -468,16 +468,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                 const int64_t rbase = m0 + wv * 32 + 4 * khalf;
                 const int rows_left = (int)max((int64_t)0, min((int64_t)64, p.M - rbase));   // rows rbase + 8*gq + j, 8*gq + j < rows_left, exist
                 const T* ybase = (const T*)p.rY + (rows_left > 0 ? rbase : 0) * p.N + cc;
+                const T* abase = RED == 2 ? pAdd + (rows_left > 0 ? rbase : 0) * p.N + cc : nullptr;   // RED = 2: earlier contributions to the same gradient
 #pragma unroll
                 for (int gq = 0; gq < 4; ++gq) {                  // four rows at a time: the loads of a group are all that is in flight
-                    float yv[4];
+                    float yv[4], av[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) yv[j] = ld1(ybase + (ccol && 8 * gq + j < rows_left ? 8 * gq + j : 0) * p.N);
+                    if (RED == 2) {                               // the sums are over the COMPLETE gradient = product + addend
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) av[j] = ld1(abase + (ccol && 8 * gq + j < rows_left ? 8 * gq + j : 0) * p.N);
+                    }
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float z = fmaf(yv[j], rsc, rsh);
                         const float dact = p.r_act >= MNY_ACT_HSWISH ? act_bwd(z, p.r_act) : (z > 0.f ? 1.f : rslope) * (z < rhi ? 1.f : 0.f);
-                        const float dz = stored<T>(acc[u][gq * 4 + j]) * dact;
+                        const float dz = stored<T>(acc[u][gq * 4 + j] + av[j]) * dact;
                         if (ccol && 8 * gq + j < rows_left) { s1[u] += dz; s2[u] = fmaf(dz, (yv[j] - rmu) * ris, s2[u]); }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -1958,16 +1963,20 @@ extern "C" int mny_pw_dgrad_bnred_parts(int64_t M, int K, int Nc) {
 }
 template <int BF>
 static int pw_dgrad_bnred_impl(const void* dy, const void* wT, void* dx, const void* y, const float* scale, const float* shift, int act,
-                               const float* mean, const float* invstd, float* red, int64_t M, int K, int Nc, void* stream) {
+                               const float* mean, const float* invstd, float* red, int64_t M, int K, int Nc, void* stream, const void* addend = nullptr) {
     MNY_REQUIRE(dy && wT && dx && y && scale && shift && mean && invstd && red, "pw_dgrad_bnred: null pointer");
     MNY_REQUIRE(dgrad_bnred_ok(M, K, Nc, act) && (!BF || (K & 7) == 0), "pw_dgrad_bnred: unsupported problem M=%lld K=%d N=%d act=%d (see mny_pw_dgrad_bnred_supported)",
                 (long long)M, K, Nc, act);
     Nt2Plan p2 = nt2_plan(M, K, Nc, false, BF, kRedMaxTn);
     MNY_REQUIRE(p2.lds <= 64 * 1024, "pw_dgrad_bnred: K=%d too large", K);
-    Gemm2Args g{dy, nullptr, nullptr, MNY_ACT_NONE, wT, nullptr, nullptr, dx, red, M, K, Nc, p2.m_tiles, p2.tiles_per_block, p2.gx, p2.n_tiles,
+    Gemm2Args g{dy, nullptr, nullptr, MNY_ACT_NONE, wT, nullptr, addend, dx, red, M, K, Nc, p2.m_tiles, p2.tiles_per_block, p2.gx, p2.n_tiles,
                 y, scale, shift, mean, invstd, act};
     Nt2Kernel k;
-    switch (p2.TN) {
+    if (addend) switch (p2.TN) {                    // RED = 2: with an addend (own instantiations: the addend loads cost the TN = 4 variant registers)
+        case 1: k = (Nt2Kernel)pw_gemm_nt_dma_kernel<1, 0, BF, 2>; break; case 2: k = (Nt2Kernel)pw_gemm_nt_dma_kernel<2, 0, BF, 2>; break;
+        case 3: k = (Nt2Kernel)pw_gemm_nt_dma_kernel<3, 0, BF, 2>; break; default: k = (Nt2Kernel)pw_gemm_nt_dma_kernel<4, 0, BF, 2>; break;
+    }
+    else switch (p2.TN) {
         case 1: k = (Nt2Kernel)pw_gemm_nt_dma_kernel<1, 0, BF, 1>; break; case 2: k = (Nt2Kernel)pw_gemm_nt_dma_kernel<2, 0, BF, 1>; break;
         case 3: k = (Nt2Kernel)pw_gemm_nt_dma_kernel<3, 0, BF, 1>; break; default: k = (Nt2Kernel)pw_gemm_nt_dma_kernel<4, 0, BF, 1>; break;
     }
@@ -1977,6 +1986,23 @@ static int pw_dgrad_bnred_impl(const void* dy, const void* wT, void* dx, const v
 extern "C" int mny_pw_dgrad_bnred(const float* dy, const float* wT, float* dx, const float* y, const float* scale, const float* shift, int act,
                                   const float* mean, const float* invstd, float* red, int64_t M, int K, int Nc, void* stream) {
     return pw_dgrad_bnred_impl<0>(dy, wT, dx, y, scale, shift, act, mean, invstd, red, M, K, Nc, stream);
+}
+// the addend variant exists for column tiles of <= 96 (TN <= 3: the 128-column tile has no registers left for the addend loads)
+extern "C" int mny_pw_dgrad_bnred_add_supported(int64_t M, int K, int Nc, int act) {
+    return dgrad_bnred_ok(M, K, Nc, act) && nt2_plan(M, K, Nc, false, 0, kRedMaxTn).TN <= 3 ? 1 : 0;
+}
+extern "C" int mny_pw_dgrad_bnred_add_supported_bf16(int64_t M, int K, int Nc, int act) {
+    return dgrad_bnred_ok(M, K, Nc, act) && (K & 7) == 0 && nt2_plan(M, K, Nc, false, 1, kRedMaxTn).TN <= 3 ? 1 : 0;
+}
+extern "C" int mny_pw_dgrad_bnred_add(const float* dy, const float* wT, const float* addend, float* dx, const float* y, const float* scale, const float* shift,
+                                      int act, const float* mean, const float* invstd, float* red, int64_t M, int K, int Nc, void* stream) {
+    MNY_REQUIRE(addend && mny_pw_dgrad_bnred_add_supported(M, K, Nc, act), "pw_dgrad_bnred_add: null addend or unsupported shape (mny_pw_dgrad_bnred_add_supported)");
+    return pw_dgrad_bnred_impl<0>(dy, wT, dx, y, scale, shift, act, mean, invstd, red, M, K, Nc, stream, addend);
+}
+extern "C" int mny_pw_dgrad_bnred_add_bf16(const void* dy, const void* wT, const void* addend, void* dx, const void* y, const float* scale, const float* shift,
+                                           int act, const float* mean, const float* invstd, float* red, int64_t M, int K, int Nc, void* stream) {
+    MNY_REQUIRE(addend && mny_pw_dgrad_bnred_add_supported_bf16(M, K, Nc, act), "pw_dgrad_bnred_add: null addend or unsupported shape");
+    return pw_dgrad_bnred_impl<1>(dy, wT, dx, y, scale, shift, act, mean, invstd, red, M, K, Nc, stream, addend);
 }
 // bf16 storage: dy, wT, dx, y are bf16; the sums are taken over the ROUNDED dx (what a separate reduce pass would read back)
 extern "C" int mny_pw_dgrad_bnred_supported_bf16(int64_t M, int K, int Nc, int act) { return dgrad_bnred_ok(M, K, Nc, act) && (K & 7) == 0 ? 1 : 0; }

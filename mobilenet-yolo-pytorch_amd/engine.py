@@ -594,6 +594,11 @@ class NetPlan:
         for v in outs:
             n_consumers[v.id] += 1
         self.fused_red = {}      # value id -> (partial-sum buffer, rows) written by the data-gradient GEMM that produced the value's gradient
+        last_consumer = {}       # value id -> the consumer node whose backward runs LAST (order = reverse topological)
+        for nd_ in order:
+            for v_ in nd_.ins:
+                last_consumer[v_.id] = nd_
+        loss_ids = {v_.id for v_ in outs}
 
         def takes_own_sums(pn):
             """True for the thin expand units handled by mny_pw_bnbwd (their stage 1 forms the BN sums itself)."""
@@ -855,6 +860,20 @@ class NetPlan:
                     contribute_kernel(i, lambda out, addend, dY=dY, wT=wT, M=M, K=oc, Nc=i.C, pu=pu, rbuf=rbuf, act_=i.act: bwd.add(
                         self.K("mny_pw_dgrad_bnred"), dY, wT, out, pu.Y, pu.scale, pu.shift, act_, pu.mean, pu.invstd, rbuf, M, K, Nc, self.stream,
                         meta=dict(flops=2 * M * K * Nc, bytes=self.eb * (M * K + 2 * M * Nc) + 4 * K * Nc, shape="dgrad+red M%d K%d N%d" % (M, K, Nc))))
+                elif (os.environ.get("MNY_NO_REDFUSE") != "1" and os.environ.get("MNY_NO_REDADD") != "1"
+                        and (not self.bf16 or os.environ.get("MNY_REDFUSE_BF16") == "1")
+                        and prod is not None and prod.op in ("dw", "pw") and gs[i.id].buf is not None and last_consumer.get(i.id) is nd
+                        and i.id not in loss_ids and not takes_own_sums(prod)
+                        and _lib.query(K("mny_pw_dgrad_bnred_add_supported"), M, oc, i.C, i.act) == 1):
+                    # the LAST contribution to the output gradient of a conv+BN+act unit (a project conv feeding a residual add and the
+                    # next block): the earlier contributions arrive as the addend, the epilogue sees the complete gradient -> BN sums here
+                    pu = self.units[i.id]
+                    rparts = _lib.query(K("mny_pw_dgrad_bnred_parts"), M, oc, i.C)
+                    rbuf = torch.empty(rparts * 2 * i.C, **f32)
+                    self.fused_red[i.id] = (rbuf, rparts)
+                    contribute_kernel(i, lambda out, addend, dY=dY, wT=wT, M=M, K=oc, Nc=i.C, pu=pu, rbuf=rbuf, act_=i.act: bwd.add(
+                        self.K("mny_pw_dgrad_bnred_add"), dY, wT, addend, out, pu.Y, pu.scale, pu.shift, act_, pu.mean, pu.invstd, rbuf, M, K, Nc, self.stream,
+                        meta=dict(flops=2 * M * K * Nc, bytes=self.eb * (M * K + 3 * M * Nc) + 4 * K * Nc, shape="dgrad+add+red M%d K%d N%d" % (M, K, Nc))))
                 else:
                     contribute_kernel(i, lambda out, addend, dY=dY, wT=wT, M=M, K=oc, Nc=i.C: bwd.add(
                         self.K("mny_pw_fwd"), dY, None, None, ACT_NONE, wT, None, addend, out, None, M, K, Nc, self.stream,

@@ -175,15 +175,19 @@ def pw_bnbwd(g, y, scale, shift, act, mean, invstd, gamma, xview, w2d, addend=No
     return dx, dw, dgamma, dbeta
 
 
-def pw_dgrad_bnred(dy, wT, y_unit, scale, shift, act, mean, invstd):
-    """dx = dy @ W (wT = [Nc][K]) and the BN-backward partial sums of the unit whose output gradient dx is.
+def pw_dgrad_bnred(dy, wT, y_unit, scale, shift, act, mean, invstd, addend=None):
+    """dx = dy @ W (wT = [Nc][K]) [+ addend] and the BN-backward partial sums of the unit whose (complete) output gradient dx is.
     -> (dx [M,Nc], red [parts,2,Nc])"""
     M, K = dy.numel() // dy.shape[-1], dy.shape[-1]
     Nc = wT.shape[0]
     parts = query("mny_pw_dgrad_bnred_parts", M, K, Nc)
     dx = torch.empty(*dy.shape[:-1], Nc, device=dy.device, dtype=torch.float32)
     red = torch.empty(parts, 2, Nc, device=dy.device, dtype=torch.float32)
-    call("mny_pw_dgrad_bnred", _p(dy), _p(wT), _p(dx), _p(y_unit), _p(scale), _p(shift), int(act), _p(mean), _p(invstd), _p(red), M, K, Nc, _st())
+    if addend is None:
+        call("mny_pw_dgrad_bnred", _p(dy), _p(wT), _p(dx), _p(y_unit), _p(scale), _p(shift), int(act), _p(mean), _p(invstd), _p(red), M, K, Nc, _st())
+    else:
+        call("mny_pw_dgrad_bnred_add", _p(dy), _p(wT), _p(addend), _p(dx), _p(y_unit), _p(scale), _p(shift), int(act), _p(mean), _p(invstd), _p(red),
+             M, K, Nc, _st())
     return dx, red
 
 

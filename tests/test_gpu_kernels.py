@@ -439,6 +439,38 @@ def test_batched_weight_transposes(dtype):
         assert torch.equal(d, want.to(dtype))
 
 
+@pytest.mark.parametrize("M,K,Nc,act", [(2 * 22 * 22 + 5, 384, 64, 0), (1000, 576, 96, 0), (777, 960, 160, 0), (900, 96, 32, 2), (3 * 128 + 1, 144, 24, 1)])
+def test_dgrad_add_with_fused_bn_backward_reduction(ops, M, K, Nc, act):
+    """mny_pw_dgrad_bnred_add: dx = dy W + addend (the last contribution to a residual block's project output) and the BN sums
+    over that COMPLETE gradient == mny_pw_fwd(addend=...) followed by mny_bn_bwd_reduce."""
+    import ctypes
+    from mobilenet_yolo_pytorch_amd import _lib
+    assert _lib.query("mny_pw_dgrad_bnred_add_supported", M, K, Nc, act) == 1
+    dy = rnd(M, K, seed=1).cuda()
+    w = (rnd(K, Nc, seed=2) / K ** 0.5)
+    y = (rnd(M, Nc, seed=3) * 2).cuda()
+    add = rnd(M, Nc, seed=8).cuda()
+    scale, shift = (1 + 0.3 * rnd(Nc, seed=4)).cuda(), (0.5 * rnd(Nc, seed=5)).cuda()
+    mean, invstd = (0.2 * rnd(Nc, seed=6)).cuda(), (1 + 0.2 * rnd(Nc, seed=7).abs()).cuda()
+    wT = ops.transpose(w.cuda())
+    dx, red = ops.pw_dgrad_bnred(dy, wT, y, scale, shift, act, mean, invstd, addend=add)
+    check(dx, dy.cpu().double() @ w.double() + add.cpu().double(), 2e-4, 2e-4, "dx + addend")
+    p = lambda t: ctypes.c_void_p(t.data_ptr())                          # noqa: E731
+    parts = _lib.query("mny_bn_bwd_parts", M, Nc)
+    ref = torch.empty(parts, 2, Nc, device="cuda")
+    _lib.call("mny_bn_bwd_reduce", p(dx), p(y), p(scale), p(shift), act, p(mean), p(invstd), p(ref), M, Nc,
+              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    got, want = red.double().sum(0).cpu(), ref.double().sum(0).cpu()
+    for k in range(2):
+        tol = 2e-5 * want[k].abs().max().item() + 1e-4
+        assert (got[k] - want[k]).abs().max().item() <= tol, (k, (got[k] - want[k]).abs().max().item(), tol)
+    # in place: the addend buffer is also the output (how the engine accumulates into an existing gradient buffer)
+    buf = add.clone()
+    _lib.call("mny_pw_dgrad_bnred_add", p(dy), p(wT), p(buf), p(buf), p(y), p(scale), p(shift), act, p(mean), p(invstd), p(red), M, K, Nc,
+              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert torch.equal(buf, dx)
+
+
 def test_dgrad_with_fused_bn_backward_reduction_bf16(ops):
     """bf16 twin: sums are taken over the ROUNDED dx (what a separate reduce pass would read back), y is bf16."""
     import ctypes
