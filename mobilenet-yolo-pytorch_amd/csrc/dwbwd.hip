@@ -397,7 +397,8 @@ static int dwb2_geom(DwbGeom& g, CgLayout& L, int& gx, int N, int H, int W, int 
     MNY_REQUIRE(N > 0 && H > 0 && W > 0, "dw_bnbwd_s2: empty tensor");
     g.N = N; g.H = H; g.W = W; g.C = C;
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
-    const int ns = (int)cdiv(Ho, 16);
+    static const int th2 = getenv("MNY_DWB2_TH") ? atoi(getenv("MNY_DWB2_TH")) : 16;     // quad rows per strip (the 4 launches of a step: 8: 2.33, 16: 2.30, 32: 2.42, 64: 2.50 ms)
+    const int ns = (int)cdiv(Ho, th2);
     g.TH = (int)cdiv(Ho, ns);
     g.nHS = (int)cdiv(Ho, g.TH);
     g.nstrips = (int64_t)N * Wo * g.nHS;
