@@ -94,3 +94,65 @@ def test_fused_units_shapes(ops):
         what = "dw_bnbwd N%d H%d W%d C%d act%d/%d" % (N, H, W, C, act, xact)
         _close(dx.permute(0, 3, 1, 2), a_in.grad, 1e-3, what + " dX")    # train-mode BN on few samples amplifies rounding
         _close(dw, wr.grad, 1e-3, what + " dW")
+
+
+def test_round2_stencil_kernels_shapes(ops):
+    """Seeded shape fuzz of the round-2 stencil kernels: odd sizes, one-pixel rows / columns, channel counts that split into
+    several chunks.  (a) 3x3 / 5x5 depthwise forward + weight gradient + stride-1 data gradient against torch;
+    (b) the fused stride-2 unit backward against the three launches it replaces; (c) the producer BN sums of the fused stride-1
+    backward against mny_bn_bwd_reduce."""
+    import ctypes
+    from mobilenet_yolo_pytorch_amd import _lib
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
+    nh = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()               # noqa: E731
+    stream = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)   # noqa: E731
+    r = np.random.RandomState(7)
+    acts = dict(ACT)
+    acts[4] = lambda z: z * F.relu6(z + 3) / 6
+    for trial in range(24):
+        N, H, W = int(r.choice([1, 2, 3])), int(r.choice([1, 2, 5, 8, 17, 33, 40])), int(r.choice([1, 3, 4, 9, 22, 41]))
+        C = int(r.choice([4, 16, 40, 132, 260, 672]))
+        K, S = int(r.choice([3, 5])), int(r.choice([1, 2]))
+        act = int(r.choice([0, 1, 2, 3, 4]))
+        g = torch.Generator().manual_seed(300 + trial)
+        x = torch.randn(N, C, H, W, generator=g)
+        w = torch.randn(C, 1, K, K, generator=g) * 0.3
+        sc, sh = 1 + 0.2 * torch.randn(C, generator=g), 0.3 * torch.randn(C, generator=g)
+        a = acts[act](x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)).requires_grad_(True)
+        wr = w.clone().requires_grad_(True)
+        yref = F.conv2d(a, wr, None, S, K // 2, 1, C)
+        dy = torch.randn(*yref.shape, generator=g)
+        yref.backward(dy)
+        what = "N%d H%d W%d C%d K%d s%d act%d" % (N, H, W, C, K, S, act)
+        view = (nh(x), sc.cuda(), sh.cuda(), act)
+        got, st = ops.dw_fwd(view, w.cuda().contiguous(), S)
+        _close(got.permute(0, 3, 1, 2), yref, 2e-4, "dw_fwd " + what)
+        _close(st[:, 0].double().sum(0), yref.detach().double().sum((0, 2, 3)), 5e-4, "dw stats " + what)
+        dwg = ops.dw_bwd_weight(view, nh(dy), K, S)
+        _close(dwg, wr.grad, 5e-4, "dw_bwd_weight " + what)
+        dxg = ops.dw_bwd_data(nh(dy), w.cuda().contiguous(), (H, W), S)
+        _close(dxg.permute(0, 3, 1, 2), a.grad, 2e-4, "dw_bwd_data " + what)
+        if K != 3:
+            continue
+        # fused unit backward (stride 1 with producer sums / stride 2) against the unfused chain on the same inputs
+        Ho, Wo = yref.shape[2], yref.shape[3]
+        yraw, gg = nh(torch.randn(N, C, Ho, Wo, generator=g)), nh(torch.randn(N, C, Ho, Wo, generator=g))
+        mk = lambda a0, b0: (a0 + b0 * torch.randn(C, generator=g)).cuda()   # noqa: E731
+        scale, shift, coef = mk(1.0, 0.2), mk(0.0, 0.3), torch.stack((mk(1.0, 0.2), mk(0.0, 0.05), mk(0.0, 0.05))).contiguous()
+        uact = int(r.choice([0, 1, 2]))
+        dyb = torch.empty_like(gg)
+        _lib.call("mny_bn_bwd_apply", p(gg), p(yraw), p(scale), p(shift), uact, p(coef), p(dyb), N * Ho * Wo, C, stream())
+        dx_ref = ops.dw_bwd_data(dyb, w.cuda().contiguous(), (H, W), S)
+        dw_ref = ops.dw_bwd_weight(view, dyb, 3, S)
+        if S == 2:
+            dx, dwf = ops.dw_bnbwd_s2(gg, yraw, scale, shift, uact, coef, view, w.cuda().contiguous())
+        else:
+            xm, xi = mk(0.0, 0.2), mk(1.0, 0.1).abs()
+            dx, dwf, red = ops.dw_bnbwd(gg, yraw, scale, shift, uact, coef, view, w.cuda().contiguous(), in_stats=(xm, xi))
+            parts = _lib.query("mny_bn_bwd_parts", N * H * W, C)
+            ref = torch.empty(parts, 2, C, device="cuda")
+            _lib.call("mny_bn_bwd_reduce", p(dx), p(view[0]), p(view[1]), p(view[2]), act, p(xm), p(xi), p(ref), N * H * W, C, stream())
+            for k in range(2):
+                _close(red.double().sum(0)[k], ref.double().sum(0)[k], 1e-4, "producer sums %d " % k + what)
+        _close(dx, dx_ref, 3e-4, "fused dX " + what)
+        _close(dwf, dw_ref, 5e-4, "fused dW " + what)
