@@ -190,4 +190,11 @@ inline CgLayout make_stencil_layout(int C, int max_cgb = 64) {
 __global__ void reduce_parts_f64_kernel(const float* __restrict__ parts, int nparts, int n, float* __restrict__ out);
 int launch_reduce_parts(const float* parts, int nparts, int n, float* out, hipStream_t st);
 
+// short-reduction pointwise conv on the vector ALU (pwthin.hip); the entry points of pwgemm.hip route K = 8/16/24/32 problems here
+bool pw_thin_ok(int bf, int red, int64_t M, int K, int N);
+int pw_thin_parts(int64_t M, int K, int N, int red);
+int pw_thin_launch(int bf, const void* A, const float* in_scale, const float* in_shift, int in_act, const void* W, const float* bias,
+                   const void* addend, void* C, float* stats, int64_t M, int K, int N, int red, const void* rY, const float* r_scale,
+                   const float* r_shift, const float* r_mean, const float* r_invstd, int r_act, hipStream_t st);
+
 }  // namespace mny

@@ -1886,11 +1886,13 @@ using namespace mny;
 
 extern "C" int mny_pw_stat_parts(int64_t M, int K, int Nc) {
     if (M <= 0 || K <= 0 || Nc <= 0) return MNY_EINVAL;
+    if (pw_thin_ok(0, 0, M, K, Nc)) return pw_thin_parts(M, K, Nc, 0);
     if ((K & 3) == 0 && getenv("MNY_GEMM_V1") == nullptr) return nt2_plan(M, K, Nc, true).gx;
     return nt_plan(M, K, Nc).gx;
 }
 extern "C" int mny_pw_stat_parts_bf16(int64_t M, int K, int Nc) {
     if (M <= 0 || K <= 0 || Nc <= 0) return MNY_EINVAL;
+    if (pw_thin_ok(1, 0, M, K, Nc)) return pw_thin_parts(M, K, Nc, 0);
     if ((K & 7) == 0 && getenv("MNY_GEMM_V1") == nullptr) return nt2_plan(M, K, Nc, true, 1).gx;
     return nt_plan(M, K, Nc).gx;
 }
@@ -1933,6 +1935,8 @@ extern "C" int mny_pw_fwd(const float* x, const float* in_scale, const float* in
     hipStream_t st = (hipStream_t)stream;
     const bool xf = in_scale != nullptr || in_act != MNY_ACT_NONE;
     static const bool force_v1 = getenv("MNY_GEMM_V1") != nullptr;   // A/B switch for profiling
+    if (pw_thin_ok(0, 0, M, K, Nc))                        // short reduction: vector-ALU stream kernel (pwthin.hip)
+        return pw_thin_launch(0, x, in_scale, in_shift, in_act, w, bias, addend, y, stats, M, K, Nc, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, st);
     if ((K & 3) == 0 && !force_v1) {                // LDS-DMA pipeline (v2): 16-B aligned input rows
         Nt2Plan p2 = nt2_plan(M, K, Nc, xf);
         MNY_REQUIRE(p2.lds <= 64 * 1024, "pw_fwd: K=%d too large for the LDS scale cache", K);
@@ -1954,11 +1958,13 @@ constexpr int kRedMaxTn = 4;
 static bool dgrad_bnred_ok(int64_t M, int K, int Nc, int act) {
     static const bool red512 = getenv("MNY_RED512") != nullptr && atoi(getenv("MNY_RED512")) != 0;
     if (K >= 512 && Nc >= 512 && !red512) return false;      // matrix-pipe-bound: the reduce pass it would save is cheaper than the longer epilogue (MNY_RED512=1: A/B)
+    if ((pw_thin_ok(0, 1, M, K, Nc) || pw_thin_ok(1, 1, M, K, Nc)) && act == MNY_ACT_HSIGMOID) return false;      // the short-reduction kernel knows the clamp family and h-swish (what units use)
     return M > 0 && K > 0 && Nc > 0 && (K & 3) == 0 && act >= MNY_ACT_NONE && act <= MNY_ACT_HSIGMOID && getenv("MNY_GEMM_V1") == nullptr;
 }
 extern "C" int mny_pw_dgrad_bnred_supported(int64_t M, int K, int Nc, int act) { return dgrad_bnred_ok(M, K, Nc, act) ? 1 : 0; }
 extern "C" int mny_pw_dgrad_bnred_parts(int64_t M, int K, int Nc) {
     if (M <= 0 || K <= 0 || Nc <= 0 || (K & 3)) return MNY_EINVAL;
+    if (pw_thin_ok(0, 1, M, K, Nc)) return pw_thin_parts(M, K, Nc, 1);
     return nt2_plan(M, K, Nc, false, 0, kRedMaxTn).gx;
 }
 template <int BF>
@@ -1967,6 +1973,9 @@ static int pw_dgrad_bnred_impl(const void* dy, const void* wT, void* dx, const v
     MNY_REQUIRE(dy && wT && dx && y && scale && shift && mean && invstd && red, "pw_dgrad_bnred: null pointer");
     MNY_REQUIRE(dgrad_bnred_ok(M, K, Nc, act) && (!BF || (K & 7) == 0), "pw_dgrad_bnred: unsupported problem M=%lld K=%d N=%d act=%d (see mny_pw_dgrad_bnred_supported)",
                 (long long)M, K, Nc, act);
+    if (pw_thin_ok(BF, 1, M, K, Nc))
+        return pw_thin_launch(BF, dy, nullptr, nullptr, MNY_ACT_NONE, wT, nullptr, addend, dx, red, M, K, Nc, addend ? 2 : 1, y, scale, shift, mean, invstd, act,
+                              (hipStream_t)stream);
     Nt2Plan p2 = nt2_plan(M, K, Nc, false, BF, kRedMaxTn);
     MNY_REQUIRE(p2.lds <= 64 * 1024, "pw_dgrad_bnred: K=%d too large", K);
     Gemm2Args g{dy, nullptr, nullptr, MNY_ACT_NONE, wT, nullptr, addend, dx, red, M, K, Nc, p2.m_tiles, p2.tiles_per_block, p2.gx, p2.n_tiles,
@@ -1989,10 +1998,10 @@ extern "C" int mny_pw_dgrad_bnred(const float* dy, const float* wT, float* dx, c
 }
 // the addend variant exists for column tiles of <= 96 (TN <= 3: the 128-column tile has no registers left for the addend loads)
 extern "C" int mny_pw_dgrad_bnred_add_supported(int64_t M, int K, int Nc, int act) {
-    return dgrad_bnred_ok(M, K, Nc, act) && nt2_plan(M, K, Nc, false, 0, kRedMaxTn).TN <= 3 ? 1 : 0;
+    return dgrad_bnred_ok(M, K, Nc, act) && (pw_thin_ok(0, 1, M, K, Nc) || nt2_plan(M, K, Nc, false, 0, kRedMaxTn).TN <= 3) ? 1 : 0;
 }
 extern "C" int mny_pw_dgrad_bnred_add_supported_bf16(int64_t M, int K, int Nc, int act) {
-    return dgrad_bnred_ok(M, K, Nc, act) && (K & 7) == 0 && nt2_plan(M, K, Nc, false, 1, kRedMaxTn).TN <= 3 ? 1 : 0;
+    return dgrad_bnred_ok(M, K, Nc, act) && (K & 7) == 0 && (pw_thin_ok(1, 1, M, K, Nc) || nt2_plan(M, K, Nc, false, 1, kRedMaxTn).TN <= 3) ? 1 : 0;
 }
 extern "C" int mny_pw_dgrad_bnred_add(const float* dy, const float* wT, const float* addend, float* dx, const float* y, const float* scale, const float* shift,
                                       int act, const float* mean, const float* invstd, float* red, int64_t M, int K, int Nc, void* stream) {
@@ -2008,6 +2017,7 @@ extern "C" int mny_pw_dgrad_bnred_add_bf16(const void* dy, const void* wT, const
 extern "C" int mny_pw_dgrad_bnred_supported_bf16(int64_t M, int K, int Nc, int act) { return dgrad_bnred_ok(M, K, Nc, act) && (K & 7) == 0 ? 1 : 0; }
 extern "C" int mny_pw_dgrad_bnred_parts_bf16(int64_t M, int K, int Nc) {
     if (M <= 0 || K <= 0 || Nc <= 0 || (K & 7)) return MNY_EINVAL;
+    if (pw_thin_ok(1, 1, M, K, Nc)) return pw_thin_parts(M, K, Nc, 1);
     return nt2_plan(M, K, Nc, false, 1, kRedMaxTn).gx;
 }
 extern "C" int mny_pw_dgrad_bnred_bf16(const void* dy, const void* wT, void* dx, const void* y, const float* scale, const float* shift, int act,
@@ -2024,6 +2034,8 @@ extern "C" int mny_pw_fwd_bf16(const void* x, const float* in_scale, const float
     hipStream_t st = (hipStream_t)stream;
     const bool xf = in_scale != nullptr || in_act != MNY_ACT_NONE;
     static const bool force_v1 = getenv("MNY_GEMM_V1") != nullptr;
+    if (pw_thin_ok(1, 0, M, K, Nc))
+        return pw_thin_launch(1, x, in_scale, in_shift, in_act, w, bias, addend, y, stats, M, K, Nc, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, st);
     if ((K & 7) == 0 && !force_v1) {                // LDS-DMA pipeline on the bf16 matrix cores (16-B aligned bf16 rows)
         Nt2Plan p2 = nt2_plan(M, K, Nc, xf, 1);
         MNY_REQUIRE(p2.lds <= 64 * 1024, "pw_fwd: K=%d too large for the LDS scale cache", K);

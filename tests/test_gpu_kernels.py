@@ -498,3 +498,74 @@ def test_dgrad_with_fused_bn_backward_reduction_bf16(ops):
     s1, s2 = red[:, 0].double().sum(0).cpu(), red[:, 1].double().sum(0).cpu()
     assert (s1 - dz.sum(0)).abs().max().item() <= 2e-5 * dz.abs().sum(0).max().item() + 1e-5
     assert (s2 - (dz * xhat).sum(0)).abs().max().item() <= 2e-5 * (dz * xhat).abs().sum(0).max().item() + 1e-5
+
+
+@pytest.mark.parametrize("M,K,Nc,act,dtype", [
+    (200003, 24, 144, 1, torch.float32), (150001, 16, 96, 1, torch.float32), (99999, 32, 192, 1, torch.float32), (130007, 32, 16, 0, torch.float32),
+    (70001, 8, 20, 2, torch.float32), (50000, 16, 256, 4, torch.float32), (1, 24, 16, 3, torch.float32), (127, 32, 252, 1, torch.float32),
+    (200003, 24, 72, 4, torch.bfloat16), (120001, 16, 64, 1, torch.bfloat16), (99999, 32, 192, 1, torch.bfloat16), (3001, 8, 16, 2, torch.bfloat16)])
+def test_short_reduction_pointwise_kernel(ops, M, K, Nc, act, dtype):
+    """pwthin.hip (K = 8/16/24/32 routed there by mny_pw_fwd / mny_pw_dgrad_bnred[_add]): many row tiles per workgroup, ragged last
+    tile, idle threads (256 % (N/4) != 0), every view activation, bias, addend, statistics, BN-backward sums — against torch fp64."""
+    import ctypes
+    from mobilenet_yolo_pytorch_amd import _lib
+    bf = dtype == torch.bfloat16
+    sfx = "_bf16" if bf else ""
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None            # noqa: E731
+    rt, at = (2 ** -7, 2 ** -7) if bf else (2e-4, 2e-5)
+    x = rnd(M, K, seed=1).cuda().to(dtype)
+    w = (rnd(Nc, K, seed=2) * K ** -0.5).cuda().to(dtype)
+    sc, sh = (1 + 0.2 * rnd(K, seed=3)).cuda(), (0.3 * rnd(K, seed=4)).cuda()
+    xd, wd = x.double().cpu(), w.double().cpu()
+    a = ACTS[act](xd * sc.double().cpu() + sh.double().cpu())
+    want = a @ wd.t()
+    # forward with the producing unit's view and column statistics
+    parts = _lib.query("mny_pw_stat_parts" + sfx, M, K, Nc)
+    assert 0 < parts <= _lib.query("mny_max_parts")
+    y = torch.empty(M, Nc, device="cuda", dtype=dtype)
+    st = torch.full((parts, 2, Nc), float("nan"), device="cuda")
+    _lib.call("mny_pw_fwd" + sfx, p(x), p(sc), p(sh), act, p(w), None, None, p(y), p(st), M, K, Nc, stream)
+    check(y.float(), want, rt, at * want.abs().max().item() if bf else at, "thin fwd")
+    yd = y.double().cpu()
+    s1, s2 = stats_got(st)
+    check(s1, yd.sum(0), 1e-4, 2e-3 * max(1.0, M / 1e4), "thin stats sum")          # over the STORED values
+    check(s2, (yd ** 2).sum(0), 1e-4, 2e-3 * max(1.0, M / 1e4), "thin stats sumsq")
+    # plain input + bias + addend (the detection-head form), in place on the addend
+    b = rnd(Nc, seed=7).cuda()
+    add = rnd(M, Nc, seed=8).cuda().to(dtype)
+    buf = add.clone()
+    _lib.call("mny_pw_fwd" + sfx, p(x), None, None, 0, p(w), p(b), p(buf), p(buf), None, M, K, Nc, stream)
+    want2 = xd @ wd.t() + b.double().cpu() + add.double().cpu()
+    check(buf.float(), want2, rt, at * want2.abs().max().item() if bf else at, "thin fwd + bias + addend")
+    # activation without scale/shift
+    if act:
+        _lib.call("mny_pw_fwd" + sfx, p(x), None, None, act, p(w), None, None, p(y), None, M, K, Nc, stream)
+        want3 = ACTS[act](xd) @ wd.t()
+        check(y.float(), want3, rt, at * want3.abs().max().item() if bf else at, "thin fwd, activation-only view")
+    # data gradient + BN-backward sums of the fed unit (x plays dy, y_raw the unit's raw output), without and with an addend
+    if K % 8 == 0 or not bf:
+        yraw = (rnd(M, Nc, seed=3) * 2).cuda().to(dtype)
+        rsc, rsh = (1 + 0.3 * rnd(Nc, seed=4)).cuda(), (0.5 * rnd(Nc, seed=5)).cuda()
+        mean, invstd = (0.2 * rnd(Nc, seed=6)).cuda(), (1 + 0.2 * rnd(Nc, seed=7).abs()).cuda()
+        rparts = _lib.query("mny_pw_dgrad_bnred_parts" + sfx, M, K, Nc)
+        z = yraw.double().cpu() * rsc.double().cpu() + rsh.double().cpu()
+        d = {0: torch.ones_like(z), 1: ((z > 0) & (z < 6)).double(), 2: torch.where(z > 0, 1.0, 0.1).double(), 3: (z > 0).double(),
+             4: torch.where(z <= -3, 0.0, torch.where(z >= 3, 1.0, (2 * z + 3) / 6)).double()}[act]
+        xhat = (yraw.double().cpu() - mean.double().cpu()) * invstd.double().cpu()
+        for with_add in (False, True):
+            dx = torch.empty(M, Nc, device="cuda", dtype=dtype)
+            red = torch.full((rparts, 2, Nc), float("nan"), device="cuda")
+            if with_add:
+                assert _lib.query("mny_pw_dgrad_bnred_add_supported" + sfx, M, K, Nc, act) == 1
+                _lib.call("mny_pw_dgrad_bnred_add" + sfx, p(x), p(w), p(add), p(dx), p(yraw), p(rsc), p(rsh), act, p(mean), p(invstd), p(red), M, K, Nc, stream)
+            else:
+                _lib.call("mny_pw_dgrad_bnred" + sfx, p(x), p(w), p(dx), p(yraw), p(rsc), p(rsh), act, p(mean), p(invstd), p(red), M, K, Nc, stream)
+            wantd = xd @ wd.t() + (add.double().cpu() if with_add else 0)
+            check(dx.float(), wantd, rt, at * wantd.abs().max().item() if bf else at, "thin dgrad (add=%s)" % with_add)
+            dz = dx.double().cpu() * d
+            # elements whose pre-activation sits within fp32 rounding of a kink may take the other branch in the kernel's fp32 z
+            kink = ((z.abs() < 1e-5) | ((z - 6).abs() < 1e-5) | ((z.abs() - 3).abs() < 1e-5)).double() * dx.double().cpu().abs()
+            r1, r2 = red[:, 0].double().sum(0).cpu(), red[:, 1].double().sum(0).cpu()
+            assert ((r1 - dz.sum(0)).abs() <= 2e-5 * dz.abs().sum(0).max().item() + 1e-5 + kink.sum(0)).all()
+            assert ((r2 - (dz * xhat).sum(0)).abs() <= 2e-5 * (dz * xhat).abs().sum(0).max().item() + 1e-5 + (kink * xhat.abs()).sum(0)).all()
