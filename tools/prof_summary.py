@@ -21,6 +21,21 @@ def family(name):
     return n[:64]
 
 
+def thin_red(k):
+    """RED template argument (4th) of a pw_thin_kernel<T, K, XF, RED, R, STATS, ADD> family name, or None."""
+    m = re.match(r"pw_thin_kernel<[^,]+, \d+, \d+, (\d+),", k)
+    return int(m.group(1)) if m else None
+
+
+def is_pw_fwd(k):
+    """kernels behind the mny_pw_fwd entry point: the tile GEMMs without a BN-backward epilogue + the short-reduction stream kernel (RED = 0)"""
+    return (k.startswith("pw_gemm_nt") and not re.search(r", [12]>$", k)) or thin_red(k) == 0
+
+
+def is_pw_dgrad_bnred(k):
+    return (k.startswith("pw_gemm_nt") and bool(re.search(r", 1>$", k))) or thin_red(k) == 1
+
+
 def pmc(dirname, counter):
     tot, cnt = defaultdict(float), defaultdict(int)
     with open(dirname + "/run_counter_collection.csv") as f:
@@ -69,10 +84,10 @@ def main():
             tms, tf, 2 * tf, tw, (2 * tf + tw) / tms))
         # entry-point aggregate bench.py's roofline object must agree with: mny_pw_fwd = every NT GEMM kernel (forward + data gradient)
         # (the RED = 1 instantiations belong to mny_pw_dgrad_bnred: data gradient + BN-backward reduction, a separate entry point)
-        g = [(ms, n, f_gb, w_gb) for ms, k, n, f_gb, w_gb in rows if k.startswith("pw_gemm_nt") and not re.search(r", [12]>$", k)]
+        g = [(ms, n, f_gb, w_gb) for ms, k, n, f_gb, w_gb in rows if is_pw_fwd(k)]
         g_ms, g_n = sum(r[0] for r in g), sum(r[1] for r in g)
         g_f, g_w = sum(r[2] for r in g), sum(r[3] for r in g)
-        o.write("\n`mny_pw_fwd` entry point (all `pw_gemm_nt*` kernels except the `RED = 1 / 2` instantiations of `mny_pw_dgrad_bnred[_add]`): %.0f launches/step, %.3f ms/step, avg %.1f us; HBM %.2f GB/step "
+        o.write("\n`mny_pw_fwd` entry point (all `pw_gemm_nt*` and `pw_thin_kernel*` kernels except the `RED = 1 / 2` instantiations of `mny_pw_dgrad_bnred[_add]`): %.0f launches/step, %.3f ms/step, avg %.1f us; HBM %.2f GB/step "
                 "(fetch x2 %.2f + write %.2f) = %.0f MB per launch.\n" % (g_n, g_ms, g_ms * 1e3 / max(g_n, 1), 2 * g_f + g_w, 2 * g_f, g_w,
                                                                           (2 * g_f + g_w) * 1e3 / max(g_n, 1)))
     import json
@@ -85,8 +100,8 @@ def main():
     except (OSError, IndexError, ValueError):
         print("warning: no bench JSON line next to the stats directory: traffic files carry no plan signature")
     groups = {
-        "mny_pw_fwd": lambda k: k.startswith("pw_gemm_nt") and not re.search(r", [12]>$", k),
-        "mny_pw_dgrad_bnred": lambda k: k.startswith("pw_gemm_nt") and bool(re.search(r", 1>$", k)),       # (", 2>" = mny_pw_dgrad_bnred_add, not priced)
+        "mny_pw_fwd": is_pw_fwd,
+        "mny_pw_dgrad_bnred": is_pw_dgrad_bnred,                                                          # (RED = 2 = mny_pw_dgrad_bnred_add, not priced)
         "mny_pw_wgrad": lambda k: k.startswith("pw_wgrad"),
         "mny_dw_fwd": lambda k: k.startswith("dw3_fwd_kernel") or bool(re.match(r"dw_slide_kernel<f32, \d, \d, 0,", k)),
     }
