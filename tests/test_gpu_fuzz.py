@@ -156,3 +156,69 @@ def test_round2_stencil_kernels_shapes(ops):
                 _close(red.double().sum(0)[k], ref.double().sum(0)[k], 1e-4, "producer sums %d " % k + what)
         _close(dx, dx_ref, 3e-4, "fused dX " + what)
         _close(dwf, dw_ref, 5e-4, "fused dW " + what)
+
+
+def test_short_reduction_kernel_shapes():
+    """pwthin.hip through the entry points that route to it: random (M, K in {8,16,24,32}, N % 4 == 0 up to 256) around the tile
+    boundaries (R*rpb rows per tile, grid = resident workgroups), with the view / bias / addend / statistics / BN-backward forms drawn
+    at random; fp32 exact-path check 2e-4, bf16 one rounding of the output."""
+    import ctypes
+    from mobilenet_yolo_pytorch_amd import _lib
+    r = np.random.RandomState(7)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None            # noqa: E731
+    for trial in range(48):
+        K = int(r.choice([8, 16, 24, 32]))
+        N = 4 * int(r.randint(4, 65))
+        nq = N // 4
+        rpb = 256 // nq
+        tile = (8 if 128 // rpb >= 8 else 2) * rpb
+        M = int(r.choice([1, tile - 1, tile, tile + 1, 3 * tile + rpb - 1, 512 * tile, 512 * tile + 5, 769 * tile + 1, int(r.randint(1, 300000))]))
+        bf = bool(r.randint(0, 2)) and K in (8, 16, 24)
+        dtype, sfx = (torch.bfloat16, "_bf16") if bf else (torch.float32, "")
+        rel = 2 ** -7 if bf else 2e-4
+        act = int(r.randint(0, 4))
+        g = torch.Generator().manual_seed(100 + trial)
+        x = torch.randn(M, K, generator=g).cuda().to(dtype)
+        w = (torch.randn(N, K, generator=g) * K ** -0.5).cuda().to(dtype)
+        sc, sh = (1 + 0.2 * torch.randn(K, generator=g)).cuda(), (0.3 * torch.randn(K, generator=g)).cuda()
+        xd, wd = x.double().cpu(), w.double().cpu()
+        form = int(r.randint(0, 4))
+        y = torch.empty(M, N, device="cuda", dtype=dtype)
+        if form == 0:                                    # view + statistics
+            a = ACT[act](xd * sc.double().cpu() + sh.double().cpu())
+            if bf:
+                a = a.to(torch.bfloat16).double()        # the bf16 operand (DESIGN 4b)
+            parts = _lib.query("mny_pw_stat_parts" + sfx, M, K, N)
+            st = torch.full((parts, 2, N), float("nan"), device="cuda")
+            _lib.call("mny_pw_fwd" + sfx, p(x), p(sc), p(sh), act, p(w), None, None, p(y), p(st), M, K, N, stream)
+            _close(y, a @ wd.t(), rel, "trial %d view+stats M=%d K=%d N=%d" % (trial, M, K, N))
+            yd = y.double().cpu()
+            _close(st[:, 0].double().sum(0), yd.sum(0), 1e-5 * max(1.0, yd.abs().sum(0).max().item() / (yd.sum(0).abs().max().item() + 1e-9)), "stats sum")
+            _close(st[:, 1].double().sum(0), (yd ** 2).sum(0), 1e-5, "stats sumsq")
+        elif form == 1:                                  # bias + addend in place
+            b = torch.randn(N, generator=g).cuda()
+            add = torch.randn(M, N, generator=g).cuda().to(dtype)
+            buf = add.clone()
+            _lib.call("mny_pw_fwd" + sfx, p(x), None, None, 0, p(w), p(b), p(buf), p(buf), None, M, K, N, stream)
+            _close(buf, xd @ wd.t() + b.double().cpu() + add.double().cpu(), rel, "trial %d bias+addend M=%d K=%d N=%d" % (trial, M, K, N))
+        else:                                            # data gradient + BN-backward sums, with / without an addend
+            yraw = (torch.randn(M, N, generator=g) * 2).cuda().to(dtype)
+            c = [(1 + 0.3 * torch.randn(N, generator=g)).cuda(), (0.5 * torch.randn(N, generator=g)).cuda(),
+                 (0.2 * torch.randn(N, generator=g)).cuda(), (1 + 0.2 * torch.randn(N, generator=g).abs()).cuda()]
+            add = torch.randn(M, N, generator=g).cuda().to(dtype) if form == 3 else None
+            parts = _lib.query("mny_pw_dgrad_bnred_parts" + sfx, M, K, N)
+            red = torch.full((parts, 2, N), float("nan"), device="cuda")
+            if add is not None:
+                _lib.call("mny_pw_dgrad_bnred_add" + sfx, p(x), p(w), p(add), p(y), p(yraw), p(c[0]), p(c[1]), act, p(c[2]), p(c[3]), p(red), M, K, N, stream)
+            else:
+                _lib.call("mny_pw_dgrad_bnred" + sfx, p(x), p(w), p(y), p(yraw), p(c[0]), p(c[1]), act, p(c[2]), p(c[3]), p(red), M, K, N, stream)
+            _close(y, xd @ wd.t() + (add.double().cpu() if add is not None else 0), rel, "trial %d dgrad form %d M=%d K=%d N=%d" % (trial, form, M, K, N))
+            z = yraw.double().cpu() * c[0].double().cpu() + c[1].double().cpu()
+            d = {0: torch.ones_like(z), 1: ((z > 0) & (z < 6)).double(), 2: torch.where(z > 0, 1.0, 0.1).double(), 3: (z > 0).double()}[act]
+            dz = y.double().cpu() * d
+            xhat = (yraw.double().cpu() - c[2].double().cpu()) * c[3].double().cpu()
+            kink = ((z.abs() < 1e-5) | ((z - 6).abs() < 1e-5)).double() * y.double().cpu().abs()
+            r1, r2 = red[:, 0].double().sum(0).cpu(), red[:, 1].double().sum(0).cpu()
+            assert ((r1 - dz.sum(0)).abs() <= 2e-5 * dz.abs().sum(0).max().item() + 1e-5 + kink.sum(0)).all(), (trial, M, K, N)
+            assert ((r2 - (dz * xhat).sum(0)).abs() <= 2e-5 * (dz * xhat).abs().sum(0).max().item() + 1e-5 + (kink * xhat.abs()).sum(0)).all(), (trial, M, K, N)
