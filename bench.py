@@ -574,6 +574,10 @@ def main():
         roof["traffic"], src = committed_traffic(plan, dom, headline)
         if src:
             roof["traffic_source"] = src
+        if dom in ("mny_pw_fwd", "mny_pw_fwd_bf16") and os.environ.get("MNY_NO_THIN") is None:
+            # the entry point routes its short-reduction launches (K = 16 / 24 / 32 channels, HBM-bound) to a vector-ALU stream kernel:
+            # their FLOPs and time are inside this object, priced against the matrix-core peak like the rest
+            roof["kernels"] = "pw_gemm_nt_dma_kernel (MFMA tiles) + pw_thin_kernel (vector ALU, the K <= 32 launches; csrc/pwthin.hip)"
         if bf16:                                       # bf16 storage: the GEMMs are HBM-bound — say so on the line
             roof["note"] = "priced against the dense bf16 MFMA peak; this configuration is HBM-bound: see algorithmic_hbm_gbs / %d GB/s" % int(PEAK_HBM_GBS)
         others = []
