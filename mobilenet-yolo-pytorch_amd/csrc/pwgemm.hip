@@ -263,7 +263,32 @@ struct Gemm2Args {   // A / B / addend / C: float* (BF = 0) or bf16_t* (BF = 1)
 //     main loop is 2 MFMAs per accumulator per stage instead of 16.
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 
-template <int TN, int XF, int BF, int RED = 0>
+// X6 (fp32 operands only): the products run on the bf16 matrix cores.  Every fp32 operand is cut into three bf16 pieces by
+// truncation (top 8 significant bits, next 8, last 8: hi + mid + lo == the fp32 value EXACTLY), a bf16 x bf16 product is exact in
+// fp32, and six of the nine partial products are accumulated (lo*mid, mid*lo, lo*lo <= 2^-24 of the product are dropped): the
+// result differs from an fp32 FMA chain by about one fp32 rounding per product.  One v_mfma_f32_32x32x16_bf16 (32 cycles) covers a
+// whole 16-deep stage that takes eight v_mfma_f32_32x32x2_f32 (8 x 64 cycles): 6 x 32 = 192 matrix-pipe cycles instead of 512
+// per accumulator and stage; the cuts cost ~36 VALU instructions per 8-value fragment.
+__device__ __forceinline__ void x6_split(v4f_t x0, v4f_t x1, bf16x8_t& h, bf16x8_t& m, bf16x8_t& l) {
+    const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    float r1[8], r2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        r1[e] = x[e] - __uint_as_float(__float_as_uint(x[e]) & 0xffff0000u);        // exact: the low 16 mantissa bits
+        r2[e] = r1[e] - __uint_as_float(__float_as_uint(r1[e]) & 0xffff0000u);
+    }
+    v4u_t hu, mu, lu;
+    // v_perm_b32: (odd element's high half << 16) | even element's high half == two truncated bf16 values
+    hu.x = __builtin_amdgcn_perm(__float_as_uint(x[1]), __float_as_uint(x[0]), 0x07060302u); hu.y = __builtin_amdgcn_perm(__float_as_uint(x[3]), __float_as_uint(x[2]), 0x07060302u);
+    hu.z = __builtin_amdgcn_perm(__float_as_uint(x[5]), __float_as_uint(x[4]), 0x07060302u); hu.w = __builtin_amdgcn_perm(__float_as_uint(x[7]), __float_as_uint(x[6]), 0x07060302u);
+    mu.x = __builtin_amdgcn_perm(__float_as_uint(r1[1]), __float_as_uint(r1[0]), 0x07060302u); mu.y = __builtin_amdgcn_perm(__float_as_uint(r1[3]), __float_as_uint(r1[2]), 0x07060302u);
+    mu.z = __builtin_amdgcn_perm(__float_as_uint(r1[5]), __float_as_uint(r1[4]), 0x07060302u); mu.w = __builtin_amdgcn_perm(__float_as_uint(r1[7]), __float_as_uint(r1[6]), 0x07060302u);
+    lu.x = __builtin_amdgcn_perm(__float_as_uint(r2[1]), __float_as_uint(r2[0]), 0x07060302u); lu.y = __builtin_amdgcn_perm(__float_as_uint(r2[3]), __float_as_uint(r2[2]), 0x07060302u);
+    lu.z = __builtin_amdgcn_perm(__float_as_uint(r2[5]), __float_as_uint(r2[4]), 0x07060302u); lu.w = __builtin_amdgcn_perm(__float_as_uint(r2[7]), __float_as_uint(r2[6]), 0x07060302u);
+    h = __builtin_bit_cast(bf16x8_t, hu); m = __builtin_bit_cast(bf16x8_t, mu); l = __builtin_bit_cast(bf16x8_t, lu);
+}
+
+template <int TN, int XF, int BF, int RED = 0, int X6 = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void pw_gemm_nt_dma_kernel(Gemm2Args p) {
     using T = typename std::conditional<BF != 0, bf16_t, float>::type;
     constexpr int EPC = BF ? 8 : 4;                                           // elements per 16-B chunk
@@ -394,6 +419,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
 #pragma unroll
                 for (int u = 0; u < TN; ++u)
                     acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, __builtin_bit_cast(bf16x8_t, bu[u]), acc[u], 0, 0, 0);
+            }
+            return;
+        }
+        if constexpr (X6 != 0) {
+            // the lane's eight k-values of this stage: chunks khalf and 2 + khalf (the same two the fp32 path reads one after the other)
+            const int c0 = khalf, c1 = 2 + khalf;
+            v4f_t a0 = lds_read_f4(a_row + ((c0 ^ swz) << 2)), a1 = lds_read_f4(a_row + ((c1 ^ swz) << 2));
+            v4f_t b0 = lds_read_f4(stB + lrow * BKD + ((c0 ^ swz) << 2)), b1 = lds_read_f4(stB + lrow * BKD + ((c1 ^ swz) << 2));
+            v4f_t sc0, sc1, sh0, sh1;
+            if (XF != 0) {
+                sc0 = lds_read_f4(sScale + kt * BKD + c0 * 4); sc1 = lds_read_f4(sScale + kt * BKD + c1 * 4);
+                sh0 = lds_read_f4(sShift + kt * BKD + c0 * 4); sh1 = lds_read_f4(sShift + kt * BKD + c1 * 4);
+            }
+            MNY_LGKM_WAIT(a0);
+            MNY_LGKM_DEP(a1); MNY_LGKM_DEP(b0); MNY_LGKM_DEP(b1);
+            if (XF != 0) {
+                MNY_LGKM_DEP(sc0); MNY_LGKM_DEP(sc1); MNY_LGKM_DEP(sh0); MNY_LGKM_DEP(sh1);
+                float z[8] = {fmaf(a0.x, sc0.x, sh0.x), fmaf(a0.y, sc0.y, sh0.y), fmaf(a0.z, sc0.z, sh0.z), fmaf(a0.w, sc0.w, sh0.w),
+                              fmaf(a1.x, sc1.x, sh1.x), fmaf(a1.y, sc1.y, sh1.y), fmaf(a1.z, sc1.z, sh1.z), fmaf(a1.w, sc1.w, sh1.w)};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) z[e] = XF == 1 ? fminf(fmaxf(z[e], slope * z[e]), hi) : z[e] * fminf(fmaxf(z[e] + 3.f, 0.f), 6.f) / 6.f;
+                a0 = v4f_t{z[0], z[1], z[2], z[3]}; a1 = v4f_t{z[4], z[5], z[6], z[7]};
+            }
+            bf16x8_t ah, am, al;
+            x6_split(a0, a1, ah, am, al);
+#pragma unroll
+            for (int u = 0; u < TN; ++u) {
+                v4f_t n0, n1;
+                if (u + 1 < TN) {                                 // next column block's fragment is requested before this one's MFMAs
+                    n0 = lds_read_f4(stB + ((u + 1) * 32 + lrow) * BKD + ((c0 ^ swz) << 2));
+                    n1 = lds_read_f4(stB + ((u + 1) * 32 + lrow) * BKD + ((c1 ^ swz) << 2));
+                }
+                bf16x8_t bh, bm, bl;
+                x6_split(b0, b1, bh, bm, bl);
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[u], 0, 0, 0);      // small terms first
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[u], 0, 0, 0);
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[u], 0, 0, 0);
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[u], 0, 0, 0);
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[u], 0, 0, 0);
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[u], 0, 0, 0);
+                if (u + 1 < TN) { MNY_LGKM_WAIT(n0); MNY_LGKM_DEP(n1); b0 = n0; b1 = n1; }
             }
             return;
         }
@@ -605,11 +671,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
 }
 
 typedef void (*Nt2Kernel)(Gemm2Args);
-static Nt2Kernel nt2_kernel(int TN, int XF, int BF = 0) {
+static Nt2Kernel nt2_kernel(int TN, int XF, int BF = 0, int X6 = 0) {
+    if (X6 && !BF) {
+#define MNY_K6(T) (XF == 0 ? (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 0, 0, 0, 1> : XF == 1 ? (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 1, 0, 0, 1> : (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 2, 0, 0, 1>)
+        switch (TN) { case 1: return MNY_K6(1); case 2: return MNY_K6(2); case 3: return MNY_K6(3); case 4: return MNY_K6(4); default: return MNY_K6(5); }
+#undef MNY_K6
+    }
 #define MNY_K(T) (BF ? (XF == 0 ? (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 0, 1> : XF == 1 ? (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 1, 1> : (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 2, 1>) \
                      : (XF == 0 ? (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 0, 0> : XF == 1 ? (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 1, 0> : (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 2, 0>))
     switch (TN) { case 1: return MNY_K(1); case 2: return MNY_K(2); case 3: return MNY_K(3); case 4: return MNY_K(4); default: return MNY_K(5); }
 #undef MNY_K
+}
+
+// fp32 GEMMs whose matrix-core time exceeds their HBM time take the six-product bf16 form (MNY_X6=0: never, =1: always, for A/B runs)
+static int nt_x6(int64_t M, int K, int N) {
+    static const int env = getenv("MNY_X6") ? atoi(getenv("MNY_X6")) : -1;
+    if (env >= 0) return env != 0;
+    const double ai = 2.0 * K * N / (4.0 * (K + N));            // FLOP per byte of the A and C rows
+    return ai >= 20.0;                                          // 157 TFLOP/s / 8 TB/s
 }
 
 struct Nt2Plan { int TN, n_tiles, m_tiles, gx, tiles_per_block, grid; size_t lds; };
@@ -899,7 +978,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgradArgs p) {
 // X rows are clamped to a valid row; BN-apply + activation is applied to X when its fragment is read.
 // Requires N % 4 == 0 and K % 4 == 0 (16-B aligned rows) and a non-hswish view.
 // ------------------------------------------------------------------------------------------------
-template <int MODE, int TI, int TJ>
+template <int MODE, int TI, int TJ, int X6 = 0>
 __global__ __launch_bounds__(256) void pw_wgrad_dma_kernel(WgradArgs p) {
     constexpr int KC = 16, S = 3;
     constexpr int BI = (MODE == 0 ? 64 : 32) * TI;
@@ -974,6 +1053,38 @@ __global__ __launch_bounds__(256) void pw_wgrad_dma_kernel(WgradArgs p) {
     auto compute = [&](int slot) {
         const float* a_base = smem + slot * STAGE + (krow0 + kk) * BI + ioff + li;
         const float* b_base = smem + slot * STAGE + A_ST + (krow0 + kk) * BJ + joff + li;
+        if constexpr (X6 != 0 && MODE == 0) {
+            // six-product bf16 form (see x6_split): the lane's eight rows of the chunk are rows 2*kp + kk, the ones the fp32 path
+            // feeds one MFMA step at a time; a whole 16-row chunk is one v_mfma_f32_32x32x16_bf16 per partial product
+            bf16x8_t ah[TI], am[TI], al[TI];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                const v4f_t x0 = {a_base[0 * BI + i * 32], a_base[2 * BI + i * 32], a_base[4 * BI + i * 32], a_base[6 * BI + i * 32]};
+                const v4f_t x1 = {a_base[8 * BI + i * 32], a_base[10 * BI + i * 32], a_base[12 * BI + i * 32], a_base[14 * BI + i * 32]};
+                x6_split(x0, x1, ah[i], am[i], al[i]);
+            }
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                float z[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float t = fmaf(b_base[2 * e * BJ + j * 32], sc[j], sh[j]);
+                    z[e] = fminf(fmaxf(t, slope * t), hi);
+                }
+                bf16x8_t bh, bm, bl;
+                x6_split(v4f_t{z[0], z[1], z[2], z[3]}, v4f_t{z[4], z[5], z[6], z[7]}, bh, bm, bl);
+#pragma unroll
+                for (int i = 0; i < TI; ++i) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh, acc[i][j], 0, 0, 0);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int kp = 0; kp < KROWS / 2; ++kp) {
             float af[TI], bf[TJ];
@@ -1256,7 +1367,11 @@ static WgKernel wg_bf16_kernel(int mode, int TI, int TJ, int XF) {
     }
 }
 
-static WgKernel wg_dma_kernel(int mode, int TI, int TJ) {
+static WgKernel wg_dma_kernel(int mode, int TI, int TJ, int x6 = 0) {
+    if (x6 && mode == 0) switch (TI * 10 + TJ) {
+        case 11: return (WgKernel)pw_wgrad_dma_kernel<0, 1, 1, 1>; case 12: return (WgKernel)pw_wgrad_dma_kernel<0, 1, 2, 1>;
+        case 21: return (WgKernel)pw_wgrad_dma_kernel<0, 2, 1, 1>; case 22: return (WgKernel)pw_wgrad_dma_kernel<0, 2, 2, 1>;
+    }
     switch (mode * 100 + TI * 10 + TJ) {
 #define MNY_W(MD, I, J) case MD * 100 + I * 10 + J: return (WgKernel)pw_wgrad_dma_kernel<MD, I, J>;
         MNY_W(0, 1, 1) MNY_W(0, 1, 2) MNY_W(0, 2, 1) MNY_W(0, 2, 2)
@@ -1944,7 +2059,7 @@ extern "C" int mny_pw_fwd(const float* x, const float* in_scale, const float* in
                     nullptr, nullptr, nullptr, nullptr, nullptr, 0};
         dim3 grid2(p2.grid), block2(256);
         const int XF = !xf ? 0 : (in_act == MNY_ACT_HSWISH ? 2 : 1);
-        hipLaunchKernelGGL(nt2_kernel(p2.TN, XF), grid2, block2, p2.lds, st, g);
+        hipLaunchKernelGGL(nt2_kernel(p2.TN, XF, 0, nt_x6(M, K, Nc)), grid2, block2, p2.lds, st, g);
         return check_launch("pw_gemm_nt_dma_kernel");
     }
     return pw_fwd_v1<float>(x, in_scale, in_shift, in_act, w, bias, addend, y, stats, M, K, Nc, st);
@@ -1981,13 +2096,19 @@ static int pw_dgrad_bnred_impl(const void* dy, const void* wT, void* dx, const v
     Gemm2Args g{dy, nullptr, nullptr, MNY_ACT_NONE, wT, nullptr, addend, dx, red, M, K, Nc, p2.m_tiles, p2.tiles_per_block, p2.gx, p2.n_tiles,
                 y, scale, shift, mean, invstd, act};
     Nt2Kernel k;
+    constexpr int X = BF ? 0 : 1;                   // the six-product bf16 form exists for fp32 operands only
+    const bool x6 = !BF && nt_x6(M, K, Nc);
     if (addend) switch (p2.TN) {                    // RED = 2: with an addend (own instantiations: the addend loads cost the TN = 4 variant registers)
-        case 1: k = (Nt2Kernel)pw_gemm_nt_dma_kernel<1, 0, BF, 2>; break; case 2: k = (Nt2Kernel)pw_gemm_nt_dma_kernel<2, 0, BF, 2>; break;
-        case 3: k = (Nt2Kernel)pw_gemm_nt_dma_kernel<3, 0, BF, 2>; break; default: k = (Nt2Kernel)pw_gemm_nt_dma_kernel<4, 0, BF, 2>; break;
+        case 1: k = x6 ? (Nt2Kernel)pw_gemm_nt_dma_kernel<1, 0, BF, 2, X> : (Nt2Kernel)pw_gemm_nt_dma_kernel<1, 0, BF, 2>; break;
+        case 2: k = x6 ? (Nt2Kernel)pw_gemm_nt_dma_kernel<2, 0, BF, 2, X> : (Nt2Kernel)pw_gemm_nt_dma_kernel<2, 0, BF, 2>; break;
+        case 3: k = x6 ? (Nt2Kernel)pw_gemm_nt_dma_kernel<3, 0, BF, 2, X> : (Nt2Kernel)pw_gemm_nt_dma_kernel<3, 0, BF, 2>; break;
+        default: k = x6 ? (Nt2Kernel)pw_gemm_nt_dma_kernel<4, 0, BF, 2, X> : (Nt2Kernel)pw_gemm_nt_dma_kernel<4, 0, BF, 2>; break;
     }
     else switch (p2.TN) {
-        case 1: k = (Nt2Kernel)pw_gemm_nt_dma_kernel<1, 0, BF, 1>; break; case 2: k = (Nt2Kernel)pw_gemm_nt_dma_kernel<2, 0, BF, 1>; break;
-        case 3: k = (Nt2Kernel)pw_gemm_nt_dma_kernel<3, 0, BF, 1>; break; default: k = (Nt2Kernel)pw_gemm_nt_dma_kernel<4, 0, BF, 1>; break;
+        case 1: k = x6 ? (Nt2Kernel)pw_gemm_nt_dma_kernel<1, 0, BF, 1, X> : (Nt2Kernel)pw_gemm_nt_dma_kernel<1, 0, BF, 1>; break;
+        case 2: k = x6 ? (Nt2Kernel)pw_gemm_nt_dma_kernel<2, 0, BF, 1, X> : (Nt2Kernel)pw_gemm_nt_dma_kernel<2, 0, BF, 1>; break;
+        case 3: k = x6 ? (Nt2Kernel)pw_gemm_nt_dma_kernel<3, 0, BF, 1, X> : (Nt2Kernel)pw_gemm_nt_dma_kernel<3, 0, BF, 1>; break;
+        default: k = x6 ? (Nt2Kernel)pw_gemm_nt_dma_kernel<4, 0, BF, 1, X> : (Nt2Kernel)pw_gemm_nt_dma_kernel<4, 0, BF, 1>; break;
     }
     hipLaunchKernelGGL(k, dim3(p2.grid), dim3(256), p2.lds, (hipStream_t)stream, g);
     return check_launch("pw_gemm_nt_dma_kernel<RED>");
@@ -2072,7 +2193,7 @@ static int pw_wgrad_impl(const T* x, const float* in_scale, const float* in_shif
     static const bool force_v1 = getenv("MNY_WGRAD_V1") != nullptr;
     WgKernel dk = nullptr;                       // LDS-DMA kernels read raw 16-B chunks: aligned rows only
     if (is_f32) {
-        if ((Nc & 3) == 0 && (K & 3) == 0 && in_act != MNY_ACT_HSWISH && !force_v1) dk = wg_dma_kernel(pl.mode, pl.TI, pl.TJ);
+        if ((Nc & 3) == 0 && (K & 3) == 0 && in_act != MNY_ACT_HSWISH && !force_v1) dk = wg_dma_kernel(pl.mode, pl.TI, pl.TJ, nt_x6(M, K, Nc));
     } else if ((Nc & 7) == 0 && (K & 7) == 0 && !force_v1) {
         const int XF = (in_scale == nullptr && in_act == MNY_ACT_NONE) ? 0 : (in_act == MNY_ACT_HSWISH ? 2 : 1);
         dk = wg_bf16_kernel(pl.mode, pl.TI, pl.TJ, XF);
