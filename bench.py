@@ -578,6 +578,14 @@ def main():
             # the entry point routes its short-reduction launches (K = 16 / 24 / 32 channels, HBM-bound) to a vector-ALU stream kernel:
             # their FLOPs and time are inside this object, priced against the matrix-core peak like the rest
             roof["kernels"] = "pw_gemm_nt_dma_kernel (MFMA tiles) + pw_thin_kernel (vector ALU, the K <= 32 launches; csrc/pwthin.hip)"
+        if not bf16 and os.environ.get("MNY_X6") != "0":
+            # fp32 GEMMs with FLOP/byte >= 20 take the six-product bf16 form (csrc/pwgemm.hip, x6_split): say so, and price the same
+            # achieved rate against the pipe that actually carries it as well
+            roof["matrix_form"] = ("shapes with >= 20 FLOP per byte run as six bf16 partial products per fp32 product on v_mfma_f32_32x32x16_bf16 "
+                                   "(every operand cut EXACTLY into three bf16 pieces, fp32 accumulate; error against an fp64 product below the "
+                                   "fp32 MFMA's: tools/x6_precision.py); `peak` stays the fp32-MFMA peak of the dtype, `frac_bf16x6` prices the "
+                                   "same achieved rate against the bf16 pipe at six products per FMA (%.0f / 6 TFLOP/s)" % PEAK_BF16_MFMA_TFLOPS)
+            roof["frac_bf16x6"] = round(roof["achieved"] / (PEAK_BF16_MFMA_TFLOPS / 6.0), 4)
         if bf16:                                       # bf16 storage: the GEMMs are HBM-bound — say so on the line
             roof["note"] = "priced against the dense bf16 MFMA peak; this configuration is HBM-bound: see algorithmic_hbm_gbs / %d GB/s" % int(PEAK_HBM_GBS)
         others = []

@@ -273,9 +273,13 @@ __device__ __forceinline__ void x6_split(v4f_t x0, v4f_t x1, bf16x8_t& h, bf16x8
     const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
     float r1[8], r2[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        r1[e] = x[e] - __uint_as_float(__float_as_uint(x[e]) & 0xffff0000u);        // exact: the low 16 mantissa bits
-        r2[e] = r1[e] - __uint_as_float(__float_as_uint(r1[e]) & 0xffff0000u);
+    for (int e = 0; e < 8; e += 2) {                 // pairs: the subtractions are v_pk_add_f32
+        const v2f a = v2f{x[e], x[e + 1]};
+        const v2f ah = v2f{__uint_as_float(__float_as_uint(x[e]) & 0xffff0000u), __uint_as_float(__float_as_uint(x[e + 1]) & 0xffff0000u)};
+        const v2f b = a - ah;                        // exact: the low 16 mantissa bits
+        const v2f bh = v2f{__uint_as_float(__float_as_uint(b.x) & 0xffff0000u), __uint_as_float(__float_as_uint(b.y) & 0xffff0000u)};
+        const v2f c = b - bh;
+        r1[e] = b.x; r1[e + 1] = b.y; r2[e] = c.x; r2[e + 1] = c.y;
     }
     v4u_t hu, mu, lu;
     // v_perm_b32: (odd element's high half << 16) | even element's high half == two truncated bf16 values

@@ -27,13 +27,25 @@ def thin_red(k):
     return int(m.group(1)) if m else None
 
 
+def nt_args(k):
+    """template arguments <TN, XF, BF, RED[, X6]> of a pw_gemm_nt_dma_kernel family name, or None"""
+    m = re.match(r"pw_gemm_nt_dma_kernel<([^>]*)>", k)
+    if not m:
+        return None
+    a = [int(v) for v in m.group(1).split(",")]
+    return a + [0] * (5 - len(a))
+
+
 def is_pw_fwd(k):
-    """kernels behind the mny_pw_fwd entry point: the tile GEMMs without a BN-backward epilogue + the short-reduction stream kernel (RED = 0)"""
-    return (k.startswith("pw_gemm_nt") and not re.search(r", [12]>$", k)) or thin_red(k) == 0
+    """kernels behind the mny_pw_fwd entry point: the tile GEMMs without a BN-backward epilogue (fp32-MFMA or six-product bf16 form) +
+    the register-staged fallback + the short-reduction stream kernel (RED = 0)"""
+    a = nt_args(k)
+    return (a is not None and a[3] == 0) or (k.startswith("pw_gemm_nt_kernel")) or thin_red(k) == 0
 
 
 def is_pw_dgrad_bnred(k):
-    return (k.startswith("pw_gemm_nt") and bool(re.search(r", 1>$", k))) or thin_red(k) == 1
+    a = nt_args(k)
+    return (a is not None and a[3] == 1) or thin_red(k) == 1
 
 
 def pmc(dirname, counter):
