@@ -569,3 +569,32 @@ def test_short_reduction_pointwise_kernel(ops, M, K, Nc, act, dtype):
             r1, r2 = red[:, 0].double().sum(0).cpu(), red[:, 1].double().sum(0).cpu()
             assert ((r1 - dz.sum(0)).abs() <= 2e-5 * dz.abs().sum(0).max().item() + 1e-5 + kink.sum(0)).all()
             assert ((r2 - (dz * xhat).sum(0)).abs() <= 2e-5 * (dz * xhat).abs().sum(0).max().item() + 1e-5 + (kink * xhat.abs()).sum(0)).all()
+
+
+@pytest.mark.parametrize("M,K,Nc", [(4096, 512, 512), (4100, 96, 576), (3000, 960, 160), (5000, 64, 384), (2049, 1280, 512)])
+def test_six_product_bf16_gemms_are_fp32_accurate(ops, M, K, Nc):
+    """The MFMA-bound fp32 GEMMs run as six bf16 partial products per fp32 product (pwgemm.hip, x6_split).  Against an fp64 product
+    their error must be what an fp32 accumulation gives (measured rms 3.5e-7 at K = 512 for unit-variance data, the native fp32 MFMA
+    4.1e-7): bounds = 2x the fp32-MFMA figures, far below anything a dropped bf16 piece would cause (2^-16 = 1.5e-5 per product)."""
+    x = rnd(M, K, seed=1).cuda()
+    w = (rnd(Nc, K, seed=2) * K ** -0.5).cuda()
+    xs = x.view(1, 1, M, K)
+    y, _ = ops.pw_fwd((xs, None, None, 0), w, want_stats=False)
+    ref = x.double() @ w.double().t()
+    err = (y.view(M, Nc).double() - ref)
+    rms = lambda t: t.pow(2).mean().sqrt().item()             # noqa: E731
+    bound = 8e-7 * rms(ref)                                    # relative to the rms of the result (measured 3.5e-7 at K = 512)
+    assert rms(err) <= bound, (rms(err), bound)
+    assert err.abs().max().item() <= 16 * bound
+    # weight gradient of the same shape
+    dy = rnd(M, Nc, seed=3).cuda()
+    dw, _ = ops.pw_wgrad((xs, None, None, 0), dy.view(1, 1, M, Nc), want_dbias=False)
+    refw = dy.double().t() @ x.double()
+    errw = (dw.double() - refw)
+    assert rms(errw) <= 8e-7 * rms(refw), (rms(errw), rms(refw))          # reduction over M; measured 1.4e-7 relative
+    # operands with a large dynamic range and exact zeros (ReLU6 outputs): the cut is exact for every finite fp32 value
+    a = torch.clamp(x * 3, 0, 6) * torch.exp2(torch.randint(-20, 20, (M, 1), generator=torch.Generator().manual_seed(5)).float()).cuda()
+    y2, _ = ops.pw_fwd((a.view(1, 1, M, K), None, None, 0), w, want_stats=False)
+    ref2 = a.double() @ w.double().t()
+    rel = ((y2.view(M, Nc).double() - ref2).abs() / (a.double().abs() @ w.double().abs().t() + 1e-300)).max().item()
+    assert rel <= 2e-6, rel                                   # row-wise relative to sum |a||w|: fp32-level
