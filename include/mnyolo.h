@@ -316,6 +316,28 @@ int mny_pw_dgrad_bnred_add(const float* dy, const float* wT, const float* addend
                            const float* shift, int act, const float* mean, const float* invstd, float* red, int64_t M, int K, int Nc,
                            void* stream);
 
+/* ---- fp32 GEMMs on pre-cut weight planes ---------------------------------------------------------------------------
+ * The MFMA-bound fp32 GEMMs run on the bf16 matrix cores as six partial products per fp32 product (every operand cut exactly into
+ * three bf16 pieces).  The weight operand is the same for every row tile: a static plan cuts all of its GEMM weights
+ * (and their transposes) ONCE per pass with mny_cut3_batch — jobs (DEVICE array) name fp32 matrices [R][C] and their plane buffers of
+ * mny_pw_w6_bytes(C, R) bytes, block_job (DEVICE int32[nblocks]) maps a workgroup (256 16-byte chunks) to its job (job.block0 = its
+ * first workgroup, ceil(R * ceil(C/16) * 2 / 256) of them) — and calls the _w6 twins, which take the planes where mny_pw_fwd /
+ * mny_pw_dgrad_bnred[_add] take the fp32 matrix.  Same tiling, same partial rows (mny_pw_stat_parts / mny_pw_dgrad_bnred_parts), same
+ * results up to fp32 rounding order.  mny_pw_w6_supported(M, K, Nc): the shape takes this form (fp32, K % 4 == 0, >= 20 FLOP per byte). */
+typedef struct mny_cut3_job {
+    const float* src; /* [R][C] fp32 */
+    void* dst;        /* three bf16 planes, mny_pw_w6_bytes(C, R) bytes */
+    int32_t R, C, block0, pad;
+} mny_cut3_job;
+int mny_pw_w6_supported(int64_t M, int K, int Nc);
+size_t mny_pw_w6_bytes(int K, int Nc);
+int mny_cut3_batch(const mny_cut3_job* jobs, const int32_t* block_job, int nblocks, void* stream);
+int mny_pw_fwd_w6(const float* x, const float* in_scale, const float* in_shift, int in_act, const void* w6, const float* bias,
+                  const float* addend, float* y, float* stats, int64_t M, int K, int Nc, void* stream);
+int mny_pw_dgrad_bnred_w6(const float* dy, const void* wT6, const float* addend, float* dx, const float* y, const float* scale,
+                          const float* shift, int act, const float* mean, const float* invstd, float* red, int64_t M, int K, int Nc,
+                          void* stream);
+
 /* ---- evaluation consumer: VOC07 11-point mAP on the device -----------------------------
  * Replaces utils/eval_mAP.py:134-187 (calculate_mAP), :69-132 (eval_class_ap), :8-65
  * (eval_single_image_recall) and utils/iou.py:4-48 (find_jaccard_overlap) on a PACKED layout: the

@@ -302,8 +302,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     const T* pAdd = (const T*)p.addend;
     T* pC = (T*)p.C;
     constexpr int BN = 32 * TN, BKD = 16, S = 3;
-    constexpr int A_ST = BM * BKD, B_ST = BN * BKD, STAGE = A_ST + B_ST;     // floats
-    constexpr int NA = BM / 16, NB = BN / 16, NL = NA + NB;                   // 1-KiB DMA instructions per stage
+    // X6 == 3: B arrives PRE-CUT (mny_cut3_batch): three bf16 planes [N][nk][2][8], the eight k-values of a 16-B chunk in the order a lane
+    // of this kernel holds them (k = 4h..4h+3, 8+4h..8+4h+3 for half h); a stage of B is 3 x 32*TN rows x 32 B, one DMA instruction per
+    // (plane, 32-row block), whose lane-linear LDS image [row][half] is exactly what the wave reads back
+    constexpr int A_ST = BM * BKD, B_ST = X6 == 3 ? BN * 24 : BN * BKD, STAGE = A_ST + B_ST;     // floats
+    constexpr int NA = BM / 16, NB = X6 == 3 ? 3 * TN : BN / 16, NL = NA + NB;                   // 1-KiB DMA instructions per stage
     constexpr int LPW = (NL + 3) / 4;                                         // per wave (surplus ones duplicate the last)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sScale = smem + S * STAGE;
@@ -349,9 +352,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         d_isA[i] = j < NA;
         d_row0[i] = (d_isA[i] ? j : j - NA) * 16;                 // scalar
         d_lds[i] = d_isA[i] ? j * 256 : A_ST + (j - NA) * 256;   // scalar
-        int n = n0 + d_row0[i] + drow;
-        if (n >= p.N) n = p.N - 1;
-        d_bptr[i] = pB + (int64_t)n * p.K + dk;
+        if constexpr (X6 == 3) {
+            const int jb = d_isA[i] ? 0 : j - NA;                 // (plane, column block) of this instruction
+            const int pl = jb / TN, u = jb - pl * TN;
+            int n = n0 + u * 32 + (lane >> 1);
+            if (n >= p.N) n = p.N - 1;
+            d_lds[i] = d_isA[i] ? j * 256 : A_ST + jb * 256;
+            d_bptr[i] = reinterpret_cast<const T*>(reinterpret_cast<const char*>(p.B) + ((int64_t)pl * p.N + n) * nk * 32 + (lane & 1) * 16);
+        } else {
+            int n = n0 + d_row0[i] + drow;
+            if (n >= p.N) n = p.N - 1;
+            d_bptr[i] = pB + (int64_t)n * p.K + dk;
+        }
     }
     const T* zero_src = reinterpret_cast<const T*>(&mny_zero16);
     const bool ragged_k = (p.K % BKE) != 0;
@@ -367,6 +379,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                 int m = mt * BM + d_row0[i] + drow;
                 if (m >= (int)p.M) m = (int)p.M - 1;
                 src = pA + (int64_t)m * p.K + (kout ? 0 : kt * BKE + dk);   // finite filler, annihilated by zero B / zero scale
+            } else if constexpr (X6 == 3) {
+                src = reinterpret_cast<const T*>(reinterpret_cast<const char*>(d_bptr[i]) + kt * 32);      // planes are zero-padded to nk * 16
             } else {
                 src = kout ? zero_src : d_bptr[i] + kt * BKE;
             }
@@ -430,7 +444,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
             // the lane's eight k-values of this stage: chunks khalf and 2 + khalf (the same two the fp32 path reads one after the other)
             const int c0 = khalf, c1 = 2 + khalf;
             v4f_t a0 = lds_read_f4(a_row + ((c0 ^ swz) << 2)), a1 = lds_read_f4(a_row + ((c1 ^ swz) << 2));
-            v4f_t b0 = lds_read_f4(stB + lrow * BKD + ((c0 ^ swz) << 2)), b1 = lds_read_f4(stB + lrow * BKD + ((c1 ^ swz) << 2));
+            v4f_t b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;          // (never a copy of a0: its register is still in flight here)
+            if constexpr (X6 != 3) { b0 = lds_read_f4(stB + lrow * BKD + ((c0 ^ swz) << 2)); b1 = lds_read_f4(stB + lrow * BKD + ((c1 ^ swz) << 2)); }
             v4f_t sc0, sc1, sh0, sh1;
             if (XF != 0) {
                 sc0 = lds_read_f4(sScale + kt * BKD + c0 * 4); sc1 = lds_read_f4(sScale + kt * BKD + c1 * 4);
@@ -448,6 +463,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
             }
             bf16x8_t ah, am, al;
             x6_split(a0, a1, ah, am, al);
+            if constexpr (X6 == 3) {
+#pragma unroll
+                for (int u = 0; u < TN; ++u) {
+                    const float* src = stB + (u * 64 + 2 * lrow + khalf) * 4;
+                    v4f_t ph = lds_read_f4(src), pm = lds_read_f4(src + TN * 256), pl = lds_read_f4(src + 2 * TN * 256);
+                    MNY_LGKM_WAIT(ph); MNY_LGKM_DEP(pm); MNY_LGKM_DEP(pl);
+                    const bf16x8_t bh = __builtin_bit_cast(bf16x8_t, ph), bm = __builtin_bit_cast(bf16x8_t, pm), bl = __builtin_bit_cast(bf16x8_t, pl);
+                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[u], 0, 0, 0);
+                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[u], 0, 0, 0);
+                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc[u], 0, 0, 0);
+                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[u], 0, 0, 0);
+                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[u], 0, 0, 0);
+                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[u], 0, 0, 0);
+                }
+                return;
+            }
 #pragma unroll
             for (int u = 0; u < TN; ++u) {
                 v4f_t n0, n1;
@@ -676,6 +707,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
 
 typedef void (*Nt2Kernel)(Gemm2Args);
 static Nt2Kernel nt2_kernel(int TN, int XF, int BF = 0, int X6 = 0) {
+    if (X6 == 3 && !BF) {                           // pre-cut weight planes (mny_pw_fwd_w6)
+#define MNY_K6(T) (XF == 0 ? (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 0, 0, 0, 3> : XF == 1 ? (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 1, 0, 0, 3> : (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 2, 0, 0, 3>)
+        switch (TN) { case 1: return MNY_K6(1); case 2: return MNY_K6(2); case 3: return MNY_K6(3); case 4: return MNY_K6(4); default: return MNY_K6(5); }
+#undef MNY_K6
+    }
     if (X6 && !BF) {
 #define MNY_K6(T) (XF == 0 ? (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 0, 0, 0, 1> : XF == 1 ? (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 1, 0, 0, 1> : (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 2, 0, 0, 1>)
         switch (TN) { case 1: return MNY_K6(1); case 2: return MNY_K6(2); case 3: return MNY_K6(3); case 4: return MNY_K6(4); default: return MNY_K6(5); }
@@ -702,6 +738,47 @@ static size_t nt2_lds(int TN, int K, bool xf, int BF = 0) {
     size_t ring = (size_t)3 * (BM * 16 + 32 * TN * 16) * sizeof(float);
     size_t red = (size_t)4 * 32 * TN * 2 * sizeof(float);
     return (ring > red ? ring : red) + (xf ? 2 * Kpad * sizeof(float) : 0);
+}
+
+// kernels whose dynamic LDS exceeds the 64 KB default need the opt-in once (the pre-cut planes mode at TN >= 4 with a deep scale cache)
+static void nt2_allow_lds(Nt2Kernel k, size_t lds) {
+    if (lds <= 64 * 1024) return;
+    static std::map<const void*, size_t> done;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = done.find((const void*)k);
+    if (it != done.end() && it->second >= lds) return;
+    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    done[(const void*)k] = lds;
+}
+
+// ---- pre-cut weight planes for the six-product form --------------------------------------------------------------------------
+// src [R][C] fp32 (a conv weight [Cout][Cin] or its transpose) -> dst: three bf16 planes [R][nk][2][8], nk = ceil(C / 16); chunk
+// (row, kt, h) holds k = 16 kt + {4h, 4h+1, 4h+2, 4h+3, 8+4h, ..., 8+4h+3} — the eight values lane-half h of the NT kernel multiplies
+// in stage kt — cut by truncation exactly like x6_split (hi + mid + lo == the fp32 value), zeros past C.  One thread per chunk.
+struct Cut3Job { const float* src; void* dst; int32_t R, C, block0, pad; };
+__global__ __launch_bounds__(256) void cut3_batch_kernel(const Cut3Job* __restrict__ jobs, const int32_t* __restrict__ block_job) {
+    const Cut3Job jb = jobs[block_job[blockIdx.x]];
+    const int nk = (jb.C + 15) / 16;
+    const int64_t idx = (int64_t)(blockIdx.x - jb.block0) * 256 + threadIdx.x;       // chunk index: (row * nk + kt) * 2 + h
+    if (idx >= (int64_t)jb.R * nk * 2) return;
+    const int h = (int)(idx & 1);
+    const int64_t rk = idx >> 1;
+    const int kt = (int)(rk % nk);
+    const int64_t row = rk / nk;
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = kt * 16 + (e < 4 ? 4 * h + e : 8 + 4 * h + (e - 4));
+        x[e] = k < jb.C ? jb.src[row * jb.C + k] : 0.f;
+    }
+    bf16x8_t hh, mm, ll;
+    x6_split(v4f_t{x[0], x[1], x[2], x[3]}, v4f_t{x[4], x[5], x[6], x[7]}, hh, mm, ll);
+    const int64_t plane = (int64_t)jb.R * nk * 32;                                     // bytes
+    char* d = reinterpret_cast<char*>(jb.dst) + idx * 16;
+    *reinterpret_cast<v4f_t*>(d) = __builtin_bit_cast(v4f_t, hh);
+    *reinterpret_cast<v4f_t*>(d + plane) = __builtin_bit_cast(v4f_t, mm);
+    *reinterpret_cast<v4f_t*>(d + 2 * plane) = __builtin_bit_cast(v4f_t, ll);
 }
 
 // resident workgroups per CU for (TN, XF) at a given dynamic-LDS size (queried once per distinct size)
@@ -2148,6 +2225,68 @@ extern "C" int mny_pw_dgrad_bnred_parts_bf16(int64_t M, int K, int Nc) {
 extern "C" int mny_pw_dgrad_bnred_bf16(const void* dy, const void* wT, void* dx, const void* y, const float* scale, const float* shift, int act,
                                        const float* mean, const float* invstd, float* red, int64_t M, int K, int Nc, void* stream) {
     return pw_dgrad_bnred_impl<1>(dy, wT, dx, y, scale, shift, act, mean, invstd, red, M, K, Nc, stream);
+}
+
+// ---- forward / data-gradient GEMMs on pre-cut weight planes (fp32 plans, six-product form) ---------------------------------------
+// Planes pay where the matrix pipe is the bound: a stage of B grows from 64 to 96 bytes per row, which costs the mid-size shapes
+// (K or N around 64-96: latency-bound, three resident workgroups per CU) their third workgroup — measured per shape (tools/ab_detail.sh):
+// 7-18 % faster from ~60 FLOP per byte up, 10-30 % slower below ~40.
+static bool w6_ok(int64_t M, int K, int Nc) {
+    static const bool off = getenv("MNY_NO_W6") != nullptr;
+    static const double min_ai = getenv("MNY_W6_AI") ? atof(getenv("MNY_W6_AI")) : 50.0;
+    const double ai = 2.0 * K * Nc / (4.0 * (K + Nc));
+    return !off && M > 0 && K > 0 && Nc > 0 && (K & 3) == 0 && !pw_thin_ok(0, 0, M, K, Nc) && nt_x6(M, K, Nc) != 0 && ai >= min_ai &&
+           getenv("MNY_GEMM_V1") == nullptr;
+}
+extern "C" int mny_pw_w6_supported(int64_t M, int K, int Nc) { return w6_ok(M, K, Nc) ? 1 : 0; }
+extern "C" size_t mny_pw_w6_bytes(int K, int Nc) { return (K <= 0 || Nc <= 0) ? 0 : (size_t)3 * Nc * ((K + 15) / 16) * 32; }
+extern "C" int mny_cut3_batch(const mny_cut3_job* jobs, const int32_t* block_job, int nblocks, void* stream) {
+    MNY_REQUIRE(jobs && block_job && nblocks > 0, "cut3_batch: bad arguments");
+    static_assert(sizeof(mny_cut3_job) == sizeof(Cut3Job), "job layout");
+    hipLaunchKernelGGL(cut3_batch_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const Cut3Job*>(jobs), block_job);
+    return check_launch("cut3_batch_kernel");
+}
+extern "C" int mny_pw_fwd_w6(const float* x, const float* in_scale, const float* in_shift, int in_act, const void* w6, const float* bias,
+                             const float* addend, float* y, float* stats, int64_t M, int K, int Nc, void* stream) {
+    MNY_REQUIRE(x && w6 && y, "pw_fwd_w6: null pointer");
+    MNY_REQUIRE(w6_ok(M, K, Nc), "pw_fwd_w6: unsupported problem M=%lld K=%d N=%d (mny_pw_w6_supported)", (long long)M, K, Nc);
+    MNY_REQUIRE(!(stats && bias), "pw_fwd_w6: stats and bias are mutually exclusive");
+    const bool xf = in_scale != nullptr || in_act != MNY_ACT_NONE;
+    Nt2Plan p2 = nt2_plan(M, K, Nc, xf);                          // same tiling and partial rows as mny_pw_fwd
+    const size_t lds = p2.lds + (size_t)3 * p2.TN * 1024;         // a stage of B: three bf16 planes instead of one fp32 image
+    MNY_REQUIRE(lds <= 96 * 1024, "pw_fwd_w6: K=%d too large for the LDS scale cache", K);
+    Gemm2Args g{x, in_scale, in_shift, in_act, w6, bias, addend, y, stats, M, K, Nc, p2.m_tiles, p2.tiles_per_block, p2.gx, p2.n_tiles,
+                nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+    const int XF = !xf ? 0 : (in_act == MNY_ACT_HSWISH ? 2 : 1);
+    const Nt2Kernel k = nt2_kernel(p2.TN, XF, 0, 3);
+    nt2_allow_lds(k, lds);
+    hipLaunchKernelGGL(k, dim3(p2.grid), dim3(256), lds, (hipStream_t)stream, g);
+    return check_launch("pw_gemm_nt_dma_kernel<w6>");
+}
+// data gradient + BN-backward sums of the fed unit (mny_pw_dgrad_bnred / _add semantics; addend may be NULL) on pre-cut W^T planes
+extern "C" int mny_pw_dgrad_bnred_w6(const float* dy, const void* wT6, const float* addend, float* dx, const float* y, const float* scale,
+                                     const float* shift, int act, const float* mean, const float* invstd, float* red, int64_t M, int K, int Nc,
+                                     void* stream) {
+    MNY_REQUIRE(dy && wT6 && dx && y && scale && shift && mean && invstd && red, "pw_dgrad_bnred_w6: null pointer");
+    MNY_REQUIRE(w6_ok(M, K, Nc) && dgrad_bnred_ok(M, K, Nc, act), "pw_dgrad_bnred_w6: unsupported problem M=%lld K=%d N=%d", (long long)M, K, Nc);
+    Nt2Plan p2 = nt2_plan(M, K, Nc, false, 0, kRedMaxTn);
+    MNY_REQUIRE(!addend || p2.TN <= 3, "pw_dgrad_bnred_w6: the addend form needs a column tile of <= 96 (mny_pw_dgrad_bnred_add_supported)");
+    const size_t lds = p2.lds + (size_t)3 * p2.TN * 1024;
+    MNY_REQUIRE(lds <= 96 * 1024, "pw_dgrad_bnred_w6: K=%d too large", K);
+    Gemm2Args g{dy, nullptr, nullptr, MNY_ACT_NONE, wT6, nullptr, addend, dx, red, M, K, Nc, p2.m_tiles, p2.tiles_per_block, p2.gx, p2.n_tiles,
+                y, scale, shift, mean, invstd, act};
+    Nt2Kernel k;
+    if (addend) switch (p2.TN) {
+        case 1: k = (Nt2Kernel)pw_gemm_nt_dma_kernel<1, 0, 0, 2, 3>; break; case 2: k = (Nt2Kernel)pw_gemm_nt_dma_kernel<2, 0, 0, 2, 3>; break;
+        default: k = (Nt2Kernel)pw_gemm_nt_dma_kernel<3, 0, 0, 2, 3>; break;
+    }
+    else switch (p2.TN) {
+        case 1: k = (Nt2Kernel)pw_gemm_nt_dma_kernel<1, 0, 0, 1, 3>; break; case 2: k = (Nt2Kernel)pw_gemm_nt_dma_kernel<2, 0, 0, 1, 3>; break;
+        case 3: k = (Nt2Kernel)pw_gemm_nt_dma_kernel<3, 0, 0, 1, 3>; break; default: k = (Nt2Kernel)pw_gemm_nt_dma_kernel<4, 0, 0, 1, 3>; break;
+    }
+    nt2_allow_lds(k, lds);
+    hipLaunchKernelGGL(k, dim3(p2.grid), dim3(256), lds, (hipStream_t)stream, g);
+    return check_launch("pw_gemm_nt_dma_kernel<RED, w6>");
 }
 
 extern "C" int mny_pw_fwd_bf16(const void* x, const float* in_scale, const float* in_shift, int in_act, const void* w,

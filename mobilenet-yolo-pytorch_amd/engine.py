@@ -38,7 +38,8 @@ class CallList:
         self.keep = []           # tensors referenced by raw pointers
         self.marks = {}          # name -> call index (for DP bucket events)
 
-    def add(self, name, *args, meta=None):
+    def add(self, name, *args, meta=None, label=None):
+        """`label`: the entry point this call stands for in timing tables / launch fingerprints (the _w6 twins of the GEMM entry points)."""
         fn = getattr(_lib.load(), name)
         conv = []
         for a in args:
@@ -48,7 +49,7 @@ class CallList:
                 conv.append(_vp(a.data_ptr()))
             else:
                 conv.append(a)
-        self.calls.append((fn, tuple(conv), name, meta))   # meta: algorithmic {flops, bytes} of the call
+        self.calls.append((fn, tuple(conv), label or name, meta))   # meta: algorithmic {flops, bytes} of the call
 
     def add_py(self, fn, name="py"):
         """A host-side step of the list (stream fork / join): any callable returning None."""
@@ -236,6 +237,7 @@ class NetPlan:
         self.fwd = CallList()
         self.cvt_batch = os.environ.get("MNY_NO_CBATCH") != "1"
         self._cvt_jobs = []
+        self._cut_jobs = []           # (fp32 matrix, plane buffer): weights of the six-product GEMMs, cut once per pass (mny_cut3_batch)
         self.head32 = {}         # bf16 storage: value id -> fp32 copy of a detection head
         self.units = {}          # value id -> _Unit
         self.reals = {}          # value id -> tensor
@@ -289,7 +291,9 @@ class NetPlan:
                     i = nd.ins[0]
                     xv = view(i)
                     parts = _lib.query(K("mny_pw_stat_parts"), M, i.C, o.C)
-                    self.fwd.add(K("mny_pw_fwd"), xv[0], xv[1], xv[2], xv[3], self._gemm_weight(w), None, None, u.Y, stats, M, i.C, o.C, self.stream,
+                    w6 = self._w6_planes(w, M, i.C, o.C)
+                    self.fwd.add("mny_pw_fwd_w6" if w6 is not None else K("mny_pw_fwd"), xv[0], xv[1], xv[2], xv[3],
+                                 w6 if w6 is not None else self._gemm_weight(w), None, None, u.Y, stats, M, i.C, o.C, self.stream, label=K("mny_pw_fwd"),
                                  meta=dict(flops=2 * M * i.C * o.C, bytes=eb * (M * i.C + M * o.C) + 4 * i.C * o.C, shape="M%d K%d N%d" % (M, i.C, o.C)))
                 gam, bet = P[nd.bn + ".weight"], P[nd.bn + ".bias"]
                 rm, rv = P[nd.bn + ".running_mean"], P[nd.bn + ".running_var"]
@@ -303,8 +307,11 @@ class NetPlan:
                 xv = view(i)
                 t = torch.empty(shp, **act)
                 self.reals[o.id] = t
-                self.fwd.add(K("mny_pw_fwd"), xv[0], xv[1], xv[2], xv[3], self._gemm_weight(P[nd.conv + ".weight"]), P[nd.conv + ".bias"], None, t, None,
-                             M, i.C, o.C, self.stream, meta=dict(flops=2 * M * i.C * o.C, bytes=eb * (M * i.C + M * o.C) + 4 * i.C * o.C, shape="M%d K%d N%d" % (M, i.C, o.C)))
+                w6 = self._w6_planes(P[nd.conv + ".weight"], M, i.C, o.C)
+                self.fwd.add("mny_pw_fwd_w6" if w6 is not None else K("mny_pw_fwd"), xv[0], xv[1], xv[2], xv[3],
+                             w6 if w6 is not None else self._gemm_weight(P[nd.conv + ".weight"]), P[nd.conv + ".bias"], None, t, None,
+                             M, i.C, o.C, self.stream, label=K("mny_pw_fwd"),
+                             meta=dict(flops=2 * M * i.C * o.C, bytes=eb * (M * i.C + M * o.C) + 4 * i.C * o.C, shape="M%d K%d N%d" % (M, i.C, o.C)))
                 if self.bf16:                    # loss / decode read the head in fp32
                     t32 = torch.empty(shp, **f32)
                     self.fwd.add("mny_cvt_bf16_f32", t, t32, t.numel(), self.stream)
@@ -334,6 +341,7 @@ class NetPlan:
                 raise AssertionError(nd.op)
 
         self._flush_cvt_jobs()
+        self._flush_cut_jobs(self.fwd, at_head=True)
         self.heads = [self.head32.get(o.id, self.reals[o.id]) for o in g.outputs]
         self.seg_head = self.head32.get(g.seg_out.id, self.reals[g.seg_out.id]) if g.seg_out is not None else None
         self.loss_outputs = list(g.outputs) + ([g.seg_out] if g.seg_out is not None else [])     # values a loss reads
@@ -629,6 +637,16 @@ class NetPlan:
                 self.t_jobs = torch.from_numpy(jt.view(np.uint8).copy()).to(dev)
                 self.t_blocks = torch.tensor(block_job, dtype=torch.int32, device=dev)
                 bwd.add(K("mny_transpose_batch"), self.t_jobs, self.t_blocks, len(block_job), self.stream)
+                # ... and, for the data-gradient GEMMs that take the six-product bf16 form, the cut of W^T right behind it
+                self.wT6 = {}
+                for nd in order:
+                    if nd.conv in self.wT and nd.conv not in self.wT6 and not takes_own_sums(nd):
+                        osh = shape(nd.out)
+                        oc = self.head_cp.get(nd.out.id, nd.out.C)
+                        pl6 = self._w6_planes(self.wT[nd.conv], osh[0] * osh[1] * osh[2], oc, nd.ins[0].C)
+                        if pl6 is not None:
+                            self.wT6[nd.conv] = pl6
+                self._flush_cut_jobs(bwd)
         for nd in order:
             o = nd.out
             shp = shape(o)
@@ -845,6 +863,7 @@ class NetPlan:
                     else:
                         bwd.add(K("mny_transpose"), w, wT, o.C, i.C, self.stream)
                 prod = i.node
+                wT6 = getattr(self, "wT6", {}).get(nd.conv)      # pre-cut W^T planes: this data gradient takes the six-product bf16 form
                 # (fp32 plans only: with bf16 storage the epilogue's 2-byte loads of the unit's output cost what the saved pass did —
                 # same-box A/B 3 281 vs 3 293 img/s on MobileNetV3 512 — MNY_REDFUSE_BF16=1 turns it on for measurements)
                 if (os.environ.get("MNY_NO_REDFUSE") != "1" and (not self.bf16 or os.environ.get("MNY_REDFUSE_BF16") == "1")
@@ -857,9 +876,15 @@ class NetPlan:
                     rparts = _lib.query(K("mny_pw_dgrad_bnred_parts"), M, oc, i.C)
                     rbuf = torch.empty(rparts * 2 * i.C, **f32)
                     self.fused_red[i.id] = (rbuf, rparts)
-                    contribute_kernel(i, lambda out, addend, dY=dY, wT=wT, M=M, K=oc, Nc=i.C, pu=pu, rbuf=rbuf, act_=i.act: bwd.add(
-                        self.K("mny_pw_dgrad_bnred"), dY, wT, out, pu.Y, pu.scale, pu.shift, act_, pu.mean, pu.invstd, rbuf, M, K, Nc, self.stream,
-                        meta=dict(flops=2 * M * K * Nc, bytes=self.eb * (M * K + 2 * M * Nc) + 4 * K * Nc, shape="dgrad+red M%d K%d N%d" % (M, K, Nc))))
+                    if wT6 is not None:
+                        contribute_kernel(i, lambda out, addend, dY=dY, wT6=wT6, M=M, K=oc, Nc=i.C, pu=pu, rbuf=rbuf, act_=i.act: bwd.add(
+                            "mny_pw_dgrad_bnred_w6", dY, wT6, None, out, pu.Y, pu.scale, pu.shift, act_, pu.mean, pu.invstd, rbuf, M, K, Nc, self.stream,
+                            label="mny_pw_dgrad_bnred",
+                            meta=dict(flops=2 * M * K * Nc, bytes=self.eb * (M * K + 2 * M * Nc) + 4 * K * Nc, shape="dgrad+red M%d K%d N%d" % (M, K, Nc))))
+                    else:
+                        contribute_kernel(i, lambda out, addend, dY=dY, wT=wT, M=M, K=oc, Nc=i.C, pu=pu, rbuf=rbuf, act_=i.act: bwd.add(
+                            self.K("mny_pw_dgrad_bnred"), dY, wT, out, pu.Y, pu.scale, pu.shift, act_, pu.mean, pu.invstd, rbuf, M, K, Nc, self.stream,
+                            meta=dict(flops=2 * M * K * Nc, bytes=self.eb * (M * K + 2 * M * Nc) + 4 * K * Nc, shape="dgrad+red M%d K%d N%d" % (M, K, Nc))))
                 elif (os.environ.get("MNY_NO_REDFUSE") != "1" and os.environ.get("MNY_NO_REDADD") != "1"
                         and (not self.bf16 or os.environ.get("MNY_REDFUSE_BF16") == "1")
                         and prod is not None and prod.op in ("dw", "pw") and gs[i.id].buf is not None and last_consumer.get(i.id) is nd
@@ -871,12 +896,19 @@ class NetPlan:
                     rparts = _lib.query(K("mny_pw_dgrad_bnred_parts"), M, oc, i.C)
                     rbuf = torch.empty(rparts * 2 * i.C, **f32)
                     self.fused_red[i.id] = (rbuf, rparts)
-                    contribute_kernel(i, lambda out, addend, dY=dY, wT=wT, M=M, K=oc, Nc=i.C, pu=pu, rbuf=rbuf, act_=i.act: bwd.add(
-                        self.K("mny_pw_dgrad_bnred_add"), dY, wT, addend, out, pu.Y, pu.scale, pu.shift, act_, pu.mean, pu.invstd, rbuf, M, K, Nc, self.stream,
-                        meta=dict(flops=2 * M * K * Nc, bytes=self.eb * (M * K + 3 * M * Nc) + 4 * K * Nc, shape="dgrad+add+red M%d K%d N%d" % (M, K, Nc))))
+                    if wT6 is not None:
+                        contribute_kernel(i, lambda out, addend, dY=dY, wT6=wT6, M=M, K=oc, Nc=i.C, pu=pu, rbuf=rbuf, act_=i.act: bwd.add(
+                            "mny_pw_dgrad_bnred_w6", dY, wT6, addend, out, pu.Y, pu.scale, pu.shift, act_, pu.mean, pu.invstd, rbuf, M, K, Nc, self.stream,
+                            label="mny_pw_dgrad_bnred_add",
+                            meta=dict(flops=2 * M * K * Nc, bytes=self.eb * (M * K + 3 * M * Nc) + 4 * K * Nc, shape="dgrad+add+red M%d K%d N%d" % (M, K, Nc))))
+                    else:
+                        contribute_kernel(i, lambda out, addend, dY=dY, wT=wT, M=M, K=oc, Nc=i.C, pu=pu, rbuf=rbuf, act_=i.act: bwd.add(
+                            self.K("mny_pw_dgrad_bnred_add"), dY, wT, addend, out, pu.Y, pu.scale, pu.shift, act_, pu.mean, pu.invstd, rbuf, M, K, Nc, self.stream,
+                            meta=dict(flops=2 * M * K * Nc, bytes=self.eb * (M * K + 3 * M * Nc) + 4 * K * Nc, shape="dgrad+add+red M%d K%d N%d" % (M, K, Nc))))
                 else:
-                    contribute_kernel(i, lambda out, addend, dY=dY, wT=wT, M=M, K=oc, Nc=i.C: bwd.add(
-                        self.K("mny_pw_fwd"), dY, None, None, ACT_NONE, wT, None, addend, out, None, M, K, Nc, self.stream,
+                    contribute_kernel(i, lambda out, addend, dY=dY, wT=wT, wT6=wT6, M=M, K=oc, Nc=i.C: bwd.add(
+                        "mny_pw_fwd_w6" if wT6 is not None else self.K("mny_pw_fwd"), dY, None, None, ACT_NONE, wT6 if wT6 is not None else wT, None, addend, out, None,
+                        M, K, Nc, self.stream, label=self.K("mny_pw_fwd"),
                         meta=dict(flops=2 * M * K * Nc, bytes=self.eb * (M * K + M * Nc) + 4 * K * Nc, shape="dgrad M%d K%d N%d" % (M, K, Nc))))
             flush_shared()
             flush_reduce()
@@ -884,6 +916,32 @@ class NetPlan:
         flush_reduce(force=True)
 
     # ------------------------------------------------------------------------------------------
+    def _w6_planes(self, w2d, M, K, Nc):
+        """Plane buffer for the weight operand `w2d` ([Nc][K] fp32) of a GEMM that takes the six-product bf16 form (fp32 plans), or None."""
+        if self.bf16 or _lib.query("mny_pw_w6_supported", M, K, Nc) != 1:
+            return None
+        planes = torch.empty(_lib.query("mny_pw_w6_bytes", K, Nc), device=self.dev, dtype=torch.uint8)
+        self._cut_jobs.append((w2d, planes, Nc, K))
+        return planes
+
+    def _flush_cut_jobs(self, calls, at_head=False):
+        """One mny_cut3_batch launch for the pending (matrix, planes) pairs; at_head: placed first in the list (forward weights)."""
+        if not self._cut_jobs:
+            return
+        import numpy as np
+        jobs, block_job = [], []
+        for src, planes, R, C in self._cut_jobs:
+            jobs.append((src.data_ptr(), planes.data_ptr(), R, C, len(block_job), 0))
+            block_job += [len(jobs) - 1] * ((R * ((C + 15) // 16) * 2 + 255) // 256)
+        jt = np.array(jobs, dtype=np.dtype([("src", np.uint64), ("dst", np.uint64), ("R", np.int32), ("C", np.int32), ("b0", np.int32), ("pad", np.int32)]))
+        jd = torch.from_numpy(jt.view(np.uint8).copy()).to(self.dev)
+        bj = torch.tensor(block_job, dtype=torch.int32, device=self.dev)
+        calls.add("mny_cut3_batch", jd, bj, len(block_job), self.stream)
+        if at_head:
+            calls.calls.insert(0, calls.calls.pop())
+        calls.keep += [t for job in self._cut_jobs for t in job[:2]]
+        self._cut_jobs = []
+
     def _gemm_weight(self, w):
         """Weight operand of a forward pointwise GEMM: the fp32 parameter itself, or (bf16 storage) a bf16 shadow copy
         refreshed by a conversion call placed right before the GEMM — the fp32 master copy is what optimizers update."""

@@ -598,3 +598,69 @@ def test_six_product_bf16_gemms_are_fp32_accurate(ops, M, K, Nc):
     ref2 = a.double() @ w.double().t()
     rel = ((y2.view(M, Nc).double() - ref2).abs() / (a.double().abs() @ w.double().abs().t() + 1e-300)).max().item()
     assert rel <= 2e-6, rel                                   # row-wise relative to sum |a||w|: fp32-level
+
+
+def _cut3(mats):
+    """mny_cut3_batch over a list of fp32 [R][C] matrices -> list of plane buffers"""
+    import ctypes
+    from mobilenet_yolo_pytorch_amd import _lib
+    outs, jobs, block_job = [], [], []
+    for i, m in enumerate(mats):
+        R, C = m.shape
+        out = torch.full((_lib.query("mny_pw_w6_bytes", C, R),), 0x7f, dtype=torch.uint8, device="cuda")
+        outs.append(out)
+        jobs.append((m.data_ptr(), out.data_ptr(), R, C, len(block_job), 0))
+        block_job += [i] * ((R * ((C + 15) // 16) * 2 + 255) // 256)
+    jt = np.array(jobs, dtype=np.dtype([("src", np.uint64), ("dst", np.uint64), ("R", np.int32), ("C", np.int32), ("b0", np.int32), ("pad", np.int32)]))
+    jd = torch.from_numpy(jt.view(np.uint8).copy()).cuda()
+    bj = torch.tensor(block_job, dtype=torch.int32, device="cuda")
+    _lib.call("mny_cut3_batch", ctypes.c_void_p(jd.data_ptr()), ctypes.c_void_p(bj.data_ptr()), len(block_job), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    return outs
+
+
+@pytest.mark.parametrize("M,K,Nc,act", [(4096, 512, 512, 1), (3001, 160, 960, 0), (2500, 960, 160, 2), (1000, 516, 384, 1), (777, 1280, 512, 1), (130, 320, 1280, 4)])
+def test_gemms_on_precut_weight_planes(ops, M, K, Nc, act):
+    """mny_pw_fwd_w6 / mny_pw_dgrad_bnred_w6 (weights cut once by mny_cut3_batch) against the fp64 product and against the in-kernel-cut
+    entry points they replace (same tiling, same partial rows)."""
+    import ctypes
+    from mobilenet_yolo_pytorch_amd import _lib
+    assert _lib.query("mny_pw_w6_supported", M, K, Nc) == 1
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None            # noqa: E731
+    x = rnd(M, K, seed=1).cuda()
+    w = (rnd(Nc, K, seed=2) * K ** -0.5).cuda()
+    sc, sh = (1 + 0.2 * rnd(K, seed=3)).cuda(), (0.3 * rnd(K, seed=4)).cuda()
+    w6, = _cut3([w])
+    parts = _lib.query("mny_pw_stat_parts", M, K, Nc)
+    y = torch.empty(M, Nc, device="cuda")
+    st = torch.full((parts, 2, Nc), float("nan"), device="cuda")
+    _lib.call("mny_pw_fwd_w6", p(x), p(sc), p(sh), act, p(w6), None, None, p(y), p(st), M, K, Nc, stream)
+    a = ACTS[act](x.double() * sc.double() + sh.double())
+    ref = a @ w.double().t()
+    rms = lambda t: t.pow(2).mean().sqrt().item()             # noqa: E731
+    assert rms(y.double() - ref) <= 1e-6 * rms(ref) and (y.double() - ref).abs().max().item() <= 3e-5 * rms(ref)
+    y0 = torch.empty(M, Nc, device="cuda")
+    st0 = torch.empty(parts, 2, Nc, device="cuda")
+    _lib.call("mny_pw_fwd", p(x), p(sc), p(sh), act, p(w), None, None, p(y0), p(st0), M, K, Nc, stream)
+    assert torch.equal(y, y0) and torch.equal(st, st0), "pre-cut and in-kernel cuts are the same arithmetic"
+    # bias + addend form (plain input)
+    b = rnd(Nc, seed=7).cuda()
+    add = rnd(M, Nc, seed=8).cuda()
+    buf = add.clone()
+    _lib.call("mny_pw_fwd_w6", p(x), None, None, 0, p(w6), p(b), p(buf), p(buf), None, M, K, Nc, stream)
+    ref2 = x.double() @ w.double().t() + b.double() + add.double()
+    assert rms(buf.double() - ref2) <= 1e-6 * rms(ref2)
+    # data gradient + BN-backward sums on W^T planes (x plays dy: [M, K] -> dx [M, Nc] with W^T rows [Nc][K] = w)
+    if act != 4 and _lib.query("mny_pw_dgrad_bnred_supported", M, K, Nc, act) == 1:
+        yraw = (rnd(M, Nc, seed=3) * 2).cuda()
+        c = [(1 + 0.3 * rnd(Nc, seed=4)).cuda(), (0.5 * rnd(Nc, seed=5)).cuda(), (0.2 * rnd(Nc, seed=6)).cuda(), (1 + 0.2 * rnd(Nc, seed=7).abs()).cuda()]
+        rparts = _lib.query("mny_pw_dgrad_bnred_parts", M, K, Nc)
+        dx, dx0 = torch.empty(M, Nc, device="cuda"), torch.empty(M, Nc, device="cuda")
+        red, red0 = torch.full((rparts, 2, Nc), float("nan"), device="cuda"), torch.empty(rparts, 2, Nc, device="cuda")
+        _lib.call("mny_pw_dgrad_bnred_w6", p(x), p(w6), None, p(dx), p(yraw), p(c[0]), p(c[1]), act, p(c[2]), p(c[3]), p(red), M, K, Nc, stream)
+        _lib.call("mny_pw_dgrad_bnred", p(x), p(w), p(dx0), p(yraw), p(c[0]), p(c[1]), act, p(c[2]), p(c[3]), p(red0), M, K, Nc, stream)
+        assert torch.equal(dx, dx0) and torch.equal(red, red0)
+        if _lib.query("mny_pw_dgrad_bnred_add_supported", M, K, Nc, act) == 1:
+            _lib.call("mny_pw_dgrad_bnred_w6", p(x), p(w6), p(add), p(dx), p(yraw), p(c[0]), p(c[1]), act, p(c[2]), p(c[3]), p(red), M, K, Nc, stream)
+            _lib.call("mny_pw_dgrad_bnred_add", p(x), p(w), p(add), p(dx0), p(yraw), p(c[0]), p(c[1]), act, p(c[2]), p(c[3]), p(red0), M, K, Nc, stream)
+            assert torch.equal(dx, dx0) and torch.equal(red, red0)
