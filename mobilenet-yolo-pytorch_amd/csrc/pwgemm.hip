@@ -464,11 +464,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
             bf16x8_t ah, am, al;
             x6_split(a0, a1, ah, am, al);
             if constexpr (X6 == 3) {
+                const float* src0 = stB + (2 * lrow + khalf) * 4;
+                v4f_t ph = lds_read_f4(src0), pm = lds_read_f4(src0 + TN * 256), pl = lds_read_f4(src0 + 2 * TN * 256);
+                MNY_LGKM_WAIT(ph); MNY_LGKM_DEP(pm); MNY_LGKM_DEP(pl);
 #pragma unroll
                 for (int u = 0; u < TN; ++u) {
-                    const float* src = stB + (u * 64 + 2 * lrow + khalf) * 4;
-                    v4f_t ph = lds_read_f4(src), pm = lds_read_f4(src + TN * 256), pl = lds_read_f4(src + 2 * TN * 256);
-                    MNY_LGKM_WAIT(ph); MNY_LGKM_DEP(pm); MNY_LGKM_DEP(pl);
+                    v4f_t nh, nm, nl;
+                    if (u + 1 < TN) {                             // the next column block's pieces are requested before this one's MFMAs
+                        const float* src = stB + ((u + 1) * 64 + 2 * lrow + khalf) * 4;
+                        nh = lds_read_f4(src); nm = lds_read_f4(src + TN * 256); nl = lds_read_f4(src + 2 * TN * 256);
+                    }
                     const bf16x8_t bh = __builtin_bit_cast(bf16x8_t, ph), bm = __builtin_bit_cast(bf16x8_t, pm), bl = __builtin_bit_cast(bf16x8_t, pl);
                     acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[u], 0, 0, 0);
                     acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[u], 0, 0, 0);
@@ -476,6 +481,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                     acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[u], 0, 0, 0);
                     acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[u], 0, 0, 0);
                     acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[u], 0, 0, 0);
+                    if (u + 1 < TN) { MNY_LGKM_WAIT(nh); MNY_LGKM_DEP(nm); MNY_LGKM_DEP(nl); ph = nh; pm = nm; pl = nl; }
                 }
                 return;
             }
