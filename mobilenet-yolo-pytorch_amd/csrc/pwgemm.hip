@@ -2050,6 +2050,186 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// stage 2, second generation: no LDS ring, no barrier in the loop.
+// The DMA-ring kernel above streams G at 3.9 TB/s: a 64-row step is 12 KB per workgroup behind a barrier, two of them in flight,
+// and the matrix pipe idles on memory latency (replacing its MFMAs by the six-product bf16 form changed nothing).  A wave can
+// instead load the A operand of v_mfma_f32_32x32x16_bf16 STRAIGHT from the row-major tensor — lane (row i, half h) owns, per
+// 16-column stage, the two 16-B chunks 16s + 4h.. and 16s + 8 + 4h.. of row i — and that access pattern streams at the copy rate
+// (tools/probe/rowfrag_probe.hip: 5.3-5.5 TB/s for N = 96 / 144 / 192, as fast as a row-linear float4 stream).  So: one wave =
+// one 32-row tile at a time, all of its G fragments (2 * N/16 float4 per lane) in registers, each pair re-requested for the wave's
+// NEXT tile the moment it has been cut (rolling prefetch: a full tile of loads always in flight, one buffer); the small operands
+// (B1 = ca o W^T [Kc][N], Q [Kc][Kc]) are cut into bf16 planes ONCE per workgroup into LDS in MFMA-operand order; products in the
+// six-product form (x6_split), two accumulators (even / odd stages); epilogue = the DPP quad transpose of the first generation.
+// N % 16 == 0, N <= 192, Kc <= 32.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NS>
+__global__ __launch_bounds__(256) void pw_bnbwd_dgrad2_kernel(BndArgs p) {
+    constexpr int N = NS * 16, NW = (N + 31) / 32;               // mask words (32 columns each) per row
+    __shared__ __attribute__((aligned(16))) float sB[(NS + 2) * 3 * 256];     // [stage][piece][lane] 16-B slots; stages NS, NS+1 = Q
+    __shared__ __attribute__((aligned(16))) float sXs[32];
+    __shared__ __attribute__((aligned(16))) float sXh[32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 31, khalf = lane >> 5;
+    const int Kc = p.Kc;
+    const int XS = (Kc + 15) / 16;                               // stages of the (X, Q) product
+    // ---- cut the small operands once per workgroup ----
+    for (int c = tid; c < (NS + 2) * 64; c += 256) {
+        const int sidx = c >> 6, l = c & 63, j = l & 31, h = l >> 5;
+        const bool isq = sidx >= NS;
+        const int st = isq ? sidx - NS : sidx;
+        const int width = isq ? Kc : N;
+        const float* src = (isq ? p.Q : p.B1) + (int64_t)j * width;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = st * 16 + (e < 4 ? 4 * h + e : 8 + 4 * h + (e - 4));
+            v[e] = (j < Kc && k < width) ? src[k] : 0.f;
+        }
+        bf16x8_t hh, mm, ll;
+        x6_split(v4f_t{v[0], v[1], v[2], v[3]}, v4f_t{v[4], v[5], v[6], v[7]}, hh, mm, ll);
+        float* dst = sB + (sidx * 3) * 256 + l * 4;
+        *reinterpret_cast<v4f_t*>(dst) = __builtin_bit_cast(v4f_t, hh);
+        *reinterpret_cast<v4f_t*>(dst + 256) = __builtin_bit_cast(v4f_t, mm);
+        *reinterpret_cast<v4f_t*>(dst + 512) = __builtin_bit_cast(v4f_t, ll);
+    }
+    if (tid < 32) {
+        sXs[tid] = (p.xsc && tid < Kc) ? p.xsc[tid] : (tid < Kc ? 1.f : 0.f);
+        sXh[tid] = (p.xsc && tid < Kc) ? p.xsh[tid] : 0.f;
+    }
+    __syncthreads();
+    const float aslope = act_slope(p.act), xslope = act_slope(p.xact), xhi = act_hi(p.xact);
+    const int quad = lrow >> 2, jq = lane & 3;
+    const int colq = quad * 4;
+    const bool cok = colq < Kc;
+    const int colc = cok ? colq : 0;
+    const float4 bv = ld4(p.bias + colc);
+    const unsigned* mask32 = reinterpret_cast<const unsigned*>(p.mask);
+    const int64_t mstride = 2 * p.npairs;                        // 32-bit mask words per 32-column tile
+
+    const int64_t ntiles = (p.M + 31) / 32;
+    const int64_t stride = (int64_t)gridDim.x * 4;
+    float4 g[2 * NS], xr[4], ad[4];
+    unsigned mk[NW];
+    auto row_of = [&](int64_t tile) { const int64_t r = tile * 32 + lrow; return r < p.M ? r : p.M - 1; };
+    auto load_g = [&](int64_t tile, int s) {
+        const float* row = p.G + row_of(tile) * N + 16 * s + 4 * khalf;
+        g[2 * s] = ld4(row); g[2 * s + 1] = ld4(row + 8);
+    };
+    auto load_mx = [&](int64_t tile) {                           // mask words and the thin X row of the lane
+        const int64_t r = row_of(tile);
+#pragma unroll
+        for (int w = 0; w < NW; ++w) mk[w] = mask32[(int64_t)w * mstride + r];
+        const float* xrow = p.X + r * Kc + 4 * khalf;
+        xr[0] = ld4(xrow); xr[1] = (8 + 4 * khalf < Kc) ? ld4(xrow + 8) : f4zero();
+        xr[2] = (16 + 4 * khalf < Kc) ? ld4(xrow + 16) : f4zero(); xr[3] = (24 + 4 * khalf < Kc) ? ld4(xrow + 24) : f4zero();
+    };
+    auto load_ad = [&](int64_t tile) {
+        if (p.addend) {
+            const int64_t m0 = tile * 32 + 4 * khalf + jq;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) { const int64_t r2 = m0 + 8 * gq; ad[gq] = ld4(p.addend + (r2 < p.M ? r2 : p.M - 1) * Kc + colc); }
+        }
+    };
+    int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+    if (tile < ntiles) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) load_g(tile, s);
+        load_mx(tile);
+        load_ad(tile);
+    }
+    for (; tile < ntiles; tile += stride) {
+        const int64_t next = tile + stride < ntiles ? tile + stride : tile;      // past the end: harmless re-reads
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const float4 a0 = g[2 * s], a1 = g[2 * s + 1];
+            const unsigned word = mk[s >> 1] >> (16 * (s & 1) + 4 * khalf);
+            float z[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                z[e] = ((word >> e) & 1u) ? z[e] : z[e] * aslope;
+                z[4 + e] = ((word >> (8 + e)) & 1u) ? z[4 + e] : z[4 + e] * aslope;
+            }
+            bf16x8_t ah, am, al;
+            x6_split(v4f_t{z[0], z[1], z[2], z[3]}, v4f_t{z[4], z[5], z[6], z[7]}, ah, am, al);
+            // this stage's registers are free: request them for the next tile — HERE, not earlier: without the fence the compiler hoists every
+            // load of the next tile to the top of the loop (SSA renames the registers) and the kernel needs two tiles of them (435 VGPRs)
+            asm volatile("" : "+v"(ah), "+v"(am), "+v"(al) :: "memory");
+            load_g(next, s);
+            const float* bsrc = sB + (s * 3) * 256 + lane * 4;
+            const bf16x8_t bh = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const v4f_t*>(bsrc));
+            const bf16x8_t bm = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const v4f_t*>(bsrc + 256));
+            const bf16x8_t bl = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const v4f_t*>(bsrc + 512));
+            f32x16& acc = (s & 1) ? acc1 : acc0;
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);                   // stages in order: the cuts of later stages would otherwise all be formed first
+        }
+        // the (act(X), Q) product
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            if (st < XS) {
+                const float4 a0 = xr[2 * st], a1 = xr[2 * st + 1];
+                float z[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                const float4 s0 = *reinterpret_cast<const float4*>(sXs + st * 16 + 4 * khalf), s1 = *reinterpret_cast<const float4*>(sXs + st * 16 + 8 + 4 * khalf);
+                const float4 h0 = *reinterpret_cast<const float4*>(sXh + st * 16 + 4 * khalf), h1 = *reinterpret_cast<const float4*>(sXh + st * 16 + 8 + 4 * khalf);
+                const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, hv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float t = fmaf(z[e], sv[e], hv[e]); z[e] = fminf(fmaxf(t, xslope * t), xhi); }
+                bf16x8_t ah, am, al;
+                x6_split(v4f_t{z[0], z[1], z[2], z[3]}, v4f_t{z[4], z[5], z[6], z[7]}, ah, am, al);
+                const float* bsrc = sB + ((NS + st) * 3) * 256 + lane * 4;
+                const bf16x8_t bh = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const v4f_t*>(bsrc));
+                const bf16x8_t bm = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const v4f_t*>(bsrc + 256));
+                const bf16x8_t bl = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const v4f_t*>(bsrc + 512));
+                f32x16& acc = st ? acc1 : acc0;
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bm, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+            }
+        }
+        asm volatile("" : "+v"(acc0), "+v"(acc1) :: "memory");     // (the next tile's small loads stay behind the last use of this tile's)
+        load_mx(next);
+        // epilogue: lane = output column lrow, registers = rows; DPP quad transpose -> lane jq of a quad holds row 8 gq + 4 khalf + jq, 4 columns
+        const int64_t m0 = tile * 32;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            float r0 = acc0[gq * 4 + 0] + acc1[gq * 4 + 0], r1 = acc0[gq * 4 + 1] + acc1[gq * 4 + 1];
+            float r2 = acc0[gq * 4 + 2] + acc1[gq * 4 + 2], r3 = acc0[gq * 4 + 3] + acc1[gq * 4 + 3];
+            {
+                const bool odd = lane & 1;
+                const float xa = odd ? r0 : r1, xb = odd ? r2 : r3;
+                const float ya = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, xa), 0xB1, 0xF, 0xF, true));
+                const float yb = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, xb), 0xB1, 0xF, 0xF, true));
+                if (odd) { r0 = ya; r2 = yb; } else { r1 = ya; r3 = yb; }
+            }
+            {
+                const bool hi2 = lane & 2;
+                const float xa = hi2 ? r0 : r2, xb = hi2 ? r1 : r3;
+                const float ya = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, xa), 0x4E, 0xF, 0xF, true));
+                const float yb = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, xb), 0x4E, 0xF, 0xF, true));
+                if (hi2) { r0 = ya; r1 = yb; } else { r2 = ya; r3 = yb; }
+            }
+            float4 o = make_float4(r0 + bv.x, r1 + bv.y, r2 + bv.z, r3 + bv.w);
+            if (p.addend) { o.x += ad[gq].x; o.y += ad[gq].y; o.z += ad[gq].z; o.w += ad[gq].w; }
+            const int64_t row = m0 + 8 * gq + 4 * khalf + jq;
+            if (cok && row < p.M) st4_stream(p.C + row * Kc + colq, o);
+        }
+        asm volatile("" ::: "memory");
+        load_ad(next);
+    }
+}
+
 struct BnwPlan { int TI, splits; int64_t rows_per_block; size_t lds1, lds2; int gx2, tiles_per_block, m_tiles; int TIs, nsl; };
 
 static bool bnw_supported(int64_t M, int K, int N) {
@@ -2513,6 +2693,16 @@ extern "C" int mny_pw_bnbwd(const float* g, const float* y, const float* scale, 
         attr = true;
     }
     BndArgs d{g, mask, act, x, in_scale, in_shift, in_act, B1, Q, bias, addend, dx, npairs, M, Nc, K, pl.TI, pl.m_tiles, pl.tiles_per_block};
+    static const int v2 = getenv("MNY_BND_V2") ? atoi(getenv("MNY_BND_V2")) : 1;
+    static const int v2_grid = getenv("MNY_BND_V2_GRID") ? atoi(getenv("MNY_BND_V2_GRID")) : 512;
+    if (v2 && (Nc == 96 || Nc == 144 || Nc == 192)) {             // second generation: barrier-free direct fragment loads (N % 16 == 0 instantiations)
+        const int64_t tiles = cdiv(M, 32);
+        const int grid = (int)(cdiv(tiles, 4) < v2_grid ? cdiv(tiles, 4) : v2_grid);
+        if (Nc == 96) hipLaunchKernelGGL(pw_bnbwd_dgrad2_kernel<6>, dim3(grid), dim3(256), 0, st, d);
+        else if (Nc == 144) hipLaunchKernelGGL(pw_bnbwd_dgrad2_kernel<9>, dim3(grid), dim3(256), 0, st, d);
+        else hipLaunchKernelGGL(pw_bnbwd_dgrad2_kernel<12>, dim3(grid), dim3(256), 0, st, d);
+        return check_launch("pw_bnbwd_dgrad2_kernel");
+    }
     hipLaunchKernelGGL(pw_bnbwd_dgrad_kernel, dim3(pl.gx2), dim3(256), pl.lds2, st, d);
     return check_launch("pw_bnbwd_dgrad_kernel");
 }

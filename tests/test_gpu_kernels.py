@@ -200,7 +200,9 @@ def test_glue(ops):
                                              (4096, 32, 160, 3, 3),
                                              # tile-boundary / ragged shapes of the pipelined stages
                                              (4097, 4, 8, 1, 1), (4159, 20, 100, 2, 0), (5001, 32, 36, 1, 2), (4100, 8, 192, 3, 1),
-                                             (6007, 12, 132, 1, 3), (4223, 28, 32, 0, 0), (70001, 16, 96, 1, 1)])
+                                             (6007, 12, 132, 1, 3), (4223, 28, 32, 0, 0), (70001, 16, 96, 1, 1),
+                                             # several 32-row tiles per wave of the barrier-free data-gradient stage (N = 96 / 144 / 192)
+                                             (200003, 24, 144, 1, 1), (150001, 32, 192, 2, 1), (131077, 8, 96, 1, 0)])
 def test_fused_bn_backward_expand_unit(ops, M, K, Nc, act, xact):
     """dW, dgamma, dbeta, dX of conv1x1 -> BN(train) -> act from (G, Y, X) in 4 passes (no dY), vs torch autograd.
     Tolerance 5e-4 relative to the tensor max: the decomposition sums large terms that partly cancel."""
