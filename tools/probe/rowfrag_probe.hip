@@ -9,6 +9,36 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
+// MODE 2: reduction-major operand (weight-gradient orientation): lane (channel c = lane & 31, half h) reads, per 16-row group and 32-channel
+// block, eight DWORDS: rows 8h .. 8h + 7 of its channel (a wave instruction = two 128-B row segments)
+template <int NB>
+__global__ __launch_bounds__(256) void kcol(const float* __restrict__ g, float* __restrict__ out, long M) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int N = NB * 32;
+    const long ngroups = M / 16;
+    float acc = 0.f;
+    float cur[8 * NB], nxt[8 * NB];
+    auto load = [&](long grp, float (&r)[8 * NB]) {
+        const float* base = g + (grp * 16 + 8 * h) * N + c;
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) r[b * 8 + e] = base[(long)e * N + 32 * b];
+    };
+    long grp = (long)blockIdx.x * 4 + wave;
+    const long stride = (long)gridDim.x * 4;
+    if (grp < ngroups) load(grp, cur);
+    for (; grp < ngroups; grp += stride) {
+        if (grp + stride < ngroups) load(grp + stride, nxt);
+#pragma unroll
+        for (int s = 0; s < 8 * NB; ++s) acc += cur[s];
+#pragma unroll
+        for (int s = 0; s < 8 * NB; ++s) cur[s] = nxt[s];
+    }
+    out[(long)blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
 template <int NS, int MODE>      // NS = N / 16 stages; MODE 0: MFMA-fragment pattern, 1: plain row-linear float4 stream (reference)
 __global__ __launch_bounds__(256) void k(const float* __restrict__ g, float* __restrict__ out, long M, int blocks_rows) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -53,6 +83,18 @@ static void run(const float* g, float* out, long M, const char* name) {
     printf("%-28s N=%3d  %.3f ms  %.0f GB/s\n", name, NS * 16, ms, (double)M * NS * 16 * 4 / ms / 1e6);
 }
 
+template <int NB>
+static void runcol(const float* g, float* out, long M) {
+    const int grid = 256 * 2;
+    hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL((kcol<NB>), dim3(grid), dim3(256), 0, 0, g, out, M);
+    CK(hipEventRecord(a));
+    for (int r = 0; r < 10; ++r) hipLaunchKernelGGL((kcol<NB>), dim3(grid), dim3(256), 0, 0, g, out, M);
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms; CK(hipEventElapsedTime(&ms, a, b)); ms /= 10;
+    printf("%-28s N=%3d  %.3f ms  %.0f GB/s\n", "reduction-major dwords", NB * 32, ms, (double)M * NB * 32 * 4 / ms / 1e6);
+}
+
 int main(int argc, char** argv) {
     const long M = argc > 1 ? atol(argv[1]) : 7929856;
     float *g, *out;
@@ -61,5 +103,6 @@ int main(int argc, char** argv) {
     run<6, 0>(g, out, M, "fragment pattern"); run<6, 1>(g, out, M, "row-linear reference");
     run<9, 0>(g, out, M / 4, "fragment pattern"); run<9, 1>(g, out, M / 4, "row-linear reference");
     run<12, 0>(g, out, M / 16, "fragment pattern"); run<12, 1>(g, out, M / 16, "row-linear reference");
+    runcol<3>(g, out, M); runcol<6>(g, out, M / 16); runcol<1>(g, out, M);
     return 0;
 }
