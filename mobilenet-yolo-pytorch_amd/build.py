@@ -28,7 +28,7 @@ def _stale(target, deps):
 
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "mnyolo.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "x6.h"), os.path.join(HERE, "..", "include", "mnyolo.h")]
     jobs, objs = [], []
     for src in sources():
         s = os.path.join(CSRC, src)

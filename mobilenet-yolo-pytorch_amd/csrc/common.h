@@ -88,6 +88,14 @@ __device__ __forceinline__ void st4_stream(bf16_t* p, float4 v) {
     const mny_u2v t = {pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
     __builtin_nontemporal_store(t, reinterpret_cast<mny_u2v*>(p));
 }
+// uniform base + 32-bit BYTE offset: the form the compiler turns into `global_load/store v, v_off, s[base:base+1]`
+template <typename T> __device__ __forceinline__ T* at_bytes(T* base, unsigned byte_off) {
+    return (T*)((char*)base + byte_off);
+}
+template <typename T> __device__ __forceinline__ const T* at_bytes(const T* base, unsigned byte_off) {
+    return (const T*)((const char*)base + byte_off);
+}
+
 __device__ __forceinline__ float ld1(const float* p) { return *p; }
 __device__ __forceinline__ void st1(float* p, float v) { *p = v; }
 __device__ __forceinline__ float ld1(const bf16_t* p) { return __uint_as_float((uint32_t)p->v << 16); }
@@ -196,5 +204,12 @@ int pw_thin_parts(int64_t M, int K, int N, int red);
 int pw_thin_launch(int bf, const void* A, const float* in_scale, const float* in_shift, int in_act, const void* W, const float* bias,
                    const void* addend, void* C, float* stats, int64_t M, int K, int N, int red, const void* rY, const float* r_scale,
                    const float* r_shift, const float* r_mean, const float* r_invstd, int r_act, hipStream_t st);
+
+// short reduction feeding a wide output (K = 52..96, N >= K): barrier-free matrix-core kernel (pwwide.hip); fp32 storage only
+bool pw_wide_ok(int64_t M, int K, int N);
+int pw_wide_parts(int64_t M, int K, int N, bool red);       // partial rows of the whole 32-row tiles
+int pw_wide_launch(const float* A, const float* in_scale, const float* in_shift, int in_act, const float* W, float* C, float* stats,
+                   int64_t M, int K, int N, const float* rY, const float* r_scale, const float* r_shift, const float* r_mean,
+                   const float* r_invstd, int r_act, const float* addend, hipStream_t st);
 
 }  // namespace mny

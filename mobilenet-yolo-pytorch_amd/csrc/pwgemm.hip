@@ -28,10 +28,9 @@
 #include <mutex>
 
 #include "common.h"
+#include "x6.h"
 
 namespace mny {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 128;
 
@@ -261,37 +260,6 @@ struct Gemm2Args {   // A / B / addend / C: float* (BF = 0) or bf16_t* (BF = 1)
 //     The LDS image is the same in bytes (64-B rows of four 16-B chunks): a chunk is 4 fp32 or 8 bf16 k-values, a stage
 //     covers 16 or 32 k, and the lane's 16-B fragment read IS the bf16 MFMA operand (k-block = lane>>5), so the bf16
 //     main loop is 2 MFMAs per accumulator per stage instead of 16.
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-
-// X6 (fp32 operands only): the products run on the bf16 matrix cores.  Every fp32 operand is cut into three bf16 pieces by
-// truncation (top 8 significant bits, next 8, last 8: hi + mid + lo == the fp32 value EXACTLY), a bf16 x bf16 product is exact in
-// fp32, and six of the nine partial products are accumulated (lo*mid, mid*lo, lo*lo <= 2^-24 of the product are dropped): the
-// result differs from an fp32 FMA chain by about one fp32 rounding per product.  One v_mfma_f32_32x32x16_bf16 (32 cycles) covers a
-// whole 16-deep stage that takes eight v_mfma_f32_32x32x2_f32 (8 x 64 cycles): 6 x 32 = 192 matrix-pipe cycles instead of 512
-// per accumulator and stage; the cuts cost ~36 VALU instructions per 8-value fragment.
-__device__ __forceinline__ void x6_split(v4f_t x0, v4f_t x1, bf16x8_t& h, bf16x8_t& m, bf16x8_t& l) {
-    const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
-    float r1[8], r2[8];
-#pragma unroll
-    for (int e = 0; e < 8; e += 2) {                 // pairs: the subtractions are v_pk_add_f32
-        const v2f a = v2f{x[e], x[e + 1]};
-        const v2f ah = v2f{__uint_as_float(__float_as_uint(x[e]) & 0xffff0000u), __uint_as_float(__float_as_uint(x[e + 1]) & 0xffff0000u)};
-        const v2f b = a - ah;                        // exact: the low 16 mantissa bits
-        const v2f bh = v2f{__uint_as_float(__float_as_uint(b.x) & 0xffff0000u), __uint_as_float(__float_as_uint(b.y) & 0xffff0000u)};
-        const v2f c = b - bh;
-        r1[e] = b.x; r1[e + 1] = b.y; r2[e] = c.x; r2[e + 1] = c.y;
-    }
-    v4u_t hu, mu, lu;
-    // v_perm_b32: (odd element's high half << 16) | even element's high half == two truncated bf16 values
-    hu.x = __builtin_amdgcn_perm(__float_as_uint(x[1]), __float_as_uint(x[0]), 0x07060302u); hu.y = __builtin_amdgcn_perm(__float_as_uint(x[3]), __float_as_uint(x[2]), 0x07060302u);
-    hu.z = __builtin_amdgcn_perm(__float_as_uint(x[5]), __float_as_uint(x[4]), 0x07060302u); hu.w = __builtin_amdgcn_perm(__float_as_uint(x[7]), __float_as_uint(x[6]), 0x07060302u);
-    mu.x = __builtin_amdgcn_perm(__float_as_uint(r1[1]), __float_as_uint(r1[0]), 0x07060302u); mu.y = __builtin_amdgcn_perm(__float_as_uint(r1[3]), __float_as_uint(r1[2]), 0x07060302u);
-    mu.z = __builtin_amdgcn_perm(__float_as_uint(r1[5]), __float_as_uint(r1[4]), 0x07060302u); mu.w = __builtin_amdgcn_perm(__float_as_uint(r1[7]), __float_as_uint(r1[6]), 0x07060302u);
-    lu.x = __builtin_amdgcn_perm(__float_as_uint(r2[1]), __float_as_uint(r2[0]), 0x07060302u); lu.y = __builtin_amdgcn_perm(__float_as_uint(r2[3]), __float_as_uint(r2[2]), 0x07060302u);
-    lu.z = __builtin_amdgcn_perm(__float_as_uint(r2[5]), __float_as_uint(r2[4]), 0x07060302u); lu.w = __builtin_amdgcn_perm(__float_as_uint(r2[7]), __float_as_uint(r2[6]), 0x07060302u);
-    h = __builtin_bit_cast(bf16x8_t, hu); m = __builtin_bit_cast(bf16x8_t, mu); l = __builtin_bit_cast(bf16x8_t, lu);
-}
-
 template <int TN, int XF, int BF, int RED = 0, int X6 = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void pw_gemm_nt_dma_kernel(Gemm2Args p) {
     using T = typename std::conditional<BF != 0, bf16_t, float>::type;
@@ -550,6 +518,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     // 4q..4q+3 -> one 16-byte store (4x fewer store instructions, full 128-B row segments per quad-row).
     const int quad = lrow >> 2, jq = lane & 3;
     const bool nvec = (p.N & 3) == 0;
+    const T* pAddS = RED == 2 ? nullptr : pAdd;          // RED = 2 folds the addend into the accumulators ahead of the transposes
+    float ry[RED ? 16 : 1], ra[RED == 2 ? 16 : 1];       // reduction epilogue: raw output / addend of the current column block, MFMA layout
+    // (wave-uniform row base in SGPRs + one 32-bit byte offset per load: sixteen 64-bit row pointers would cost 32 VGPRs)
+    auto red_load = [&](int u, int64_t m0) {
+        const int col = n0 + u * 32 + lrow;
+        const int cc = col < p.N ? col : 0;
+        const int64_t wrow = m0 + wv * 32;
+        const int rl0 = (int)max((int64_t)0, min((int64_t)32, p.M - wrow));      // rows of this wave's 32 inside M
+        const int lim = rl0 > 0 ? rl0 - 1 : 0;
+        const unsigned rowb = (unsigned)p.N * (unsigned)sizeof(T), colb = (unsigned)cc * (unsigned)sizeof(T);
+        const T* ub = (const T*)p.rY + (rl0 > 0 ? wrow : 0) * p.N;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rw = 8 * (r >> 2) + (r & 3) + 4 * khalf;
+            unsigned off = (unsigned)min(rw, lim) * rowb + colb;
+            asm volatile("" : "+v"(off));
+            ry[r] = ld1(at_bytes(ub, off));
+        }
+        if constexpr (RED == 2) {
+            const T* ua = pAdd + (rl0 > 0 ? wrow : 0) * p.N;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rw = 8 * (r >> 2) + (r & 3) + 4 * khalf;
+                unsigned off = (unsigned)min(rw, lim) * rowb + colb;
+                asm volatile("" : "+v"(off));
+                ra[r] = ld1(at_bytes(ua, off));
+            }
+        }
+    };
     auto epilogue = [&](int mt) {
         const int64_t m0 = (int64_t)mt * BM;
 #pragma unroll
@@ -567,33 +564,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                 }
             }
             if (RED) {                                            // BN-backward sums of the unit this gradient belongs to
+                // The unit's raw output (and, RED = 2, the earlier contributions to the same gradient) are read in the MFMA layout:
+                // lane = column, 16 rows.  All 16 (32) loads of a column block are in flight at once, and the NEXT block's are
+                // issued before this block's transposes and stores, so a tile exposes one load round trip instead of 4 * TN
+                // (the thin-K, wide-N data gradients of the project convs were bound by exactly that latency).
                 const int col = n0 + u * 32 + lrow;
                 const bool ccol = col < p.N;
                 const int cc = ccol ? col : 0;
                 const float rsc = p.r_scale[cc], rsh = p.r_shift[cc], rmu = p.r_mean[cc], ris = p.r_invstd[cc];
                 const float rslope = act_slope(p.r_act), rhi = act_hi(p.r_act);
-                const int64_t rbase = m0 + wv * 32 + 4 * khalf;
-                const int rows_left = (int)max((int64_t)0, min((int64_t)64, p.M - rbase));   // rows rbase + 8*gq + j, 8*gq + j < rows_left, exist
-                const T* ybase = (const T*)p.rY + (rows_left > 0 ? rbase : 0) * p.N + cc;
-                const T* abase = RED == 2 ? pAdd + (rows_left > 0 ? rbase : 0) * p.N + cc : nullptr;   // RED = 2: earlier contributions to the same gradient
+                const int rl0 = (int)max((int64_t)0, min((int64_t)32, p.M - (m0 + wv * 32)));     // rows of this wave's 32 inside M
+                if (u == 0) red_load(0, m0);
 #pragma unroll
-                for (int gq = 0; gq < 4; ++gq) {                  // four rows at a time: the loads of a group are all that is in flight
-                    float yv[4], av[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) yv[j] = ld1(ybase + (ccol && 8 * gq + j < rows_left ? 8 * gq + j : 0) * p.N);
-                    if (RED == 2) {                               // the sums are over the COMPLETE gradient = product + addend
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) av[j] = ld1(abase + (ccol && 8 * gq + j < rows_left ? 8 * gq + j : 0) * p.N);
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float z = fmaf(yv[j], rsc, rsh);
-                        const float dact = p.r_act >= MNY_ACT_HSWISH ? act_bwd(z, p.r_act) : (z > 0.f ? 1.f : rslope) * (z < rhi ? 1.f : 0.f);
-                        const float dz = stored<T>(acc[u][gq * 4 + j] + av[j]) * dact;
-                        if (ccol && 8 * gq + j < rows_left) { s1[u] += dz; s2[u] = fmaf(dz, (yv[j] - rmu) * ris, s2[u]); }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int r = 0; r < 16; ++r) {
+                    const int rw = 8 * (r >> 2) + (r & 3) + 4 * khalf;
+                    const float z = fmaf(ry[r], rsc, rsh);
+                    const float dact = p.r_act >= MNY_ACT_HSWISH ? act_bwd(z, p.r_act) : (z > 0.f ? 1.f : rslope) * (z < rhi ? 1.f : 0.f);
+                    if (RED == 2) acc[u][r] += ra[r];             // the sums are over the COMPLETE gradient = product + addend (stored below as such)
+                    const float dz = stored<T>(acc[u][r]) * dact;
+                    if (ccol && rw < rl0) { s1[u] += dz; s2[u] = fmaf(dz, (ry[r] - rmu) * ris, s2[u]); }
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                if (u + 1 < TN) { red_load(u + 1, m0); __builtin_amdgcn_sched_barrier(0); }
             } else if (p.stats) {                                 // column sums come from the un-transposed registers
                 const bool ccol = n0 + u * 32 + lrow < p.N;
                 if (m0 + BM <= p.M) {                             // whole tile inside M (all but the last one): packed pairs, no row tests
@@ -636,13 +628,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                     float4 v = make_float4(r0, r1, r2, r3);
                     if (p.bias) { v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }        // wave-uniform: only the two head convs carry a bias
                     if (nvec) {
-                        if (pAdd) add4(v, ld4(pAdd + row * p.N + colq));
+                        if (pAddS) add4(v, ld4(pAddS + row * p.N + colq));
                         st4_stream(pC + row * p.N + colq, v);
                     } else {
                         // ragged width (75-channel heads, 10-channel gate): rows are not 16-B aligned -> up to four element stores
                         // off ONE address (the transposed layout keeps this cheap: one row, consecutive columns)
                         T* dst = pC + row * p.N + colq;
-                        const T* ad = pAdd ? pAdd + row * p.N + colq : nullptr;
+                        const T* ad = pAddS ? pAddS + row * p.N + colq : nullptr;
                         st1(dst, v.x + (ad ? ld1(ad) : 0.f));
                         if (colq + 1 < p.N) st1(dst + 1, v.y + (ad ? ld1(ad + 1) : 0.f));
                         if (colq + 2 < p.N) st1(dst + 2, v.z + (ad ? ld1(ad + 2) : 0.f));
@@ -2269,6 +2261,7 @@ using namespace mny;
 extern "C" int mny_pw_stat_parts(int64_t M, int K, int Nc) {
     if (M <= 0 || K <= 0 || Nc <= 0) return MNY_EINVAL;
     if (pw_thin_ok(0, 0, M, K, Nc)) return pw_thin_parts(M, K, Nc, 0);
+    if (pw_wide_ok(M, K, Nc)) return pw_wide_parts(M, K, Nc, false) + ((M & 31) ? nt2_plan(M & 31, K, Nc, true).gx : 0);      // + the last M % 32 rows
     if ((K & 3) == 0 && getenv("MNY_GEMM_V1") == nullptr) return nt2_plan(M, K, Nc, true).gx;
     return nt_plan(M, K, Nc).gx;
 }
@@ -2319,6 +2312,17 @@ extern "C" int mny_pw_fwd(const float* x, const float* in_scale, const float* in
     static const bool force_v1 = getenv("MNY_GEMM_V1") != nullptr;   // A/B switch for profiling
     if (pw_thin_ok(0, 0, M, K, Nc))                        // short reduction: vector-ALU stream kernel (pwthin.hip)
         return pw_thin_launch(0, x, in_scale, in_shift, in_act, w, bias, addend, y, stats, M, K, Nc, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, st);
+    if (pw_wide_ok(M, K, Nc)) {                     // short reduction, wide output: barrier-free matrix-core kernel (pwwide.hip)
+        if (!bias && !addend && in_act != MNY_ACT_HSIGMOID) {
+            const int64_t Mf = M & ~(int64_t)31;    // it takes whole 32-row tiles; the last M % 32 rows follow below (one more partial row)
+            const int rc = pw_wide_launch(x, in_scale, in_shift, in_act, w, y, stats, Mf, K, Nc, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, st);
+            if (rc != 0 || Mf == M) return rc;
+            if (stats) stats += (int64_t)pw_wide_parts(M, K, Nc, false) * 2 * Nc;
+            x += Mf * K; y += Mf * Nc; M -= Mf;
+        } else {
+            MNY_REQUIRE(!stats, "pw_fwd: statistics with a bias / addend / h-sigmoid input on a wide-kernel shape");   // (its partial rows follow mny_pw_stat_parts)
+        }
+    }
     if ((K & 3) == 0 && !force_v1) {                // LDS-DMA pipeline (v2): 16-B aligned input rows
         Nt2Plan p2 = nt2_plan(M, K, Nc, xf);
         MNY_REQUIRE(p2.lds <= 64 * 1024, "pw_fwd: K=%d too large for the LDS scale cache", K);
@@ -2347,6 +2351,7 @@ extern "C" int mny_pw_dgrad_bnred_supported(int64_t M, int K, int Nc, int act) {
 extern "C" int mny_pw_dgrad_bnred_parts(int64_t M, int K, int Nc) {
     if (M <= 0 || K <= 0 || Nc <= 0 || (K & 3)) return MNY_EINVAL;
     if (pw_thin_ok(0, 1, M, K, Nc)) return pw_thin_parts(M, K, Nc, 1);
+    if (pw_wide_ok(M, K, Nc)) return pw_wide_parts(M, K, Nc, true) + ((M & 31) ? nt2_plan(M & 31, K, Nc, false, 0, kRedMaxTn).gx : 0);
     return nt2_plan(M, K, Nc, false, 0, kRedMaxTn).gx;
 }
 template <int BF>
@@ -2358,6 +2363,16 @@ static int pw_dgrad_bnred_impl(const void* dy, const void* wT, void* dx, const v
     if (pw_thin_ok(BF, 1, M, K, Nc))
         return pw_thin_launch(BF, dy, nullptr, nullptr, MNY_ACT_NONE, wT, nullptr, addend, dx, red, M, K, Nc, addend ? 2 : 1, y, scale, shift, mean, invstd, act,
                               (hipStream_t)stream);
+    if (!BF && pw_wide_ok(M, K, Nc)) {              // whole 32-row tiles on the barrier-free kernel, the last M % 32 rows below (one more partial row)
+        const int64_t Mf = M & ~(int64_t)31;
+        const int rc = pw_wide_launch((const float*)dy, nullptr, nullptr, MNY_ACT_NONE, (const float*)wT, (float*)dx, red, Mf, K, Nc, (const float*)y, scale, shift,
+                                      mean, invstd, act, (const float*)addend, (hipStream_t)stream);
+        if (rc != 0 || Mf == M) return rc;
+        red += (int64_t)pw_wide_parts(M, K, Nc, true) * 2 * Nc;
+        dy = (const float*)dy + Mf * K; dx = (float*)dx + Mf * Nc; y = (const float*)y + Mf * Nc;
+        if (addend) addend = (const float*)addend + Mf * Nc;
+        M -= Mf;
+    }
     Nt2Plan p2 = nt2_plan(M, K, Nc, false, BF, kRedMaxTn);
     MNY_REQUIRE(p2.lds <= 64 * 1024, "pw_dgrad_bnred: K=%d too large", K);
     Gemm2Args g{dy, nullptr, nullptr, MNY_ACT_NONE, wT, nullptr, addend, dx, red, M, K, Nc, p2.m_tiles, p2.tiles_per_block, p2.gx, p2.n_tiles,
@@ -2386,7 +2401,7 @@ extern "C" int mny_pw_dgrad_bnred(const float* dy, const float* wT, float* dx, c
 }
 // the addend variant exists for column tiles of <= 96 (TN <= 3: the 128-column tile has no registers left for the addend loads)
 extern "C" int mny_pw_dgrad_bnred_add_supported(int64_t M, int K, int Nc, int act) {
-    return dgrad_bnred_ok(M, K, Nc, act) && (pw_thin_ok(0, 1, M, K, Nc) || nt2_plan(M, K, Nc, false, 0, kRedMaxTn).TN <= 3) ? 1 : 0;
+    return dgrad_bnred_ok(M, K, Nc, act) && (pw_thin_ok(0, 1, M, K, Nc) || pw_wide_ok(M, K, Nc) || nt2_plan(M, K, Nc, false, 0, kRedMaxTn).TN <= 3) ? 1 : 0;
 }
 extern "C" int mny_pw_dgrad_bnred_add_supported_bf16(int64_t M, int K, int Nc, int act) {
     return dgrad_bnred_ok(M, K, Nc, act) && (K & 7) == 0 && (pw_thin_ok(1, 1, M, K, Nc) || nt2_plan(M, K, Nc, false, 1, kRedMaxTn).TN <= 3) ? 1 : 0;
@@ -2421,7 +2436,7 @@ static bool w6_ok(int64_t M, int K, int Nc) {
     static const bool off = getenv("MNY_NO_W6") != nullptr;
     static const double min_ai = getenv("MNY_W6_AI") ? atof(getenv("MNY_W6_AI")) : 50.0;
     const double ai = 2.0 * K * Nc / (4.0 * (K + Nc));
-    return !off && M > 0 && K > 0 && Nc > 0 && (K & 3) == 0 && !pw_thin_ok(0, 0, M, K, Nc) && nt_x6(M, K, Nc) != 0 && ai >= min_ai &&
+    return !off && M > 0 && K > 0 && Nc > 0 && (K & 3) == 0 && !pw_thin_ok(0, 0, M, K, Nc) && !pw_wide_ok(M, K, Nc) && nt_x6(M, K, Nc) != 0 && ai >= min_ai &&
            getenv("MNY_GEMM_V1") == nullptr;
 }
 extern "C" int mny_pw_w6_supported(int64_t M, int K, int Nc) { return w6_ok(M, K, Nc) ? 1 : 0; }

@@ -27,14 +27,6 @@ struct ThinArgs {
     const void* rY; const float* r_scale; const float* r_shift; const float* r_mean; const float* r_invstd; int r_act;
 };
 
-// uniform base + 32-bit BYTE offset: the form the compiler turns into `global_load/store v, v_off, s[base:base+1]`
-template <typename T> __device__ __forceinline__ T* at_bytes(T* base, unsigned byte_off) {
-    return (T*)((char*)base + byte_off);
-}
-template <typename T> __device__ __forceinline__ const T* at_bytes(const T* base, unsigned byte_off) {
-    return (const T*)((const char*)base + byte_off);
-}
-
 // four stored elements as they sit in memory: widening a bf16 load where it is issued would put the wait for it there too
 template <typename T> struct Raw4;
 template <> struct Raw4<float> { typedef float4 type; };

@@ -1,5 +1,7 @@
 """Per-kernel parity on a real MI355X: every HIP kernel, called through the C ABI, against a plain
 torch-CPU fp32 reference of the same op (floating-point kernels; tolerance stated per test)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -666,3 +668,56 @@ def test_gemms_on_precut_weight_planes(ops, M, K, Nc, act):
             _lib.call("mny_pw_dgrad_bnred_w6", p(x), p(w6), p(add), p(dx), p(yraw), p(c[0]), p(c[1]), act, p(c[2]), p(c[3]), p(red), M, K, Nc, stream)
             _lib.call("mny_pw_dgrad_bnred_add", p(x), p(w), p(add), p(dx0), p(yraw), p(c[0]), p(c[1]), act, p(c[2]), p(c[3]), p(red0), M, K, Nc, stream)
             assert torch.equal(dx, dx0) and torch.equal(red, red0)
+
+
+@pytest.mark.parametrize("M,K,Nc,act", [(8192, 64, 384, 1), (12345, 96, 576, 1), (9001, 76, 512, 2), (8200, 96, 96, 0), (10007, 64, 200, 4), (8195, 80, 1024, 3),
+                                        (16411, 56, 64, 1)])
+def test_wide_output_pointwise_kernel(ops, M, K, Nc, act):
+    """K = 52..96 reduction, N >= K outputs, M >= 8192 rows: mny_pw_fwd / mny_pw_dgrad_bnred[_add] run the barrier-free matrix-core kernel
+    (pwwide.hip): forward with input transform + column statistics, plain product, data gradient + BN-backward sums (with and without
+    an addend), ragged row counts, column counts that are no multiple of the column block, a reduction that is no multiple of 16."""
+    import ctypes
+    from mobilenet_yolo_pytorch_amd import _lib
+    assert os.environ.get("MNY_NO_WIDE") is None
+    x = rnd(M, K, seed=1)
+    w = rnd(Nc, K, seed=2, scale=K ** -0.5)
+    sc, sh = 1 + 0.2 * rnd(K, seed=3), 0.3 * rnd(K, seed=4)
+    a = ACTS[act](x.double() * sc.double() + sh.double())
+    yref = a @ w.double().t()
+    xs = x.view(1, 1, M, K).cuda()
+    got, st = ops.pw_fwd((xs, sc.cuda(), sh.cuda(), act), w.cuda(), want_stats=True)
+    check(got.view(M, Nc), yref, 2e-5, 2e-5, "wide fwd")
+    assert st.shape[0] == _lib.query("mny_pw_stat_parts", M, K, Nc)
+    s1, s2 = stats_got(st)
+    gd = got.view(M, Nc).double().cpu()
+    check(s1, gd.sum(0), 1e-5, 2e-3, "wide stats sum")              # against the kernel's own output: isolates the statistics
+    check(s2, (gd ** 2).sum(0), 1e-5, 2e-3, "wide stats sumsq")
+    got2, _ = ops.pw_fwd((xs, None, None, 0), w.cuda(), want_stats=False)
+    check(got2.view(M, Nc), x.double() @ w.double().t(), 2e-5, 2e-5, "wide plain")
+    # data gradient of a conv [Cout=K][Cin=Nc] + the BN-backward sums of the unit it feeds
+    dy = rnd(M, K, seed=11).cuda()
+    wg = rnd(K, Nc, seed=12) / K ** 0.5
+    y = (rnd(M, Nc, seed=13) * 2).cuda()
+    scale, shift = (1 + 0.3 * rnd(Nc, seed=14)).cuda(), (0.5 * rnd(Nc, seed=15)).cuda()
+    mean, invstd = (0.2 * rnd(Nc, seed=16)).cuda(), (1 + 0.2 * rnd(Nc, seed=17).abs()).cuda()
+    wT = ops.transpose(wg.cuda())
+    p = lambda t: ctypes.c_void_p(t.data_ptr())                          # noqa: E731
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    parts = _lib.query("mny_bn_bwd_parts", M, Nc)
+    for add in (None, rnd(M, Nc, seed=18).cuda()):
+        if add is not None:
+            assert _lib.query("mny_pw_dgrad_bnred_add_supported", M, K, Nc, act) == 1
+        dx, red = ops.pw_dgrad_bnred(dy, wT, y, scale, shift, act, mean, invstd, addend=add)
+        ref_dx = dy.cpu().double() @ wg.double() + (add.cpu().double() if add is not None else 0)
+        check(dx, ref_dx, 2e-5, 2e-5, "wide dx")
+        assert red.shape[0] == _lib.query("mny_pw_dgrad_bnred_parts", M, K, Nc)
+        ref = torch.empty(parts, 2, Nc, device="cuda")
+        _lib.call("mny_bn_bwd_reduce", p(dx), p(y), p(scale), p(shift), act, p(mean), p(invstd), p(ref), M, Nc, stream)
+        gotr, want = red.double().sum(0).cpu(), ref.double().sum(0).cpu()
+        for k in range(2):
+            tol = 2e-5 * want[k].abs().max().item() + 1e-4
+            assert (gotr[k] - want[k]).abs().max().item() <= tol, (k, (gotr[k] - want[k]).abs().max().item(), tol)
+        if add is not None:                                              # in place: the addend buffer is also the output
+            buf = add.clone()
+            _lib.call("mny_pw_dgrad_bnred_add", p(dy), p(wT), p(buf), p(buf), p(y), p(scale), p(shift), act, p(mean), p(invstd), p(red), M, K, Nc, stream)
+            assert torch.equal(buf, dx)
