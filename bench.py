@@ -577,7 +577,8 @@ def main():
         if dom in ("mny_pw_fwd", "mny_pw_fwd_bf16") and os.environ.get("MNY_NO_THIN") is None:
             # the entry point routes its short-reduction launches (K = 16 / 24 / 32 channels, HBM-bound) to a vector-ALU stream kernel:
             # their FLOPs and time are inside this object, priced against the matrix-core peak like the rest
-            roof["kernels"] = "pw_gemm_nt_dma_kernel (MFMA tiles) + pw_thin_kernel (vector ALU, the K <= 32 launches; csrc/pwthin.hip)"
+            roof["kernels"] = ("pw_gemm_nt_dma_kernel (MFMA tiles) + pw_wide_kernel (barrier-free MFMA kernel, K 52..96 into N >= K; csrc/pwwide.hip) + "
+                               "pw_thin_kernel (vector ALU, the K <= 32 launches; csrc/pwthin.hip)")
         if not bf16 and os.environ.get("MNY_X6") != "0":
             # fp32 GEMMs with FLOP/byte >= 20 take the six-product bf16 form (csrc/pwgemm.hip, x6_split): say so, and price the same
             # achieved rate against the pipe that actually carries it as well

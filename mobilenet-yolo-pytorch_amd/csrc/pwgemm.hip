@@ -518,35 +518,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     // 4q..4q+3 -> one 16-byte store (4x fewer store instructions, full 128-B row segments per quad-row).
     const int quad = lrow >> 2, jq = lane & 3;
     const bool nvec = (p.N & 3) == 0;
-    const T* pAddS = RED == 2 ? nullptr : pAdd;          // RED = 2 folds the addend into the accumulators ahead of the transposes
-    float ry[RED ? 16 : 1], ra[RED == 2 ? 16 : 1];       // reduction epilogue: raw output / addend of the current column block, MFMA layout
-    // (wave-uniform row base in SGPRs + one 32-bit byte offset per load: sixteen 64-bit row pointers would cost 32 VGPRs)
-    auto red_load = [&](int u, int64_t m0) {
-        const int col = n0 + u * 32 + lrow;
-        const int cc = col < p.N ? col : 0;
-        const int64_t wrow = m0 + wv * 32;
-        const int rl0 = (int)max((int64_t)0, min((int64_t)32, p.M - wrow));      // rows of this wave's 32 inside M
-        const int lim = rl0 > 0 ? rl0 - 1 : 0;
-        const unsigned rowb = (unsigned)p.N * (unsigned)sizeof(T), colb = (unsigned)cc * (unsigned)sizeof(T);
-        const T* ub = (const T*)p.rY + (rl0 > 0 ? wrow : 0) * p.N;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rw = 8 * (r >> 2) + (r & 3) + 4 * khalf;
-            unsigned off = (unsigned)min(rw, lim) * rowb + colb;
-            asm volatile("" : "+v"(off));
-            ry[r] = ld1(at_bytes(ub, off));
-        }
-        if constexpr (RED == 2) {
-            const T* ua = pAdd + (rl0 > 0 ? wrow : 0) * p.N;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rw = 8 * (r >> 2) + (r & 3) + 4 * khalf;
-                unsigned off = (unsigned)min(rw, lim) * rowb + colb;
-                asm volatile("" : "+v"(off));
-                ra[r] = ld1(at_bytes(ua, off));
-            }
-        }
-    };
     auto epilogue = [&](int mt) {
         const int64_t m0 = (int64_t)mt * BM;
 #pragma unroll
@@ -564,28 +535,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                 }
             }
             if (RED) {                                            // BN-backward sums of the unit this gradient belongs to
-                // The unit's raw output (and, RED = 2, the earlier contributions to the same gradient) are read in the MFMA layout:
-                // lane = column, 16 rows.  All 16 (32) loads of a column block are in flight at once, and the NEXT block's are
-                // issued before this block's transposes and stores, so a tile exposes one load round trip instead of 4 * TN
-                // (the thin-K, wide-N data gradients of the project convs were bound by exactly that latency).
                 const int col = n0 + u * 32 + lrow;
                 const bool ccol = col < p.N;
                 const int cc = ccol ? col : 0;
                 const float rsc = p.r_scale[cc], rsh = p.r_shift[cc], rmu = p.r_mean[cc], ris = p.r_invstd[cc];
                 const float rslope = act_slope(p.r_act), rhi = act_hi(p.r_act);
-                const int rl0 = (int)max((int64_t)0, min((int64_t)32, p.M - (m0 + wv * 32)));     // rows of this wave's 32 inside M
-                if (u == 0) red_load(0, m0);
+                const int64_t rbase = m0 + wv * 32 + 4 * khalf;
+                const int rows_left = (int)max((int64_t)0, min((int64_t)64, p.M - rbase));   // rows rbase + 8*gq + j, 8*gq + j < rows_left, exist
+                const T* ybase = (const T*)p.rY + (rows_left > 0 ? rbase : 0) * p.N + cc;
+                const T* abase = RED == 2 ? pAdd + (rows_left > 0 ? rbase : 0) * p.N + cc : nullptr;   // RED = 2: earlier contributions to the same gradient
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int rw = 8 * (r >> 2) + (r & 3) + 4 * khalf;
-                    const float z = fmaf(ry[r], rsc, rsh);
-                    const float dact = p.r_act >= MNY_ACT_HSWISH ? act_bwd(z, p.r_act) : (z > 0.f ? 1.f : rslope) * (z < rhi ? 1.f : 0.f);
-                    if (RED == 2) acc[u][r] += ra[r];             // the sums are over the COMPLETE gradient = product + addend (stored below as such)
-                    const float dz = stored<T>(acc[u][r]) * dact;
-                    if (ccol && rw < rl0) { s1[u] += dz; s2[u] = fmaf(dz, (ry[r] - rmu) * ris, s2[u]); }
+                for (int gq = 0; gq < 4; ++gq) {                  // four rows at a time: the loads of a group are all that is in flight
+                    float yv[4], av[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) yv[j] = ld1(ybase + (ccol && 8 * gq + j < rows_left ? 8 * gq + j : 0) * p.N);
+                    if (RED == 2) {                               // the sums are over the COMPLETE gradient = product + addend
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) av[j] = ld1(abase + (ccol && 8 * gq + j < rows_left ? 8 * gq + j : 0) * p.N);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float z = fmaf(yv[j], rsc, rsh);
+                        const float dact = p.r_act >= MNY_ACT_HSWISH ? act_bwd(z, p.r_act) : (z > 0.f ? 1.f : rslope) * (z < rhi ? 1.f : 0.f);
+                        const float dz = stored<T>(acc[u][gq * 4 + j] + av[j]) * dact;
+                        if (ccol && 8 * gq + j < rows_left) { s1[u] += dz; s2[u] = fmaf(dz, (yv[j] - rmu) * ris, s2[u]); }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-                if (u + 1 < TN) { red_load(u + 1, m0); __builtin_amdgcn_sched_barrier(0); }
             } else if (p.stats) {                                 // column sums come from the un-transposed registers
                 const bool ccol = n0 + u * 32 + lrow < p.N;
                 if (m0 + BM <= p.M) {                             // whole tile inside M (all but the last one): packed pairs, no row tests
@@ -628,13 +604,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                     float4 v = make_float4(r0, r1, r2, r3);
                     if (p.bias) { v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }        // wave-uniform: only the two head convs carry a bias
                     if (nvec) {
-                        if (pAddS) add4(v, ld4(pAddS + row * p.N + colq));
+                        if (pAdd) add4(v, ld4(pAdd + row * p.N + colq));
                         st4_stream(pC + row * p.N + colq, v);
                     } else {
                         // ragged width (75-channel heads, 10-channel gate): rows are not 16-B aligned -> up to four element stores
                         // off ONE address (the transposed layout keeps this cheap: one row, consecutive columns)
                         T* dst = pC + row * p.N + colq;
-                        const T* ad = pAddS ? pAddS + row * p.N + colq : nullptr;
+                        const T* ad = pAdd ? pAdd + row * p.N + colq : nullptr;
                         st1(dst, v.x + (ad ? ld1(ad) : 0.f));
                         if (colq + 1 < p.N) st1(dst + 1, v.y + (ad ? ld1(ad + 1) : 0.f));
                         if (colq + 2 < p.N) st1(dst + 2, v.z + (ad ? ld1(ad + 2) : 0.f));

@@ -36,16 +36,22 @@ def nt_args(k):
     return a + [0] * (5 - len(a))
 
 
+def wide_mode(k):
+    """MODE template argument (4th) of a pw_wide_kernel<KS, TNB, XF, MODE> family name (0/1 forward, 2/3 data gradient + BN sums), or None."""
+    m = re.match(r"pw_wide_kernel<\d+, \d+, \d+, (\d+)>", k)
+    return int(m.group(1)) if m else None
+
+
 def is_pw_fwd(k):
     """kernels behind the mny_pw_fwd entry point: the tile GEMMs without a BN-backward epilogue (fp32-MFMA or six-product bf16 form) +
     the register-staged fallback + the short-reduction stream kernel (RED = 0)"""
     a = nt_args(k)
-    return (a is not None and a[3] == 0) or (k.startswith("pw_gemm_nt_kernel")) or thin_red(k) == 0
+    return (a is not None and a[3] == 0) or (k.startswith("pw_gemm_nt_kernel")) or thin_red(k) == 0 or wide_mode(k) in (0, 1)
 
 
 def is_pw_dgrad_bnred(k):
     a = nt_args(k)
-    return (a is not None and a[3] == 1) or thin_red(k) == 1
+    return (a is not None and a[3] == 1) or thin_red(k) == 1 or wide_mode(k) == 2
 
 
 def pmc(dirname, counter):
@@ -99,7 +105,7 @@ def main():
         g = [(ms, n, f_gb, w_gb) for ms, k, n, f_gb, w_gb in rows if is_pw_fwd(k)]
         g_ms, g_n = sum(r[0] for r in g), sum(r[1] for r in g)
         g_f, g_w = sum(r[2] for r in g), sum(r[3] for r in g)
-        o.write("\n`mny_pw_fwd` entry point (all `pw_gemm_nt*` and `pw_thin_kernel*` kernels except the `RED = 1 / 2` instantiations of `mny_pw_dgrad_bnred[_add]`): %.0f launches/step, %.3f ms/step, avg %.1f us; HBM %.2f GB/step "
+        o.write("\n`mny_pw_fwd` entry point (all `pw_gemm_nt*`, `pw_thin_kernel*` and `pw_wide_kernel*` kernels except the `RED = 1 / 2` / `MODE = 2 / 3` instantiations of `mny_pw_dgrad_bnred[_add]`): %.0f launches/step, %.3f ms/step, avg %.1f us; HBM %.2f GB/step "
                 "(fetch x2 %.2f + write %.2f) = %.0f MB per launch.\n" % (g_n, g_ms, g_ms * 1e3 / max(g_n, 1), 2 * g_f + g_w, 2 * g_f, g_w,
                                                                           (2 * g_f + g_w) * 1e3 / max(g_n, 1)))
     import json
