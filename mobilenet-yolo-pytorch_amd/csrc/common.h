@@ -212,4 +212,10 @@ int pw_wide_launch(const float* A, const float* in_scale, const float* in_shift,
                    int64_t M, int K, int N, const float* rY, const float* r_scale, const float* r_shift, const float* r_mean,
                    const float* r_invstd, int r_act, const float* addend, hipStream_t st);
 
+// weight gradient with one narrow side (64 / 96 channels): barrier-free stream kernel (pwwgs.hip); fp32 storage, no bias gradient
+bool pw_wgs_ok(int64_t M, int K, int N);
+int pw_wgs_splits(int64_t M, int K, int N);
+int pw_wgs_launch(const float* x, const float* in_scale, const float* in_shift, int in_act, const float* dy, float* partial,
+                  int64_t M, int K, int N, hipStream_t st);
+
 }  // namespace mny

@@ -2493,10 +2493,16 @@ extern "C" int mny_pw_fwd_bf16(const void* x, const float* in_scale, const float
 extern "C" size_t mny_pw_wgrad_ws_floats(int64_t M, int K, int Nc) {
     if (M <= 0 || K <= 0 || Nc <= 0) return 0;
     WgPlan pl = wg_plan(M, K, Nc);
-    return (size_t)pl.splits * Nc * K + (size_t)colsum_parts(M) * Nc;
+    size_t splits = (size_t)pl.splits;
+    if (pw_wgs_ok(M, K, Nc) && (size_t)pw_wgs_splits(M, K, Nc) > splits) splits = (size_t)pw_wgs_splits(M, K, Nc);     // whichever kernel the call takes
+    return splits * Nc * K + (size_t)colsum_parts(M) * Nc;
 }
 
-extern "C" int mny_pw_wgrad_splits(int64_t M, int K, int Nc) { return (M <= 0 || K <= 0 || Nc <= 0) ? MNY_EINVAL : wg_plan(M, K, Nc, false).splits; }
+// (without a bias gradient the narrow-sided shapes run the stream kernel of pwwgs.hip: its partial-row count)
+extern "C" int mny_pw_wgrad_splits(int64_t M, int K, int Nc) {
+    if (M <= 0 || K <= 0 || Nc <= 0) return MNY_EINVAL;
+    return pw_wgs_ok(M, K, Nc) ? pw_wgs_splits(M, K, Nc) : wg_plan(M, K, Nc, false).splits;
+}
 extern "C" int mny_pw_wgrad_splits_bf16(int64_t M, int K, int Nc) { return (M <= 0 || K <= 0 || Nc <= 0) ? MNY_EINVAL : wg_plan(M, K, Nc, true).splits; }
 
 template <typename T>
@@ -2506,6 +2512,13 @@ static int pw_wgrad_impl(const T* x, const float* in_scale, const float* in_shif
     MNY_REQUIRE(dw || !dbias, "pw_wgrad: a deferred combine (dw == NULL) cannot carry a bias gradient");
     MNY_REQUIRE(M > 0 && K > 0 && Nc > 0, "pw_wgrad: empty problem");
     constexpr bool is_f32 = sizeof(T) == 4;
+    if (is_f32 && pw_wgs_ok(M, K, Nc) && !dbias) {              // narrow-sided shape: barrier-free stream kernel (pwwgs.hip), partial rows [pw_wgs_splits][Nc][K]
+        int rc = pw_wgs_launch((const float*)x, in_scale, in_shift, in_act, (const float*)dy, ws, M, K, Nc, (hipStream_t)stream);
+        if (rc || !dw) return rc;
+        const int64_t n = (int64_t)Nc * K;
+        hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(n, 32)), dim3(256), 0, (hipStream_t)stream, ws, pw_wgs_splits(M, K, Nc), n, dw);
+        return check_launch("reduce_parts_kernel");
+    }
     WgPlan pl = wg_plan(M, K, Nc, !is_f32);
     WgradArgs a{x, in_scale, in_shift, in_act, dy, ws, M, K, Nc, pl.rows_per_block};
     dim3 grid(pl.gx, pl.gy, pl.splits), block(256);

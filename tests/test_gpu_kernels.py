@@ -721,3 +721,34 @@ def test_wide_output_pointwise_kernel(ops, M, K, Nc, act):
             buf = add.clone()
             _lib.call("mny_pw_dgrad_bnred_add", p(dy), p(wT), p(buf), p(buf), p(y), p(scale), p(shift), act, p(mean), p(invstd), p(red), M, K, Nc, stream)
             assert torch.equal(buf, dx)
+
+
+@pytest.mark.parametrize("M,K,Nc,act", [(16384, 96, 576, 1), (20480, 576, 96, 1), (16400, 64, 384, 2), (32768, 384, 64, 0), (16384, 96, 192, 4), (17008, 192, 64, 3)])
+def test_narrow_sided_weight_gradient_stream_kernel(ops, M, K, Nc, act):
+    """One side of dW is 64 or 96 channels wide, M >= 16384, M % 16 == 0: mny_pw_wgrad runs the barrier-free stream kernel (pwwgs.hip);
+    checked against an fp64 product, directly and through the deferred-combine form (dw == NULL: partial rows [mny_pw_wgrad_splits][N][K])."""
+    import ctypes
+    from mobilenet_yolo_pytorch_amd import _lib
+    assert os.environ.get("MNY_NO_WGS") is None
+    x = rnd(M, K, seed=1)
+    sc, sh = 1 + 0.2 * rnd(K, seed=3), 0.3 * rnd(K, seed=4)
+    a = ACTS[act](x.double() * sc.double() + sh.double())
+    dy = rnd(M, Nc, seed=9)
+    ref = dy.double().t() @ a
+    xs = x.view(1, 1, M, K).cuda()
+    dw, _ = ops.pw_wgrad((xs, sc.cuda(), sh.cuda(), act), dy.view(1, 1, M, Nc).cuda(), want_dbias=False)
+    err = (dw.double().cpu() - ref)
+    assert err.pow(2).mean().sqrt().item() <= 1e-6 * ref.pow(2).mean().sqrt().item(), "rms"         # fp32-accurate (six bf16 products, fp32 accumulate)
+    assert err.abs().max().item() <= 2e-5 * ref.abs().max().item()
+    # deferred combine: the partial rows add up to the same gradient
+    splits = _lib.query("mny_pw_wgrad_splits", M, K, Nc)
+    ws = torch.zeros(_lib.query("mny_pw_wgrad_ws_floats", M, K, Nc), device="cuda")
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None          # noqa: E731
+    xc, dyc, scc, shc = x.cuda(), dy.cuda(), sc.cuda(), sh.cuda()
+    _lib.call("mny_pw_wgrad", p(xc), p(scc), p(shc), act, p(dyc), None, None, p(ws), M, K, Nc, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    parts = ws[:splits * Nc * K].view(splits, Nc, K).double().sum(0).cpu()
+    assert (parts - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    # plain view (no transform): the other operand mode
+    dw2, _ = ops.pw_wgrad((xs, None, None, 0), dy.view(1, 1, M, Nc).cuda(), want_dbias=False)
+    ref2 = dy.double().t() @ x.double()
+    assert (dw2.double().cpu() - ref2).abs().max().item() <= 2e-5 * ref2.abs().max().item()
