@@ -222,3 +222,75 @@ def test_short_reduction_kernel_shapes():
             r1, r2 = red[:, 0].double().sum(0).cpu(), red[:, 1].double().sum(0).cpu()
             assert ((r1 - dz.sum(0)).abs() <= 2e-5 * dz.abs().sum(0).max().item() + 1e-5 + kink.sum(0)).all(), (trial, M, K, N)
             assert ((r2 - (dz * xhat).sum(0)).abs() <= 2e-5 * (dz * xhat).abs().sum(0).max().item() + 1e-5 + (kink * xhat.abs()).sum(0)).all(), (trial, M, K, N)
+
+
+def test_barrier_free_matrix_core_kernel_shapes():
+    """pwwide.hip (forward with view + statistics / plain, data gradient + BN-backward sums with / without an addend) and pwwgs.hip (weight
+    gradient, direct and deferred combine) through the entry points that route to them: random K in 52..96 (K % 4 == 0), N a multiple of
+    64 / 96 / 128, row counts around the 32-row tile, the per-wave tile stride and the 16-row chunk (remainder rows take the LDS-DMA kernel
+    and one more partial row; M % 16 != 0 takes the LDS-DMA weight gradient).  fp32-accurate path: 2e-5 of the result's scale."""
+    import ctypes
+    from mobilenet_yolo_pytorch_amd import _lib
+    r = np.random.RandomState(11)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None            # noqa: E731
+    for trial in range(24):
+        K = 4 * int(r.randint(13, 25))                                                # 52..96
+        N = int(r.choice([64, 96, 128, 192, 256, 288, 384, 512, 576]))
+        if N < K:
+            N = 192
+        M = int(r.choice([8192, 8192 + 31, 8224, 16384, 16400, 20480 + 1, 4 * 128 * 32 * 2 + 32, int(r.randint(8192, 70000)), 16 * int(r.randint(1024, 4000))]))
+        act = int(r.randint(0, 4))
+        g = torch.Generator().manual_seed(500 + trial)
+        x = torch.randn(M, K, generator=g).cuda()
+        w = (torch.randn(N, K, generator=g) * K ** -0.5).cuda()
+        sc, sh = (1 + 0.2 * torch.randn(K, generator=g)).cuda(), (0.3 * torch.randn(K, generator=g)).cuda()
+        xd, wd = x.double().cpu(), w.double().cpu()
+        what = "trial %d M=%d K=%d N=%d act=%d" % (trial, M, K, N, act)
+        form = trial % 4
+        y = torch.empty(M, N, device="cuda")
+        if form == 0:                                    # view + statistics
+            a = ACT[act](xd * sc.double().cpu() + sh.double().cpu())
+            parts = _lib.query("mny_pw_stat_parts", M, K, N)
+            st = torch.full((parts, 2, N), float("nan"), device="cuda")
+            _lib.call("mny_pw_fwd", p(x), p(sc), p(sh), act, p(w), None, None, p(y), p(st), M, K, N, stream)
+            _close(y, a @ wd.t(), 2e-5, "view+stats " + what)
+            yd = y.double().cpu()
+            assert not torch.isnan(st).any(), what
+            _close(st[:, 0].double().sum(0), yd.sum(0), 1e-5 * max(1.0, yd.abs().sum(0).max().item() / (yd.sum(0).abs().max().item() + 1e-9)), "stats sum " + what)
+            _close(st[:, 1].double().sum(0), (yd ** 2).sum(0), 1e-5, "stats sumsq " + what)
+        elif form == 1:                                  # weight gradient of a conv K -> N and of its mirror image N -> K
+            dy = torch.randn(M, N, generator=g).cuda()
+            a = ACT[act](xd * sc.double().cpu() + sh.double().cpu())
+            for (xin, s1, s2, ac, dyin, kk, nn, ref) in ((x, sc, sh, act, dy, K, N, dy.double().cpu().t() @ a), (dy, None, None, 0, x, N, K, xd.t() @ dy.double().cpu())):
+                ws = torch.zeros(_lib.query("mny_pw_wgrad_ws_floats", M, kk, nn), device="cuda")
+                dw = torch.empty(nn, kk, device="cuda")
+                _lib.call("mny_pw_wgrad", p(xin), p(s1), p(s2), ac, p(dyin), p(dw), None, p(ws), M, kk, nn, stream)
+                _close(dw, ref, 2e-5, "wgrad %d->%d " % (kk, nn) + what)
+                splits = _lib.query("mny_pw_wgrad_splits", M, kk, nn)
+                ws.zero_()
+                _lib.call("mny_pw_wgrad", p(xin), p(s1), p(s2), ac, p(dyin), None, None, p(ws), M, kk, nn, stream)
+                _close(ws[:splits * nn * kk].view(splits, nn, kk).double().sum(0), ref, 2e-5, "wgrad partial rows %d->%d " % (kk, nn) + what)
+        else:                                            # data gradient + BN-backward sums, with / without an addend (in place)
+            yraw = (torch.randn(M, N, generator=g) * 2).cuda()
+            c = [(1 + 0.3 * torch.randn(N, generator=g)).cuda(), (0.5 * torch.randn(N, generator=g)).cuda(),
+                 (0.2 * torch.randn(N, generator=g)).cuda(), (1 + 0.2 * torch.randn(N, generator=g).abs()).cuda()]
+            add = torch.randn(M, N, generator=g).cuda() if form == 3 else None
+            parts = _lib.query("mny_pw_dgrad_bnred_parts", M, K, N)
+            red = torch.full((parts, 2, N), float("nan"), device="cuda")
+            if add is not None:
+                assert _lib.query("mny_pw_dgrad_bnred_add_supported", M, K, N, act) == 1
+                y.copy_(add)
+                _lib.call("mny_pw_dgrad_bnred_add", p(x), p(w), p(y), p(y), p(yraw), p(c[0]), p(c[1]), act, p(c[2]), p(c[3]), p(red), M, K, N, stream)
+            else:
+                _lib.call("mny_pw_dgrad_bnred", p(x), p(w), p(y), p(yraw), p(c[0]), p(c[1]), act, p(c[2]), p(c[3]), p(red), M, K, N, stream)
+            _close(y, xd @ wd.t() + (add.double().cpu() if add is not None else 0), 2e-5, "dgrad form %d " % form + what)
+            assert not torch.isnan(red).any(), what
+            z = yraw.double().cpu() * c[0].double().cpu() + c[1].double().cpu()
+            d = {0: torch.ones_like(z), 1: ((z > 0) & (z < 6)).double(), 2: torch.where(z > 0, 1.0, 0.1).double(), 3: (z > 0).double()}[act]
+            dz = y.double().cpu() * d
+            xhat = (yraw.double().cpu() - c[2].double().cpu()) * c[3].double().cpu()
+            kink = ((z.abs() < 1e-5) | ((z - 6).abs() < 1e-5)).double() * y.double().cpu().abs()
+            r1, r2 = red[:, 0].double().sum(0).cpu(), red[:, 1].double().sum(0).cpu()
+            assert ((r1 - dz.sum(0)).abs() <= 2e-5 * dz.abs().sum(0).max().item() + 1e-5 + kink.sum(0)).all(), what
+            assert ((r2 - (dz * xhat).sum(0)).abs() <= 2e-5 * (dz * xhat).abs().sum(0).max().item() + 1e-5 + (kink * xhat.abs()).sum(0)).all(), what
