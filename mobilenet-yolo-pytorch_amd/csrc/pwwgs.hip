@@ -1,5 +1,6 @@
-// Weight gradient of a pointwise conv with one NARROW side (64 or 96 channels) and one wide side — the expand / project convs of the
-// 22x22 bottlenecks: dW[N][K] = sum_m dY[m][:]^T act(X[m][:]) — as a barrier-free stream kernel on the bf16 matrix cores.
+// Weight gradient of a pointwise conv with one NARROW side (64 ... 320 channels, a multiple of 32) and a wide one (>= 2x) — the expand /
+// project convs of the 22x22 and 11x11 bottlenecks: dW[N][K] = sum_m dY[m][:]^T act(X[m][:]) — as a barrier-free stream kernel on the
+// bf16 matrix cores.
 //
 // The LDS-DMA weight-gradient kernels (pwgemm.hip) run these shapes at 70-79 TFLOP/s, 1.7-2.8 TB/s: a 16-row chunk behind a barrier,
 // fp32 MFMAs (the six-product form needs whole 16-row chunks per wave, the all-waves-share-the-tile mode hands a wave 4 rows).  Here a
@@ -155,7 +156,8 @@ struct WgsPlan { int TA, TB, slices_a, slices_b, splits; int64_t rows_per_block;
 bool pw_wgs_ok(int64_t M, int K, int N) {
     static const bool off = getenv("MNY_NO_WGS") != nullptr || getenv("MNY_WGRAD_V1") != nullptr;
     const int thin = K < N ? K : N, wide = K < N ? N : K;
-    return !off && M >= 16384 && (M & 15) == 0 && (thin == 64 || thin == 96) && wide >= 2 * thin && (wide & 3) == 0;
+    static const int max_thin = getenv("MNY_WGS_MAXTHIN") ? atoi(getenv("MNY_WGS_MAXTHIN")) : 320;      // same-box A/B: 160 and 320 gain 20-25 %, 512 loses 5 %
+    return !off && M >= 16384 && (M & 15) == 0 && thin >= 64 && thin <= max_thin && (thin & 31) == 0 && wide >= 2 * thin && (wide & 3) == 0;
 }
 
 static WgsPlan wgs_plan(int64_t M, int K, int N) {
@@ -164,10 +166,12 @@ static WgsPlan wgs_plan(int64_t M, int K, int N) {
     // the vector-ALU cost — are shared by more matrix work: 5 cuts per 6 tiles instead of 4 per 4), else 64
     static const int force_ws = getenv("MNY_WGS_SLICE") ? atoi(getenv("MNY_WGS_SLICE")) : 0;
     const int thin = K <= N ? K : N, wide = K <= N ? N : K;
-    int ws = (thin == 64 && wide % 96 == 0) ? 3 : 2;
-    if (force_ws == 2 || (force_ws == 3 && thin == 64)) ws = force_ws;
-    if (K <= N) { pl.TB = K / 32; pl.TA = ws; pl.slices_a = (int)cdiv(N, 32 * ws); pl.slices_b = 1; }      // X narrow: slices of the dY columns
-    else { pl.TA = N / 32; pl.TB = ws; pl.slices_a = 1; pl.slices_b = (int)cdiv(K, 32 * ws); }           // dY narrow: slices of the X columns
+    // a narrow side of more than 96 channels is taken in parts of 96 (the last one partly masked): 2-D tiling, both operands re-read from L2
+    const int tblocks = thin / 32, tpart = tblocks <= 3 ? tblocks : ((tblocks % 2 == 0 && tblocks % 3 != 0) ? 2 : 3), tslices = (int)cdiv(tblocks, tpart);
+    int ws = (tpart == 2 && wide % 96 == 0) ? 3 : 2;
+    if (force_ws == 2 || (force_ws == 3 && tpart == 2)) ws = force_ws;
+    if (K <= N) { pl.TB = tpart; pl.TA = ws; pl.slices_a = (int)cdiv(N, 32 * ws); pl.slices_b = tslices; }      // X narrow: slices of the dY columns
+    else { pl.TA = tpart; pl.TB = ws; pl.slices_a = tslices; pl.slices_b = (int)cdiv(K, 32 * ws); }           // dY narrow: slices of the X columns
     static const int blocks = getenv("MNY_WGS_BLOCKS") ? atoi(getenv("MNY_WGS_BLOCKS")) : 512;      // two workgroups per CU
     const int slices = pl.slices_a * pl.slices_b;
     int64_t splits = blocks / slices;

@@ -723,9 +723,10 @@ def test_wide_output_pointwise_kernel(ops, M, K, Nc, act):
             assert torch.equal(buf, dx)
 
 
-@pytest.mark.parametrize("M,K,Nc,act", [(16384, 96, 576, 1), (20480, 576, 96, 1), (16400, 64, 384, 2), (32768, 384, 64, 0), (16384, 96, 192, 4), (17008, 192, 64, 3)])
+@pytest.mark.parametrize("M,K,Nc,act", [(16384, 96, 576, 1), (20480, 576, 96, 1), (16400, 64, 384, 2), (32768, 384, 64, 0), (16384, 96, 192, 4), (17008, 192, 64, 3),
+                                        (30976, 160, 960, 1), (16384, 576, 160, 1), (16384, 128, 256, 2), (16384, 960, 320, 1), (16384, 320, 1280, 2)])
 def test_narrow_sided_weight_gradient_stream_kernel(ops, M, K, Nc, act):
-    """One side of dW is 64 or 96 channels wide, M >= 16384, M % 16 == 0: mny_pw_wgrad runs the barrier-free stream kernel (pwwgs.hip);
+    """One side of dW is 64 ... 320 channels wide (a multiple of 32), the other at least twice that, M >= 16384, M % 16 == 0: mny_pw_wgrad runs the barrier-free stream kernel (pwwgs.hip);
     checked against an fp64 product, directly and through the deferred-combine form (dw == NULL: partial rows [mny_pw_wgrad_splits][N][K])."""
     import ctypes
     from mobilenet_yolo_pytorch_amd import _lib
