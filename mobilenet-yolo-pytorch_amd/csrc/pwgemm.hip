@@ -2316,7 +2316,7 @@ extern "C" int mny_pw_fwd(const float* x, const float* in_scale, const float* in
 // transposed -> NT), and in the same epilogue that unit's BN-backward reduction over (dx, its raw output y): the separate
 // mny_bn_bwd_reduce pass (one more read of dx and of y) disappears — only y is read, by the tile that just produced dx.
 // the reduction epilogue holds four more per-column constants and a group of loads: the 160-column tile (TN = 5) spills with it
-constexpr int kRedMaxTn = 4;
+static const int kRedMaxTn = getenv("MNY_RED_TN") ? atoi(getenv("MNY_RED_TN")) : 4;      // (A/B: 3 = no 128-column reduction tiles)
 static bool dgrad_bnred_ok(int64_t M, int K, int Nc, int act) {
     static const bool red512 = getenv("MNY_RED512") != nullptr && atoi(getenv("MNY_RED512")) != 0;
     if (K >= 512 && Nc >= 512 && !red512) return false;      // matrix-pipe-bound: the reduce pass it would save is cheaper than the longer epilogue (MNY_RED512=1: A/B)

@@ -22,6 +22,7 @@ struct WgsArgs {
     int64_t M; int K, N;
     int slices_a, slices_b;               // slices of the dY columns (32*TA each) and of the X columns (32*TB each): one of them is 1
     int64_t rows_per_block;               // multiple of 64
+    int splits, xcd_groups;
 };
 
 template <int TA, int TB>
@@ -30,10 +31,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, kk = lane >> 5;
-    const int sa = blockIdx.x % p.slices_a, sb = blockIdx.x / p.slices_a;
+    // block -> (slice, row split z): the slices of one row split are consecutive within one XCD — they re-read the same rows of the narrow
+    // operand, which then comes from that XCD's L2 (dispatched round-robin over the XCDs, 9 slices re-read it from HBM: 1.5x counted traffic)
+    // (p.xcd_groups == 0: few row splits — many slices, small M, everything L2-resident anyway —: plain order, slice fastest)
+    const int bid = blockIdx.x, xcd = bid & 7, local = bid >> 3;
+    const int nsl = p.slices_a * p.slices_b;
+    const int slice = p.xcd_groups ? local % nsl : bid % nsl, z = p.xcd_groups ? (local / nsl) * 8 + xcd : bid / nsl;
+    if (z >= p.splits) return;
+    const int sa = slice % p.slices_a, sb = slice / p.slices_a;
     const int ca0 = sa * 32 * TA, cb0 = sb * 32 * TB;
     const int K = p.K, N = p.N;
-    const int64_t m_begin = (int64_t)blockIdx.y * p.rows_per_block;
+    const int64_t m_begin = (int64_t)z * p.rows_per_block;
     const int64_t m_end = min(m_begin + p.rows_per_block, p.M);
     const int nchunks = (int)((m_end - m_begin) / 16);           // whole chunks: M % 16 == 0, rows_per_block % 64 == 0
     const bool has_xf = p.in_scale != nullptr;
@@ -127,7 +135,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 
     // the four waves' accumulators -> one partial row (fixed order: wave 0 + 1 + 2 + 3)
-    float* dst = p.partial + (int64_t)blockIdx.y * N * K;
+    float* dst = p.partial + (int64_t)z * N * K;
 #pragma unroll
     for (int i = 0; i < TA; ++i)
 #pragma unroll
@@ -151,7 +159,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------
-struct WgsPlan { int TA, TB, slices_a, slices_b, splits; int64_t rows_per_block; };
+struct WgsPlan { int TA, TB, slices_a, slices_b, splits, xcd_groups; int64_t rows_per_block; };
 
 bool pw_wgs_ok(int64_t M, int K, int N) {
     static const bool off = getenv("MNY_NO_WGS") != nullptr || getenv("MNY_WGRAD_V1") != nullptr;
@@ -175,6 +183,8 @@ static WgsPlan wgs_plan(int64_t M, int K, int N) {
     static const int blocks = getenv("MNY_WGS_BLOCKS") ? atoi(getenv("MNY_WGS_BLOCKS")) : 512;      // two workgroups per CU
     const int slices = pl.slices_a * pl.slices_b;
     int64_t splits = blocks / slices;
+    pl.xcd_groups = splits >= 32;                     // same-box A/B: with fewer row splits the grouping only costs parallelism (320->1280: 5 splits on 5 XCDs)
+    if (pl.xcd_groups) splits = splits / 8 * 8;       // whole groups of 8 row splits: the same number of workgroups on every XCD
     if (splits < 1) splits = 1;
     const int64_t max_splits = cdiv(M, 256);
     if (splits > max_splits) splits = max_splits;
@@ -189,8 +199,8 @@ int pw_wgs_launch(const float* x, const float* in_scale, const float* in_shift, 
                   int64_t M, int K, int N, hipStream_t st) {
     MNY_REQUIRE(pw_wgs_ok(M, K, N), "pw_wgs: unsupported problem M=%lld K=%d N=%d", (long long)M, K, N);
     const WgsPlan pl = wgs_plan(M, K, N);
-    WgsArgs a{x, in_scale, in_shift, in_act, dy, partial, M, K, N, pl.slices_a, pl.slices_b, pl.rows_per_block};
-    const dim3 grid(pl.slices_a * pl.slices_b, pl.splits), block(256);
+    WgsArgs a{x, in_scale, in_shift, in_act, dy, partial, M, K, N, pl.slices_a, pl.slices_b, pl.rows_per_block, pl.splits, pl.xcd_groups};
+    const dim3 grid((unsigned)(pl.slices_a * pl.slices_b * (pl.xcd_groups ? cdiv(pl.splits, 8) * 8 : pl.splits))), block(256);
     if (pl.TA == 2 && pl.TB == 2) hipLaunchKernelGGL((pw_wgrad_stream_kernel<2, 2>), grid, block, 0, st, a);
     else if (pl.TA == 2 && pl.TB == 3) hipLaunchKernelGGL((pw_wgrad_stream_kernel<2, 3>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((pw_wgrad_stream_kernel<3, 2>), grid, block, 0, st, a);
