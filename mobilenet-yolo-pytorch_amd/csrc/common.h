@@ -206,7 +206,7 @@ int pw_thin_launch(int bf, const void* A, const float* in_scale, const float* in
                    const float* r_shift, const float* r_mean, const float* r_invstd, int r_act, hipStream_t st);
 
 // short reduction feeding a wide output (K = 52..96, N >= K): barrier-free matrix-core kernel (pwwide.hip); fp32 storage only
-bool pw_wide_ok(int64_t M, int K, int N);
+bool pw_wide_ok(int64_t M, int K, int N, bool red);       // red: the data-gradient + BN-backward-sums form
 int pw_wide_parts(int64_t M, int K, int N, bool red);       // partial rows of the whole 32-row tiles
 int pw_wide_launch(const float* A, const float* in_scale, const float* in_shift, int in_act, const float* W, float* C, float* stats,
                    int64_t M, int K, int N, const float* rY, const float* r_scale, const float* r_shift, const float* r_mean,

@@ -2237,7 +2237,7 @@ using namespace mny;
 extern "C" int mny_pw_stat_parts(int64_t M, int K, int Nc) {
     if (M <= 0 || K <= 0 || Nc <= 0) return MNY_EINVAL;
     if (pw_thin_ok(0, 0, M, K, Nc)) return pw_thin_parts(M, K, Nc, 0);
-    if (pw_wide_ok(M, K, Nc)) return pw_wide_parts(M, K, Nc, false) + ((M & 31) ? nt2_plan(M & 31, K, Nc, true).gx : 0);      // + the last M % 32 rows
+    if (pw_wide_ok(M, K, Nc, false)) return pw_wide_parts(M, K, Nc, false) + ((M & 31) ? nt2_plan(M & 31, K, Nc, true).gx : 0);      // + the last M % 32 rows
     if ((K & 3) == 0 && getenv("MNY_GEMM_V1") == nullptr) return nt2_plan(M, K, Nc, true).gx;
     return nt_plan(M, K, Nc).gx;
 }
@@ -2288,7 +2288,7 @@ extern "C" int mny_pw_fwd(const float* x, const float* in_scale, const float* in
     static const bool force_v1 = getenv("MNY_GEMM_V1") != nullptr;   // A/B switch for profiling
     if (pw_thin_ok(0, 0, M, K, Nc))                        // short reduction: vector-ALU stream kernel (pwthin.hip)
         return pw_thin_launch(0, x, in_scale, in_shift, in_act, w, bias, addend, y, stats, M, K, Nc, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, st);
-    if (pw_wide_ok(M, K, Nc)) {                     // short reduction, wide output: barrier-free matrix-core kernel (pwwide.hip)
+    if (pw_wide_ok(M, K, Nc, false)) {              // short reduction, wide output: barrier-free matrix-core kernel (pwwide.hip)
         if (!bias && !addend && in_act != MNY_ACT_HSIGMOID) {
             const int64_t Mf = M & ~(int64_t)31;    // it takes whole 32-row tiles; the last M % 32 rows follow below (one more partial row)
             const int rc = pw_wide_launch(x, in_scale, in_shift, in_act, w, y, stats, Mf, K, Nc, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, st);
@@ -2320,14 +2320,15 @@ static const int kRedMaxTn = getenv("MNY_RED_TN") ? atoi(getenv("MNY_RED_TN")) :
 static bool dgrad_bnred_ok(int64_t M, int K, int Nc, int act) {
     static const bool red512 = getenv("MNY_RED512") != nullptr && atoi(getenv("MNY_RED512")) != 0;
     if (K >= 512 && Nc >= 512 && !red512) return false;      // matrix-pipe-bound: the reduce pass it would save is cheaper than the longer epilogue (MNY_RED512=1: A/B)
-    if ((pw_thin_ok(0, 1, M, K, Nc) || pw_thin_ok(1, 1, M, K, Nc)) && act == MNY_ACT_HSIGMOID) return false;      // the short-reduction kernel knows the clamp family and h-swish (what units use)
+    if ((pw_thin_ok(0, 1, M, K, Nc) || pw_thin_ok(1, 1, M, K, Nc)) && act == MNY_ACT_HSIGMOID) return false;
+    if (pw_wide_ok(M, K, Nc, true) && act >= MNY_ACT_HSWISH) return false;      // the wide-output kernel's reduction form knows the clamp family (its h-swish builds spill)      // the short-reduction kernel knows the clamp family and h-swish (what units use)
     return M > 0 && K > 0 && Nc > 0 && (K & 3) == 0 && act >= MNY_ACT_NONE && act <= MNY_ACT_HSIGMOID && getenv("MNY_GEMM_V1") == nullptr;
 }
 extern "C" int mny_pw_dgrad_bnred_supported(int64_t M, int K, int Nc, int act) { return dgrad_bnred_ok(M, K, Nc, act) ? 1 : 0; }
 extern "C" int mny_pw_dgrad_bnred_parts(int64_t M, int K, int Nc) {
     if (M <= 0 || K <= 0 || Nc <= 0 || (K & 3)) return MNY_EINVAL;
     if (pw_thin_ok(0, 1, M, K, Nc)) return pw_thin_parts(M, K, Nc, 1);
-    if (pw_wide_ok(M, K, Nc)) return pw_wide_parts(M, K, Nc, true) + ((M & 31) ? nt2_plan(M & 31, K, Nc, false, 0, kRedMaxTn).gx : 0);
+    if (pw_wide_ok(M, K, Nc, true)) return pw_wide_parts(M, K, Nc, true) + ((M & 31) ? nt2_plan(M & 31, K, Nc, false, 0, kRedMaxTn).gx : 0);
     return nt2_plan(M, K, Nc, false, 0, kRedMaxTn).gx;
 }
 template <int BF>
@@ -2339,7 +2340,7 @@ static int pw_dgrad_bnred_impl(const void* dy, const void* wT, void* dx, const v
     if (pw_thin_ok(BF, 1, M, K, Nc))
         return pw_thin_launch(BF, dy, nullptr, nullptr, MNY_ACT_NONE, wT, nullptr, addend, dx, red, M, K, Nc, addend ? 2 : 1, y, scale, shift, mean, invstd, act,
                               (hipStream_t)stream);
-    if (!BF && pw_wide_ok(M, K, Nc)) {              // whole 32-row tiles on the barrier-free kernel, the last M % 32 rows below (one more partial row)
+    if (!BF && pw_wide_ok(M, K, Nc, true)) {        // whole 32-row tiles on the barrier-free kernel, the last M % 32 rows below (one more partial row)
         const int64_t Mf = M & ~(int64_t)31;
         const int rc = pw_wide_launch((const float*)dy, nullptr, nullptr, MNY_ACT_NONE, (const float*)wT, (float*)dx, red, Mf, K, Nc, (const float*)y, scale, shift,
                                       mean, invstd, act, (const float*)addend, (hipStream_t)stream);
@@ -2377,7 +2378,7 @@ extern "C" int mny_pw_dgrad_bnred(const float* dy, const float* wT, float* dx, c
 }
 // the addend variant exists for column tiles of <= 96 (TN <= 3: the 128-column tile has no registers left for the addend loads)
 extern "C" int mny_pw_dgrad_bnred_add_supported(int64_t M, int K, int Nc, int act) {
-    return dgrad_bnred_ok(M, K, Nc, act) && (pw_thin_ok(0, 1, M, K, Nc) || pw_wide_ok(M, K, Nc) || nt2_plan(M, K, Nc, false, 0, kRedMaxTn).TN <= 3) ? 1 : 0;
+    return dgrad_bnred_ok(M, K, Nc, act) && (pw_thin_ok(0, 1, M, K, Nc) || pw_wide_ok(M, K, Nc, true) || nt2_plan(M, K, Nc, false, 0, kRedMaxTn).TN <= 3) ? 1 : 0;
 }
 extern "C" int mny_pw_dgrad_bnred_add_supported_bf16(int64_t M, int K, int Nc, int act) {
     return dgrad_bnred_ok(M, K, Nc, act) && (K & 7) == 0 && (pw_thin_ok(1, 1, M, K, Nc) || nt2_plan(M, K, Nc, false, 1, kRedMaxTn).TN <= 3) ? 1 : 0;
@@ -2412,7 +2413,7 @@ static bool w6_ok(int64_t M, int K, int Nc) {
     static const bool off = getenv("MNY_NO_W6") != nullptr;
     static const double min_ai = getenv("MNY_W6_AI") ? atof(getenv("MNY_W6_AI")) : 50.0;
     const double ai = 2.0 * K * Nc / (4.0 * (K + Nc));
-    return !off && M > 0 && K > 0 && Nc > 0 && (K & 3) == 0 && !pw_thin_ok(0, 0, M, K, Nc) && !pw_wide_ok(M, K, Nc) && nt_x6(M, K, Nc) != 0 && ai >= min_ai &&
+    return !off && M > 0 && K > 0 && Nc > 0 && (K & 3) == 0 && !pw_thin_ok(0, 0, M, K, Nc) && !pw_wide_ok(M, K, Nc, false) && !pw_wide_ok(M, K, Nc, true) && nt_x6(M, K, Nc) != 0 && ai >= min_ai &&
            getenv("MNY_GEMM_V1") == nullptr;
 }
 extern "C" int mny_pw_w6_supported(int64_t M, int K, int Nc) { return w6_ok(M, K, Nc) ? 1 : 0; }
