@@ -6,9 +6,15 @@ from oracle import procedural
 from mobilenet_yolo_pytorch_amd import yolo
 bs = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 runs = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+arch = sys.argv[3] if len(sys.argv) > 3 else "mbv2"          # mbv2 | mbv3 | mbv3bf16 (512x512)
+size = 352 if arch == "mbv2" else 512
 torch.manual_seed(0)
-m = procedural.fill_state_dict_(yolo(procedural.VOC_CONFIG, sync_metrics=True)).cuda().train()
-x = procedural.images(bs, 352, 352, seed=5).cuda()
+if arch == "mbv2":
+    m = procedural.fill_state_dict_(yolo(procedural.VOC_CONFIG, sync_metrics=True)).cuda().train()
+else:
+    from mobilenet_yolo_pytorch_amd import mbv3, synthetic
+    m = mbv3.yolo(synthetic.VOC_CONFIG, act_dtype=torch.bfloat16 if arch == "mbv3bf16" else torch.float32).cuda().train()
+x = procedural.images(bs, size, size, seed=5).cuda()
 tg = procedural.targets(bs, seed=6, empty_every=5)
 first, nbad = None, 0
 for it in range(runs):
@@ -26,4 +32,4 @@ for it in range(runs):
     if bad or cur[0] != first[0]:
         nbad += 1
         print("run %d differs: loss equal %s, %d gradients differ, e.g. %s" % (it, cur[0] == first[0], len(bad), bad[:4]))
-print("bs=%d: %d of %d repeat runs differ from the first" % (bs, nbad, runs - 1))
+print("%s bs=%d: %d of %d repeat runs differ from the first" % (arch, bs, nbad, runs - 1))
