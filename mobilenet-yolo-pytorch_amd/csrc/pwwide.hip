@@ -148,6 +148,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         float* cbase = p.C + wrow * N;                           // wave-uniform
 #pragma unroll
         for (int u = 0; u < TNB; ++u) {
+            // scale, shift, mean, invstd of the lane's column — from global memory (L1 / L2 hits), requested ahead of the block's matrix work,
+            // NOT from an LDS table: with the table the sign tests below saw a wrong scale / shift in 1-15 of 40 runs on the 6-stage builds
+            // (tools/ab/stress_red.py; sums of single elements off, dx always right, cause not found); with these loads every run is bit-identical
+            float4 rc = f4zero();
+            if (MODE >= 2) {
+                const int colx = n0 + u * 32 + lrow;
+                rc = make_float4(p.r_scale[colx], p.r_shift[colx], p.r_mean[colx], p.r_invstd[colx]);
+            }
             f32x16 acc, acc1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc1[r] = 0.f; }
@@ -170,11 +178,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int r = 0; r < 16; ++r) acc[r] += acc1[r];
             }
             if (MODE >= 2) {
-                // scale, shift, mean, invstd of the lane's column — from global memory (L1 / L2 hits), NOT from an LDS table: with the table
-                // the sign tests below saw a wrong scale / shift in 1-15 of 40 runs on the 6-stage builds (tools/ab/stress_red.py; sums of
-                // single elements off, dx always right, cause not found), with these loads every run is bit-identical
-                const int colx = n0 + u * 32 + lrow;
-                const float4 rc = make_float4(p.r_scale[colx], p.r_shift[colx], p.r_mean[colx], p.r_invstd[colx]);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float zz = fmaf(ry[r], rc.x, rc.y);
@@ -275,13 +278,11 @@ static bool wide_on() {
     return !off;
 }
 
-static int wide_tnb(int K, int N, bool red) {         // column block = 32 * TNB columns, whole blocks only; 0 = no kernel
+static int wide_tnb(int /*K*/, int N, bool red) {     // column block = 32 * TNB columns, whole blocks only; 0 = no kernel
     static const int force = getenv("MNY_WIDE_TNB") ? atoi(getenv("MNY_WIDE_TNB")) : 0;
-    const bool k6 = K > 80;                           // 6 stages
-    // The reduction form with 6 stages and 96-column blocks does not fit 256 VGPRs — and its spilling builds were NOT deterministic
-    // (tools/ab/stress_red.py: the BN sums of a few columns differed in 1-5 of 40 runs; every build without scratch is bit-stable):
-    // those shapes take 64-column blocks; the test suite pins run-to-run determinism of every reduction instantiation.
-    const int cap = red ? (k6 ? 2 : 3) : 4;
+    // (the reduction form takes blocks of at most 96 columns: its 128-column builds need scratch; every instantiation below is spill-free,
+    // and tests/test_gpu_kernels.py pins run-to-run determinism of each one the nets use)
+    const int cap = red ? 3 : 4;
     if (force >= 2 && force <= cap && N % (32 * force) == 0) return force;
     if (N % 96 == 0 && cap >= 3) return 3;
     if (N % 128 == 0 && cap >= 4) return 4;
@@ -332,7 +333,7 @@ static WideKernel wide_pick(int KS, int TNB, int xf, int mode) {
     if (mode >= 2) switch (KS * 10 + TNB) {
         case 42: return wide_pick_red<4, 2>(xf, mode); case 43: return wide_pick_red<4, 3>(xf, mode);
         case 52: return wide_pick_red<5, 2>(xf, mode); case 53: return wide_pick_red<5, 3>(xf, mode);
-        default: return wide_pick_red<6, 2>(xf, mode);      // (6 stages: 64-column blocks only, see wide_tnb)
+        case 62: return wide_pick_red<6, 2>(xf, mode); default: return wide_pick_red<6, 3>(xf, mode);
     }
     switch (KS * 10 + TNB) {
         case 42: return wide_pick_fwd<4, 2>(xf, mode); case 43: return wide_pick_fwd<4, 3>(xf, mode); case 44: return wide_pick_fwd<4, 4>(xf, mode);
