@@ -757,9 +757,10 @@ def test_narrow_sided_weight_gradient_stream_kernel(ops, M, K, Nc, act):
 
 @pytest.mark.parametrize("K,Nc,addend", [(96, 576, False), (96, 576, True), (96, 384, True), (64, 384, True), (76, 512, False), (80, 192, True), (56, 128, True)])
 def test_wide_output_reduction_form_is_run_to_run_deterministic(K, Nc, addend):
-    """Every instantiation of the wide-output kernel's data-gradient + BN-sums form must be free of register spills: the spilling builds
-    of the first cut returned different sums for a few columns in 1-5 of 40 runs (tools/ab/stress_red.py).  Repeated launches on the
-    same inputs, with allocator / cache churn in between, must be bit-identical in both outputs."""
+    """The first cut of the wide-output kernel's data-gradient + BN-sums form (per-column constants in an LDS table) returned different
+    sums for a few columns in 1-15 of 40 runs on its 6-stage builds, with dx bit-stable (tools/ab/stress_red.py).  Repeated
+    launches of every reduction instantiation the nets use, on the same inputs with allocator / cache churn in between, must be
+    bit-identical in both outputs."""
     import ctypes
     from mobilenet_yolo_pytorch_amd import _lib
     M, act = 20480, 1
