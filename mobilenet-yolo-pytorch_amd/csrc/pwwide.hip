@@ -149,8 +149,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int u = 0; u < TNB; ++u) {
             // scale, shift, mean, invstd of the lane's column — from global memory (L1 / L2 hits), requested ahead of the block's matrix work,
-            // NOT from an LDS table: with the table the sign tests below saw a wrong scale / shift in 1-15 of 40 runs on the 6-stage builds
-            // (tools/ab/stress_red.py; sums of single elements off, dx always right, cause not found); with these loads every run is bit-identical
+            // NOT from an LDS table read next to the MFMAs.  With the table, the 6-stage builds returned BN sums that differed in single
+            // elements in 1-15 of 40 runs (tools/ab/stress_red.py; dx always right).  What the ISA showed: the compiler had given the table
+            // read the registers an MFMA issued two instructions earlier uses as SrcB, and the vector ALU consumed them right after the
+            // (correctly counted) `s_waitcnt lgkmcnt(4)`; the same build with an explicit `lgkmcnt(0)` after the read is bit-stable.  So on
+            // gfx950 the LDS counter can run ahead of the register write while an MFMA still in the pipe reads those registers: do not let the
+            // vector ALU consume an LDS result that lands in operand registers of a just-issued MFMA.
             float4 rc = f4zero();
             if (MODE >= 2) {
                 const int colx = n0 + u * 32 + lrow;
