@@ -5,7 +5,10 @@ import torch
 from mobilenet_yolo_pytorch_amd import _lib
 p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
 stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-for K, N, M in ((96, 576, 20480), (64, 384, 20480), (96, 512, 40960), (80, 192, 20480), (576, 96, 20480), (160, 960, 30976)):
+shapes = ((96, 576, 20480), (64, 384, 20480), (96, 512, 40960), (80, 192, 20480), (576, 96, 20480), (160, 960, 30976))
+if len(sys.argv) > 1 and sys.argv[1] == "more":      # LDS-DMA and short-reduction kernels
+    shapes = ((512, 512, 30976), (1280, 512, 30976), (384, 64, 123904), (24, 144, 495616), (16, 96, 495616), (144, 24, 495616), (320, 1280, 30976), (960, 160, 30976))
+for K, N, M in shapes:
     g = torch.Generator().manual_seed(1)
     x = torch.randn(M, K, generator=g).cuda(); w = (torch.randn(N, K, generator=g) * K ** -0.5).cuda()
     sc, sh = (1 + 0.2 * torch.randn(K, generator=g)).cuda(), (0.3 * torch.randn(K, generator=g)).cuda()
