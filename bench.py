@@ -65,6 +65,8 @@ def parse():
                     help="inline: bracket the MFMA kernels with HIP events inside the timed steps (eager replay); "
                          "after: time K hipGraph-replayed steps, then K more event-bracketed steps for the roofline object")
     ap.add_argument("--breakdown", action="store_true", help="print a per-entry-point time table to stderr")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="CPU-only self-test of the N-rank launch path: the ranks meet over gloo, rank 0 prints one JSON line (tests/test_host_logic_cpu.py)")
     ap.add_argument("--detail", default="", help="comma list of entry points: print their per-call table to stderr")
     return ap.parse_args()
 
@@ -456,14 +458,109 @@ def config3_leg(device, steps=12, warmup=4):
     return res
 
 
+def self_launch(n):
+    """Run this very command under `python -m torch.distributed.run --nnodes=1 --nproc-per-node n` (127.0.0.1 rendezvous, a free
+    port) as a child process.  Nothing here touches the GPU: torch.cuda.device_count() only counts devices."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n and "--launch-check" not in sys.argv:
+        print("bench: --gpus %d but this node exposes %d GPU(s)" % (n, have), file=sys.stderr)
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL's cross-process buffer sharing needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def allreduce_model(payload_bytes, n_buckets):
+    """Modelled gradient all-reduce time per step for N = 2, 4, 8 (no multi-GPU box is available to the builder; the driver's
+    SCALE run is the measurement).  xGMI is point-to-point, ~153 GB/s per link and direction (MI355X_MICROARCH.md); a ring
+    all-reduce moves 2 (N-1)/N of the payload over every GPU's outgoing link and pays 2 (N-1) hop latencies per bucket."""
+    link, hop_us = 153e9, 6.0
+    out = {"payload_mb": round(payload_bytes / 1e6, 2), "buckets": n_buckets, "link_gbs": link / 1e9, "hop_latency_us": hop_us,
+           "model": "single ring per bucket: 2(N-1)/N * bytes / link + 2(N-1) * hop latency per bucket; buckets 1..n-1 overlap the rest of backward, "
+                    "the last one the next forward"}
+    for n in (2, 4, 8):
+        out["n%d_ms" % n] = round((2.0 * (n - 1) / n * payload_bytes / link + n_buckets * 2 * (n - 1) * hop_us * 1e-6) * 1e3, 3)
+    return out
+
+
+def dp_overhead_leg(model, step, steps, plain_ms):
+    """The data-parallel code path on ONE rank (RCCL process group of size 1, bucketed all-reduce launched from inside backward):
+    its cost over the plain step on the same box, same plan.  Runs after the timed region; never part of `value`."""
+    import torch.distributed as dist
+    from mobilenet_yolo_pytorch_amd.dp import attach_data_parallel
+    os.environ.setdefault("NCCL_DEBUG", "WARN")
+    os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
+    s = __import__("socket").socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+    try:
+        red = attach_data_parallel(model)
+        for _ in range(3):
+            step()
+        red.wait()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        red.wait()
+        torch.cuda.synchronize()
+        dp_ms = (time.perf_counter() - t0) / steps * 1e3
+        plan = next(iter(model._plans.values()))
+        nb = len(red.for_plan(plan).buckets)
+        payload = plan.gflat.numel() * 4
+        red.detach()
+        del model.dp_reducer
+        plan.reducer = None
+        # the plain step again, right after, so both numbers see the same clocks / box state
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        plain2 = (time.perf_counter() - t0) / steps * 1e3
+    finally:
+        dist.destroy_process_group()
+    return {"one_rank_rccl_ms_per_step": round(dp_ms, 3), "plain_ms_per_step": round(plain2, 3), "timed_region_ms_per_step": round(plain_ms, 3),
+            "overhead_frac": round(dp_ms / plain2 - 1.0, 4), "buckets": nb,
+            "note": "1-rank RCCL group on this GPU: segmented backward replay + %d all-reduce launches per step; not part of `value`" % nb,
+            "allreduce_model": allreduce_model(payload, nb)}
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1 and a.gpus > 1 and "RANK" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (one per GPU, RCCL over xGMI) before this
+        # process has made any GPU call, hand their output through (rank 0 prints the one JSON line) and exit with their code
+        sys.exit(self_launch(a.gpus))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (a.gpus, a.gpus))
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, a.gpus))
+    if a.launch_check:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t)
+        dist.barrier()
+        if rank == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world, "rank_sum": float(t.item())}))
+        dist.destroy_process_group()
+        return
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     force_dp = os.environ.get("MNY_FORCE_DP") == "1"      # run the RCCL path even with one rank (validation aid)
@@ -622,6 +719,11 @@ def main():
             res["roofline_more"] = [o for o in others if o["bound"] != "hbm"]
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
+        if world == 1 and not a.no_nms and headline and not use_dp:
+            try:
+                res["dp_overhead"] = dp_overhead_leg(model, step, max(5, min(a.steps, 10)), dt / a.steps * 1e3)
+            except Exception as e:                                              # noqa: BLE001 — a side leg must never cost the headline line
+                res["dp_overhead"] = {"error": repr(e)[:300]}
         if world == 1 and not a.no_nms and headline:
             del out
             res["config3"] = config3_leg(device)

@@ -43,9 +43,7 @@ def main():
         outputs = model(x, tg)                            # train.py:260
         loss = sum(o[0] for o in outputs)                 # train.py:265-276
         loss.backward()                                   # train.py:282
-        if reducer is not None:
-            reducer.wait()
-        opt.step()                                        # train.py:283
+        opt.step()                                        # train.py:283 (data parallel: attach_data_parallel's optimizer-step pre-hook waits for the last gradient bucket)
         v = float(loss.detach())
         first = v if first is None else first
         last = v

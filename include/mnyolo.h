@@ -338,6 +338,20 @@ int mny_pw_dgrad_bnred_w6(const float* dy, const void* wT6, const float* addend,
                           const float* shift, int act, const float* mean, const float* invstd, float* red, int64_t M, int K, int Nc,
                           void* stream);
 
+/* ---- which kernel family a pointwise-conv call takes (pure host query; tests and tools/plan_stats.py use it to PROVE that a
+ * plan compared with the oracle contains the kernels the benchmark runs) ----------------------------------------------------------
+ * op: 0 = mny_pw_fwd (forward / plain data gradient of nn.Conv2d(K,Nc,1), mobilenetv2.py:63-85), 1 = mny_pw_dgrad_bnred[_add],
+ * 2 = mny_pw_wgrad (no bias gradient).  bf16: the storage type of the plan (0 = fp32).  Returns one of MNY_ROUTE_*. */
+enum {
+    MNY_ROUTE_TILE_V1 = 0,      /* register-staged tile kernels (unaligned channel counts) */
+    MNY_ROUTE_DMA_F32 = 1,      /* LDS-DMA tile kernel, fp32 MFMA (or the bf16 MFMA with bf16 storage) */
+    MNY_ROUTE_DMA_X6 = 2,       /* LDS-DMA tile kernel, six-product bf16 form */
+    MNY_ROUTE_THIN = 3,         /* short-reduction vector-ALU stream kernel (pwthin.hip) */
+    MNY_ROUTE_WIDE = 4,         /* barrier-free wide-output kernel (pwwide.hip) */
+    MNY_ROUTE_WGRAD_STREAM = 5  /* barrier-free stream weight-gradient kernel (pwwgs.hip) */
+};
+int mny_pw_route(int op, int bf16, int64_t M, int K, int Nc);
+
 /* ---- evaluation consumer: VOC07 11-point mAP on the device -----------------------------
  * Replaces utils/eval_mAP.py:134-187 (calculate_mAP), :69-132 (eval_class_ap), :8-65
  * (eval_single_image_recall) and utils/iou.py:4-48 (find_jaccard_overlap) on a PACKED layout: the

@@ -8,6 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MNY_LIB") or os.path.join(HERE, "libmnyolo.so")     # MNY_LIB: A/B another build on the same GPU box
 
 ACT_NONE, ACT_RELU6, ACT_LEAKY, ACT_RELU, ACT_HSWISH, ACT_HSIGMOID = 0, 1, 2, 3, 4, 5
+ROUTE_TILE_V1, ROUTE_DMA_F32, ROUTE_DMA_X6, ROUTE_THIN, ROUTE_WIDE, ROUTE_WGRAD_STREAM = 0, 1, 2, 3, 4, 5      # mny_pw_route
 
 
 class MnyError(RuntimeError):
@@ -55,6 +56,7 @@ _SIGS = {
     "mny_pw_dgrad_bnred": (c_int, [P, P, P, P, P, P, c_int, P, P, P, c_int64, c_int, c_int, P]),
     "mny_pw_dgrad_bnred_add_supported": (c_int, [c_int64, c_int, c_int, c_int]),
     "mny_pw_dgrad_bnred_add": (c_int, [P, P, P, P, P, P, P, c_int, P, P, P, c_int64, c_int, c_int, P]),
+    "mny_pw_route": (c_int, [c_int, c_int, c_int64, c_int, c_int]),
     "mny_pw_w6_supported": (c_int, [c_int64, c_int, c_int]),
     "mny_pw_w6_bytes": (c_size_t, [c_int, c_int]),
     "mny_cut3_batch": (c_int, [P, P, c_int, P]),

@@ -2491,6 +2491,22 @@ extern "C" int mny_pw_fwd_bf16(const void* x, const float* in_scale, const float
                              M, K, Nc, st);
 }
 
+// which kernel family a call takes: the same predicates, in the same order, as the three dispatchers (tests prove plan coverage with it)
+extern "C" int mny_pw_route(int op, int bf16, int64_t M, int K, int Nc) {
+    if (M <= 0 || K <= 0 || Nc <= 0 || op < 0 || op > 2) return MNY_EINVAL;
+    static const bool gemm_v1 = getenv("MNY_GEMM_V1") != nullptr, wgrad_v1 = getenv("MNY_WGRAD_V1") != nullptr;
+    const int al = bf16 ? 7 : 3;
+    if (op == 2) {
+        if (!bf16 && pw_wgs_ok(M, K, Nc)) return MNY_ROUTE_WGRAD_STREAM;
+        if ((Nc & al) || (K & al) || wgrad_v1) return MNY_ROUTE_TILE_V1;
+        return (!bf16 && nt_x6(M, K, Nc)) ? MNY_ROUTE_DMA_X6 : MNY_ROUTE_DMA_F32;
+    }
+    if (pw_thin_ok(bf16 ? 1 : 0, op, M, K, Nc)) return MNY_ROUTE_THIN;
+    if (!bf16 && pw_wide_ok(M, K, Nc, op == 1)) return MNY_ROUTE_WIDE;
+    if ((K & al) || gemm_v1) return MNY_ROUTE_TILE_V1;
+    return (!bf16 && nt_x6(M, K, Nc)) ? MNY_ROUTE_DMA_X6 : MNY_ROUTE_DMA_F32;
+}
+
 extern "C" size_t mny_pw_wgrad_ws_floats(int64_t M, int K, int Nc) {
     if (M <= 0 || K <= 0 || Nc <= 0) return 0;
     WgPlan pl = wg_plan(M, K, Nc);

@@ -13,6 +13,11 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 // result differs from an fp32 FMA chain by about one fp32 rounding per product.  One v_mfma_f32_32x32x16_bf16 (32 cycles) covers a
 // whole 16-deep stage that takes eight v_mfma_f32_32x32x2_f32 (8 x 64 cycles): 6 x 32 = 192 matrix-pipe cycles instead of 512
 // per accumulator and stage; the cuts cost ~36 VALU instructions per 8-value fragment.
+// Non-finite operands: the cut is exact for every FINITE fp32 value (denormals included; the bf16 pipe may flush denormal pieces, an
+// error below 1e-38 per product).  +-inf gives mid = inf - inf = NaN, and passing the infinity through in `hi` alone would not help:
+// hi(inf) * mid(w) is inf * 0 = NaN for every bf16-representable w.  So an inf or NaN operand poisons exactly the outputs it
+// poisons in an fp32 FMA chain, but always as NaN — the SIGN of an infinity is lost.  Pinned by tests/test_gpu_kernels.py
+// (test_six_product_form_on_non_finite_...: same non-finite set as MNY_X6=0, finite outputs equal); MNY_X6=0 is the strict-fp32 mode.
 __device__ __forceinline__ void x6_split(v4f_t x0, v4f_t x1, bf16x8_t& h, bf16x8_t& m, bf16x8_t& l) {
     const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
     float r1[8], r2[8];

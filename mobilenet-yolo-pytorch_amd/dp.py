@@ -12,6 +12,8 @@ backward call boundaries; bucket k's all-reduce is enqueued the moment the backw
 it has been launched, so it rides under the remaining backward kernels, and the last one under the next
 step's forward (the arena is only waited for before it is overwritten or read by the optimizer).
 """
+import weakref
+
 import torch
 import torch.distributed as dist
 
@@ -83,7 +85,8 @@ class PlanReducer:
     def __init__(self, plan, group=None, n_buckets=4):
         sizes = self.slot_extents(plan)
         ready = self._ready_calls(plan)
-        self.plan = plan
+        self._plan = weakref.ref(plan)            # the plan owns its reducer (plan._dp), never the other way round
+        self.owner = lambda: None
         self.buckets = plan_buckets(sizes, ready, n_buckets)
         if self.buckets[0][0] != 0 or self.buckets[-1][1] != plan.gflat.numel():
             raise RuntimeError("gradient buckets [%d, %d) do not cover the arena of %d floats" % (
@@ -115,42 +118,75 @@ class PlanReducer:
             ready[i] = max(ready[i], ready[i - 1])
         return ready
 
+    @property
+    def plan(self):
+        return self._plan()
+
     def run_backward(self):
         self.ar.wait()                          # previous step's reduction must finish before the arena is rewritten
+        plan = self._plan()
         pos = 0
         for k, (_b, _e, call_end) in enumerate(self.buckets):
-            self.plan.run_bwd_segment(pos, call_end)
+            plan.run_bwd_segment(pos, call_end)
             pos = call_end
             self.ar.launch(k)
-        self.plan.run_bwd_segment(pos, None)
+        plan.run_bwd_segment(pos, None)
 
     def wait(self):
         self.ar.wait()
 
 
 class _ModelReducer:
+    """Per-model handle returned by attach_data_parallel.  The PlanReducer of a plan is OWNED BY THE PLAN (`plan._dp`); this object
+    only keeps weak references, so a plan evicted from the model's plan cache (multi-scale training: one ~40 GB plan per size at
+    bs 256) frees its memory — round 2 kept every plan it had ever seen alive through a strong by_plan table."""
+
     def __init__(self, model, group, n_buckets):
-        self.model, self.group, self.n_buckets = model, group, n_buckets
-        self.by_plan = {}
+        self.model, self.group, self.n_buckets = weakref.ref(model), group, n_buckets
+        self.live = weakref.WeakSet()              # PlanReducers of the plans that are still alive
+        self._hook = None
 
     def for_plan(self, plan):
-        r = self.by_plan.get(id(plan))
-        if r is None or r.plan is not plan:
+        r = getattr(plan, "_dp", None)
+        if r is None or r.owner() is not self:
             r = PlanReducer(plan, self.group, self.n_buckets)
-            self.by_plan[id(plan)] = r
+            r.owner = weakref.ref(self)
+            plan._dp = r
+            self.live.add(r)
         return r
 
     def wait(self):
-        for r in self.by_plan.values():
+        for r in list(self.live):
             r.wait()
+
+    def detach(self):
+        if self._hook is not None:
+            self._hook.remove()
+            self._hook = None
 
 
 def attach_data_parallel(model, group=None, n_buckets=4):
     """Broadcast rank 0's parameters/buffers and make `loss.backward()` average gradients across ranks.
-    Returns an object whose `.wait()` must be called before the optimizer reads `p.grad`."""
+
+    The last gradient bucket's all-reduce is left in flight when backward() returns (it overlaps whatever comes next).  So that
+    the literal train loop of the reference (`loss.backward(); optimizer.step()`, train.py:282-283) is safe with ANY
+    torch.optim.Optimizer — the fused `optim.AdamW` of this package included — a global optimizer-step pre-hook makes the current
+    stream wait for the pending all-reduces before the optimizer reads `p.grad`.  Code that reads `p.grad` by other means right after
+    backward (gradient clipping, logging) calls `.wait()` on the returned object first."""
     with torch.no_grad():
         for t in model.state_dict().values():
             dist.broadcast(t, src=0, group=group)
     red = _ModelReducer(model, group, n_buckets)
     model.dp_reducer = red
+    ref = weakref.ref(red)
+
+    def _before_optimizer_step(_opt, _args, _kwargs):
+        r = ref()
+        if r is not None:
+            r.wait()
+    try:
+        from torch.optim.optimizer import register_optimizer_step_pre_hook
+        red._hook = register_optimizer_step_pre_hook(_before_optimizer_step)
+    except ImportError:                               # very old torch: the caller waits by hand
+        red._hook = None
     return red

@@ -230,6 +230,8 @@ class NetPlan:
         self.side_on = training and not self.use_graphs and (env_side == "1" or (env_side is None and auto_side))
         self.stream_side = _vp(0)
         self._side_stream = torch.cuda.Stream(dev) if self.side_on else None
+        self._ev_fork = torch.cuda.Event() if self.side_on else None
+        self._ev_join = torch.cuda.Event() if self.side_on else None
         self._side_used = False
         self.graphs = {}
         self.eager_steps = 0
@@ -973,6 +975,24 @@ class NetPlan:
         """Entry point for the plan's activation storage type."""
         return name + "_bf16" if self.bf16 else name
 
+    def kernel_routes(self):
+        """[(entry point as called, label, (M, K, N), mny_pw_route family)] for every pointwise-conv call of the plan's two lists —
+        which kernel family each launch takes (tests assert that a plan compared with the oracle contains the families the benchmark
+        runs; tools/plan_stats.py prints the table)."""
+        import re
+        out = []
+        lists = [self.fwd.calls] + ([self.bwd.calls] if getattr(self, "bwd", None) is not None else [])
+        for calls in lists:
+            for fn, _args, label, meta in calls:
+                base = label[:-5] if label.endswith("_bf16") else label
+                op = {"mny_pw_fwd": 0, "mny_pw_dgrad_bnred": 1, "mny_pw_dgrad_bnred_add": 1, "mny_pw_wgrad": 2}.get(base)
+                m = re.search(r"M(\d+) K(\d+) N(\d+)", (meta or {}).get("shape", ""))
+                if op is None or m is None:
+                    continue
+                M, K, N = (int(v) for v in m.groups())
+                out.append((getattr(fn, "__name__", label), label, (M, K, N), _lib.query("mny_pw_route", op, int(self.bf16), M, K, N)))
+        return out
+
     def stale(self):
         return any(t.data_ptr() != p for t, p in self.param_ptrs)
 
@@ -1065,17 +1085,17 @@ class NetPlan:
         self.eager_steps += 1
 
     def _fork_side(self):
+        # one fork and one join event per plan, reused by every fork / join of a step (a wait captures the record that precedes it, so
+        # re-recording the same event later is safe): round 2 created ~70 fresh torch.cuda.Event objects per step
         if self.side_on and self.timing is None:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.dev))
-            self._side_stream.wait_event(ev)
+            self._ev_fork.record(torch.cuda.current_stream(self.dev))
+            self._side_stream.wait_event(self._ev_fork)
             self._side_used = True
 
     def _join_side(self):
         if self._side_used:
-            ev = torch.cuda.Event()
-            ev.record(self._side_stream)
-            torch.cuda.current_stream(self.dev).wait_event(ev)
+            self._ev_join.record(self._side_stream)
+            torch.cuda.current_stream(self.dev).wait_event(self._ev_join)
             self._side_used = False
 
     def run_bwd_segment(self, begin, end):

@@ -81,6 +81,21 @@ class _TrainStep(torch.autograd.Function):
         return None, None, None, None, None, None
 
 
+class _EvalLossEdge(torch.autograd.Function):
+    """Graph edge of the validation loss (`model.eval()(images, targets)` with grad mode on): the reference's eval-mode losses are
+    differentiable (mbv2_yolo.py:157 — frozen-BatchNorm fine-tuning works there); this build has no backward list for the
+    running-statistics plan, and says so when backward() reaches it instead of failing with a generic 'does not require grad'."""
+
+    @staticmethod
+    def forward(ctx, losses, anchor):
+        return losses.clone()
+
+    @staticmethod
+    def backward(ctx, _g):
+        raise _lib.MnyError("backward() through model.eval()(images, targets): the eval-mode (running-statistics) plan is forward only — "
+                            "frozen-BatchNorm fine-tuning is not implemented; call model.train() for gradients, or wrap validation in torch.no_grad()")
+
+
 class yolo(nn.Module):
     ARCH = "mbv2"
 
@@ -206,8 +221,13 @@ class yolo(nn.Module):
             # multi-scale training keeps one plan per size: bound them by resident BYTES (a bs=256/352x352 training plan holds
             # ~40 GB), oldest first, never the one just built
             budget = self.PLAN_BUDGET_FRAC * torch.cuda.get_device_properties(self.device).total_memory
+            evicted = False
             while len(self._plans) > 1 and (len(self._plans) > 8 or sum(q.resident_bytes for q in self._plans.values()) > budget):
                 self._plans.pop(next(iter(self._plans)))
+                evicted = True
+            if evicted:
+                import gc
+                gc.collect()                                                    # a plan holds reference cycles (its builder closures): free its HBM now, not at some later collection
         else:
             self._plans[key] = self._plans.pop(key)                             # most recently used last
         return p
@@ -238,7 +258,7 @@ class yolo(nn.Module):
             losses, metrics = _TrainStep.apply(x, self._anchor, self, plan, targets, seg_maps if self.has_seg else None)
         else:
             # model.eval()(images, targets) — a validation loss: nn.BatchNorm2d normalises with the running statistics and leaves
-            # them untouched (mobilenetv2.py:41-84 in eval mode).  Forward only: the result carries no autograd graph.
+            # them untouched (mobilenetv2.py:41-84 in eval mode).  Forward only: backward() through it raises an explicit MnyError.
             plan = self._plan(N, H, W, "evalloss")
             with torch.no_grad():
                 res = plan.forward_train(x, targets, seg_maps if self.has_seg else None).clone()
@@ -247,6 +267,10 @@ class yolo(nn.Module):
                     seg3 = plan.seg_out3.clone()
                     losses = torch.cat((losses, seg3[:1]))
                     metrics = torch.cat((metrics.reshape(-1), seg3[1:]))
+            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+                if self._anchor is None or self._anchor.device != x.device:
+                    self._anchor = torch.zeros((), device=x.device, requires_grad=True)
+                losses = _EvalLossEdge.apply(losses, self._anchor)             # backward() raises an explicit MnyError
         seg_metrics = None
         if self.has_seg:
             seg_metrics, metrics = metrics[12:], metrics[:12].view(2, 6)

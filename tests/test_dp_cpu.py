@@ -94,8 +94,28 @@ def _worker(rank, world, port, q):
         m = torch.nn.Linear(3, 2)
         with torch.no_grad():
             m.weight.fill_(float(rank + 5))
-        dp.attach_data_parallel(m)
+        mred = dp.attach_data_parallel(m)
         assert float(m.weight[0, 0]) == 5.0
+        # (i) any torch optimizer's step() first waits for the all-reduces still in flight (global step pre-hook), so the
+        # literal `loss.backward(); optimizer.step()` of train.py:282-283 cannot read a half-reduced arena; (ii) the per-plan reducer is
+        # owned by the PLAN — dropping the plan (plan-cache eviction under multi-scale training) frees it and its arena
+        import gc
+        import weakref
+        plan2 = FakePlan(rank, sizes)
+        pr = mred.for_plan(plan2)
+        assert mred.for_plan(plan2) is pr and plan2._dp is pr and pr.plan is plan2
+        pr.run_backward()
+        assert pr.ar.pending, "gloo on CPU tensors reduces asynchronously: the last bucket must still be pending here"
+        m.weight.grad = torch.zeros_like(m.weight)
+        torch.optim.SGD(m.parameters(), lr=0.0).step()
+        assert not pr.ar.pending, "optimizer.step() did not wait for the pending all-reduce"
+        for i, n in enumerate(plan2.grad_params):
+            assert torch.allclose(plan2.gviews[n], torch.full((sizes[i],), 1.5 * (i + 1))), (rank, n)
+        wplan, warena = weakref.ref(plan2), weakref.ref(plan2.gflat)
+        del plan2, pr
+        gc.collect()
+        assert wplan() is None and warena() is None and len(mred.live) == 0, "an evicted plan stayed alive through its reducer"
+        mred.detach()
         q.put((rank, "ok"))
     except Exception as e:                          # noqa: BLE001
         q.put((rank, repr(e)))

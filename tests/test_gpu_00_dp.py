@@ -166,6 +166,61 @@ def _worker_one_rank_rccl(rank, world, port, arch, bf16, q):
             dist.destroy_process_group()
 
 
+def _worker_two_sizes(rank, world, port, arch, bf16, q):
+    """data-parallel + multi-scale training.  The plan cache evicts by resident bytes; the reducer of an evicted plan
+    must not keep it (and its activations / gradient buffers) alive."""
+    try:
+        import gc
+        import weakref
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.cuda.set_device(0)
+        from mobilenet_yolo_pytorch_amd import dp, optim
+        m = _make(arch, torch.float32)
+        red = dp.attach_data_parallel(m, n_buckets=3)
+        opt = optim.AdamW(m.parameters(), lr=1e-4)
+        bs = 4
+        x, tg = _shard(rank, bs, 128)
+        opt.zero_grad(set_to_none=True)
+        _step(m, x, tg)
+        opt.step()                                           # no explicit red.wait(): the optimizer-step pre-hook waits (train.py:282-283 literally)
+        plan1 = m._plans[(bs, 128, 128, True)]
+        assert not plan1._dp.ar.pending
+        w1 = weakref.ref(plan1)
+        bytes1 = plan1.resident_bytes
+        assert bytes1 > 0
+        del plan1
+        torch.cuda.synchronize()
+        before = torch.cuda.memory_allocated()
+        m.PLAN_BUDGET_FRAC = 1e-9                            # any second plan exceeds the budget -> the oldest plan is evicted
+        x2, tg2 = _shard(rank, bs, 96)
+        opt.zero_grad(set_to_none=True)                      # drops p.grad views into plan 1's arena
+        out = _step(m, x2, tg2)
+        opt.step()
+        del out
+        gc.collect()
+        torch.cuda.synchronize()
+        assert list(m._plans) == [(bs, 96, 96, True)], list(m._plans)
+        assert w1() is None, "the evicted plan is still referenced (reducer / autograd context / gradient views)"
+        assert len(red.live) == 1
+        after = torch.cuda.memory_allocated()
+        plan2 = m._plans[(bs, 96, 96, True)]
+        assert after <= before - bytes1 + plan2.resident_bytes + (8 << 20), (before, after, bytes1, plan2.resident_bytes)
+        # and the second size still trains data-parallel: gradients equal on both ranks
+        g = torch.cat([p.grad.flatten() for p in m.parameters() if p.grad is not None])
+        red.wait()
+        torch.cuda.synchronize()
+        gl = [torch.empty_like(g).cpu() for _ in range(world)]
+        dist.all_gather(gl, g.cpu())
+        assert torch.equal(gl[0], gl[1])
+        q.put((rank, "ok"))
+    except Exception:                                   # noqa: BLE001
+        q.put((rank, traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
 def _run(target, world, arch, bf16, timeout=420):
     port = _free_port()
     ctx = mp.get_context("spawn")
@@ -192,3 +247,8 @@ def test_two_ranks_one_gpu_grads_equal_mean_of_single_rank_grads(arch, bf16):
 @pytest.mark.timeout(600)
 def test_one_rank_rccl_reducer_leaves_gradients_identical():
     _run(_worker_one_rank_rccl, 1, "mbv2", False)
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_two_sizes_evicted_plan_is_released_and_optimizer_waits():
+    _run(_worker_two_sizes, 2, "mbv2", False)

@@ -412,3 +412,56 @@ def test_mbv3_512_bf16_matches_oracle():
         cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
         print("(C) cos", k, round(cos, 4))
         assert cos > 0.4, (k, cos)                       # measured 0.65 - 0.89
+
+
+def test_mbv3_512_bf16_bs16_train_step_matches_oracle_at_a_benchmark_sized_plan():
+    """VERDICT r2 #1b: configs[3] is benchmarked at bs 64; at bs 2 the 16x16 BatchNorms see 512 samples and single gradient tensors are
+    chaos-sensitive, so the bs-2 test above can only bound them within 5x.  At bs 16 (M = 4 096 ... 1 M rows per layer: the GEMM tilings,
+    short-reduction kernels and fused backward units of the bs-64 plan) the statistics are averages over >= 4 096 samples and the bounds
+    tighten to what a wrong scale on ONE tensor cannot pass: losses within 1 % of the fp32 oracle (oracle/net_ref_v3.py restating
+    models/mbv3_yolo.py:97-145, mobilenetv3.py:44-136), assigned-target counts exact, L2 norms of the significant parameter gradients
+    within a median factor 1.05 and EVERY one within 1.5x, cosine > 0.8 on three sampled tensors."""
+    from mobilenet_yolo_pytorch_amd import mbv3
+    from oracle import net_ref_v3
+    N, S = 16, 512
+    x = procedural.images(N, S, S, seed=15)
+    tg = procedural.targets(N, seed=16, empty_every=8)
+    ref = procedural.fill_state_dict_(net_ref_v3.RefYoloV3(procedural.VOC_CONFIG)).train()
+    m = mbv3.yolo(procedural.VOC_CONFIG, sync_metrics=True, act_dtype=BF)
+    m.load_state_dict(ref.state_dict())
+    m = m.cuda().train()
+    res = m(x.cuda(), tg)
+    (res[0][0] + res[1][0]).backward()
+    plan = m._plans[(N, S, S, True, "bf16")]
+    assert all(u.Y.dtype == BF for u in plan.units.values())
+    rf = ref(x, tg)
+    (rf[0][0] + rf[1][0]).backward()
+    got = [np.array([float(v) for v in res[i]]) for i in range(2)]
+    f32 = [np.array([float(v) for v in rf[i]]) for i in range(2)]
+    for i in range(2):
+        print("head %d (loss, recall, iou, obj, no_obj, cls, count)\n  hip bf16 %s\n  fp32     %s" % (i, got[i], f32[i]))
+        np.testing.assert_allclose(got[i][0], f32[i][0], rtol=0.01, atol=1e-5)
+        np.testing.assert_allclose(got[i][4], f32[i][4], rtol=0.02)
+        assert got[i][6] == f32[i][6]
+    gp, rp = dict(m.named_parameters()), dict(ref.named_parameters())
+    norms = {k: (p.grad.double().norm().item(), rp[k].grad.double().norm().item()) for k, p in gp.items()}
+    gmax = max(b for _a, b in norms.values())
+    logs, worst = [], (1.0, "")
+    for k, p in gp.items():
+        assert bool(torch.isfinite(p.grad).all()), k
+        a, b = norms[k]
+        if b >= 1e-3 * gmax:
+            logs.append(abs(np.log(a / b)))
+            if logs[-1] > abs(np.log(worst[0])):
+                worst = (a / b, k)
+        else:
+            assert a <= 2e-2 * gmax, (k, a, gmax)
+    med, p90 = float(np.exp(np.median(logs))), float(np.exp(np.percentile(logs, 90)))
+    print("grad-norm ratio vs fp32 oracle over %d tensors: median factor %.3f, 90th percentile %.3f, worst %.3f at %s" % ((len(logs), med, p90) + worst))
+    assert med < 1.05 and p90 < 1.2, (med, p90)
+    assert 1 / 1.5 <= worst[0] <= 1.5, worst
+    for k in ("yolo_headS32.2.conv.weight", "backbone.conv2.weight", "backbone.bneck.0.conv1.weight"):
+        a, b = gp[k].grad.double().flatten().cpu(), rp[k].grad.double().flatten()
+        cos = float((a @ b) / (a.norm() * b.norm() + 1e-30))
+        print("cos", k, round(cos, 4))
+        assert cos > 0.8, (k, cos)

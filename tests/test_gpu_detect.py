@@ -250,3 +250,55 @@ def test_nms_config5_100k_boxes_20_classes_indices_equal_cpu(ops):
         kc = k[k[:, 6] == c]
         s = kc[:, 4] * kc[:, 5]
         assert bool((s[:-1] >= s[1:]).all())
+
+
+@pytest.mark.parametrize("val_conf", [1e-6, 0.5])
+def test_decode_config5_full_size_99825_candidates_equal_oracle(ops, val_conf):
+    """BASELINE configs[4] / SURVEY §8d C5(i) at the size bench.py times (VERDICT r2 #1c): both heads of 55 images at 352x352 =
+    99 825 candidates, second head appended behind the first on the device, against yolo_ref.decode_rows (restating
+    models/yolo_loss.py:180-204): per-image counts and row order exact, class index exact, box coordinates / confidences <= 1e-4."""
+    y = procedural.VOC_CONFIG["yolo"]
+    specs = yolo_ref.specs_from_config(procedural.VOC_CONFIG)
+    N, S = 55, 352
+    g = torch.Generator().manual_seed(4)
+    heads = [torch.randn(N, grid, grid, len(y["mask"][hi]) * (5 + y["num_classes"]), generator=g) for hi, grid in enumerate((S // 32, S // 16))]
+    args = [_head_args(ops, specs[hi], N, heads[hi].shape[1], S) for hi in range(2)]
+    cap = sum(hp.A * hp.g * hp.g for _a, _m, hp in args)
+    assert N * cap == 99825
+    rows, c0 = ops.yolo_decode(heads[0].cuda(), args[0][0], args[0][1], args[0][2], val_conf, row_stride=cap)
+    rows, c1 = ops.yolo_decode(heads[1].cuda(), args[1][0], args[1][1], args[1][2], val_conf, rows=rows, row_stride=cap, base_counts=c0)
+    c0, c1, rows = c0.cpu().numpy(), c1.cpu().numpy(), rows.cpu()
+    ref = []
+    for hi in range(2):
+        specs[hi].val_conf = val_conf
+        ref.append(yolo_ref.decode_rows(heads[hi], specs[hi], [S, S], layout="nhwc"))
+    assert c0.tolist() == [len(r) for r in ref[0]]
+    assert c1.tolist() == [len(a) + len(b) for a, b in zip(ref[0], ref[1])]          # utils/box.py:17: the two heads' rows back to back
+    if val_conf < 1e-3:
+        assert int(c1.sum()) > 0.999 * N * cap                                        # ~every candidate passes, as in the bench leg
+    for b in range(N):
+        want = torch.cat((ref[0][b], ref[1][b])).numpy()
+        got = rows[b, :c1[b]].numpy()
+        np.testing.assert_allclose(got[:, :6], want[:, :6], rtol=0, atol=1e-4)
+        assert np.array_equal(got[:, 6], want[:, 6])
+
+
+def test_nms_reference_shaped_batch_256_images_x_1815_candidates(ops):
+    """the reference-shaped NMS case — one eval batch of 256 images with all 1 815 candidates of both heads each
+    (464 640 rows, 5 120 (image, class) buckets of ~90 rows: utils/box.py:11-31 runs 256 x 20 torchvision.ops.nms calls here).
+    Kept indices per image identical to oracle/nms_ref.c (parity-unpinned restatement of torchvision's CPU kernel), order included."""
+    S, n, C = 256, 1815, 20
+    segs = [_rand_rows(n, C, seed=1000 + i) for i in range(S)]
+    rows = torch.cat(segs)
+    off = np.arange(S + 1, dtype=np.int32) * n
+    beg, cnt = torch.from_numpy(off[:-1].copy()).cuda(), torch.full((S,), n, dtype=torch.int32).cuda()
+    out_idx, out_counts, out_rows, prefix, status = ops.nms_per_class(rows.cuda(), beg, cnt, C, 0.45, max_seg_rows=n)
+    assert int(status.cpu()) == 0
+    out_idx, oc, prefix = out_idx.cpu().numpy(), out_counts.cpu().numpy(), prefix.cpu().numpy()
+    out_rows = out_rows.cpu().numpy()
+    assert np.array_equal(prefix, np.concatenate(([0], np.cumsum(oc))))
+    for s, seg in enumerate(segs):
+        ref_rows, ref_idx = nms_ref.nms_rows(seg, C, 0.45)
+        assert oc[s] == len(ref_idx), s
+        assert np.array_equal(out_idx[off[s]:off[s] + oc[s]] - off[s], ref_idx.numpy()), s
+        assert np.array_equal(out_rows[prefix[s]:prefix[s + 1]], ref_rows.numpy()), s

@@ -604,6 +604,64 @@ def test_six_product_bf16_gemms_are_fp32_accurate(ops, M, K, Nc):
     assert rel <= 2e-6, rel                                   # row-wise relative to sum |a||w|: fp32-level
 
 
+_X6_SPECIAL = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from mobilenet_yolo_pytorch_amd import ops
+M, K, Nc = 4096, 512, 512
+g = torch.Generator().manual_seed(1)
+x = torch.randn(M, K, generator=g)
+w = torch.randn(Nc, K, generator=g) * K ** -0.5
+w[5, 3] = 0.0                                  # inf * 0 -> NaN on both paths
+w[6] = torch.round(w[6] * 64) / 64             # bf16-representable weights: their mid / lo pieces are exactly 0
+x[0, 3] = float("inf"); x[1, 7] = float("-inf"); x[2, 9] = float("nan"); x[3, 1] = float("inf"); x[3, 2] = float("-inf")
+x[4] = 1e-40                                   # a row of denormals
+x[5, ::2] = 3e-39                              # denormals next to normal values
+x[6] = x[6] * 1e30; x[7] = x[7] * 1e-30        # large / small but finite rows: the cut is exact, nothing overflows
+y, _ = ops.pw_fwd((x.cuda().view(1, 1, M, K), None, None, 0), w.cuda(), want_stats=False)
+dw, _ = ops.pw_wgrad((x.cuda().view(1, 1, M, K), None, None, 0), torch.randn(M, Nc, generator=g).cuda().view(1, 1, M, Nc))
+torch.cuda.synchronize()
+np.savez(sys.argv[1], y=y.view(M, Nc).cpu().numpy(), dw=dw.cpu().numpy(), x=x.numpy(), w=w.numpy())
+"""
+
+
+def test_six_product_form_on_non_finite_and_denormal_operands_vs_the_fp32_mfma_path(tmp_path):
+    """VERDICT r2 #1d / ADVICE r2: x6_split cuts an fp32 value as hi + mid + lo by subtraction, so +-inf gives mid = inf - inf = NaN;
+    and even with the infinity passed through in hi alone, hi(inf) * mid(w) is inf * 0 = NaN for every bf16-representable w.  The
+    six-product form therefore CANNOT keep the sign of an infinity: where the fp32 MFMA (MNY_X6=0, the reference's fp32 conv,
+    mobilenetv2.py:63-85) returns +-inf or NaN, it returns NaN.  Asserted here, both builds run in child processes on the same
+    operands: (1) the set of non-finite outputs is IDENTICAL (an inf / NaN input poisons exactly its output row / weight-gradient
+    column on both paths, and nothing else); (2) every output that is finite agrees to fp32 accuracy, rows scaled by 1e+-30 included;
+    (3) denormal inputs contribute at most their own magnitude (the bf16 pipe may flush them): |difference| <= 1e-36.
+    The loss guard of the caller (yolo_loss.py:231 checks the loss for NaN, and so do train loops) sees a non-finite loss either way."""
+    import subprocess
+    import sys
+    outs = {}
+    for mode in ("0", "1"):
+        f = str(tmp_path / ("x6_%s.npz" % mode))
+        env = dict(os.environ, MNY_X6=mode)
+        subprocess.run([sys.executable, "-c", _X6_SPECIAL % os.path.dirname(os.path.dirname(os.path.abspath(__file__))), f], check=True, env=env, timeout=600)
+        outs[mode] = np.load(f)
+    y0, y1, x, w = outs["0"]["y"], outs["1"]["y"], outs["0"]["x"], outs["0"]["w"]
+    bad0, bad1 = ~np.isfinite(y0), ~np.isfinite(y1)
+    assert np.array_equal(bad0, bad1)                                      # (1) same poisoned elements ...
+    assert bad0[:4].all() and not bad0[4:].any()                           # ... = exactly the four rows holding an inf / NaN
+    assert np.isnan(y1[:4]).all()                                          # six-product form: always NaN (sign of the infinity lost)
+    assert np.isposinf(y0[0, w[:, 3] > 0]).all() and np.isneginf(y0[0, w[:, 3] < 0]).all() and np.isnan(y0[0, 5])   # fp32 MFMA: IEEE
+    ref = x[4:].astype(np.float64) @ w.astype(np.float64).T
+    scale = np.abs(x[4:]).astype(np.float64) @ np.abs(w).astype(np.float64).T + 1e-300
+    for y in (y0, y1):                                                     # (2) finite part at fp32 accuracy, relative to sum |x||w| per element
+        rel = np.abs(y[4:] - ref) / scale
+        assert rel[2:].max() <= 2e-6, rel[2:].max()
+    assert np.abs(y1[4:6].astype(np.float64) - y0[4:6]).max() <= 1e-36 + 2e-6 * scale[1].max()   # (3) rows 4 (all denormal) and 5 (denormals + normals)
+    assert np.abs(y1[4]).max() <= 1e-36 and np.abs(y0[4]).max() <= 1e-36
+    d0, d1 = outs["0"]["dw"], outs["1"]["dw"]                              # weight gradient: x columns 1, 2, 3, 7, 9 hold the non-finite values
+    assert np.array_equal(~np.isfinite(d0), ~np.isfinite(d1))
+    cols = np.zeros(d0.shape[1], bool); cols[[1, 2, 3, 7, 9]] = True
+    assert (~np.isfinite(d0))[:, cols].all() and np.isfinite(d0[:, ~cols]).all()
+    assert np.abs(d1[:, ~cols] - d0[:, ~cols]).max() <= 1e-4 * np.abs(d0[:, ~cols]).max()
+
+
 def _cut3(mats):
     """mny_cut3_batch over a list of fp32 [R][C] matrices -> list of plane buffers"""
     import ctypes

@@ -67,3 +67,81 @@ def test_step_is_bitwise_deterministic(arch, bf16):
         assert snap[0] == ref[0] and snap[1] == ref[1], (it, snap[:2], ref[:2])
         for a, b in zip(snap[2:], ref[2:]):
             assert torch.equal(a, b), it
+
+
+@pytest.mark.parametrize("arch,bf16,bs,size", [("mbv3", True, 16, 512), ("mbv3", False, 16, 384), ("mbv2", True, 32, 352)])
+def test_step_is_bitwise_deterministic_at_benchmark_sized_plans(arch, bf16, bs, size):
+    """the whole-step determinism guard of tests/test_gpu_net.py (MobileNetV2 fp32, bs 64) extended to MobileNetV3 (h-swish /
+    gate units, 5x5 depthwise, the module applied twice), to bf16 storage and to plans large enough for the M-gated kernel families:
+    six replays with allocator churn in between, loss tuples and every parameter gradient bit-identical."""
+    from mobilenet_yolo_pytorch_amd import mbv3, yolo
+    from oracle import procedural
+    torch.manual_seed(0)
+    cls = yolo if arch == "mbv2" else mbv3.yolo
+    m = cls(procedural.VOC_CONFIG, act_dtype=torch.bfloat16 if bf16 else torch.float32)
+    procedural.fill_state_dict_(m)
+    m = m.cuda().train()
+    x = procedural.images(bs, size, size, seed=21).cuda()
+    tg = procedural.targets(bs, seed=22, empty_every=5)
+    ref = None
+    for it in range(6):
+        m.zero_grad(set_to_none=True)
+        junk = torch.randn(1 << 22, device="cuda")
+        res = m(x, tg)
+        (res[0][0] + res[1][0]).backward()
+        torch.cuda.synchronize()
+        del junk
+        snap = [[float(v) for r in res for v in r]] + [p.grad.clone() for p in m.parameters() if p.grad is not None]
+        if ref is None:
+            ref = snap
+            continue
+        assert snap[0] == ref[0], (it, snap[0], ref[0])
+        bad = [i for i, (a, b) in enumerate(zip(snap[1:], ref[1:])) if not torch.equal(a, b)]
+        assert not bad, (it, bad[:8])
+
+
+@pytest.mark.parametrize("arch,bf16", [("mbv2", False), ("mbv3", False), ("mbv3", True)])
+def test_side_stream_weight_gradients_equal_single_stream(arch, bf16, monkeypatch):
+    """the weight-gradient kernels of small plans run on a second HIP stream (fork after dY is ready, join before every
+    batched combine and at the end of every replayed segment).  The same step with MNY_SIDE_STREAM=0 and =1 (read when a plan is
+    built) must give bit-identical losses and gradients — MobileNetV3 covers the module applied twice (its contributions stay in
+    order on the main stream), bf16 the shadow-weight path; the data-parallel segments are covered by the 4-bucket replay below."""
+    from mobilenet_yolo_pytorch_amd import mbv3, yolo
+    from oracle import procedural
+    cls = yolo if arch == "mbv2" else mbv3.yolo
+    x = procedural.images(8, 160, 160, seed=31).cuda()
+    tg = procedural.targets(8, seed=32, empty_every=3)
+    snaps = {}
+    for side in ("0", "1"):
+        monkeypatch.setenv("MNY_SIDE_STREAM", side)
+        m = cls(procedural.VOC_CONFIG, act_dtype=torch.bfloat16 if bf16 else torch.float32)
+        procedural.fill_state_dict_(m)
+        m = m.cuda().train()
+        for rep in range(3):                                     # later replays reuse the plan's two events
+            m.zero_grad(set_to_none=True)
+            res = m(x, tg)
+            plan = next(iter(m._plans.values()))
+            assert plan.side_on == (side == "1")
+            if side == "1" and rep == 2:                         # segmented replay as the data-parallel reducer drives it (joins at segment ends)
+                g = torch.ones(plan.g_scale.numel(), device="cuda")
+                plan.stream.value = torch.cuda.current_stream().cuda_stream
+                plan.stream_side.value = plan._side_stream.cuda_stream
+                plan.x_ptr.value = plan.saved_x.data_ptr()
+                plan.g_scale.copy_(g)
+                n = len(plan.bwd.calls)
+                for b, e in ((0, n // 4), (n // 4, n // 2), (n // 2, 3 * n // 4), (3 * n // 4, None)):
+                    plan.run_bwd_segment(b, e)
+                grads = [plan.gviews[k].clone() for k in plan.grad_params]
+            else:
+                (res[0][0] + res[1][0]).backward()
+                grads = [plan.gviews[k].clone() for k in plan.grad_params]
+            torch.cuda.synchronize()
+            snap = [[float(v) for r in res for v in r]] + grads
+            if side in snaps:
+                assert snap[0] == snaps[side][0]
+                assert all(torch.equal(a, b) for a, b in zip(snap[1:], snaps[side][1:])), (side, rep)
+            snaps[side] = snap
+        del m
+    assert snaps["0"][0] == snaps["1"][0]
+    bad = [i for i, (a, b) in enumerate(zip(snaps["0"][1:], snaps["1"][1:])) if not torch.equal(a, b)]
+    assert not bad, bad[:8]
