@@ -130,8 +130,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const float4 a0 = g[2 * s], a1 = g[2 * s + 1];
             float z[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
             if (XF != 0 && MODE < 2) {
-                const float4 c0 = *reinterpret_cast<const float4*>(scl + 16 * s), c1 = *reinterpret_cast<const float4*>(scl + 16 * s + 8);
-                const float4 h0 = *reinterpret_cast<const float4*>(shl + 16 * s), h1 = *reinterpret_cast<const float4*>(shl + 16 * s + 8);
+                // RULE (DESIGN 4 "Determinism"): in a kernel that keeps MFMAs in flight the vector ALU consumes an LDS result only
+                // behind an EXPLICIT `s_waitcnt lgkmcnt(0)` that carries the destination registers — never behind the compiler's counted
+                // lgkmcnt(N > 0) alone (the reduction form's table read, consumed behind a counted wait, returned run-to-run different
+                // values on its 6-stage builds; cause unresolved).  The LDS-DMA kernels comply by construction (MNY_LGKM_WAIT), this is
+                // the one compiler-visible LDS read next to this kernel's MFMAs.
+                v4f_t c0 = *reinterpret_cast<const v4f_t*>(scl + 16 * s), c1 = *reinterpret_cast<const v4f_t*>(scl + 16 * s + 8);
+                v4f_t h0 = *reinterpret_cast<const v4f_t*>(shl + 16 * s), h1 = *reinterpret_cast<const v4f_t*>(shl + 16 * s + 8);
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(c0), "+v"(c1), "+v"(h0), "+v"(h1));
                 const float sv[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w}, hv[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {

@@ -866,9 +866,10 @@ class NetPlan:
                         bwd.add(K("mny_transpose"), w, wT, o.C, i.C, self.stream)
                 prod = i.node
                 wT6 = getattr(self, "wT6", {}).get(nd.conv)      # pre-cut W^T planes: this data gradient takes the six-product bf16 form
-                # (fp32 plans only: with bf16 storage the epilogue's 2-byte loads of the unit's output cost what the saved pass did —
-                # same-box A/B 3 281 vs 3 293 img/s on MobileNetV3 512 — MNY_REDFUSE_BF16=1 turns it on for measurements)
-                if (os.environ.get("MNY_NO_REDFUSE") != "1" and (not self.bf16 or os.environ.get("MNY_REDFUSE_BF16") == "1")
+                # (bf16 storage: round 2 measured the epilogue's 2-byte loads of the unit's output at what the saved pass cost, 3 281 vs
+                # 3 293 img/s on MobileNetV3 512; with round 3's kernels it wins — same-box A/B 17.65-17.70 vs 17.93-17.99 ms/step — and is on;
+                # MNY_REDFUSE_BF16=0 turns it off for A/B)
+                if (os.environ.get("MNY_NO_REDFUSE") != "1" and (not self.bf16 or os.environ.get("MNY_REDFUSE_BF16") != "0")
                         and prod is not None and prod.op in ("dw", "pw") and gs[i.id].buf is None
                         and n_consumers[i.id] == 1 and not takes_own_sums(prod)
                         and _lib.query(K("mny_pw_dgrad_bnred_supported"), M, oc, i.C, i.act) == 1):
@@ -888,7 +889,7 @@ class NetPlan:
                             self.K("mny_pw_dgrad_bnred"), dY, wT, out, pu.Y, pu.scale, pu.shift, act_, pu.mean, pu.invstd, rbuf, M, K, Nc, self.stream,
                             meta=dict(flops=2 * M * K * Nc, bytes=self.eb * (M * K + 2 * M * Nc) + 4 * K * Nc, shape="dgrad+red M%d K%d N%d" % (M, K, Nc))))
                 elif (os.environ.get("MNY_NO_REDFUSE") != "1" and os.environ.get("MNY_NO_REDADD") != "1"
-                        and (not self.bf16 or os.environ.get("MNY_REDFUSE_BF16") == "1")
+                        and (not self.bf16 or os.environ.get("MNY_REDFUSE_BF16") != "0")
                         and prod is not None and prod.op in ("dw", "pw") and gs[i.id].buf is not None and last_consumer.get(i.id) is nd
                         and i.id not in loss_ids and not takes_own_sums(prod)
                         and _lib.query(K("mny_pw_dgrad_bnred_add_supported"), M, oc, i.C, i.act) == 1):

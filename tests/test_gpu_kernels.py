@@ -813,6 +813,28 @@ def test_narrow_sided_weight_gradient_stream_kernel(ops, M, K, Nc, act):
     assert (dw2.double().cpu() - ref2).abs().max().item() <= 2e-5 * ref2.abs().max().item()
 
 
+@pytest.mark.parametrize("K,Nc,act", [(96, 576, 1), (64, 384, 1), (96, 512, 2), (80, 192, 4), (56, 128, 3)])
+def test_wide_output_forward_form_is_run_to_run_deterministic(ops, K, Nc, act):
+    """the forward form of the wide-output kernel reads its per-k scale / shift from LDS right after the previous tile's MFMAs
+    (XF = 1: clamp family, XF = 2: h-swish) — the same neighbourhood in which the reduction form's table read misbehaved.  Outputs and the
+    BN-statistics partial rows of 24 launches on the same inputs (allocator churn in between) must be bit-identical."""
+    M = 20480
+    x = rnd(M, K, seed=1).view(1, 1, M, K).cuda()
+    w = (rnd(Nc, K, seed=2) * K ** -0.5).cuda()
+    sc, sh = (1 + 0.2 * rnd(K, seed=3)).cuda(), (0.3 * rnd(K, seed=4)).cuda()
+    first = None
+    for it in range(24):
+        junk = torch.randn(1 << 22, device="cuda")
+        y, st = ops.pw_fwd((x, sc, sh, act), w, want_stats=True)
+        torch.cuda.synchronize()
+        del junk
+        if first is None:
+            first = (y.clone(), st.clone())
+        else:
+            assert torch.equal(y, first[0]), "output differs in run %d" % it
+            assert torch.equal(st, first[1]), "statistics differ in run %d" % it
+
+
 @pytest.mark.parametrize("K,Nc,addend", [(96, 576, False), (96, 576, True), (96, 384, True), (64, 384, True), (76, 512, False), (80, 192, True), (56, 128, True)])
 def test_wide_output_reduction_form_is_run_to_run_deterministic(K, Nc, addend):
     """The first cut of the wide-output kernel's data-gradient + BN-sums form (per-column constants in an LDS table) returned different
