@@ -1732,6 +1732,201 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     }
 }
 
+// Stage 1, second generation (round 3).  Same tiling, LDS-DMA ring, lane mapping, partial-row layout and arithmetic (order
+// included: bit-identical results) as pw_bnbwd_stage1_kernel; what changed is the instruction stream.  The counters of the first
+// generation (profiles/r03_pmc_pw_bnbwd.md, 16 -> 96 @ 176x176) showed 15 scalar and 20 vector instructions per MFMA, 44 % of the
+// wave cycles stalled at issue and the matrix pipe 30 % busy at 4.45 TB/s: every LDS read sat in its own basic block behind a
+// `lane == 0` mask store (s_cbranch_execz + lgkmcnt(0) per read), the DMA issue went through per-instruction kind / range branches.
+// Here the row loop body is ONE basic block: all 2 + 4 TI fragment reads of a stage are issued together, the ballots of a stage are
+// kept in scalar registers and leave through one exec-masked group of 16-byte stores, the DMA sources are running pointers
+// (select, not branch, for the rows past the slice), the Gram MFMA is unconditional (its column-slice twin is simply not stored).
+template <int TI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) void pw_bnbwd_stage1b_kernel(BnwArgs p) {
+    constexpr int KC = 16, S = 3, BI = 32 * TI, BJ = 32;
+    constexpr int G_ST = KC * BI, X_ST = KC * BJ, STAGE = 2 * G_ST + X_ST;   // floats: G | Y | X
+    constexpr int NG = G_ST / 256, NX = X_ST / 256, NL = 2 * NG + NX;
+    constexpr int LPW = (NL + 3) / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, kk = lane >> 5;
+    const int64_t m_begin = (int64_t)blockIdx.x * p.rows_per_block;
+    const int64_t m_end = min(m_begin + p.rows_per_block, p.M);
+    const bool has_xf = p.xsc != nullptr;
+    const float xslope = act_slope(p.xact), xhi = act_hi(p.xact);
+    const float aslope = act_slope(p.act), ahi = act_hi(p.act);
+    const int krow0 = wave * (KC / 4);
+    const int tile_off = blockIdx.y * TI, n_off = tile_off * 32;
+    const bool slice0 = blockIdx.y == 0;
+
+    float sc[TI], sh[TI], mu[TI], is[TI], s1[TI], s2[TI];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        const int co = n_off + i * 32 + li;
+        const bool ok = co < p.N;
+        sc[i] = ok ? p.sc[co] : 0.f; sh[i] = ok ? p.sh[co] : 0.f; mu[i] = ok ? p.mean[co] : 0.f; is[i] = ok ? p.invstd[co] : 0.f;
+        s1[i] = 0.f; s2[i] = 0.f;
+    }
+    const float xs = (has_xf && li < p.K) ? p.xsc[li] : 1.f, xh = (has_xf && li < p.K) ? p.xsh[li] : 0.f;
+    float s3 = 0.f;
+
+    // DMA instruction slots of this wave: a running source pointer per slot (row m_begin + d_row of its tensor), the clamp target
+    // for rows past the slice (Y, X: the slice's last row — finite filler, its products are annihilated by dz = 0 / b = 0; G: zeros)
+    const float* zero_src = reinterpret_cast<const float*>(&mny_zero16);
+    const float* d_cur[LPW];
+    const float* d_past[LPW];
+    int d_row[LPW], d_lds[LPW], d_step[LPW];
+#pragma unroll
+    for (int i = 0; i < LPW; ++i) {
+        int j = wave + 4 * i;
+        if (j >= NL) j = NL - 1;
+        const int kind = j < NG ? 0 : (j < 2 * NG ? 1 : 2);              // 0: G, 1: Y, 2: X
+        const int jj = kind == 0 ? j : (kind == 1 ? j - NG : j - 2 * NG);
+        const int q = jj * 64 + lane;
+        const int W4 = (kind == 2 ? BJ : BI) / 4;
+        d_row[i] = q / W4;
+        const int c = (q % W4) * 4;
+        d_lds[i] = (kind == 0 ? 0 : (kind == 1 ? G_ST : 2 * G_ST)) + jj * 256;
+        const bool ok = kind == 2 ? c < p.K : n_off + c < p.N;
+        const float* base = kind == 0 ? p.G : (kind == 1 ? p.Y : p.X);
+        const int stride = kind == 2 ? p.K : p.N;
+        const int off = kind == 2 ? c : n_off + c;
+        d_cur[i] = ok ? base + (m_begin + d_row[i]) * stride + off : zero_src;
+        d_past[i] = (ok && kind != 0) ? base + (m_end - 1) * stride + off : zero_src;
+        d_step[i] = ok ? KC * stride : 0;
+    }
+    auto issue = [&](int64_t m0, int slot) {
+        float* stage = smem + slot * STAGE;
+#pragma unroll
+        for (int i = 0; i < LPW; ++i) {
+            const float* src = (m0 + d_row[i] < m_end) ? d_cur[i] : d_past[i];
+            d_cur[i] += d_step[i];
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(stage + d_lds[i]), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[TI], gram;
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gram[r] = 0.f;
+
+    auto compute = [&](int64_t m0, int slot) {
+        const float* gb = smem + slot * STAGE + (krow0 + kk) * BI + li;
+        const float* yb = gb + G_ST;
+        const float* xb = smem + slot * STAGE + 2 * G_ST + (krow0 + kk) * BJ + li;
+        float xr[KC / 8], gr[KC / 8][TI], yr[KC / 8][TI];
+#pragma unroll
+        for (int kp = 0; kp < KC / 8; ++kp) {                             // every fragment read of the stage, one wait
+            xr[kp] = xb[kp * 2 * BJ];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) { gr[kp][i] = gb[kp * 2 * BI + i * 32]; yr[kp][i] = yb[kp * 2 * BI + i * 32]; }
+        }
+        unsigned long long bal[KC / 8][TI];
+#pragma unroll
+        for (int kp = 0; kp < KC / 8; ++kp) {
+            const bool rok = m0 + krow0 + kp * 2 + kk < m_end;
+            const float xz = fmaf(xr[kp], xs, xh);
+            const float b = rok ? fminf(fmaxf(xz, xslope * xz), xhi) : 0.f;     // rows past the slice contribute nothing
+            s3 += b;
+            float af[TI];
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                const float g = gr[kp][i], y = yr[kp][i];
+                const float z = fmaf(y, sc[i], sh[i]);
+                const bool on = z > 0.f && z < ahi;                                // act' = on ? 1 : slope
+                bal[kp][i] = __ballot(on);
+                const float dz = on ? g : g * aslope;
+                s1[i] += dz;
+                s2[i] = fmaf(dz, (y - mu[i]) * is[i], s2[i]);
+                af[i] = dz;
+            }
+#pragma unroll
+            for (int i = 0; i < TI; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], b, acc[i], 0, 0, 0);
+            gram = __builtin_amdgcn_mfma_f32_32x32x2f32(b, b, gram, 0, 0, 0);
+        }
+        // the stage's mask words (rows 2 pair, 2 pair + 1 <-> the two lane halves; kp = 0, 1 are consecutive pairs, pair0 is even):
+        // one 16-byte store per column tile from lane 0
+        if (lane == 0) {
+            const int64_t pair0 = (m0 + krow0) >> 1;
+            const bool full = m0 + krow0 + 2 < m_end;                              // both pairs of this wave start inside the slice
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                if (tile_off + i < p.tiles_total) {
+                    unsigned long long* dstw = p.mask + (int64_t)(tile_off + i) * p.npairs + pair0;
+                    if (full) *reinterpret_cast<ulonglong2*>(dstw) = make_ulonglong2(bal[0][i], bal[1][i]);
+                    else if (m0 + krow0 < m_end) dstw[0] = bal[0][i];
+                }
+            }
+        }
+    };
+
+    const int total = (int)((m_end - m_begin + KC - 1) / KC);
+    int i_t = 0, i_slot = 0, c_slot = 0, c_t = 0;
+    auto issue_next = [&]() { issue(m_begin + (int64_t)i_t * KC, i_slot); ++i_t; if (++i_slot == S) i_slot = 0; };
+    auto consume = [&]() { compute(m_begin + (int64_t)c_t * KC, c_slot); ++c_t; if (++c_slot == S) c_slot = 0; };
+    const int pre = total < S - 1 ? total : S - 1;
+    for (int t = 0; t < pre; ++t) issue_next();
+    for (int t = 0; t < total - pre; ++t) {
+        wait_vmcnt<LPW*(S - 2)>();
+        __builtin_amdgcn_s_barrier();
+        issue_next();
+        consume();
+    }
+    for (int t = 0; t < pre; ++t) {
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        consume();
+    }
+
+    // ---- block reduction over the 4 waves (fixed order) and the two k-halves, then one partial row (as the first generation)
+    float* dst = p.partial + (int64_t)blockIdx.x * bnw_stride(p.N, p.K);
+    float* red = smem;                         // [3][16][64]
+    auto reduce_tile = [&](f32x16& t, float* out, int rows, int cols, int ld, int row0) {
+        __syncthreads();
+        if (wave > 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((wave - 1) * 16 + r) * 64 + lane] = t[r];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = ((t[r] + red[(0 * 16 + r) * 64 + lane]) + red[(1 * 16 + r) * 64 + lane]) + red[(2 * 16 + r) * 64 + lane];
+                const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                if (row < rows && li < cols) out[(int64_t)row * ld + li] = v;
+            }
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < TI; ++i) reduce_tile(acc[i], dst, p.N, p.K, p.K, n_off + i * 32);
+    if (slice0) reduce_tile(gram, dst + (int64_t)p.N * p.K, p.K, p.K, p.K, 0);
+    __syncthreads();
+    float* vred = smem;                        // [4][2*TI+1][32]
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        const float a = s1[i] + __shfl_xor(s1[i], 32), b2 = s2[i] + __shfl_xor(s2[i], 32);
+        if (kk == 0) { vred[(wave * (2 * TI + 1) + i) * 32 + li] = a; vred[(wave * (2 * TI + 1) + TI + i) * 32 + li] = b2; }
+    }
+    {
+        const float c3 = s3 + __shfl_xor(s3, 32);
+        if (kk == 0) vred[(wave * (2 * TI + 1) + 2 * TI) * 32 + li] = c3;
+    }
+    __syncthreads();
+    float* vdst = dst + (int64_t)p.N * p.K + (int64_t)p.K * p.K;
+    for (int e = tid; e < (2 * TI + 1) * 32; e += 256) {
+        const int v = e / 32, l = e % 32;
+        float a = 0.f;
+        for (int w = 0; w < 4; ++w) a += vred[(w * (2 * TI + 1) + v) * 32 + l];
+        if (v < TI) { const int co = n_off + v * 32 + l; if (co < p.N) vdst[co] = a; }
+        else if (v < 2 * TI) { const int co = n_off + (v - TI) * 32 + l; if (co < p.N) vdst[p.N + co] = a; }
+        else if (l < p.K && slice0) vdst[2 * p.N + l] = a;
+    }
+}
+
 // finalize.  red = [P1 | Gram | s1 | s2 | s3] summed over splits.  Every block recomputes the N coefficient triples (cheap) and
 // takes a grid-stride share of the fp64 element loops (one block took 80 us per unit).
 __global__ __launch_bounds__(256) void pw_bnbwd_finalize_kernel(const float* __restrict__ red, const float* __restrict__ W,
@@ -2691,7 +2886,25 @@ extern "C" int mny_pw_bnbwd(const float* g, const float* y, const float* scale, 
         }
         attr1 = true;
     }
-    switch (pl.TIs) {
+    static const bool s1v2 = getenv("MNY_BNW_S1V2") == nullptr || atoi(getenv("MNY_BNW_S1V2")) != 0;     // (=0: first-generation stage 1, A/B)
+    if (s1v2) {
+        static bool attr1b = false;
+        if (!attr1b) {
+            if (hipFuncSetAttribute((const void*)pw_bnbwd_stage1b_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ||
+                hipFuncSetAttribute((const void*)pw_bnbwd_stage1b_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) {
+                set_error("pw_bnbwd: hipFuncSetAttribute failed"); return MNY_EHIP;
+            }
+            attr1b = true;
+        }
+        switch (pl.TIs) {
+            case 1: hipLaunchKernelGGL((pw_bnbwd_stage1b_kernel<1>), grid, block, pl.lds1, st, a); break;
+            case 2: hipLaunchKernelGGL((pw_bnbwd_stage1b_kernel<2>), grid, block, pl.lds1, st, a); break;
+            case 3: hipLaunchKernelGGL((pw_bnbwd_stage1b_kernel<3>), grid, block, pl.lds1, st, a); break;
+            case 4: hipLaunchKernelGGL((pw_bnbwd_stage1b_kernel<4>), grid, block, pl.lds1, st, a); break;
+            case 5: hipLaunchKernelGGL((pw_bnbwd_stage1b_kernel<5>), grid, block, pl.lds1, st, a); break;
+            default: hipLaunchKernelGGL((pw_bnbwd_stage1b_kernel<6>), grid, block, pl.lds1, st, a); break;
+        }
+    } else switch (pl.TIs) {
         case 1: hipLaunchKernelGGL((pw_bnbwd_stage1_kernel<1>), grid, block, pl.lds1, st, a); break;
         case 2: hipLaunchKernelGGL((pw_bnbwd_stage1_kernel<2>), grid, block, pl.lds1, st, a); break;
         case 3: hipLaunchKernelGGL((pw_bnbwd_stage1_kernel<3>), grid, block, pl.lds1, st, a); break;
