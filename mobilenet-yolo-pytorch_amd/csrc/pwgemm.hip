@@ -336,22 +336,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     const T* zero_src = reinterpret_cast<const T*>(&mny_zero16);
     const bool ragged_k = (p.K % BKE) != 0;
 
-    auto issue = [&](int mt, int kt, int slot) {
-        float* stage = smem + slot * STAGE;
-        const bool tail = ragged_k && kt == nk - 1;
-        const bool kout = tail && kt * BKE + dk >= p.K;           // this lane's chunk lies past K
+    // Running DMA sources (round 3): one pointer per slot, advanced by one k-stage per issue and re-seated when the flat walk enters a
+    // new M tile.  The first cut recomputed every source from (tile, k-tile) per instruction — a 64-bit multiply-add, clamps and a
+    // wave-uniform A / B branch per DMA instruction: ~30 vector + ~20 scalar instructions and 4-6 branches per stage in a loop whose
+    // waves are latency-bound; now a stage's issue is LPW pointer bumps.
+    const T* d_cur[LPW];
+    int d_step[LPW];                                              // elements of T per k-stage (wave-uniform)
+#pragma unroll
+    for (int i = 0; i < LPW; ++i) d_step[i] = d_isA[i] ? BKE : (X6 == 3 ? 32 / (int)sizeof(T) : BKE);
+    auto seat = [&](int mt) {                                     // sources of stage (mt, k-tile 0)
 #pragma unroll
         for (int i = 0; i < LPW; ++i) {
-            const T* src;
             if (d_isA[i]) {
                 int m = mt * BM + d_row0[i] + drow;
                 if (m >= (int)p.M) m = (int)p.M - 1;
-                src = pA + (int64_t)m * p.K + (kout ? 0 : kt * BKE + dk);   // finite filler, annihilated by zero B / zero scale
-            } else if constexpr (X6 == 3) {
-                src = reinterpret_cast<const T*>(reinterpret_cast<const char*>(d_bptr[i]) + kt * 32);      // planes are zero-padded to nk * 16
+                d_cur[i] = pA + (int64_t)m * p.K + dk;
             } else {
-                src = kout ? zero_src : d_bptr[i] + kt * BKE;
+                d_cur[i] = d_bptr[i];
             }
+        }
+    };
+    auto issue = [&](int kt, int slot) {
+        float* stage = smem + slot * STAGE;
+#pragma unroll
+        for (int i = 0; i < LPW; ++i) {
+            const T* src = d_cur[i];
+            if (ragged_k) {                                       // kernel-uniform; K % 16 != 0 only
+                const bool kout = kt == nk - 1 && kt * BKE + dk >= p.K;      // this lane's chunk lies past K
+                if (kout) src = d_isA[i] ? d_cur[i] - (kt * BKE + dk) : (X6 == 3 ? src : zero_src);   // A: finite filler (row start), annihilated by zero B / zero scale
+            }
+            d_cur[i] += d_step[i];
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(stage + d_lds[i]), 16, 0, 0);
         }
@@ -628,9 +642,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
 
     // flat (tile, k-tile) walk; stage t lives in ring slot t % 3, two stages stay in flight behind the consumer
     int i_mt = mt_begin, i_kt = 0, i_slot = 0;           // next stage to issue
+    seat(mt_begin);
     auto issue_next = [&]() {
-        issue(i_mt, i_kt, i_slot);
-        if (++i_kt == nk) { i_kt = 0; ++i_mt; }
+        issue(i_kt, i_slot);
+        if (++i_kt == nk) { i_kt = 0; ++i_mt; if (i_mt < mt_end) seat(i_mt); }
         if (++i_slot == S) i_slot = 0;
     };
     int c_mt = mt_begin, c_kt = 0, c_slot = 0;           // stage being consumed
@@ -1067,31 +1082,35 @@ __global__ __launch_bounds__(256) void pw_wgrad_dma_kernel(WgradArgs p) {
 
     // per-lane constants of this wave's DMA instructions
     const float* zero_src = reinterpret_cast<const float*>(&mny_zero16);
-    int d_row[LPW], d_lds[LPW];
-    bool d_isA[LPW], d_ok[LPW];
-    int64_t d_off[LPW];
+    // running sources (round 3, as in the NT GEMM): one pointer per slot, bumped by 16 rows per stage; rows past the block's M slice
+    // select a fixed filler (dY: zeros, X: the slice's last row) — no per-instruction branch, no 64-bit multiply in the loop
+    int d_row[LPW], d_lds[LPW], d_step[LPW];
+    const float* d_cur[LPW];
+    const float* d_past[LPW];
 #pragma unroll
     for (int i = 0; i < LPW; ++i) {
         int j = wave + 4 * i;
         if (j >= NL) j = NL - 1;
-        d_isA[i] = j < NA;
-        const int q = (d_isA[i] ? j : j - NA) * 64 + lane;          // float4 index inside the tile
-        const int W4 = (d_isA[i] ? BI : BJ) / 4;
+        const bool isA = j < NA;
+        const int q = (isA ? j : j - NA) * 64 + lane;                // float4 index inside the tile
+        const int W4 = (isA ? BI : BJ) / 4;
         d_row[i] = q / W4;
         const int c = (q % W4) * 4;
-        d_lds[i] = d_isA[i] ? j * 256 : A_ST + (j - NA) * 256;
-        if (d_isA[i]) { d_ok[i] = co0 + c < p.N; d_off[i] = co0 + c; }
-        else { d_ok[i] = ci0 + c < p.K; d_off[i] = ci0 + c; }
+        d_lds[i] = isA ? j * 256 : A_ST + (j - NA) * 256;
+        const bool ok = isA ? co0 + c < p.N : ci0 + c < p.K;
+        const float* base = isA ? (const float*)p.dY : (const float*)p.X;
+        const int stride = isA ? p.N : p.K, off = isA ? co0 + c : ci0 + c;
+        d_cur[i] = ok ? base + (m_begin + d_row[i]) * stride + off : zero_src;
+        d_past[i] = (ok && !isA) ? base + (m_end - 1) * stride + off : zero_src;
+        d_step[i] = ok ? KC * stride : 0;
     }
 
     auto issue = [&](int64_t m0, int slot) {
         float* stage = smem + slot * STAGE;
 #pragma unroll
         for (int i = 0; i < LPW; ++i) {
-            const int64_t m = m0 + d_row[i];
-            const float* src;
-            if (d_isA[i]) src = (d_ok[i] && m < m_end) ? (const float*)p.dY + m * p.N + d_off[i] : zero_src;
-            else src = d_ok[i] ? (const float*)p.X + (m < m_end ? m : m_end - 1) * p.K + d_off[i] : zero_src;
+            const float* src = (m0 + d_row[i] < m_end) ? d_cur[i] : d_past[i];
+            d_cur[i] += d_step[i];
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(stage + d_lds[i]), 16, 0, 0);
         }
@@ -1268,31 +1287,34 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_kernel(WgradArgs p) {
     }
 
     const bf16_t* zero_src = reinterpret_cast<const bf16_t*>(&mny_zero16);
-    int d_row[LPW], d_lds[LPW];
-    bool d_isA[LPW], d_ok[LPW];
-    int d_off[LPW];
+    // running sources (round 3): see pw_wgrad_dma_kernel
+    int d_row[LPW], d_lds[LPW], d_step[LPW];
+    const bf16_t* d_cur[LPW];
+    const bf16_t* d_past[LPW];
 #pragma unroll
     for (int i = 0; i < LPW; ++i) {
         int j = wave + 4 * i;
         if (j >= NL) j = NL - 1;
-        d_isA[i] = j < NA;
-        const int q = (d_isA[i] ? j : j - NA) * 64 + lane;          // 16-B chunk index inside the tile
-        const int W8 = (d_isA[i] ? BI : BJ) / 8;
+        const bool isA = j < NA;
+        const int q = (isA ? j : j - NA) * 64 + lane;                // 16-B chunk index inside the tile
+        const int W8 = (isA ? BI : BJ) / 8;
         d_row[i] = q / W8;
         const int c = (q % W8) * 8;
-        d_lds[i] = d_isA[i] ? j * 512 : A_ST + (j - NA) * 512;     // bf16 elements
-        if (d_isA[i]) { d_ok[i] = co0 + c < p.N; d_off[i] = co0 + c; }
-        else { d_ok[i] = ci0 + c < p.K; d_off[i] = ci0 + c; }
+        d_lds[i] = isA ? j * 512 : A_ST + (j - NA) * 512;            // bf16 elements
+        const bool ok = isA ? co0 + c < p.N : ci0 + c < p.K;
+        const bf16_t* base = isA ? pdY : pX;
+        const int stride = isA ? p.N : p.K, off = isA ? co0 + c : ci0 + c;
+        d_cur[i] = ok ? base + (m_begin + d_row[i]) * stride + off : zero_src;
+        d_past[i] = (ok && !isA) ? base + (m_end - 1) * stride + off : zero_src;
+        d_step[i] = ok ? KC * stride : 0;
     }
 
     auto issue = [&](int64_t m0, int slot) {
         bf16_t* stage = smem + slot * STAGE;
 #pragma unroll
         for (int i = 0; i < LPW; ++i) {
-            const int64_t m = m0 + d_row[i];
-            const bf16_t* src;
-            if (d_isA[i]) src = (d_ok[i] && m < m_end) ? pdY + m * p.N + d_off[i] : zero_src;
-            else src = d_ok[i] ? pX + (m < m_end ? m : m_end - 1) * p.K + d_off[i] : zero_src;
+            const bf16_t* src = (m0 + d_row[i] < m_end) ? d_cur[i] : d_past[i];
+            d_cur[i] += d_step[i];
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(stage + d_lds[i]), 16, 0, 0);
         }
