@@ -276,8 +276,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     constexpr int A_ST = BM * BKD, B_ST = X6 == 3 ? BN * 24 : BN * BKD, STAGE = A_ST + B_ST;     // floats
     constexpr int NA = BM / 16, NB = X6 == 3 ? 3 * TN : BN / 16, NL = NA + NB;                   // 1-KiB DMA instructions per stage
     constexpr int LPW = (NL + 3) / 4;                                         // per wave (surplus ones duplicate the last)
+    // Ring layout: [S slots of A][SB slots of B][scale / shift cache].  Planes mode (round 3): the pre-cut weight planes are L2-resident
+    // and need less lead than the activation rows from HBM, so their ring is TWO slots deep (stage t+1 is requested while stage t is
+    // multiplied, A stays two stages ahead): 3 x 8 KB + 2 x 3 TN KB is exactly the LDS of the plain mode (3 x (8 + 2 TN) KB), so the planes
+    // kernels keep the plain mode's THREE resident workgroups per CU — with a three-slot plane ring (60 KB at TN = 4) they ran two.
+    constexpr int SB = X6 == 3 ? 2 : S;
+    constexpr int NA_W = NA / 4;                                              // A instructions per wave: slots [0, NA_W) are A, the rest B
+    static_assert(NA % 4 == 0 && NA_W < LPW, "slot split");
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sScale = smem + S * STAGE;
+    float* const sA = smem;
+    float* const sB = smem + S * A_ST;
+    float* sScale = sB + SB * B_ST;
 
     // block -> (m-run x, n-tile y): the n_tiles blocks of one m-run are consecutive within one XCD
     const int bid = blockIdx.x, xcd = bid & 7, local = bid >> 3;
@@ -317,15 +326,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     for (int i = 0; i < LPW; ++i) {
         int j = wv + 4 * i;
         if (j >= NL) j = NL - 1;
-        d_isA[i] = j < NA;
+        d_isA[i] = j < NA;                                        // (== i < NA_W: NA is a multiple of 4)
         d_row0[i] = (d_isA[i] ? j : j - NA) * 16;                 // scalar
-        d_lds[i] = d_isA[i] ? j * 256 : A_ST + (j - NA) * 256;   // scalar
+        d_lds[i] = d_isA[i] ? j * 256 : (j - NA) * 256;           // scalar, relative to the slot of its own ring
         if constexpr (X6 == 3) {
             const int jb = d_isA[i] ? 0 : j - NA;                 // (plane, column block) of this instruction
             const int pl = jb / TN, u = jb - pl * TN;
             int n = n0 + u * 32 + (lane >> 1);
             if (n >= p.N) n = p.N - 1;
-            d_lds[i] = d_isA[i] ? j * 256 : A_ST + jb * 256;
+            d_lds[i] = d_isA[i] ? j * 256 : jb * 256;
             d_bptr[i] = reinterpret_cast<const T*>(reinterpret_cast<const char*>(p.B) + ((int64_t)pl * p.N + n) * nk * 32 + (lane & 1) * 16);
         } else {
             int n = n0 + d_row0[i] + drow;
@@ -356,10 +365,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
             }
         }
     };
-    auto issue = [&](int kt, int slot) {
-        float* stage = smem + slot * STAGE;
+    auto issue_part = [&](int kt, float* stage, int i0, int i1) {  // slots [i0, i1) of this wave into `stage` (a slot of the A or the B ring)
 #pragma unroll
         for (int i = 0; i < LPW; ++i) {
+            if (i < i0 || i >= i1) continue;
             const T* src = d_cur[i];
             if (ragged_k) {                                       // kernel-uniform; K % 16 != 0 only
                 const bool kout = kt == nk - 1 && kt * BKE + dk >= p.K;      // this lane's chunk lies past K
@@ -370,6 +379,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                                              (__attribute__((address_space(3))) void*)(stage + d_lds[i]), 16, 0, 0);
         }
     };
+    auto issue_a = [&](int kt, int slot) { issue_part(kt, sA + slot * A_ST, 0, NA_W); };
+    auto issue_b = [&](int kt, int slot) { issue_part(kt, sB + slot * B_ST, NA_W, LPW); };
 
     f32x16 acc[TN];
 #pragma unroll
@@ -380,9 +391,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
 #pragma unroll
     for (int t = 0; t < TN; ++t) { s1[t] = 0.f; s2[t] = 0.f; }
 
-    auto compute = [&](int kt, int slot) {
-        const float* stA = smem + slot * STAGE;
-        const float* stB = stA + A_ST;
+    auto compute = [&](int kt, int slot, int slot_b) {
+        const float* stA = sA + slot * A_ST;
+        const float* stB = sB + slot_b * B_ST;
         const float* a_row = stA + (wv * 32 + lrow) * BKD;
         if constexpr (BF != 0) {
 #pragma unroll
@@ -641,33 +652,74 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     };
 
     // flat (tile, k-tile) walk; stage t lives in ring slot t % 3, two stages stay in flight behind the consumer
-    int i_mt = mt_begin, i_kt = 0, i_slot = 0;           // next stage to issue
-    seat(mt_begin);
-    auto issue_next = [&]() {
-        issue(i_kt, i_slot);
-        if (++i_kt == nk) { i_kt = 0; ++i_mt; if (i_mt < mt_end) seat(i_mt); }
-        if (++i_slot == S) i_slot = 0;
-    };
-    int c_mt = mt_begin, c_kt = 0, c_slot = 0;           // stage being consumed
+    int c_mt = mt_begin, c_kt = 0, c_slot = 0, c_slot_b = 0;           // stage being consumed
     auto consume = [&]() {
-        compute(c_kt, c_slot);
+        compute(c_kt, c_slot, SB == S ? c_slot : c_slot_b);
         if (++c_kt == nk) { epilogue(c_mt); c_kt = 0; ++c_mt; }
         if (++c_slot == S) c_slot = 0;
+        c_slot_b ^= 1;
     };
-
-    const int pre = total < S - 1 ? total : S - 1;
-    for (int t = 0; t < pre; ++t) issue_next();
-    const int steady = total - pre;                      // steps that still have a stage to issue
-    for (int t = 0; t < steady; ++t) {
-        wait_vmcnt<LPW*(S - 2)>();                       // my share of the oldest stage has landed
-        __builtin_amdgcn_s_barrier();                    // ... for every wave; the slot refilled below is fully consumed
-        issue_next();
-        consume();
-    }
-    for (int t = 0; t < pre; ++t) {                      // drain
-        wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        consume();
+    if constexpr (SB == S) {
+        int i_mt = mt_begin, i_kt = 0, i_slot = 0;       // next stage to issue
+        seat(mt_begin);
+        auto issue_next = [&]() {
+            issue_a(i_kt, i_slot); issue_b(i_kt, i_slot);
+            if (++i_kt == nk) { i_kt = 0; ++i_mt; if (i_mt < mt_end) seat(i_mt); }
+            if (++i_slot == S) i_slot = 0;
+        };
+        const int pre = total < S - 1 ? total : S - 1;
+        for (int t = 0; t < pre; ++t) issue_next();
+        const int steady = total - pre;                      // steps that still have a stage to issue
+        for (int t = 0; t < steady; ++t) {
+            wait_vmcnt<LPW*(S - 2)>();                       // my share of the oldest stage has landed
+            __builtin_amdgcn_s_barrier();                    // ... for every wave; the slot refilled below is fully consumed
+            issue_next();
+            consume();
+        }
+        for (int t = 0; t < pre; ++t) {                      // drain
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            consume();
+        }
+    } else {
+        // planes mode: A two stages ahead (3 slots), B one stage ahead (2 slots).  The A and the B sources walk the same (tile, k-tile)
+        // sequence with their own cursors; issue order inside an iteration is B(t+1) THEN A(t+2), so that at the top of iteration t+1 the
+        // in-order counter may leave exactly A(t+2)'s NA_W instructions outstanding: everything older — A(t+1), B(t+1) — has landed.
+        int a_mt = mt_begin, a_kt = 0, a_slot = 0, a_n = 0;   // next A stage to issue
+        int b_mt = mt_begin, b_kt = 0, b_slot = 0, b_n = 0;   // next B stage to issue
+        auto seat_part = [&](int mt, bool part_a) {
+#pragma unroll
+            for (int i = 0; i < LPW; ++i) {
+                if ((i < NA_W) != part_a) continue;
+                if (part_a) {
+                    int m = mt * BM + d_row0[i] + drow;
+                    if (m >= (int)p.M) m = (int)p.M - 1;
+                    d_cur[i] = pA + (int64_t)m * p.K + dk;
+                } else {
+                    d_cur[i] = d_bptr[i];
+                }
+            }
+        };
+        seat_part(mt_begin, true); seat_part(mt_begin, false);
+        auto next_a = [&]() {
+            issue_a(a_kt, a_slot); ++a_n;
+            if (++a_kt == nk) { a_kt = 0; ++a_mt; if (a_mt < mt_end) seat_part(a_mt, true); }
+            if (++a_slot == S) a_slot = 0;
+        };
+        auto next_b = [&]() {
+            issue_b(b_kt, b_slot); ++b_n;
+            if (++b_kt == nk) { b_kt = 0; ++b_mt; if (b_mt < mt_end) seat_part(b_mt, false); }
+            b_slot ^= 1;
+        };
+        if (total > 0) { next_a(); next_b(); }               // A(0), B(0), then A(1): the order the counted wait below assumes
+        if (total > 1) next_a();
+        for (int t = 0; t < total; ++t) {
+            if (t + 1 < total) wait_vmcnt<NA_W>(); else wait_vmcnt<0>();     // A(t), B(t) landed; A(t+1) may still be in flight
+            __builtin_amdgcn_s_barrier();                    // every wave is past stage t-1: B slot (t+1) % 2 and A slot (t+2) % 3 are free
+            if (b_n < total) next_b();                       // B(t+1)
+            if (a_n < total) next_a();                       // A(t+2)
+            consume();
+        }
     }
 
     if (p.stats) {
@@ -2623,12 +2675,14 @@ extern "C" int mny_pw_dgrad_bnred_bf16(const void* dy, const void* wT, void* dx,
 }
 
 // ---- forward / data-gradient GEMMs on pre-cut weight planes (fp32 plans, six-product form) ---------------------------------------
-// Planes pay where the matrix pipe is the bound: a stage of B grows from 64 to 96 bytes per row, which costs the mid-size shapes
-// (K or N around 64-96: latency-bound, three resident workgroups per CU) their third workgroup — measured per shape (tools/ab_detail.sh):
-// 7-18 % faster from ~60 FLOP per byte up, 10-30 % slower below ~40.
+// Planes pay where the matrix pipe is the bound.  Round 2: a stage of B grew from 64 to 96 bytes per row, which cost the mid-size shapes
+// their third resident workgroup (7-18 % faster from ~60 FLOP per byte up, 10-30 % slower below ~40).  Round 3: the plane ring is two
+// slots deep (the A ring stays at three), the LDS footprint equals the plain mode's and the threshold moved down to 30 FLOP per byte.
 static bool w6_ok(int64_t M, int K, int Nc) {
     static const bool off = getenv("MNY_NO_W6") != nullptr;
-    static const double min_ai = getenv("MNY_W6_AI") ? atof(getenv("MNY_W6_AI")) : 50.0;
+    // (round 3: with the two-slot plane ring the planes no longer cost a resident workgroup; same-box A/B per shape: K576 N96 -11 %,
+    // K384 N96 -10 %, the 75-channel heads -9..-11 %, K384 N64 (27 FLOP per byte) +0..+7 % -> threshold 30, was 50)
+    static const double min_ai = getenv("MNY_W6_AI") ? atof(getenv("MNY_W6_AI")) : 30.0;
     const double ai = 2.0 * K * Nc / (4.0 * (K + Nc));
     return !off && M > 0 && K > 0 && Nc > 0 && (K & 3) == 0 && !pw_thin_ok(0, 0, M, K, Nc) && !pw_wide_ok(M, K, Nc, false) && !pw_wide_ok(M, K, Nc, true) && nt_x6(M, K, Nc) != 0 && ai >= min_ai &&
            getenv("MNY_GEMM_V1") == nullptr;
@@ -2648,7 +2702,7 @@ extern "C" int mny_pw_fwd_w6(const float* x, const float* in_scale, const float*
     MNY_REQUIRE(!(stats && bias), "pw_fwd_w6: stats and bias are mutually exclusive");
     const bool xf = in_scale != nullptr || in_act != MNY_ACT_NONE;
     Nt2Plan p2 = nt2_plan(M, K, Nc, xf);                          // same tiling and partial rows as mny_pw_fwd
-    const size_t lds = p2.lds + (size_t)3 * p2.TN * 1024;         // a stage of B: three bf16 planes instead of one fp32 image
+    const size_t lds = p2.lds;                                    // three-slot A ring + two-slot plane ring = the plain mode's three-slot (A + fp32 B) ring, to the byte
     MNY_REQUIRE(lds <= 96 * 1024, "pw_fwd_w6: K=%d too large for the LDS scale cache", K);
     Gemm2Args g{x, in_scale, in_shift, in_act, w6, bias, addend, y, stats, M, K, Nc, p2.m_tiles, p2.tiles_per_block, p2.gx, p2.n_tiles,
                 nullptr, nullptr, nullptr, nullptr, nullptr, 0};
@@ -2666,7 +2720,7 @@ extern "C" int mny_pw_dgrad_bnred_w6(const float* dy, const void* wT6, const flo
     MNY_REQUIRE(w6_ok(M, K, Nc) && dgrad_bnred_ok(M, K, Nc, act), "pw_dgrad_bnred_w6: unsupported problem M=%lld K=%d N=%d", (long long)M, K, Nc);
     Nt2Plan p2 = nt2_plan(M, K, Nc, false, 0, kRedMaxTn);
     MNY_REQUIRE(!addend || p2.TN <= 3, "pw_dgrad_bnred_w6: the addend form needs a column tile of <= 96 (mny_pw_dgrad_bnred_add_supported)");
-    const size_t lds = p2.lds + (size_t)3 * p2.TN * 1024;
+    const size_t lds = p2.lds;
     MNY_REQUIRE(lds <= 96 * 1024, "pw_dgrad_bnred_w6: K=%d too large", K);
     Gemm2Args g{dy, nullptr, nullptr, MNY_ACT_NONE, wT6, nullptr, addend, dx, red, M, K, Nc, p2.m_tiles, p2.tiles_per_block, p2.gx, p2.n_tiles,
                 y, scale, shift, mean, invstd, act};
