@@ -33,7 +33,7 @@ sys.path.insert(0, HERE)
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
-PROFILE_TAG = "r02"               # profiles/<tag>_traffic_*.json: PMC passes of this round (tools/prof_round.sh + tools/prof_summary.py)
+PROFILE_TAG = "r03"               # profiles/<tag>_traffic_*.json: PMC passes of this round (tools/prof_round.sh + tools/prof_summary.py)
 BATCH = 256
 SIZE = 352
 
@@ -381,6 +381,14 @@ def plan_signature(plan, entry):
     return len(items), hashlib.sha256("|".join(items).encode()).hexdigest()[:16]
 
 
+def step_signature(plan):
+    """Fingerprint of the WHOLE step (every call of both lists, in order, with its shape): whole-step counter traffic is only valid
+    for exactly this launch list."""
+    import hashlib
+    items = ["%s:%s" % (name, (meta or {}).get("shape", "")) for calls in (plan.fwd.calls, plan.bwd.calls) for _fn, _args, name, meta in calls]
+    return len(items), hashlib.sha256("|".join(items).encode()).hexdigest()[:16]
+
+
 def committed_traffic(plan, entry, headline):
     """HBM bytes per launch of `entry` from the PMC counters.  bench.py cannot run rocprofv3 on itself, so this is the committed
     result of the prescribed separate --pmc passes over this very command (profiles/README.md) — accepted only while the plan
@@ -446,11 +454,23 @@ def config3_leg(device, steps=12, warmup=4):
             if (c[3] or {}).get("flops", 0) > 0:       # convolution work only (forward, data / weight gradient); the separate BN passes
                 by += c[3].get("bytes", 0)             # of the un-fused units are overhead, not algorithmic traffic
                 fl += c[3]["flops"]
+    traffic, traffic_src = None, None
+    tpath = os.path.join(HERE, "profiles", "%s_traffic_config3.json" % PROFILE_TAG)
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        n_sig, sig = step_signature(plan)
+        if tj.get("calls_per_step") == n_sig and tj.get("step_signature") == sig:
+            traffic = round(tj["hbm_bytes_per_step"])
+            traffic_src = "profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over the whole step (separate passes), calibrated as the file states" % os.path.basename(tpath)
+        else:
+            print("bench: %s is STALE (profiled %s calls / %s, plan now %d / %s): config3.roofline.traffic left null" % (
+                os.path.basename(tpath), tj.get("calls_per_step"), tj.get("step_signature"), n_sig, sig), file=sys.stderr)
+            traffic_src = "stale: " + os.path.basename(tpath)
     res = {"workload": "MobileNetV3-YOLO 512x512 bs=64 fwd+loss+bwd, bf16 activation storage (BASELINE configs[3])",
            "value": round(bs / dt, 1), "unit": "images/s", "ms_per_step": round(dt * 1e3, 3), "steps": steps, "warmup": warmup, "dtype": "bf16",
            "loss": round(float(out[0][0].detach()) + float(out[1][0].detach()), 5),
            "roofline": {"bound": "hbm", "achieved": round(by / dt / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(by / dt / 1e9 / PEAK_HBM_GBS, 4),
-                        "traffic": None, "algorithmic_gb_per_step": round(by / 1e9, 3), "algorithmic_tflop_per_step": round(fl / 1e12, 3),
+                        "traffic": traffic, "traffic_source": traffic_src, "algorithmic_gb_per_step": round(by / 1e9, 3), "algorithmic_tflop_per_step": round(fl / 1e12, 3),
                         "launches_per_step": len(plan.fwd.calls) + len(plan.bwd.calls),
                         "note": "whole step: algorithmic bytes of every convolution call of the plan (forward + data gradient + weight gradient; BN / elementwise passes not counted) over the step time"}}
     del model, plan
@@ -497,14 +517,24 @@ def dp_overhead_leg(model, step, steps, plain_ms):
     its cost over the plain step on the same box, same plan.  Runs after the timed region; never part of `value`."""
     import torch.distributed as dist
     from mobilenet_yolo_pytorch_amd.dp import attach_data_parallel
-    os.environ.setdefault("NCCL_DEBUG", "WARN")
+    if os.environ.get("NCCL_DEBUG", "").upper() in ("", "VERSION"):
+        os.environ["NCCL_DEBUG"] = "WARN"                    # keep RCCL's version banner off stdout: this process prints ONE JSON line
     os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
     s = __import__("socket").socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
-    dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+    # whatever RCCL still writes to the C-level stdout (it has printed its banner there on some boxes) goes to stderr for the duration of the leg
+    sys.stdout.flush()
+    saved_fd = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
+    except Exception:
+        os.dup2(saved_fd, 1)
+        os.close(saved_fd)
+        raise
     try:
         red = attach_data_parallel(model)
         for _ in range(3):
@@ -533,7 +563,12 @@ def dp_overhead_leg(model, step, steps, plain_ms):
         torch.cuda.synchronize()
         plain2 = (time.perf_counter() - t0) / steps * 1e3
     finally:
-        dist.destroy_process_group()
+        try:
+            dist.destroy_process_group()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
     return {"one_rank_rccl_ms_per_step": round(dp_ms, 3), "plain_ms_per_step": round(plain2, 3), "timed_region_ms_per_step": round(plain_ms, 3),
             "overhead_frac": round(dp_ms / plain2 - 1.0, 4), "buckets": nb,
             "note": "1-rank RCCL group on this GPU: segmented backward replay + %d all-reduce launches per step; not part of `value`" % nb,
@@ -712,6 +747,13 @@ def main():
             "roofline": roof,
         }
         res["plan_signatures"] = {e: list(plan_signature(plan, e)) for e in [dom] + sorted(SECOND_PASS) if plan_signature(plan, e)[0]}
+        res["plan_signatures"]["__step__"] = list(step_signature(plan))
+        alg = {}
+        for calls in (plan.fwd.calls, plan.bwd.calls):        # algorithmic bytes per step and entry point (what tools/prof_*summary.py calibrate the counters on)
+            for _fn, _args, name, meta in calls:
+                if meta and meta.get("bytes"):
+                    alg[name] = alg.get(name, 0) + int(meta["bytes"])
+        res["algorithmic_bytes_per_step"] = alg
         hb = [o for o in others if o["bound"] == "hbm"]
         if hb:
             res["roofline_hbm"] = hb[0]               # the bandwidth-bound depthwise forward (north-star target: frac >= 0.6)

@@ -668,6 +668,11 @@ __global__ __launch_bounds__(256) void nms_resolve_kernel(const unsigned long lo
 // scratch — a second scan of the segment to collect the bucket (stable), a bitonic sort over global memory (same key = score
 // descending, original position ascending, so the order is the one the LDS sort produces), then the same 64-candidates-at-a-time
 // greedy loop as nms_bucket_kernel (kept boxes re-read from kbox).  grid (S, C); every bucket that fitted exits at once.
+// This is a RARE-PATH FALLBACK, deliberately not a fast path: log^2(n) barrier-separated passes over global memory and a
+// kept list re-read per 64-candidate tile make one 50 000-box bucket cost milliseconds on one CU while the rest of the GPU idles; the
+// large-segment driver (nms_bucket_kernel<SORT_ONLY> -> nms_mask_kernel -> nms_resolve_kernel, 106 M boxes/s on 100 k x 20) is the
+// fast path for big inputs, and this kernel only sees a single (image, class) bucket of more than 8 192 boxes inside a batch of
+// small segments.  It is launched only when the caller's max_seg_rows bound admits such a bucket at all.
 //   gkeys  [2 * capacity] u64: bucket at 2 * bbase (padded to a power of two < 2n: regions of different buckets stay disjoint)
 //   growidx[capacity]      i32: bucket at bbase
 __global__ __launch_bounds__(1024) void nms_big_bucket_kernel(const float* __restrict__ rows, const int32_t* __restrict__ seg_begin,
