@@ -260,8 +260,11 @@ struct Gemm2Args {   // A / B / addend / C: float* (BF = 0) or bf16_t* (BF = 1)
 //     The LDS image is the same in bytes (64-B rows of four 16-B chunks): a chunk is 4 fp32 or 8 bf16 k-values, a stage
 //     covers 16 or 32 k, and the lane's 16-B fragment read IS the bf16 MFMA operand (k-block = lane>>5), so the bf16
 //     main loop is 2 MFMAs per accumulator per stage instead of 16.
+#ifndef MNY_W6_PAIR
+#define MNY_W6_PAIR 1             // planes mode: column blocks advanced in pairs (0: one at a time, the round-2 form; build-time A/B)
+#endif
 template <int TN, int XF, int BF, int RED = 0, int X6 = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void pw_gemm_nt_dma_kernel(Gemm2Args p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((X6 == 3 && RED == 0 && MNY_W6_PAIR) ? 2 : 3, 8))) void pw_gemm_nt_dma_kernel(Gemm2Args p) {
     using T = typename std::conditional<BF != 0, bf16_t, float>::type;
     constexpr int EPC = BF ? 8 : 4;                                           // elements per 16-B chunk
     constexpr int BKE = 4 * EPC;                                              // k-values per stage
@@ -272,7 +275,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     constexpr int BN = 32 * TN, BKD = 16, S = 3;
     // X6 == 3: B arrives PRE-CUT (mny_cut3_batch): three bf16 planes [N][nk][2][8], the eight k-values of a 16-B chunk in the order a lane
     // of this kernel holds them (k = 4h..4h+3, 8+4h..8+4h+3 for half h); a stage of B is 3 x 32*TN rows x 32 B, one DMA instruction per
-    // (plane, 32-row block), whose lane-linear LDS image [row][half] is exactly what the wave reads back
+    // (plane, 32-row block).  Lane l of that instruction fetches (column l & 31, half l >> 5), so the lane-linear LDS image is
+    // [half][column] and lane (column, half) reads back ITS OWN 16 bytes: consecutive lanes, consecutive chunks, no bank conflict.
+    // (Round 2 laid the image out [column][half]: the lanes of a half then read every OTHER chunk — SQ_LDS_BANK_CONFLICT was 40 % of
+    // the LDS-active cycles of every planes kernel, profiles/r03_pmc_step_lds.md.)
     constexpr int A_ST = BM * BKD, B_ST = X6 == 3 ? BN * 24 : BN * BKD, STAGE = A_ST + B_ST;     // floats
     constexpr int NA = BM / 16, NB = X6 == 3 ? 3 * TN : BN / 16, NL = NA + NB;                   // 1-KiB DMA instructions per stage
     constexpr int LPW = (NL + 3) / 4;                                         // per wave (surplus ones duplicate the last)
@@ -332,10 +338,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         if constexpr (X6 == 3) {
             const int jb = d_isA[i] ? 0 : j - NA;                 // (plane, column block) of this instruction
             const int pl = jb / TN, u = jb - pl * TN;
-            int n = n0 + u * 32 + (lane >> 1);
+            int n = n0 + u * 32 + (lane & 31);                    // LDS image of a (plane, column block): [k half][32 columns] 16-B chunks, lane-linear
             if (n >= p.N) n = p.N - 1;
             d_lds[i] = d_isA[i] ? j * 256 : jb * 256;
-            d_bptr[i] = reinterpret_cast<const T*>(reinterpret_cast<const char*>(p.B) + ((int64_t)pl * p.N + n) * nk * 32 + (lane & 1) * 16);
+            d_bptr[i] = reinterpret_cast<const T*>(reinterpret_cast<const char*>(p.B) + ((int64_t)pl * p.N + n) * nk * 32 + (lane >> 5) * 16);
         } else {
             int n = n0 + d_row0[i] + drow;
             if (n >= p.N) n = p.N - 1;
@@ -456,15 +462,53 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
             }
             bf16x8_t ah, am, al;
             x6_split(a0, a1, ah, am, al);
+            if constexpr (X6 == 3 && RED == 0 && MNY_W6_PAIR) {      // (the reduction-epilogue variants lost 10-40 % at two waves per SIMD: they keep the one-at-a-time form)
+                // column blocks in PAIRS (round 3): the six products of one accumulator are a dependent chain (a dependent 8-pass MFMA issues
+                // every ~40 cycles, an independent one every 32), so two accumulators are advanced alternately — every MFMA's predecessor
+                // on the same accumulator is two issues back.  Costs a second set of plane pieces in registers (the kernel then holds
+                // two waves per SIMD instead of three — which measured neutral for these shapes: they are not occupancy-bound).
+                auto rd = [&](int u, v4f_t& h, v4f_t& m, v4f_t& l) {
+                    const float* src = stB + (u * 64 + khalf * 32 + lrow) * 4;      // = the lane's own 16 B of the block: conflict-free
+                    h = lds_read_f4(src); m = lds_read_f4(src + TN * 256); l = lds_read_f4(src + 2 * TN * 256);
+                };
+                v4f_t ph0, pm0, pl0, ph1, pm1, pl1;
+                rd(0, ph0, pm0, pl0);
+                if (TN > 1) rd(1, ph1, pm1, pl1);
+                MNY_LGKM_WAIT(ph0); MNY_LGKM_DEP(pm0); MNY_LGKM_DEP(pl0);
+                if (TN > 1) { MNY_LGKM_DEP(ph1); MNY_LGKM_DEP(pm1); MNY_LGKM_DEP(pl1); }
+#pragma unroll
+                for (int u = 0; u < TN; u += 2) {
+                    const bool two = u + 1 < TN;
+                    v4f_t nh0, nm0, nl0, nh1, nm1, nl1;
+                    if (u + 2 < TN) rd(u + 2, nh0, nm0, nl0);
+                    if (u + 3 < TN) rd(u + 3, nh1, nm1, nl1);
+                    const bf16x8_t bh0 = __builtin_bit_cast(bf16x8_t, ph0), bm0 = __builtin_bit_cast(bf16x8_t, pm0), bl0 = __builtin_bit_cast(bf16x8_t, pl0);
+                    const bf16x8_t bh1 = __builtin_bit_cast(bf16x8_t, ph1), bm1 = __builtin_bit_cast(bf16x8_t, pm1), bl1 = __builtin_bit_cast(bf16x8_t, pl1);
+#define MNY_P(A_, B0_, B1_) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B0_, acc[u], 0, 0, 0); \
+                            if (two) acc[u + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B1_, acc[u + 1], 0, 0, 0)
+                    MNY_P(al, bh0, bh1);      // small terms first (same order as the one-at-a-time form: bit-identical sums)
+                    MNY_P(ah, bl0, bl1);
+                    MNY_P(am, bm0, bm1);
+                    MNY_P(am, bh0, bh1);
+                    MNY_P(ah, bm0, bm1);
+                    MNY_P(ah, bh0, bh1);
+#undef MNY_P
+                    if (u + 2 < TN) {
+                        MNY_LGKM_WAIT(nh0); MNY_LGKM_DEP(nm0); MNY_LGKM_DEP(nl0); ph0 = nh0; pm0 = nm0; pl0 = nl0;
+                        if (u + 3 < TN) { MNY_LGKM_DEP(nh1); MNY_LGKM_DEP(nm1); MNY_LGKM_DEP(nl1); ph1 = nh1; pm1 = nm1; pl1 = nl1; }
+                    }
+                }
+                return;
+            }
             if constexpr (X6 == 3) {
-                const float* src0 = stB + (2 * lrow + khalf) * 4;
+                const float* src0 = stB + (khalf * 32 + lrow) * 4;
                 v4f_t ph = lds_read_f4(src0), pm = lds_read_f4(src0 + TN * 256), pl = lds_read_f4(src0 + 2 * TN * 256);
                 MNY_LGKM_WAIT(ph); MNY_LGKM_DEP(pm); MNY_LGKM_DEP(pl);
 #pragma unroll
                 for (int u = 0; u < TN; ++u) {
                     v4f_t nh, nm, nl;
                     if (u + 1 < TN) {                             // the next column block's pieces are requested before this one's MFMAs
-                        const float* src = stB + ((u + 1) * 64 + 2 * lrow + khalf) * 4;
+                        const float* src = stB + ((u + 1) * 64 + khalf * 32 + lrow) * 4;
                         nh = lds_read_f4(src); nm = lds_read_f4(src + TN * 256); nl = lds_read_f4(src + 2 * TN * 256);
                     }
                     const bf16x8_t bh = __builtin_bit_cast(bf16x8_t, ph), bm = __builtin_bit_cast(bf16x8_t, pm), bl = __builtin_bit_cast(bf16x8_t, pl);
