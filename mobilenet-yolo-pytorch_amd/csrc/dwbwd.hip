@@ -117,8 +117,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
             for (int q = 0; q < 3; ++q) { const int wi = wo - 1 + q; cokf[q] = (wi >= 0 && wi < gm.W) ? 1.f : 0.f; col[q] = min(max(wi, 0), gm.W - 1); }
 
             F4P P0 = f4p0(), P1 = f4p0();
-            F4P aprev[3] = {f4p0(), f4p0(), f4p0()};
-            F4P dc1 = f4p0(), dc2 = f4p0();
+            // weight gradient, round 3: dW[kr][kq] += a[i][w] * dY[i - kr + 1][w - kq + 1] summed over the INPUT pixels (i, w) this strip
+            // owns — the activated input is needed at the thread's own column only (one load and one transform per row instead of
+            // three: 7 instead of 9 tensor loads per row), the three columns of dY it meets are the ones the data gradient already
+            // rebuilds.  State: dY of rows r-1 and r-2 (three columns each) + the input of row r-1.
+            F4P dyp1[3] = {f4p0(), f4p0(), f4p0()}, dyp2[3] = {f4p0(), f4p0(), f4p0()};
+            F4P aprev = f4p0();
             for (int r = h0 - 1; r <= h1; ++r) {
                 int lo = cgl;
                 asm volatile("" : "+v"(lo));                       // opaque per iteration: keeps the LDS constant reads IN the loop
@@ -126,24 +130,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                 const int rc = min(max(r, 0), gm.H - 1);
                 const float rokf = (r >= 0 && r < gm.H) ? 1.f : 0.f;
                 const int64_t rowoff = img + (int64_t)rc * gm.W * gm.C;
-                float4 gv[3], yv[3], xv[3];
+                float4 gv[3], yv[3];
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     const int64_t o = rowoff + (int64_t)col[q] * gm.C;
-                    gv[q] = ld4(g + o); yv[q] = ld4(y + o); xv[q] = ld4(x + o);
+                    gv[q] = ld4(g + o); yv[q] = ld4(y + o);
                 }
-                F4P dyr[3], ar[3];
+                const float4 xc4 = ld4(x + rowoff + (int64_t)col[1] * gm.C);
+                F4P dyr[3];
                 const F4P sc = f4p(my[9 * gm.cgb]), sh = f4p(my[10 * gm.cgb]), ca = f4p(my[11 * gm.cgb]), cb = f4p(my[12 * gm.cgb]), cc = f4p(my[13 * gm.cgb]);
                 const F4P xsc = f4p(my[14 * gm.cgb]), xsh = f4p(my[15 * gm.cgb]);
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
-                    const float m = rokf * cokf[q];                // dY and the activated input are 0 outside the image
+                    const float m = rokf * cokf[q];                // dY is 0 outside the image
                     const v2f m2 = v2f{m, m};
-                    const F4P G4 = f4p(gv[q]), Y4 = f4p(yv[q]), X4 = f4p(xv[q]);
+                    const F4P G4 = f4p(gv[q]), Y4 = f4p(yv[q]);
                     dyr[q].lo = dy2(G4.lo, Y4.lo, sc.lo, sh.lo, ca.lo, cb.lo, cc.lo) * m2;
                     dyr[q].hi = dy2(G4.hi, Y4.hi, sc.hi, sh.hi, ca.hi, cb.hi, cc.hi) * m2;
-                    ar[q].lo = xf2(X4.lo, xsc.lo, xsh.lo) * m2;
-                    ar[q].hi = xf2(X4.hi, xsc.hi, xsh.hi) * m2;
+                }
+                // activated input of row r at the thread's own column; it contributes (as row i = r, one step later) only if the strip owns it
+                F4P ar;
+                {
+                    const float own = (r >= h0 && r < h1) ? 1.f : 0.f;
+                    const F4P X4 = f4p(xc4);
+                    ar.lo = xf2(X4.lo, xsc.lo, xsh.lo) * v2f{own, own};
+                    ar.hi = xf2(X4.hi, xsc.hi, xsh.hi) * v2f{own, own};
                 }
                 // data gradient: dX[i][w] += sum_kq dY[r][w+1-kq] * wt[i-r+1][kq]  (dyr[q] sits at column w-1+q -> q = 2-kq)
                 F4P P2 = f4p0();
@@ -176,25 +187,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                         xcs[256 + tid] = a1; xcs[512 + tid] = a2;
                     }
                 }
-                if (RED) xcs[tid] = xv[1];                          // raw centre input of row r, for the store of the next iteration
+                if (RED) xcs[tid] = xc4;                            // raw centre input of row r, for the store of the next iteration
                 P0 = P1; P1 = P2;
-                // weight gradient: input row r-1 against the centre dY of rows r, r-1, r-2 (only rows this strip owns)
-                const float own = (r >= h0 && r < h1) ? 1.f : 0.f;
-                F4P dc0;
-                dc0.lo = dyr[1].lo * v2f{own, own}; dc0.hi = dyr[1].hi * v2f{own, own};
+                // weight gradient: input row i = r-1 (own column) against dY rows i+1 = r (kr = 0), i (kr = 1), i-1 (kr = 2), columns w+1-kq
 #pragma unroll
                 for (int kq = 0; kq < 3; ++kq) {
-                    pfma(wp[0 + kq], aprev[kq], dc0);
-                    pfma(wp[3 + kq], aprev[kq], dc1);
-                    pfma(wp[6 + kq], aprev[kq], dc2);
+                    pfma(wp[0 + kq], aprev, dyr[2 - kq]);
+                    pfma(wp[3 + kq], aprev, dyp1[2 - kq]);
+                    pfma(wp[6 + kq], aprev, dyp2[2 - kq]);
                 }
-                dc2 = dc1; dc1 = dc0;
 #pragma unroll
-                for (int q = 0; q < 3; ++q) aprev[q] = ar[q];
+                for (int q = 0; q < 3; ++q) { dyp2[q] = dyp1[q]; dyp1[q] = dyr[q]; }
+                aprev = ar;
             }
-            // tail: input row h1 meets the centre dY of row h1-1 (kr = 2)
-#pragma unroll
-            for (int kq = 0; kq < 3; ++kq) pfma(wp[6 + kq], aprev[kq], dc2);
+            // (input row h1-1 was processed in the last iteration, r = h1: nothing is left over)
         }
 #pragma unroll
         for (int t = 0; t < 9; ++t) wacc[t] = f4u(wp[t]);
