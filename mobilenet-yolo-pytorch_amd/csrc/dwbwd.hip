@@ -320,41 +320,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                 d0.lo = dy2(G0.lo, Y0.lo, sc.lo, sh.lo, ca.lo, cb.lo, cc.lo) * m0; d0.hi = dy2(G0.hi, Y0.hi, sc.hi, sh.hi, ca.hi, cb.hi, cc.hi) * m0;
                 d1.lo = dy2(G1.lo, Y1.lo, sc.lo, sh.lo, ca.lo, cb.lo, cc.lo) * m1; d1.hi = dy2(G1.hi, Y1.hi, sc.hi, sh.hi, ca.hi, cb.hi, cc.hi) * m1;
             };
-            // activated input row hi, columns 2j-1, 2j, 2j+1 (zero outside the image)
-            auto x_row = [&](int hi, const float4* my, F4P (&a)[3]) {
+            // activated input row hi, columns 2j, 2j+1 — the thread's OWN input quad (zero outside the image).  Round 3: the weight gradient is
+            // summed over the input pixels a thread owns (each meets the one to four dY values whose window covers it, with the taps the
+            // data gradient uses), so no halo column 2j-1 and no halo row 2i-1 of the 4x-sized input tensor is read any more: 4 input
+            // loads per quad row instead of 6 (+ a carried row).
+            auto x_row = [&](int hi, const float4* my, F4P (&a)[2]) {
                 const float rm = (hi >= 0 && hi < gm.H) ? 1.f : 0.f;
                 const T* p = xn + (int64_t)min(max(hi, 0), gm.H - 1) * pitch;
-                float4 raw[3];
+                float4 raw[2];
 #pragma unroll
-                for (int q = 0; q < 3; ++q) raw[q] = ld4(p + xoff[q]);
+                for (int q = 0; q < 2; ++q) raw[q] = ld4(p + xoff[q + 1]);
                 const F4P xsc = f4p(my[14 * gm.cgb]), xsh = f4p(my[15 * gm.cgb]);
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const float m = rm * xm[q];
+                for (int q = 0; q < 2; ++q) {
+                    const float m = rm * xm[q + 1];
                     const F4P X4 = f4p(raw[q]);
                     a[q].lo = xf2(X4.lo, xsc.lo, xsh.lo) * v2f{m, m};
                     a[q].hi = xf2(X4.hi, xsc.hi, xsh.hi) * v2f{m, m};
                 }
             };
-            F4P d00, d01, atop[3];
+            F4P d00, d01;
             {
                 int lo = cgl;
                 asm volatile("" : "+v"(lo));
                 const float4* my = cst + lo;
                 dy_row(i0, my, d00, d01);
-                x_row(2 * i0 - 1, my, atop);
             }
             for (int i = i0; i < i1; ++i) {
                 int lo = cgl;
                 asm volatile("" : "+v"(lo));                       // keeps the LDS constant reads inside the loop (see the stride-1 kernel)
                 const float4* my = cst + lo;
-                F4P d10, d11, amid[3], abot[3];
+                F4P d10, d11, a0[2], a1[2];
                 dy_row(i + 1, my, d10, d11);
-                x_row(2 * i, my, amid);
-                x_row(2 * i + 1, my, abot);
-                // weight gradient: dY[i][j] against the 3x3 input patch around (2i, 2j)
-#pragma unroll
-                for (int q = 0; q < 3; ++q) { pfma(wp[q], atop[q], d00); pfma(wp[3 + q], amid[q], d00); pfma(wp[6 + q], abot[q], d00); }
+                x_row(2 * i, my, a0);
+                x_row(2 * i + 1, my, a1);
+                // weight gradient: input (2i, 2j) <-> tap 4 of dY[i][j]; (2i, 2j+1) <-> taps 5 / 3 of dY[i][j] / dY[i][j+1]; (2i+1, 2j) <-> 7 / 1 of
+                // dY[i][j] / dY[i+1][j]; (2i+1, 2j+1) <-> 8 / 6 / 2 / 0 of dY[i][j] / dY[i][j+1] / dY[i+1][j] / dY[i+1][j+1]
+                pfma(wp[4], a0[0], d00);
+                pfma(wp[5], a0[1], d00); pfma(wp[3], a0[1], d01);
+                pfma(wp[7], a1[0], d00); pfma(wp[1], a1[0], d10);
+                pfma(wp[8], a1[1], d00); pfma(wp[6], a1[1], d01); pfma(wp[2], a1[1], d10); pfma(wp[0], a1[1], d11);
                 // data gradient of the quad (2i..2i+1, 2j..2j+1): taps as in dw_bwd_data_s2k3_kernel
                 F4P o00 = f4p0(), o01 = f4p0(), o10 = f4p0(), o11 = f4p0();
                 pfma(o00, d00, WG(4));
@@ -376,8 +381,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                 if (hv) st4_stream(dx + base + pitch, f10);
                 if (hv && wv2) st4_stream(dx + base + pitch + gm.C, f11);
                 d00 = d10; d01 = d11;
-#pragma unroll
-                for (int q = 0; q < 3; ++q) atop[q] = abot[q];
             }
         }
 #undef WG
