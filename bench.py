@@ -45,7 +45,7 @@ SIZE = 352
 MFMA_KERNELS = {"mny_pw_fwd", "mny_pw_fwd_bf16"}
 # priced in a SECOND, untimed pass of K event-bracketed steps (brackets cost the GPU its back-to-back dispatch, so they stay out
 # of the timed region): the depthwise forward against HBM (north-star target >= 60 %), the other two GEMM entry points against MFMA
-SECOND_PASS = {"mny_dw_fwd": "hbm", "mny_pw_wgrad": "mfma", "mny_pw_dgrad_bnred": "mfma",
+SECOND_PASS = {"mny_dw_fwd": "hbm", "mny_pw_wgrad": "mfma", "mny_pw_dgrad_bnred": "mfma", "mny_pw_bnbwd": "hbm",
                "mny_dw_fwd_bf16": "hbm", "mny_pw_wgrad_bf16": "mfma", "mny_pw_dgrad_bnred_bf16": "mfma"}
 
 
@@ -754,11 +754,11 @@ def main():
                 if meta and meta.get("bytes"):
                     alg[name] = alg.get(name, 0) + int(meta["bytes"])
         res["algorithmic_bytes_per_step"] = alg
-        hb = [o for o in others if o["bound"] == "hbm"]
+        hb = [o for o in others if o["kernel"].startswith("mny_dw_fwd")]
         if hb:
             res["roofline_hbm"] = hb[0]               # the bandwidth-bound depthwise forward (north-star target: frac >= 0.6)
         if others:
-            res["roofline_more"] = [o for o in others if o["bound"] != "hbm"]
+            res["roofline_more"] = [o for o in others if not o["kernel"].startswith("mny_dw_fwd")]   # wgrad, dgrad+reduce (MFMA) and the fused expand-unit backward (HBM)
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         if world == 1 and not a.no_nms and headline and not use_dp:

@@ -713,7 +713,7 @@ class NetPlan:
                 contribute_kernel(i, lambda out, addend, G=G, u=u, xv=xv, w=w, gam=gam, dwv=dwv, dgv=dgv, dbv=dbv, M=M, K=i.C, Nc=o.C, act=o.act:
                                   bwd.add("mny_pw_bnbwd", G, u.Y, u.scale, u.shift, act, u.mean, u.invstd, gam, xv[0], xv[1], xv[2], xv[3],
                                           w, addend, out, dwv, dgv, dbv, self.ws, M, K, Nc, self.stream,
-                                          meta=dict(flops=6 * M * K * Nc, bytes=4 * (2 * 2 * M * Nc + 2 * M * K), shape="M%d K%d N%d" % (M, K, Nc))))
+                                          meta=dict(flops=6 * M * K * Nc, bytes=4 * (3 * M * Nc + 3 * M * K), shape="M%d K%d N%d" % (M, K, Nc))))      # algorithmic: G, Y (stage 1) + G (stage 2); X twice, dX once
                 flush_shared()
                 bwd.marks[o.name] = len(bwd.calls)
                 continue

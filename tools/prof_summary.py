@@ -122,6 +122,8 @@ def main():
         "mny_pw_dgrad_bnred": is_pw_dgrad_bnred,                                                          # (RED = 2 = mny_pw_dgrad_bnred_add, not priced)
         "mny_pw_wgrad": lambda k: k.startswith("pw_wgrad"),
         "mny_dw_fwd": lambda k: k.startswith("dw3_fwd_kernel") or bool(re.match(r"dw_slide_kernel<f32, \d, \d, 0,", k)),
+        # the fused backward of the thin expand units: stage 1 + finalize + stage 2 (the entry point's own partial combine rides along)
+        "mny_pw_bnbwd": lambda k: k.startswith("pw_bnbwd_"),
     }
     for entry, pred in groups.items():
         g = [(ms, n, f_gb, w_gb) for ms, k, n, f_gb, w_gb in rows if pred(k)]
