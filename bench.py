@@ -37,7 +37,7 @@ PROFILE_TAG = "r03"               # profiles/<tag>_traffic_*.json: PMC passes of
 BATCH = 256
 SIZE = 352
 
-# entry points bracketed by HIP events inside the timed region: the dominant one only (forward + data-gradient GEMMs, 87 launches
+# entry points bracketed by HIP events inside the timed region: the dominant one only (forward + plain data-gradient GEMMs, 62 launches
 # per step) — every bracket costs the GPU a few microseconds of lost back-to-back dispatch, so nothing else is bracketed there
 # the pure NT GEMM entry point (forward + data gradient).  mny_pw_dgrad_bnred (data gradient + the fed unit's BN-backward
 # reduction in the epilogue: MFMA work plus an HBM-bound read of that unit's output) is a different entry point with its own,
@@ -236,6 +236,35 @@ def nms_bench(device):
     res = {"workload": "per-class NMS, 100000 boxes x 20 classes, thr 0.45", "boxes_per_s": round(n / gpu_dt, 1),
            "ms": round(gpu_dt * 1e3, 3), "kept": kept, "matches_cpu_indices": bool(same),
            "cpu_boxes_per_s": round(n / cpu_dt, 1), "cpu_kind": "port (oracle/nms_ref.c, 1 thread)"}
+    # the reference-shaped case: one eval batch of 256 images x 1 815 candidates (utils/box.py runs 256 x 20 torchvision.ops.nms calls here)
+    S, m = 256, 1815
+    rr = np.random.RandomState(3)
+    ctr2 = rr.rand(S * m, 2).astype(np.float32)
+    wh2 = (0.02 + 0.28 * rr.rand(S * m, 2)).astype(np.float32)
+    rows2 = torch.from_numpy(np.concatenate((ctr2 - wh2 / 2, ctr2 + wh2 / 2, rr.rand(S * m, 2).astype(np.float32),
+                                             rr.randint(0, C, (S * m, 1)).astype(np.float32)), 1).astype(np.float32))
+    dev2 = rows2.to(device)
+    beg2 = (torch.arange(S, dtype=torch.int32) * m).to(device)
+    cnt2 = torch.full((S,), m, dtype=torch.int32, device=device)
+    o2 = ops.nms_per_class(dev2, beg2, cnt2, C, max_seg_rows=m)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        o2 = ops.nms_per_class(dev2, beg2, cnt2, C, max_seg_rows=m)
+    torch.cuda.synchronize()
+    g2 = (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter()
+    same2, kept2 = True, 0
+    oc = o2[1].cpu().numpy()
+    oi = o2[0].cpu().numpy()
+    for si in range(S):
+        _, ri = nms_ref.nms_rows(rows2[si * m:(si + 1) * m], C, 0.45)
+        kept2 += len(ri)
+        same2 = same2 and oc[si] == len(ri) and np.array_equal(oi[si * m:si * m + oc[si]] - si * m, ri.numpy())
+    c2 = time.perf_counter() - t0
+    res["reference_shape"] = {"workload": "per-class NMS, 256 images x 1815 candidates x 20 classes (one eval batch, utils/box.py:11-31)",
+                              "boxes_per_s": round(S * m / g2, 1), "ms": round(g2 * 1e3, 3), "kept": int(kept2), "matches_cpu_indices": bool(same2),
+                              "cpu_boxes_per_s": round(S * m / c2, 1), "cpu_kind": "port (oracle/nms_ref.c, 1 thread, incl. the python per-image driver)"}
     # anchor decode (C5 i): both heads of 55 images at 352x352 = 99,825 candidates, confidence threshold low enough that ~all pass
     from mobilenet_yolo_pytorch_amd import synthetic
     y = synthetic.VOC_CONFIG["yolo"]
