@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((X6 == 3 &&
     // (plane, 32-row block).  Lane l of that instruction fetches (column l & 31, half l >> 5), so the lane-linear LDS image is
     // [half][column] and lane (column, half) reads back ITS OWN 16 bytes: consecutive lanes, consecutive chunks, no bank conflict.
     // (Round 2 laid the image out [column][half]: the lanes of a half then read every OTHER chunk — SQ_LDS_BANK_CONFLICT was 40 % of
-    // the LDS-active cycles of every planes kernel, profiles/r03_pmc_step_lds.md.)
+    // the LDS-active cycles of every planes kernel, profiles/r03_pmc_step_lds.txt.)
     constexpr int A_ST = BM * BKD, B_ST = X6 == 3 ? BN * 24 : BN * BKD, STAGE = A_ST + B_ST;     // floats
     constexpr int NA = BM / 16, NB = X6 == 3 ? 3 * TN : BN / 16, NL = NA + NB;                   // 1-KiB DMA instructions per stage
     constexpr int LPW = (NL + 3) / 4;                                         // per wave (surplus ones duplicate the last)
@@ -1852,7 +1852,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
 
 // Stage 1, second generation (round 3).  Same tiling, LDS-DMA ring, lane mapping, partial-row layout and arithmetic (order
 // included: bit-identical results) as pw_bnbwd_stage1_kernel; what changed is the instruction stream.  The counters of the first
-// generation (profiles/r03_pmc_pw_bnbwd.md, 16 -> 96 @ 176x176) showed 15 scalar and 20 vector instructions per MFMA, 44 % of the
+// generation (profiles/r03_pmc_pw_bnbwd.txt, 16 -> 96 @ 176x176) showed 15 scalar and 20 vector instructions per MFMA, 44 % of the
 // wave cycles stalled at issue and the matrix pipe 30 % busy at 4.45 TB/s: every LDS read sat in its own basic block behind a
 // `lane == 0` mask store (s_cbranch_execz + lgkmcnt(0) per read), the DMA issue went through per-instruction kind / range branches.
 // Here the row loop body is ONE basic block: all 2 + 4 TI fragment reads of a stage are issued together, the ballots of a stage are
