@@ -467,6 +467,13 @@ int mny_pad_rows_bf16(const float* src, const float* alpha, void* dst, int64_t M
 int mny_transpose_pad_bf16(const float* src, void* dst, int R, int Cc, int Rp, void* stream);
 int mny_stem_bnwgrad_bf16(const float* x_nchw, const void* g, const void* y, const float* scale, const float* shift, int act,
                           const float* coef, float* dw, float* ws, int N, int H, int W, int Cout, void* stream);
+/* fused BN-backward + weight gradient + data gradient of a thin expand unit (mny_pw_bnbwd) under bf16 storage: g, y, x, addend, dx are
+ * bf16; w, statistics, dw / dgamma / dbeta and the workspace (mny_pw_bnbwd_ws_floats) fp32.  K in {8,16,24,32}, N in {64,72,96,144,192}:
+ * the ReLU expand units of models/mobilenetv3.py:44-74 (16->64, 24->72) and the ReLU6 ones of models/mobilenetv2.py:75-77. */
+int mny_pw_bnbwd_supported_bf16(int64_t M, int K, int Nc);
+int mny_pw_bnbwd_bf16(const void* g, const void* y, const float* scale, const float* shift, int act, const float* mean, const float* invstd,
+                      const float* gamma, const void* x, const float* in_scale, const float* in_shift, int in_act, const float* w,
+                      const void* addend, void* dx, float* dw, float* dgamma, float* dbeta, float* ws, int64_t M, int K, int Nc, void* stream);
 int mny_pw_dgrad_bnred_supported_bf16(int64_t M, int K, int Nc, int act);
 int mny_pw_dgrad_bnred_parts_bf16(int64_t M, int K, int Nc);
 int mny_pw_dgrad_bnred_bf16(const void* dy, const void* wT, void* dx, const void* y, const float* scale, const float* shift, int act,

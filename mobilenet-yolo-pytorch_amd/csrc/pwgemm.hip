@@ -1858,13 +1858,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
 // Here the row loop body is ONE basic block: all 2 + 4 TI fragment reads of a stage are issued together, the ballots of a stage are
 // kept in scalar registers and leave through one exec-masked group of 16-byte stores, the DMA sources are running pointers
 // (select, not branch, for the rows past the slice), the Gram MFMA is unconditional (its column-slice twin is simply not stored).
-template <int TI>
+// T: storage type of G, Y, X (float, or bf16_t for bf16-storage plans: the LDS image holds bf16, a 16-byte DMA chunk is 8 elements, the
+// arithmetic is the same fp32; K % 8 == 0 and N % 8 == 0 there)
+template <int TI, typename T = float>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) void pw_bnbwd_stage1b_kernel(BnwArgs p) {
     constexpr int KC = 16, S = 3, BI = 32 * TI, BJ = 32;
-    constexpr int G_ST = KC * BI, X_ST = KC * BJ, STAGE = 2 * G_ST + X_ST;   // floats: G | Y | X
-    constexpr int NG = G_ST / 256, NX = X_ST / 256, NL = 2 * NG + NX;
+    constexpr int EPC = 16 / (int)sizeof(T), EPI = 64 * EPC;                  // elements per 16-byte chunk / per 1-KiB DMA instruction
+    constexpr int G_ST = KC * BI, X_ST = KC * BJ, STAGE = 2 * G_ST + X_ST;   // elements of T: G | Y | X
+    constexpr int NG = (G_ST + EPI - 1) / EPI, NX = (X_ST + EPI - 1) / EPI, NL = 2 * NG + NX;
+    static_assert(G_ST % EPI == 0 && X_ST % EPI == 0, "whole DMA instructions per tile");
     constexpr int LPW = (NL + 3) / 4;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    T* const smem = reinterpret_cast<T*>(smem_f);
+    const T* const pG = reinterpret_cast<const T*>(p.G);
+    const T* const pY = reinterpret_cast<const T*>(p.Y);
+    const T* const pX = reinterpret_cast<const T*>(p.X);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, kk = lane >> 5;
@@ -1890,9 +1898,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
 
     // DMA instruction slots of this wave: a running source pointer per slot (row m_begin + d_row of its tensor), the clamp target
     // for rows past the slice (Y, X: the slice's last row — finite filler, its products are annihilated by dz = 0 / b = 0; G: zeros)
-    const float* zero_src = reinterpret_cast<const float*>(&mny_zero16);
-    const float* d_cur[LPW];
-    const float* d_past[LPW];
+    const T* zero_src = reinterpret_cast<const T*>(&mny_zero16);
+    const T* d_cur[LPW];
+    const T* d_past[LPW];
     int d_row[LPW], d_lds[LPW], d_step[LPW];
 #pragma unroll
     for (int i = 0; i < LPW; ++i) {
@@ -1900,13 +1908,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
         if (j >= NL) j = NL - 1;
         const int kind = j < NG ? 0 : (j < 2 * NG ? 1 : 2);              // 0: G, 1: Y, 2: X
         const int jj = kind == 0 ? j : (kind == 1 ? j - NG : j - 2 * NG);
-        const int q = jj * 64 + lane;
-        const int W4 = (kind == 2 ? BJ : BI) / 4;
+        const int q = jj * 64 + lane;                                     // 16-byte chunk index inside the tile
+        const int W4 = (kind == 2 ? BJ : BI) / EPC;
         d_row[i] = q / W4;
-        const int c = (q % W4) * 4;
-        d_lds[i] = (kind == 0 ? 0 : (kind == 1 ? G_ST : 2 * G_ST)) + jj * 256;
+        const int c = (q % W4) * EPC;
+        d_lds[i] = (kind == 0 ? 0 : (kind == 1 ? G_ST : 2 * G_ST)) + jj * EPI;
         const bool ok = kind == 2 ? c < p.K : n_off + c < p.N;
-        const float* base = kind == 0 ? p.G : (kind == 1 ? p.Y : p.X);
+        const T* base = kind == 0 ? pG : (kind == 1 ? pY : pX);
         const int stride = kind == 2 ? p.K : p.N;
         const int off = kind == 2 ? c : n_off + c;
         d_cur[i] = ok ? base + (m_begin + d_row[i]) * stride + off : zero_src;
@@ -1914,10 +1922,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
         d_step[i] = ok ? KC * stride : 0;
     }
     auto issue = [&](int64_t m0, int slot) {
-        float* stage = smem + slot * STAGE;
+        T* stage = smem + slot * STAGE;
 #pragma unroll
         for (int i = 0; i < LPW; ++i) {
-            const float* src = (m0 + d_row[i] < m_end) ? d_cur[i] : d_past[i];
+            const T* src = (m0 + d_row[i] < m_end) ? d_cur[i] : d_past[i];
             d_cur[i] += d_step[i];
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(stage + d_lds[i]), 16, 0, 0);
@@ -1933,15 +1941,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     for (int r = 0; r < 16; ++r) gram[r] = 0.f;
 
     auto compute = [&](int64_t m0, int slot) {
-        const float* gb = smem + slot * STAGE + (krow0 + kk) * BI + li;
-        const float* yb = gb + G_ST;
-        const float* xb = smem + slot * STAGE + 2 * G_ST + (krow0 + kk) * BJ + li;
+        const T* gb = smem + slot * STAGE + (krow0 + kk) * BI + li;
+        const T* yb = gb + G_ST;
+        const T* xb = smem + slot * STAGE + 2 * G_ST + (krow0 + kk) * BJ + li;
         float xr[KC / 8], gr[KC / 8][TI], yr[KC / 8][TI];
 #pragma unroll
         for (int kp = 0; kp < KC / 8; ++kp) {                             // every fragment read of the stage, one wait
-            xr[kp] = xb[kp * 2 * BJ];
+            xr[kp] = ld1(xb + kp * 2 * BJ);
 #pragma unroll
-            for (int i = 0; i < TI; ++i) { gr[kp][i] = gb[kp * 2 * BI + i * 32]; yr[kp][i] = yb[kp * 2 * BI + i * 32]; }
+            for (int i = 0; i < TI; ++i) { gr[kp][i] = ld1(gb + kp * 2 * BI + i * 32); yr[kp][i] = ld1(yb + kp * 2 * BI + i * 32); }
         }
         unsigned long long bal[KC / 8][TI];
 #pragma unroll
@@ -2002,7 +2010,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
 
     // ---- block reduction over the 4 waves (fixed order) and the two k-halves, then one partial row (as the first generation)
     float* dst = p.partial + (int64_t)blockIdx.x * bnw_stride(p.N, p.K);
-    float* red = smem;                         // [3][16][64]
+    float* red = smem_f;                       // [3][16][64]
     auto reduce_tile = [&](f32x16& t, float* out, int rows, int cols, int ld, int row0) {
         __syncthreads();
         if (wave > 0) {
@@ -2023,7 +2031,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     for (int i = 0; i < TI; ++i) reduce_tile(acc[i], dst, p.N, p.K, p.K, n_off + i * 32);
     if (slice0) reduce_tile(gram, dst + (int64_t)p.N * p.K, p.K, p.K, p.K, 0);
     __syncthreads();
-    float* vred = smem;                        // [4][2*TI+1][32]
+    float* vred = smem_f;                      // [4][2*TI+1][32]
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
         const float a = s1[i] + __shfl_xor(s1[i], 32), b2 = s2[i] + __shfl_xor(s2[i], 32);
@@ -2344,9 +2352,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
 // six-product form (x6_split), two accumulators (even / odd stages); epilogue = the DPP quad transpose of the first generation.
 // N % 16 == 0, N <= 192, Kc <= 32.
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NS>
+// T: storage type of G, X, the addend and dX (bf16_t for bf16-storage plans: 8-byte loads widened to fp32, the same cuts and products —
+// the bf16-exact G has empty mid / lo pieces, which costs matrix-pipe cycles this HBM-bound kernel has to spare — one RNE on store).
+// HALF: N = 16 NS - 8 (the last stage's upper eight columns do not exist: N = 72 of MobileNetV3).
+template <int NS, typename T = float, bool HALF = false>
 __global__ __launch_bounds__(256) void pw_bnbwd_dgrad2_kernel(BndArgs p) {
-    constexpr int N = NS * 16, NW = (N + 31) / 32;               // mask words (32 columns each) per row
+    constexpr int N = NS * 16 - (HALF ? 8 : 0), NW = (N + 31) / 32;               // mask words (32 columns each) per row
+    const T* const pG = reinterpret_cast<const T*>(p.G);
+    const T* const pX = reinterpret_cast<const T*>(p.X);
+    const T* const pAd = reinterpret_cast<const T*>(p.addend);
+    T* const pC = reinterpret_cast<T*>(p.C);
     __shared__ __attribute__((aligned(16))) float sB[(NS + 2) * 3 * 256];     // [stage][piece][lane] 16-B slots; stages NS, NS+1 = Q
     __shared__ __attribute__((aligned(16))) float sXs[32];
     __shared__ __attribute__((aligned(16))) float sXh[32];
@@ -2394,14 +2409,15 @@ __global__ __launch_bounds__(256) void pw_bnbwd_dgrad2_kernel(BndArgs p) {
     unsigned mk[NW];
     auto row_of = [&](int64_t tile) { const int64_t r = tile * 32 + lrow; return r < p.M ? r : p.M - 1; };
     auto load_g = [&](int64_t tile, int s) {
-        const float* row = p.G + row_of(tile) * N + 16 * s + 4 * khalf;
-        g[2 * s] = ld4(row); g[2 * s + 1] = ld4(row + 8);
+        const T* row = pG + row_of(tile) * N + 16 * s + 4 * khalf;
+        g[2 * s] = ld4(row);
+        if (HALF && s == NS - 1) g[2 * s + 1] = f4zero(); else g[2 * s + 1] = ld4(row + 8);
     };
     auto load_mx = [&](int64_t tile) {                           // mask words and the thin X row of the lane
         const int64_t r = row_of(tile);
 #pragma unroll
         for (int w = 0; w < NW; ++w) mk[w] = mask32[(int64_t)w * mstride + r];
-        const float* xrow = p.X + r * Kc + 4 * khalf;
+        const T* xrow = pX + r * Kc + 4 * khalf;
         xr[0] = ld4(xrow); xr[1] = (8 + 4 * khalf < Kc) ? ld4(xrow + 8) : f4zero();
         xr[2] = (16 + 4 * khalf < Kc) ? ld4(xrow + 16) : f4zero(); xr[3] = (24 + 4 * khalf < Kc) ? ld4(xrow + 24) : f4zero();
     };
@@ -2409,7 +2425,7 @@ __global__ __launch_bounds__(256) void pw_bnbwd_dgrad2_kernel(BndArgs p) {
         if (p.addend) {
             const int64_t m0 = tile * 32 + 4 * khalf + jq;
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) { const int64_t r2 = m0 + 8 * gq; ad[gq] = ld4(p.addend + (r2 < p.M ? r2 : p.M - 1) * Kc + colc); }
+            for (int gq = 0; gq < 4; ++gq) { const int64_t r2 = m0 + 8 * gq; ad[gq] = ld4(pAd + (r2 < p.M ? r2 : p.M - 1) * Kc + colc); }
         }
     };
     int64_t tile = (int64_t)blockIdx.x * 4 + wave;
@@ -2502,9 +2518,16 @@ __global__ __launch_bounds__(256) void pw_bnbwd_dgrad2_kernel(BndArgs p) {
                 if (hi2) { r0 = ya; r1 = yb; } else { r2 = ya; r3 = yb; }
             }
             float4 o = make_float4(r0 + bv.x, r1 + bv.y, r2 + bv.z, r3 + bv.w);
-            if (p.addend) { o.x += ad[gq].x; o.y += ad[gq].y; o.z += ad[gq].z; o.w += ad[gq].w; }
+            if (p.addend) {
+                // scalar adds, spelled out: left to the compiler the bf16 instantiations get v_pk_add_f32 ... op_sel:[0,1] op_sel_hi:[1,0]
+                // (the addend's widened halves sit swapped in their register pair) for row groups 2 and 3, and on MI355X exactly those
+                // sums came out WITHOUT the addend in lanes 48-63 of a few waves per launch, differently from launch to launch
+                // (tools/ab/stress_bnbwd_bf16.py; the registers themselves were intact — DESIGN.md, round 3)
+                asm("v_add_f32 %0, %0, %1" : "+v"(o.x) : "v"(ad[gq].x)); asm("v_add_f32 %0, %0, %1" : "+v"(o.y) : "v"(ad[gq].y));
+                asm("v_add_f32 %0, %0, %1" : "+v"(o.z) : "v"(ad[gq].z)); asm("v_add_f32 %0, %0, %1" : "+v"(o.w) : "v"(ad[gq].w));
+            }
             const int64_t row = m0 + 8 * gq + 4 * khalf + jq;
-            if (cok && row < p.M) st4_stream(p.C + row * Kc + colq, o);
+            if (cok && row < p.M) st4_stream(pC + row * Kc + colq, o);
         }
         asm volatile("" ::: "memory");
         load_ad(next);
@@ -3059,4 +3082,66 @@ extern "C" int mny_pw_bnbwd(const float* g, const float* y, const float* scale, 
     }
     hipLaunchKernelGGL(pw_bnbwd_dgrad_kernel, dim3(pl.gx2), dim3(256), pl.lds2, st, d);
     return check_launch("pw_bnbwd_dgrad_kernel");
+}
+
+// ---- bf16-storage twin (round 3): G, Y, X, addend, dX are bf16; W, statistics, dW / dgamma / dbeta, the workspace stay fp32 --------------
+// Shapes: K in {8, 16, 24, 32}, N in {64, 72, 96, 144, 192} (the expand units of MobileNetV3 / MobileNetV2), M >= 4096.  Same three steps:
+// second-generation stage 1 on a bf16 LDS image, the fp32 finalize, the barrier-free data-gradient stage with widened 8-byte loads.
+static bool bnw_supported_bf16(int64_t M, int K, int N) {
+    return bnw_supported(M, K, N) && (K & 7) == 0 && (N == 64 || N == 72 || N == 96 || N == 144 || N == 192);
+}
+extern "C" int mny_pw_bnbwd_supported_bf16(int64_t M, int K, int Nc) { return bnw_supported_bf16(M, K, Nc) ? 1 : 0; }
+extern "C" int mny_pw_bnbwd_bf16(const void* g, const void* y, const float* scale, const float* shift, int act,
+                                 const float* mean, const float* invstd, const float* gamma,
+                                 const void* x, const float* in_scale, const float* in_shift, int in_act,
+                                 const float* w, const void* addend, void* dx /* may be NULL: no data gradient */,
+                                 float* dw, float* dgamma, float* dbeta, float* ws, int64_t M, int K, int Nc, void* stream) {
+    MNY_REQUIRE(g && y && scale && shift && mean && invstd && gamma && x && w && dw && dgamma && dbeta && ws, "pw_bnbwd_bf16: null pointer");
+    MNY_REQUIRE(bnw_supported_bf16(M, K, Nc), "pw_bnbwd_bf16: shape M=%lld K=%d N=%d not supported (mny_pw_bnbwd_supported_bf16)", (long long)M, K, Nc);
+    MNY_REQUIRE(in_act != MNY_ACT_HSWISH && in_act != MNY_ACT_HSIGMOID && act != MNY_ACT_HSWISH && act != MNY_ACT_HSIGMOID,
+                "pw_bnbwd_bf16: h-swish / h-sigmoid activations are not supported");
+    BnwPlan pl = bnw_plan(M, K, Nc);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t stride = bnw_stride(Nc, K);
+    float* red = ws + (size_t)pl.splits * stride;
+    float* B1 = red + stride;
+    float* Q = B1 + (size_t)Nc * K;
+    float* bias = Q + (size_t)K * K;
+    size_t moff = (size_t)(bias + 64 - ws);
+    moff = (moff + 15) / 16 * 16;
+    unsigned long long* mask = reinterpret_cast<unsigned long long*>(ws + moff);
+    const int64_t npairs = (M / 2 + 66) / 2 * 2;
+    BnwArgs a{(const float*)g, (const float*)y, scale, shift, act, mean, invstd, (const float*)x, in_scale, in_shift, in_act, ws, mask, npairs, M, K, Nc,
+              pl.rows_per_block, pl.TI};
+    dim3 grid(pl.splits, pl.nsl), block(256);
+    // LDS: the bf16 ring is half the fp32 one, but the block reductions at the end use [3][16][64] + vector scratch in fp32
+    size_t lds1 = (size_t)3 * 16 * (2 * 32 * pl.TIs + 32) * sizeof(bf16_t);
+    const size_t need = (size_t)4 * (2 * pl.TIs + 1) * 32 * sizeof(float);
+    if (lds1 < need) lds1 = need;
+    if (lds1 < 3 * 16 * 64 * sizeof(float)) lds1 = 3 * 16 * 64 * sizeof(float);
+    switch (pl.TIs) {
+        case 2: hipLaunchKernelGGL((pw_bnbwd_stage1b_kernel<2, bf16_t>), grid, block, lds1, st, a); break;
+        case 3: hipLaunchKernelGGL((pw_bnbwd_stage1b_kernel<3, bf16_t>), grid, block, lds1, st, a); break;
+        default: set_error("pw_bnbwd_bf16: no stage-1 kernel for %d column tiles", pl.TIs); return MNY_EUNSUPPORTED;
+    }
+    int rc = check_launch("pw_bnbwd_stage1b_kernel<bf16>");
+    if (rc) return rc;
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(stride, 32)), dim3(256), 0, st, ws, pl.splits, stride, red);
+    hipLaunchKernelGGL(pw_bnbwd_finalize_kernel, dim3((unsigned)cdiv((int64_t)Nc * K, 256)), dim3(256), (size_t)3 * Nc * sizeof(double), st, red, w, gamma, mean, invstd,
+                       (double)M, Nc, K, dw, dgamma, dbeta, B1, Q, bias);
+    rc = check_launch("pw_bnbwd_finalize_kernel");
+    if (rc || !dx) return rc;
+    BndArgs d{(const float*)g, mask, act, (const float*)x, in_scale, in_shift, in_act, B1, Q, bias, (const float*)addend, (float*)dx, npairs, M, Nc, K, pl.TI,
+              pl.m_tiles, pl.tiles_per_block};
+    static const int v2_grid = getenv("MNY_BND_V2_GRID") ? atoi(getenv("MNY_BND_V2_GRID")) : 512;
+    const int64_t tiles = cdiv(M, 32);
+    const int grid2 = (int)(cdiv(tiles, 4) < v2_grid ? cdiv(tiles, 4) : v2_grid);
+    switch (Nc) {
+        case 64: hipLaunchKernelGGL((pw_bnbwd_dgrad2_kernel<4, bf16_t, false>), dim3(grid2), dim3(256), 0, st, d); break;
+        case 72: hipLaunchKernelGGL((pw_bnbwd_dgrad2_kernel<5, bf16_t, true>), dim3(grid2), dim3(256), 0, st, d); break;
+        case 96: hipLaunchKernelGGL((pw_bnbwd_dgrad2_kernel<6, bf16_t, false>), dim3(grid2), dim3(256), 0, st, d); break;
+        case 144: hipLaunchKernelGGL((pw_bnbwd_dgrad2_kernel<9, bf16_t, false>), dim3(grid2), dim3(256), 0, st, d); break;
+        default: hipLaunchKernelGGL((pw_bnbwd_dgrad2_kernel<12, bf16_t, false>), dim3(grid2), dim3(256), 0, st, d); break;
+    }
+    return check_launch("pw_bnbwd_dgrad2_kernel<bf16>");
 }

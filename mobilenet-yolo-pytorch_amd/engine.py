@@ -612,13 +612,13 @@ class NetPlan:
 
         def takes_own_sums(pn):
             """True for the thin expand units handled by mny_pw_bnbwd (their stage 1 forms the BN sums itself)."""
-            if pn.op != "pw" or self.bf16 or os.environ.get("MNY_NO_BNFUSE") == "1":
+            if pn.op != "pw" or os.environ.get("MNY_NO_BNFUSE") == "1" or (self.bf16 and os.environ.get("MNY_BNFUSE_BF16") == "0"):
                 return False
             po, pi = pn.out, pn.ins[0]
             if pi.act in (_lib.ACT_HSWISH, _lib.ACT_HSIGMOID) or po.act in (_lib.ACT_HSWISH, _lib.ACT_HSIGMOID):
                 return False
             psh = shape(po)
-            return _lib.query("mny_pw_bnbwd_supported", psh[0] * psh[1] * psh[2], pi.C, po.C) == 1
+            return _lib.query(K("mny_pw_bnbwd_supported"), psh[0] * psh[1] * psh[2], pi.C, po.C) == 1
         # W^T of every generic pointwise unit, all in one launch at the head of the backward list (one per layer was 39 launches)
         self.t_batch = os.environ.get("MNY_NO_TBATCH") != "1"
         if self.t_batch:
@@ -701,8 +701,7 @@ class NetPlan:
                         emit(ts.buf, 1)
                 bwd.marks[o.name] = len(bwd.calls)
                 continue
-            if (nd.op == "pw" and nd.ins[0].act not in (_lib.ACT_HSWISH, _lib.ACT_HSIGMOID) and o.act not in (_lib.ACT_HSWISH, _lib.ACT_HSIGMOID)
-                    and os.environ.get("MNY_NO_BNFUSE") != "1" and not self.bf16 and _lib.query("mny_pw_bnbwd_supported", M, nd.ins[0].C, o.C) == 1):
+            if nd.op == "pw" and takes_own_sums(nd):
                 # thin "expand" unit: BN-backward + wgrad + dgrad from (G, Y, X) in 4 passes, dY never materialised
                 u = self.units[o.id]
                 i = nd.ins[0]
@@ -711,9 +710,9 @@ class NetPlan:
                 gam = P[nd.bn + ".weight"]
                 w = P[nd.conv + ".weight"]
                 contribute_kernel(i, lambda out, addend, G=G, u=u, xv=xv, w=w, gam=gam, dwv=dwv, dgv=dgv, dbv=dbv, M=M, K=i.C, Nc=o.C, act=o.act:
-                                  bwd.add("mny_pw_bnbwd", G, u.Y, u.scale, u.shift, act, u.mean, u.invstd, gam, xv[0], xv[1], xv[2], xv[3],
+                                  bwd.add(self.K("mny_pw_bnbwd"), G, u.Y, u.scale, u.shift, act, u.mean, u.invstd, gam, xv[0], xv[1], xv[2], xv[3],
                                           w, addend, out, dwv, dgv, dbv, self.ws, M, K, Nc, self.stream,
-                                          meta=dict(flops=6 * M * K * Nc, bytes=4 * (3 * M * Nc + 3 * M * K), shape="M%d K%d N%d" % (M, K, Nc))))      # algorithmic: G, Y (stage 1) + G (stage 2); X twice, dX once
+                                          meta=dict(flops=6 * M * K * Nc, bytes=self.eb * (3 * M * Nc + 3 * M * K), shape="M%d K%d N%d" % (M, K, Nc))))      # algorithmic: G, Y (stage 1) + G (stage 2); X twice, dX once
                 flush_shared()
                 bwd.marks[o.name] = len(bwd.calls)
                 continue

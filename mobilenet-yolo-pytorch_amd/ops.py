@@ -166,11 +166,11 @@ def pw_bnbwd(g, y, scale, shift, act, mean, invstd, gamma, xview, w2d, addend=No
     x, xs, xh, xact = xview
     K, Nc = x.shape[-1], y.shape[-1]
     M = y.numel() // Nc
-    assert query("mny_pw_bnbwd_supported", M, K, Nc) == 1
-    ws = _new(query("mny_pw_bnbwd_ws_floats", M, K, Nc), like=y)
+    assert query(_k("mny_pw_bnbwd_supported", y), M, K, Nc) == 1
+    ws = _new(query("mny_pw_bnbwd_ws_floats", M, K, Nc), like=y, dtype=torch.float32)
     dx = torch.empty_like(x) if want_dx else None
-    dw, dgamma, dbeta = _new(Nc, K, like=y), _new(Nc, like=y), _new(Nc, like=y)
-    call("mny_pw_bnbwd", _p(g), _p(y), _p(scale), _p(shift), act, _p(mean), _p(invstd), _p(gamma), _p(x), _p(xs), _p(xh), xact,
+    dw, dgamma, dbeta = _new(Nc, K, like=y, dtype=torch.float32), _new(Nc, like=y, dtype=torch.float32), _new(Nc, like=y, dtype=torch.float32)
+    call(_k("mny_pw_bnbwd", y), _p(g), _p(y), _p(scale), _p(shift), act, _p(mean), _p(invstd), _p(gamma), _p(x), _p(xs), _p(xh), xact,
          _p(w2d), _p(addend), _p(dx), _p(dw), _p(dgamma), _p(dbeta), _p(ws), M, K, Nc, _st())
     return dx, dw, dgamma, dbeta
 

@@ -241,6 +241,76 @@ def test_fused_bn_backward_expand_unit(ops, M, K, Nc, act, xact):
     rel(dx.view(M, K), a_in.grad + add, 5e-4, "dX")
 
 
+@pytest.mark.parametrize("M,K,Nc,act,xact", [(8192, 16, 64, 3, 0), (5000, 24, 72, 3, 3), (4100, 32, 192, 2, 1), (6007, 16, 96, 1, 1),
+                                             (70001, 24, 144, 1, 0), (131077, 8, 96, 1, 3), (262147, 24, 72, 3, 1), (4223, 8, 64, 0, 0)])
+def test_fused_bn_backward_expand_unit_bf16_storage(ops, M, K, Nc, act, xact):
+    """mny_pw_bnbwd_bf16 (round 3: the thin ReLU expand units of MobileNetV3 — 16->64, 24->72 — and MobileNetV2's under bf16 storage):
+    G, Y, X, addend, dX in bf16, everything else fp32.  Reference = the fp32 fused kernel (itself checked against torch autograd above)
+    on the same tensors widened to fp32: dW / dgamma / dbeta are fp32 outputs of the same arithmetic (1e-5), dX is rounded once on
+    store (2^-8 relative to the tensor's maximum + the rounding of the addend sum)."""
+    from mobilenet_yolo_pytorch_amd import _lib
+    assert _lib.query("mny_pw_bnbwd_supported_bf16", M, K, Nc) == 1
+    q = lambda t: t.to(torch.bfloat16).float()                 # noqa: E731
+    x = q(rnd(M, K, seed=1))
+    w = rnd(Nc, K, seed=2, scale=K ** -0.5)
+    xs, xh = 1 + 0.2 * rnd(K, seed=3), 0.3 * rnd(K, seed=4)
+    gamma, beta = 1 + 0.3 * rnd(Nc, seed=5), 0.2 * rnd(Nc, seed=6)
+    g, add = q(rnd(M, Nc, seed=7)), q(rnd(M, K, seed=8))
+    bf = torch.bfloat16
+    xd = x.view(1, 1, M, K).cuda().to(bf)
+    yd, st = ops.pw_fwd((xd, xs.cuda(), xh.cuda(), xact), w.cuda().to(bf))
+    assert yd.dtype == bf
+    scale, shift, mean, invstd = ops.bn_finalize(st, M, gamma.cuda(), beta.cuda())
+    gd, ad = g.view(1, 1, M, Nc).cuda().to(bf), add.view(1, 1, M, K).cuda().to(bf)
+    dx, dw, dgamma, dbeta = ops.pw_bnbwd(gd, yd, scale, shift, act, mean, invstd, gamma.cuda(), (xd, xs.cuda(), xh.cuda(), xact), w.cuda(), addend=ad)
+    assert dx.dtype == bf and dw.dtype == torch.float32
+    dx32, dw32, dg32, db32 = ops.pw_bnbwd(gd.float(), yd.float(), scale, shift, act, mean, invstd, gamma.cuda(),
+                                          (xd.float(), xs.cuda(), xh.cuda(), xact), w.cuda(), addend=ad.float())
+    def rel(a, b, tol, what):
+        a, b = a.detach().cpu().double().reshape(-1), b.detach().cpu().double().reshape(-1)
+        err = (a - b).abs().max().item()
+        assert err <= tol * (b.abs().max().item() + 1e-12), "%s rel err %.2e" % (what, err / (b.abs().max().item() + 1e-12))
+    rel(dw, dw32, 1e-5, "dW")
+    rel(dgamma, dg32, 1e-5, "dgamma")
+    rel(dbeta, db32, 1e-5, "dbeta")
+    rel(dx, dx32, 2 ** -8, "dX")
+    # without a data gradient / without an addend
+    dxn, dwn, _, _ = ops.pw_bnbwd(gd, yd, scale, shift, act, mean, invstd, gamma.cuda(), (xd, xs.cuda(), xh.cuda(), xact), w.cuda())
+    dxr, _, _, _ = ops.pw_bnbwd(gd.float(), yd.float(), scale, shift, act, mean, invstd, gamma.cuda(), (xd.float(), xs.cuda(), xh.cuda(), xact), w.cuda())
+    rel(dxn, dxr, 2 ** -8, "dX (no addend)")
+    assert torch.equal(dwn, dw)
+
+
+@pytest.mark.parametrize("M,K,Nc,bf", [(262144, 24, 72, True), (262144, 32, 64, True), (262144, 16, 64, True), (524288, 16, 96, False)])
+def test_fused_bn_backward_expand_unit_is_run_to_run_deterministic(ops, M, K, Nc, bf):
+    """Round 3: the first bf16 build of this unit dropped the addend from a few output quads per launch, differently each launch
+    (a compiler-chosen v_pk_add_f32 with swapped source halves in the epilogue).  Twelve launches on the same inputs
+    with allocator churn in between: every output bit for bit the same, and dX within bf16 rounding of the fp32 kernel's."""
+    dt = torch.bfloat16 if bf else torch.float32
+    x = rnd(M, K, seed=1).view(1, 1, M, K).cuda().to(dt)
+    w = rnd(Nc, K, seed=2, scale=K ** -0.5).cuda()
+    xs, xh = (1 + 0.2 * rnd(K, seed=3)).cuda(), (0.3 * rnd(K, seed=4)).cuda()
+    gamma, beta = (1 + 0.3 * rnd(Nc, seed=5)).cuda(), (0.2 * rnd(Nc, seed=6)).cuda()
+    y, st = ops.pw_fwd((x, xs, xh, 0), w.to(dt))
+    scale, shift, mean, invstd = ops.bn_finalize(st, M, gamma, beta)
+    gd, ad = rnd(M, Nc, seed=7).view(1, 1, M, Nc).cuda().to(dt), rnd(M, K, seed=8).view(1, 1, M, K).cuda().to(dt)
+    first = None
+    for it in range(12):
+        junk = torch.full((1 << 22,), float("nan"), device="cuda")
+        out = ops.pw_bnbwd(gd, y, scale, shift, 3, mean, invstd, gamma, (x, xs, xh, 0), w, addend=ad)
+        torch.cuda.synchronize()
+        del junk
+        if first is None:
+            first = [o.clone() for o in out]
+        else:
+            for nm, a, b in zip(("dx", "dw", "dgamma", "dbeta"), out, first):
+                assert torch.equal(a, b), "%s differs in launch %d: %d elements" % (nm, it, int((a != b).sum()))
+    if bf:
+        ref = ops.pw_bnbwd(gd.float(), y.float(), scale, shift, 3, mean, invstd, gamma, (x.float(), xs, xh, 0), w, addend=ad.float())[0]
+        err = (first[0].float() - ref).abs().max().item()
+        assert err <= 2 ** -7 * ref.abs().max().item(), err
+
+
 @pytest.mark.parametrize("N,H,W,C,act,xact,dtype", [(2, 11, 11, 32, 1, 1, "f32"), (3, 22, 19, 96, 2, 2, "f32"), (2, 37, 8, 144, 1, 0, "f32"),
                                                     (1, 5, 5, 960, 0, 1, "f32"), (2, 16, 16, 72, 3, 3, "f32"), (2, 20, 20, 120, 4, 4, "f32"),
                                                     (2, 33, 17, 64, 1, 1, "bf16"), (2, 9, 9, 240, 4, 4, "bf16")])
