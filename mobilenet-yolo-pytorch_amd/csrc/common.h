@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #include "../../include/mnyolo.h"
 
@@ -149,6 +150,22 @@ __device__ __forceinline__ v4u_t lds_read_u4(const float* p) {
     v4u_t v;
     asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(lds_off(p)) : "memory");
     return v;
+}
+// ds_read_b128 at byte address `base` + the immediate OFF (< 64 KB): no address arithmetic per read
+template <int OFF>
+__device__ __forceinline__ v4f_t lds_read_f4_at(unsigned base) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field");
+    v4f_t v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(base), "n"(OFF) : "memory");
+    return v;
+}
+// compile-time loop: f(std::integral_constant<int, I>) for I in [B, E)
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
 }
 #define MNY_LGKM_WAIT(first) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(first))
 #define MNY_LGKM_DEP(x) asm volatile("" : "+v"(x))

@@ -260,11 +260,14 @@ struct Gemm2Args {   // A / B / addend / C: float* (BF = 0) or bf16_t* (BF = 1)
 //     The LDS image is the same in bytes (64-B rows of four 16-B chunks): a chunk is 4 fp32 or 8 bf16 k-values, a stage
 //     covers 16 or 32 k, and the lane's 16-B fragment read IS the bf16 MFMA operand (k-block = lane>>5), so the bf16
 //     main loop is 2 MFMAs per accumulator per stage instead of 16.
-#ifndef MNY_W6_PAIR
-#define MNY_W6_PAIR 1             // planes mode: column blocks advanced in pairs (0: one at a time, the round-2 form; build-time A/B)
+#ifndef MNY_W6_GROUP
+#define MNY_W6_GROUP 4            // SWP: column blocks advanced together (an accumulator's next product is this many MFMA issues away)
+#endif
+#ifndef MNY_W6_SWP
+#define MNY_W6_SWP 1              // planes mode without a reduction epilogue: the A fragment of stage t is read, transformed and cut BETWEEN the MFMAs of stage t-1 (0: one stage at a time)
 #endif
 template <int TN, int XF, int BF, int RED = 0, int X6 = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((X6 == 3 && RED == 0 && MNY_W6_PAIR) ? 2 : 3, 8))) void pw_gemm_nt_dma_kernel(Gemm2Args p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((X6 == 3 && RED == 0 && MNY_W6_SWP) ? 2 : 3, 8))) void pw_gemm_nt_dma_kernel(Gemm2Args p) {
     using T = typename std::conditional<BF != 0, bf16_t, float>::type;
     constexpr int EPC = BF ? 8 : 4;                                           // elements per 16-B chunk
     constexpr int BKE = 4 * EPC;                                              // k-values per stage
@@ -286,7 +289,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((X6 == 3 &&
     // and need less lead than the activation rows from HBM, so their ring is TWO slots deep (stage t+1 is requested while stage t is
     // multiplied, A stays two stages ahead): 3 x 8 KB + 2 x 3 TN KB is exactly the LDS of the plain mode (3 x (8 + 2 TN) KB), so the planes
     // kernels keep the plain mode's THREE resident workgroups per CU — with a three-slot plane ring (60 KB at TN = 4) they ran two.
-    constexpr int SB = X6 == 3 ? 2 : S;
+    // Software-pipelined form (round 3, SWP): the products of stage t-1 and the cut of stage t share an iteration, so a plane slot is
+    // read one iteration after it landed: the plane ring is three slots again (24 + 9 TN KB per workgroup; this form runs two
+    // workgroups per CU on registers — 200-250 VGPRs — anyway, 2 x 69 KB fits).
+    constexpr bool SWP = X6 == 3 && RED == 0 && MNY_W6_SWP != 0;
+    constexpr int SB = X6 == 3 ? (SWP ? 3 : 2) : S;
     constexpr int NA_W = NA / 4;                                              // A instructions per wave: slots [0, NA_W) are A, the rest B
     static_assert(NA % 4 == 0 && NA_W < LPW, "slot split");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -462,44 +469,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((X6 == 3 &&
             }
             bf16x8_t ah, am, al;
             x6_split(a0, a1, ah, am, al);
-            if constexpr (X6 == 3 && RED == 0 && MNY_W6_PAIR) {      // (the reduction-epilogue variants lost 10-40 % at two waves per SIMD: they keep the one-at-a-time form)
-                // column blocks in PAIRS (round 3): the six products of one accumulator are a dependent chain (a dependent 8-pass MFMA issues
-                // every ~40 cycles, an independent one every 32), so two accumulators are advanced alternately — every MFMA's predecessor
-                // on the same accumulator is two issues back.  Costs a second set of plane pieces in registers (the kernel then holds
-                // two waves per SIMD instead of three — which measured neutral for these shapes: they are not occupancy-bound).
-                auto rd = [&](int u, v4f_t& h, v4f_t& m, v4f_t& l) {
-                    const float* src = stB + (u * 64 + khalf * 32 + lrow) * 4;      // = the lane's own 16 B of the block: conflict-free
-                    h = lds_read_f4(src); m = lds_read_f4(src + TN * 256); l = lds_read_f4(src + 2 * TN * 256);
-                };
-                v4f_t ph0, pm0, pl0, ph1, pm1, pl1;
-                rd(0, ph0, pm0, pl0);
-                if (TN > 1) rd(1, ph1, pm1, pl1);
-                MNY_LGKM_WAIT(ph0); MNY_LGKM_DEP(pm0); MNY_LGKM_DEP(pl0);
-                if (TN > 1) { MNY_LGKM_DEP(ph1); MNY_LGKM_DEP(pm1); MNY_LGKM_DEP(pl1); }
-#pragma unroll
-                for (int u = 0; u < TN; u += 2) {
-                    const bool two = u + 1 < TN;
-                    v4f_t nh0, nm0, nl0, nh1, nm1, nl1;
-                    if (u + 2 < TN) rd(u + 2, nh0, nm0, nl0);
-                    if (u + 3 < TN) rd(u + 3, nh1, nm1, nl1);
-                    const bf16x8_t bh0 = __builtin_bit_cast(bf16x8_t, ph0), bm0 = __builtin_bit_cast(bf16x8_t, pm0), bl0 = __builtin_bit_cast(bf16x8_t, pl0);
-                    const bf16x8_t bh1 = __builtin_bit_cast(bf16x8_t, ph1), bm1 = __builtin_bit_cast(bf16x8_t, pm1), bl1 = __builtin_bit_cast(bf16x8_t, pl1);
-#define MNY_P(A_, B0_, B1_) acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B0_, acc[u], 0, 0, 0); \
-                            if (two) acc[u + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B1_, acc[u + 1], 0, 0, 0)
-                    MNY_P(al, bh0, bh1);      // small terms first (same order as the one-at-a-time form: bit-identical sums)
-                    MNY_P(ah, bl0, bl1);
-                    MNY_P(am, bm0, bm1);
-                    MNY_P(am, bh0, bh1);
-                    MNY_P(ah, bm0, bm1);
-                    MNY_P(ah, bh0, bh1);
-#undef MNY_P
-                    if (u + 2 < TN) {
-                        MNY_LGKM_WAIT(nh0); MNY_LGKM_DEP(nm0); MNY_LGKM_DEP(nl0); ph0 = nh0; pm0 = nm0; pl0 = nl0;
-                        if (u + 3 < TN) { MNY_LGKM_DEP(nh1); MNY_LGKM_DEP(nm1); MNY_LGKM_DEP(nl1); ph1 = nh1; pm1 = nm1; pl1 = nl1; }
-                    }
-                }
-                return;
-            }
             if constexpr (X6 == 3) {
                 const float* src0 = stB + (khalf * 32 + lrow) * 4;
                 v4f_t ph = lds_read_f4(src0), pm = lds_read_f4(src0 + TN * 256), pl = lds_read_f4(src0 + 2 * TN * 256);
@@ -698,12 +667,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((X6 == 3 &&
     // flat (tile, k-tile) walk; stage t lives in ring slot t % 3, two stages stay in flight behind the consumer
     int c_mt = mt_begin, c_kt = 0, c_slot = 0, c_slot_b = 0;           // stage being consumed
     auto consume = [&]() {
-        compute(c_kt, c_slot, SB == S ? c_slot : c_slot_b);
+        compute(c_kt, c_slot, X6 != 3 ? c_slot : c_slot_b);
         if (++c_kt == nk) { epilogue(c_mt); c_kt = 0; ++c_mt; }
         if (++c_slot == S) c_slot = 0;
         c_slot_b ^= 1;
     };
-    if constexpr (SB == S) {
+    if constexpr (X6 != 3) {
         int i_mt = mt_begin, i_kt = 0, i_slot = 0;       // next stage to issue
         seat(mt_begin);
         auto issue_next = [&]() {
@@ -724,6 +693,219 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((X6 == 3 &&
             wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             consume();
+        }
+    } else if constexpr (SWP) {
+        // ---- planes mode, software-pipelined -------------------------------------------------------------------------------------
+        // Measured on the one-stage-at-a-time form (profiles/r03_pmc_step.txt, ISA): per k-stage a wave issues ~110 vector-ALU
+        // instructions (LDS addresses, BN-apply + activation of the A fragment, the three-way cut) BEFORE its 6 TN MFMAs, back to back —
+        // ~450 cycles in which it feeds the matrix pipe nothing; SQ_VALU_MFMA_BUSY 40-44 % on the fat shapes.  Here iteration t cuts
+        // stage t while the products of stage t-1 issue: the cut is split into 24 pieces of 2-4 instructions and one piece follows each
+        // MFMA (an 8-pass MFMA occupies the pipe for 32 cycles, a piece issues in 8-16), LDS reads carry their offsets as immediates.
+        // Same products in the same order per accumulator as the one-at-a-time form: bit-identical results.
+        // Measured (tools/ab/w6_bench.py, same box): 512x512 at 22x22 0.499 -> 0.464 ms (130 -> 140 TF/s), K960 N160 -12 %, K576 N96 -9 %,
+        // K1280 N512 -6 %.  What it did NOT fix: the kernel is not bound by any one thing — timing builds with a part removed give, for
+        // 512x512: no plane DMA -18 %, no plane LDS reads -17 %, no A DMA -9 %, no cut -7 %, no barrier / vmcnt wait -5 %, all of them
+        // together 0.27 ms (the MFMAs + epilogue alone, 57 % of the bf16 peak / 6).  Issuing the DMA pieces between the MFMAs, requesting
+        // the next stage's first planes a stage ahead and the size of the accumulator group (2 / 4) all measured neutral.  The plane
+        // traffic (12 KB of DMA per stage per workgroup, 12 KB of LDS reads per stage per WAVE) is the largest single share: the next
+        // step is a 64-row wave tile (two row blocks share a plane read) — DESIGN.md, round 3.
+        int a_mt = mt_begin, a_kt = 0, a_slot = 0, a_n = 0;   // next A stage to issue
+        int b_mt = mt_begin, b_kt = 0, b_slot = 0, b_n = 0;   // next B stage to issue
+        auto seat_part = [&](int mt, bool part_a) {
+#pragma unroll
+            for (int i = 0; i < LPW; ++i) {
+                if ((i < NA_W) != part_a) continue;
+                if (part_a) {
+                    int m = mt * BM + d_row0[i] + drow;
+                    if (m >= (int)p.M) m = (int)p.M - 1;
+                    d_cur[i] = pA + (int64_t)m * p.K + dk;
+                } else {
+                    d_cur[i] = d_bptr[i];
+                }
+            }
+        };
+        seat_part(mt_begin, true); seat_part(mt_begin, false);
+        auto next_a = [&]() {
+            issue_a(a_kt, a_slot); ++a_n;
+            if (++a_kt == nk) { a_kt = 0; ++a_mt; if (a_mt < mt_end) seat_part(a_mt, true); }
+            if (++a_slot == S) a_slot = 0;
+        };
+        auto next_b = [&]() {
+            issue_b(b_kt, b_slot); ++b_n;
+            if (++b_kt == nk) { b_kt = 0; ++b_mt; if (b_mt < mt_end) seat_part(b_mt, false); }
+            if (++b_slot == SB) b_slot = 0;
+        };
+        // loop-invariant LDS byte addresses of the lane
+        const unsigned oA0 = lds_off(sA + (wv * 32 + lrow) * BKD + ((khalf ^ swz) << 2));
+        const unsigned oA1 = lds_off(sA + (wv * 32 + lrow) * BKD + (((2 + khalf) ^ swz) << 2));
+        const unsigned oB = lds_off(sB + lane * 4);
+        const unsigned oS = lds_off(sScale + khalf * 4);
+        const unsigned shift_off = (unsigned)Kpad * 4u;
+        bf16x8_t qh, qm, ql;                                  // the cut A fragment whose products come next
+        int p_kt = 0, p_slot = 0;                             // stage being cut
+        int m_slot_b = 0;                                     // plane slot of the stage being multiplied (its tile / k-tile: c_mt, c_kt)
+        auto step = [&](auto prep_c, auto mma_c) -> bool {
+            constexpr bool PREP = decltype(prep_c)::value, MMA = decltype(mma_c)::value;
+            constexpr int NPIECE = 24, NISSUE = MMA ? 6 * TN : 1;
+            v4f_t a0, a1, sc0, sc1, sh0, sh1;
+            float z[8];
+            v2f r1[4], r2[4];
+            v4u_t nhu, nmu, nlu;
+            auto piece = [&](auto pc) {
+                constexpr int P = decltype(pc)::value;
+                if constexpr (PREP) {
+                    if constexpr (P < 8) {                            // element P: BN-apply + activation of the producer
+                        const float av = P < 4 ? a0[P & 3] : a1[P & 3];
+                        if constexpr (XF != 0) {
+                            const float zz = fmaf(av, P < 4 ? sc0[P & 3] : sc1[P & 3], P < 4 ? sh0[P & 3] : sh1[P & 3]);
+                            z[P] = XF == 1 ? fminf(fmaxf(zz, slope * zz), hi) : zz * fminf(fmaxf(zz + 3.f, 0.f), 6.f) / 6.f;
+                        } else {
+                            z[P] = av;
+                        }
+                        asm volatile("" : "+v"(z[P]));               // pins the piece HERE (values used only by the next iteration are otherwise sunk below the MFMAs)
+                    } else if constexpr (P < 16) {                    // three-way cut of the pair (2i, 2i+1), in two halves (x6_split's arithmetic)
+                        constexpr int i = (P - 8) >> 1;
+                        if constexpr (((P - 8) & 1) == 0) {
+                            const v2f a = v2f{z[2 * i], z[2 * i + 1]};
+                            const v2f ah = v2f{__uint_as_float(__float_as_uint(a.x) & 0xffff0000u), __uint_as_float(__float_as_uint(a.y) & 0xffff0000u)};
+                            r1[i] = a - ah;
+                            asm volatile("" : "+v"(r1[i]));
+                        } else {
+                            const v2f b = r1[i];
+                            const v2f bh = v2f{__uint_as_float(__float_as_uint(b.x) & 0xffff0000u), __uint_as_float(__float_as_uint(b.y) & 0xffff0000u)};
+                            r2[i] = b - bh;
+                            asm volatile("" : "+v"(r2[i]));
+                        }
+                    } else if constexpr (P < 22) {                    // pack the high halves: two dwords per piece
+                        constexpr int q = P - 16, w = q >> 1, d = (q & 1) * 2;
+                        auto pk = [](float lo, float hi_) { return __builtin_amdgcn_perm(__float_as_uint(hi_), __float_as_uint(lo), 0x07060302u); };
+                        unsigned t0, t1;
+                        if constexpr (w == 0) { t0 = pk(z[2 * d], z[2 * d + 1]); t1 = pk(z[2 * d + 2], z[2 * d + 3]); }
+                        if constexpr (w == 1) { t0 = pk(r1[d].x, r1[d].y); t1 = pk(r1[d + 1].x, r1[d + 1].y); }
+                        if constexpr (w == 2) { t0 = pk(r2[d].x, r2[d].y); t1 = pk(r2[d + 1].x, r2[d + 1].y); }
+                        asm volatile("" : "+v"(t0), "+v"(t1));
+                        if constexpr (w == 0) { nhu[d] = t0; nhu[d + 1] = t1; }
+                        if constexpr (w == 1) { nmu[d] = t0; nmu[d + 1] = t1; }
+                        if constexpr (w == 2) { nlu[d] = t0; nlu[d + 1] = t1; }
+                    }
+                }
+            };
+            auto pieces_of = [&](auto ic) {                           // the pieces that follow issue point I
+                constexpr int I = decltype(ic)::value;
+                static_for<0, NPIECE>([&](auto pc) {
+                    constexpr int P = decltype(pc)::value;
+                    if constexpr (P * NISSUE / NPIECE == I) piece(pc);
+                });
+            };
+            if constexpr (!MMA) {                                     // first stage of the walk: nothing to multiply yet
+                const unsigned bA = (unsigned)p_slot * (A_ST * 4);
+                a0 = lds_read_f4_at<0>(oA0 + bA); a1 = lds_read_f4_at<0>(oA1 + bA);
+                if constexpr (XF != 0) {
+                    const unsigned bS = oS + (unsigned)p_kt * (BKD * 4), bH = bS + shift_off;
+                    sc0 = lds_read_f4_at<0>(bS); sc1 = lds_read_f4_at<32>(bS); sh0 = lds_read_f4_at<0>(bH); sh1 = lds_read_f4_at<32>(bH);
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(sc0), "+v"(sc1), "+v"(sh0), "+v"(sh1));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0), "+v"(a1));
+                }
+                pieces_of(std::integral_constant<int, 0>{});
+            } else {
+                // Column blocks in GROUPS of up to four (MNY_W6_GROUP; TN = 5: 3 + 2): product k is issued for every block of the group before
+                // product k+1, so an MFMA's predecessor on the same accumulator is `group size` issues back (the pairs form left 38 % of the
+                // wave cycles in issue stalls with the pipe 58 % idle: dependent issues).  A group's planes are requested up front in the
+                // order the products need them — high, (the cut's operands), low, mid — and waited for with counted lgkmcnt.
+                const unsigned bB = oB + (unsigned)m_slot_b * (B_ST * 4);
+                v4f_t PH[TN], PM[TN], PL[TN];
+                constexpr int NPREP = PREP ? (XF != 0 ? 6 : 2) : 0;  // LDS reads of the cut
+                constexpr int G0 = TN <= MNY_W6_GROUP ? TN : (TN + 1) / 2;     // size of the first group (TN = 5 -> 3 + 2)
+                auto rdH = [&](auto uc) { constexpr int u = decltype(uc)::value; PH[u] = lds_read_f4_at<u * 1024>(bB); };
+                auto rdM = [&](auto uc) { constexpr int u = decltype(uc)::value; PM[u] = lds_read_f4_at<(TN + u) * 1024>(bB); };
+                auto rdL = [&](auto uc) { constexpr int u = decltype(uc)::value; PL[u] = lds_read_f4_at<(2 * TN + u) * 1024>(bB); };
+                auto tie = [&](auto uc, v4f_t* P_) { constexpr int u = decltype(uc)::value; asm volatile("" : "+v"(P_[u])); };
+                auto group = [&](auto u0c, auto gsc, auto firstc) {
+                    constexpr int u0 = decltype(u0c)::value, gs = decltype(gsc)::value;
+                    constexpr bool first = decltype(firstc)::value;
+                    constexpr bool more = u0 + gs < TN;              // a second group follows (its planes are requested before this group's third product)
+                    constexpr int I0 = 6 * u0;
+                    if constexpr (first) {
+                        static_for<u0, u0 + gs>(rdH);
+                        if constexpr (PREP) {
+                            const unsigned bA = (unsigned)p_slot * (A_ST * 4);
+                            a0 = lds_read_f4_at<0>(oA0 + bA); a1 = lds_read_f4_at<0>(oA1 + bA);
+                            if constexpr (XF != 0) {
+                                const unsigned bS = oS + (unsigned)p_kt * (BKD * 4), bH = bS + shift_off;
+                                sc0 = lds_read_f4_at<0>(bS); sc1 = lds_read_f4_at<32>(bS); sh0 = lds_read_f4_at<0>(bH); sh1 = lds_read_f4_at<32>(bH);
+                            }
+                        }
+                        static_for<u0, u0 + gs>(rdL);
+                        static_for<u0, u0 + gs>(rdM);
+                        asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(NPREP + 2 * gs) : "memory");      // high planes landed
+                        static_for<u0, u0 + gs>([&](auto uc) { tie(uc, PH); });
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                             // requested during the first group
+                        static_for<u0, u0 + gs>([&](auto uc) { tie(uc, PH); tie(uc, PL); tie(uc, PM); });
+                    }
+                    auto prod = [&](auto kc, const bf16x8_t& A_, v4f_t* P_) {
+                        constexpr int k = decltype(kc)::value;
+                        static_for<0, gs>([&](auto jc) {
+                            constexpr int j = decltype(jc)::value, u = u0 + j, IA = I0 + k * gs + j;
+                            acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, __builtin_bit_cast(bf16x8_t, P_[u]), acc[u], 0, 0, 0);
+                            if constexpr (PREP && first && k == 0 && j == 0) {     // the cut's operands: queued behind the high planes
+                                if constexpr (XF != 0) asm volatile("s_waitcnt lgkmcnt(%6)" : "+v"(a0), "+v"(a1), "+v"(sc0), "+v"(sc1), "+v"(sh0), "+v"(sh1) : "n"(2 * gs));
+                                else asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(a0), "+v"(a1) : "n"(2 * gs));
+                            }
+                            pieces_of(std::integral_constant<int, IA>{});
+                            __builtin_amdgcn_sched_barrier(0);
+                        });
+                    };
+                    prod(std::integral_constant<int, 0>{}, ql, PH);                // small terms first (the order of the one-at-a-time form)
+                    if constexpr (first) {
+                        asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(gs) : "memory");               // low planes landed
+                        static_for<u0, u0 + gs>([&](auto uc) { tie(uc, PL); });
+                    }
+                    prod(std::integral_constant<int, 1>{}, qh, PL);
+                    if constexpr (first) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                          // mid planes landed
+                        static_for<u0, u0 + gs>([&](auto uc) { tie(uc, PM); });
+                        if constexpr (more) { static_for<u0 + gs, TN>(rdH); static_for<u0 + gs, TN>(rdL); static_for<u0 + gs, TN>(rdM); }
+                    }
+                    prod(std::integral_constant<int, 2>{}, qm, PM);
+                    prod(std::integral_constant<int, 3>{}, qm, PH);
+                    prod(std::integral_constant<int, 4>{}, qh, PM);
+                    prod(std::integral_constant<int, 5>{}, qh, PH);
+                };
+                group(std::integral_constant<int, 0>{}, std::integral_constant<int, G0>{}, std::true_type{});
+                if constexpr (G0 < TN) group(std::integral_constant<int, G0>{}, std::integral_constant<int, TN - G0>{}, std::false_type{});
+            }
+            bool fin = false;
+            if constexpr (MMA) {
+                if (++c_kt == nk) { c_kt = 0; fin = true; }
+                if (++m_slot_b == SB) m_slot_b = 0;
+            }
+            if constexpr (PREP) {
+                qh = __builtin_bit_cast(bf16x8_t, nhu); qm = __builtin_bit_cast(bf16x8_t, nmu); ql = __builtin_bit_cast(bf16x8_t, nlu);
+                if (++p_kt == nk) p_kt = 0;
+                if (++p_slot == S) p_slot = 0;
+            }
+            return fin;
+        };
+        if (total > 0) { next_a(); next_b(); }               // A(0), B(0), then A(1): the order the counted wait below assumes
+        if (total > 1) next_a();
+        if (total > 0) {                                     // (three separate code paths, not one loop with a three-way branch: the accumulators
+            wait_vmcnt<NA_W>();                              //  then merge only at the loop header and are not copied per iteration)
+            if (total == 1) wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();                    // A(0), B(0) landed
+            if (b_n < total) next_b();                       // B(1)
+            if (a_n < total) next_a();                       // A(2)
+            step(std::true_type{}, std::false_type{});
+            for (int t = 1; t < total; ++t) {
+                if (t + 1 < total) wait_vmcnt<NA_W>(); else wait_vmcnt<0>();     // A(t), B(t) landed; A(t+1) may still be in flight
+                __builtin_amdgcn_s_barrier();                // every wave has cut stage t-1 and multiplied stage t-2: A slot (t+2) % 3, B slot (t+1) % 3 are free
+                if (b_n < total) next_b();                   // B(t+1)
+                if (a_n < total) next_a();                   // A(t+2)
+                if (step(std::true_type{}, std::true_type{})) { epilogue(c_mt); ++c_mt; }
+            }
+            step(std::false_type{}, std::true_type{});
+            epilogue(c_mt);
         }
     } else {
         // planes mode: A two stages ahead (3 slots), B one stage ahead (2 slots).  The A and the B sources walk the same (tile, k-tile)
@@ -2769,7 +2951,13 @@ extern "C" int mny_pw_fwd_w6(const float* x, const float* in_scale, const float*
     MNY_REQUIRE(!(stats && bias), "pw_fwd_w6: stats and bias are mutually exclusive");
     const bool xf = in_scale != nullptr || in_act != MNY_ACT_NONE;
     Nt2Plan p2 = nt2_plan(M, K, Nc, xf);                          // same tiling and partial rows as mny_pw_fwd
+#if MNY_W6_SWP
+    // software-pipelined form: three-slot A ring + THREE-slot plane ring (24 + 9 TN KB) + the scale / shift cache
+    const int Kpad16 = (int)cdiv(K, 16) * 16;
+    const size_t lds = (size_t)(3 * BM * 16 + 3 * 32 * p2.TN * 24) * sizeof(float) + (xf ? 2 * Kpad16 * sizeof(float) : 0);
+#else
     const size_t lds = p2.lds;                                    // three-slot A ring + two-slot plane ring = the plain mode's three-slot (A + fp32 B) ring, to the byte
+#endif
     MNY_REQUIRE(lds <= 96 * 1024, "pw_fwd_w6: K=%d too large for the LDS scale cache", K);
     Gemm2Args g{x, in_scale, in_shift, in_act, w6, bias, addend, y, stats, M, K, Nc, p2.m_tiles, p2.tiles_per_block, p2.gx, p2.n_tiles,
                 nullptr, nullptr, nullptr, nullptr, nullptr, 0};
