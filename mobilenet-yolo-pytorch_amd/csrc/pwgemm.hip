@@ -1155,7 +1155,24 @@ struct WgradArgs {   // X / dY are T* of the kernel instantiation
     const void* dY; float* partial;
     int64_t M; int K; int N;
     int64_t rows_per_block;
+    int gx, gy, splits;          // XCD-aware launches of the LDS-DMA kernels (1-D grid): output tiles gx x gy, M splits; gx == 0: plain 3-D grid
 };
+
+// XCD-aware block order of the LDS-DMA weight-gradient kernels (round 3).  The gx*gy output tiles of one M split read the SAME rows of X
+// and dY; launched as a (gx, gy, splits) grid their workgroups have consecutive linear ids and the dispatcher deals those round-robin
+// over the 8 XCDs — each with its own L2 — so every tile fetched its operands from HBM again: counter traffic 1.67x the algorithmic bytes
+// (profiles/r02_traffic_mny_pw_wgrad.json; K64 N384 = 6 tiles: (384 + 6*64) / (384 + 64) = 1.71).  A 1-D grid of 8*ceil(splits/8)*gx*gy
+// blocks, block L -> XCD L & 7, puts all tiles of a split on one XCD, next to each other in its dispatch order.
+struct WgBlock { int bx, by, bz; bool live; };
+__device__ __forceinline__ WgBlock wg_block(const WgradArgs& p) {
+    WgBlock b;
+    if (p.gx == 0) { b.bx = blockIdx.x; b.by = blockIdx.y; b.bz = blockIdx.z; b.live = true; return b; }
+    const int T = p.gx * p.gy, L = blockIdx.x, idx = L >> 3, grp = idx / T, t = idx - grp * T;
+    b.bz = grp * 8 + (L & 7);
+    b.bx = t % p.gx; b.by = t / p.gx;
+    b.live = b.bz < p.splits;
+    return b;
+}
 
 template <typename T, int MODE, int TI, int TJ>
 __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgradArgs p) {
@@ -1339,8 +1356,10 @@ __global__ __launch_bounds__(256) void pw_wgrad_dma_kernel(WgradArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, kk = lane >> 5;
-    const int co0 = blockIdx.x * BI, ci0 = blockIdx.y * BJ;
-    const int64_t m_begin = (int64_t)blockIdx.z * p.rows_per_block;
+    const WgBlock blk = wg_block(p);
+    if (!blk.live) return;
+    const int co0 = blk.bx * BI, ci0 = blk.by * BJ;
+    const int64_t m_begin = (int64_t)blk.bz * p.rows_per_block;
     const int64_t m_end = min(m_begin + p.rows_per_block, p.M);
     const bool has_xf = p.in_scale != nullptr;
     const float slope = act_slope(p.in_act), hi = act_hi(p.in_act);
@@ -1479,7 +1498,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_dma_kernel(WgradArgs p) {
         if (++c_slot == S) c_slot = 0;
     }
 
-    float* dst = p.partial + (int64_t)blockIdx.z * p.N * p.K;
+    float* dst = p.partial + (int64_t)blk.bz * p.N * p.K;
     if (MODE == 0) {
 #pragma unroll
         for (int i = 0; i < TI; ++i)
@@ -1546,8 +1565,10 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_kernel(WgradArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, kk = lane >> 5;
-    const int co0 = blockIdx.x * BI, ci0 = blockIdx.y * BJ;
-    const int64_t m_begin = (int64_t)blockIdx.z * p.rows_per_block;
+    const WgBlock blk = wg_block(p);
+    if (!blk.live) return;
+    const int co0 = blk.bx * BI, ci0 = blk.by * BJ;
+    const int64_t m_begin = (int64_t)blk.bz * p.rows_per_block;
     const int64_t m_end = min(m_begin + p.rows_per_block, p.M);
     const bool has_xf = p.in_scale != nullptr;
     const float slope = act_slope(p.in_act), hi = act_hi(p.in_act);
@@ -1672,7 +1693,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_kernel(WgradArgs p) {
         if (++c_slot == S) c_slot = 0;
     }
 
-    float* dst = p.partial + (int64_t)blockIdx.z * p.N * p.K;
+    float* dst = p.partial + (int64_t)blk.bz * p.N * p.K;
     if (MODE == 0) {
 #pragma unroll
         for (int i = 0; i < TI; ++i)
@@ -3063,8 +3084,14 @@ static int pw_wgrad_impl(const T* x, const float* in_scale, const float* in_shif
         return check_launch("reduce_parts_kernel");
     }
     WgPlan pl = wg_plan(M, K, Nc, !is_f32);
-    WgradArgs a{x, in_scale, in_shift, in_act, dy, ws, M, K, Nc, pl.rows_per_block};
+    WgradArgs a{x, in_scale, in_shift, in_act, dy, ws, M, K, Nc, pl.rows_per_block, 0, pl.gy, pl.splits};
     dim3 grid(pl.gx, pl.gy, pl.splits), block(256);
+    static const bool xcd_order = getenv("MNY_WGRAD_NO_XCD") == nullptr;      // (same-box A/B switch)
+    WgradArgs a_dma = a;
+    // (only with >= 64 splits, i.e. >= 8 per XCD: K1280 N512 — 40 tiles, 38 splits — lost 11 % to XCD imbalance)
+    const bool use_xcd = xcd_order && pl.gx * pl.gy > 1 && pl.splits >= 64;
+    if (use_xcd) a_dma.gx = pl.gx;
+    const dim3 grid_dma = use_xcd ? dim3((unsigned)(cdiv(pl.splits, 8) * 8 * pl.gx * pl.gy)) : grid;
     hipStream_t st = (hipStream_t)stream;
     static const bool force_v1 = getenv("MNY_WGRAD_V1") != nullptr;
     WgKernel dk = nullptr;                       // LDS-DMA kernels read raw 16-B chunks: aligned rows only
@@ -3086,7 +3113,7 @@ static int pw_wgrad_impl(const T* x, const float* in_scale, const float* in_shif
         }
     }
     const int key = dk ? -1 : pl.mode * 100 + pl.TI * 10 + pl.TJ;
-    if (dk) hipLaunchKernelGGL(dk, grid, block, pl.lds_dma, st, a);
+    if (dk) hipLaunchKernelGGL(dk, grid_dma, block, pl.lds_dma, st, a_dma);
 #define MNY_WG(MD, I, J) hipLaunchKernelGGL((pw_wgrad_kernel<T, MD, I, J>), grid, block, pl.lds, st, a)
     switch (key) {
         case -1: break;
