@@ -707,8 +707,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((X6 == 3 &&
         // 512x512: no plane DMA -18 %, no plane LDS reads -17 %, no A DMA -9 %, no cut -7 %, no barrier / vmcnt wait -5 %, all of them
         // together 0.27 ms (the MFMAs + epilogue alone, 57 % of the bf16 peak / 6).  Issuing the DMA pieces between the MFMAs, requesting
         // the next stage's first planes a stage ahead and the size of the accumulator group (2 / 4) all measured neutral.  The plane
-        // traffic (12 KB of DMA per stage per workgroup, 12 KB of LDS reads per stage per WAVE) is the largest single share: the next
-        // step is a 64-row wave tile (two row blocks share a plane read) — DESIGN.md, round 3.
+        // traffic (12 KB of DMA per stage per workgroup, 12 KB of LDS reads per stage per WAVE) is the largest single share.  The 64-row
+        // wave tile that halves it per FLOP (two row blocks share each plane read and DMA: 256 x 128 workgroup tile, 128 accumulators
+        // pinned to accumulation registers, 84 KB of LDS, hence ONE wave per SIMD) was built on this scaffold and measured: 512x512
+        // 0.47 -> 0.55 ms, K1280 N512 0.29 -> 0.34 — a lone wave per SIMD exposes every barrier, vmcnt and LDS round trip that the
+        // second wave covers here; removed again.
         int a_mt = mt_begin, a_kt = 0, a_slot = 0, a_n = 0;   // next A stage to issue
         int b_mt = mt_begin, b_kt = 0, b_slot = 0, b_n = 0;   // next B stage to issue
         auto seat_part = [&](int mt, bool part_a) {
