@@ -732,6 +732,42 @@ def test_six_product_form_on_non_finite_and_denormal_operands_vs_the_fp32_mfma_p
     assert np.abs(d1[:, ~cols] - d0[:, ~cols]).max() <= 1e-4 * np.abs(d0[:, ~cols]).max()
 
 
+_WGRAD_ORDER = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np, torch
+from mobilenet_yolo_pytorch_amd import ops
+out = {}
+for M, K, N, bf in ((123904, 64, 384, 0), (30976, 512, 512, 0), (123904, 96, 576, 0), (123904, 512, 512, 0), (30976, 160, 960, 0)):
+    g = torch.Generator().manual_seed(M + K)
+    dt = torch.bfloat16 if bf else torch.float32
+    x = torch.randn(1, 1, M, K, generator=g).cuda().to(dt); dy = torch.randn(1, 1, M, N, generator=g).cuda().to(dt)
+    sc, sh = (1 + 0.2 * torch.randn(K, generator=g)).cuda(), (0.3 * torch.randn(K, generator=g)).cuda()
+    out["dw_%%d_%%d_%%d" %% (M, K, N)] = ops.pw_wgrad((x, sc, sh, 1), dy)[0].float().cpu().numpy()
+np.savez(sys.argv[1], **out)
+"""
+
+
+def test_weight_gradient_is_bitwise_the_same_in_either_block_order(tmp_path):
+    """Round 3: the LDS-DMA weight-gradient kernels walk their (output tile, M split) space in an XCD-aware 1-D order (all tiles of a split on
+    one XCD).  The partial rows are per split either way, so the result must not change by a bit against the plain 3-D grid
+    (MNY_WGRAD_NO_XCD=1, read once per process: child processes)."""
+    import subprocess
+    import sys
+    outs = {}
+    for mode in ("xcd", "plain"):
+        f = str(tmp_path / ("wg_%s.npz" % mode))
+        env = dict(os.environ)
+        if mode == "plain":
+            env["MNY_WGRAD_NO_XCD"] = "1"
+        subprocess.run([sys.executable, "-c", _WGRAD_ORDER % os.path.dirname(os.path.dirname(os.path.abspath(__file__))), f], check=True, env=env, timeout=600)
+        outs[mode] = np.load(f)
+    assert sorted(outs["xcd"].files) == sorted(outs["plain"].files) and len(outs["xcd"].files) == 5
+    for k in outs["xcd"].files:
+        assert np.array_equal(outs["xcd"][k], outs["plain"][k]), k
+        assert np.isfinite(outs["xcd"][k]).all()
+
+
 def _cut3(mats):
     """mny_cut3_batch over a list of fp32 [R][C] matrices -> list of plane buffers"""
     import ctypes
