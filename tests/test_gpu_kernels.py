@@ -786,7 +786,8 @@ def _cut3(mats):
     return outs
 
 
-@pytest.mark.parametrize("M,K,Nc,act", [(4096, 512, 512, 1), (3001, 160, 960, 0), (2500, 960, 160, 2), (1000, 516, 384, 1), (777, 1280, 512, 1), (130, 320, 1280, 4)])
+@pytest.mark.parametrize("M,K,Nc,act", [(4096, 512, 512, 1), (3001, 160, 960, 0), (2500, 960, 160, 2), (1000, 516, 384, 1), (777, 1280, 512, 1), (130, 320, 1280, 4),
+                                        (20000, 576, 96, 1), (9000, 1024, 64, 2), (70001, 512, 512, 0)])   # round 3: 3- and 2-block column tiles, several tiles per workgroup run
 def test_gemms_on_precut_weight_planes(ops, M, K, Nc, act):
     """mny_pw_fwd_w6 / mny_pw_dgrad_bnred_w6 (weights cut once by mny_cut3_batch) against the fp64 product and against the in-kernel-cut
     entry points they replace (same tiling, same partial rows)."""
