@@ -25,10 +25,77 @@ import os
 import sys
 import time
 
-import torch
-
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
+
+
+def kfd_gpu_count():
+    """GPUs of this node as the kernel driver lists them (/sys/class/kfd/kfd/topology/nodes/*/properties, simd_count > 0 = a GPU
+    node; CPU nodes carry simd_count 0).  Reads sysfs only: no HIP, no amdsmi, no torch — the launcher parent must not initialise
+    the GPU (on this pool a process that has must never be replaced or fork GPU work).  None when the topology is unreadable."""
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        nodes = os.listdir(root)
+    except OSError:
+        return None
+    n = 0
+    for d in nodes:
+        try:
+            for line in open(os.path.join(root, d, "properties")):
+                f = line.split()
+                if len(f) == 2 and f[0] == "simd_count" and int(f[1]) > 0:
+                    n += 1
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def self_launch(n):
+    """Run this very command under `python -m torch.distributed.run --nnodes=1 --nproc-per-node n` (127.0.0.1 rendezvous, a free
+    port) as a CHILD process and return its exit code.  Runs BEFORE `import torch`: the parent makes no torch / HIP / amdsmi call
+    at all (round 3 called torch.cuda.device_count() here, which falls back to hipGetDeviceCount = HIP initialisation when amdsmi
+    is unavailable); devices are counted from sysfs.  `--launch-check` asserts that (tests/test_host_logic_cpu.py)."""
+    import socket
+    import subprocess
+    check = "--launch-check" in sys.argv
+    have = kfd_gpu_count()
+    if not check:
+        if not have:
+            print("bench: --gpus %d but this node exposes %s GPU(s) (kfd topology)" % (n, "no" if have is None else have), file=sys.stderr)
+            return 2
+        if have < n:                              # partitioned / filtered nodes can miscount: warn, let the ranks fail loudly at set_device
+            print("bench: --gpus %d but the kfd topology lists %d GPU node(s); starting the ranks anyway" % (n, have), file=sys.stderr)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL's cross-process buffer sharing needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    if check:
+        bad = sorted(m for m in sys.modules if m == "torch" or m.startswith("torch.") or m == "amdsmi" or m.startswith("mobilenet_yolo_pytorch_amd"))
+        assert not bad, "launcher parent imported GPU-capable modules before starting its ranks: %s" % bad[:5]
+        env["MNY_LAUNCHER_PARENT_CLEAN"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def _gpus_arg(argv):
+    for i, t in enumerate(argv):
+        if t == "--gpus" and i + 1 < len(argv):
+            return int(argv[i + 1])
+        if t.startswith("--gpus="):
+            return int(t.split("=", 1)[1])
+    return 1
+
+
+if __name__ == "__main__" and "RANK" not in os.environ and int(os.environ.get("WORLD_SIZE", "1")) == 1 and _gpus_arg(sys.argv[1:]) > 1:
+    # `python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (one per GPU, RCCL over xGMI) before this
+    # process has imported torch or made any GPU call, hand their output through (rank 0 prints the one JSON line), exit with their code
+    sys.exit(self_launch(_gpus_arg(sys.argv[1:])))
+
+import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak
@@ -67,6 +134,7 @@ def parse():
     ap.add_argument("--breakdown", action="store_true", help="print a per-entry-point time table to stderr")
     ap.add_argument("--launch-check", action="store_true",
                     help="CPU-only self-test of the N-rank launch path: the ranks meet over gloo, rank 0 prints one JSON line (tests/test_host_logic_cpu.py)")
+    ap.add_argument("--dp-overhead-child", action="store_true", help="internal: the 1-rank RCCL leg of the default run, in its own process")
     ap.add_argument("--detail", default="", help="comma list of entry points: print their per-call table to stderr")
     return ap.parse_args()
 
@@ -507,27 +575,6 @@ def config3_leg(device, steps=12, warmup=4):
     return res
 
 
-def self_launch(n):
-    """Run this very command under `python -m torch.distributed.run --nnodes=1 --nproc-per-node n` (127.0.0.1 rendezvous, a free
-    port) as a child process.  Nothing here touches the GPU: torch.cuda.device_count() only counts devices."""
-    import socket
-    import subprocess
-    have = torch.cuda.device_count()
-    if have < n and "--launch-check" not in sys.argv:
-        print("bench: --gpus %d but this node exposes %d GPU(s)" % (n, have), file=sys.stderr)
-        return 2
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL's cross-process buffer sharing needs it on this driver
-    env.setdefault("OMP_NUM_THREADS", "4")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd, env=env)
-
-
 def allreduce_model(payload_bytes, n_buckets):
     """Modelled gradient all-reduce time per step for N = 2, 4, 8 (no multi-GPU box is available to the builder; the driver's
     SCALE run is the measurement).  xGMI is point-to-point, ~153 GB/s per link and direction (MI355X_MICROARCH.md); a ring
@@ -541,67 +588,147 @@ def allreduce_model(payload_bytes, n_buckets):
     return out
 
 
-def dp_overhead_leg(model, step, steps, plain_ms):
-    """The data-parallel code path on ONE rank (RCCL process group of size 1, bucketed all-reduce launched from inside backward):
-    its cost over the plain step on the same box, same plan.  Runs after the timed region; never part of `value`."""
+def dp_overhead_child(a):
+    """`bench.py --dp-overhead-child`: the data-parallel code path on ONE rank (RCCL process group of size 1, bucketed all-reduce
+    launched from inside backward) against the plain step, same process, same plan, interleaved.  Prints one JSON line.  Runs in its
+    OWN process so that an RCCL / rendezvous stall can only cost this leg (the parent kills it at a hard timeout), never the
+    headline line."""
+    import datetime
+    import socket
     import torch.distributed as dist
+    from mobilenet_yolo_pytorch_amd import synthetic, yolo
     from mobilenet_yolo_pytorch_amd.dp import attach_data_parallel
+    torch.cuda.set_device(0)
+    device = torch.device("cuda", 0)
     if os.environ.get("NCCL_DEBUG", "").upper() in ("", "VERSION"):
-        os.environ["NCCL_DEBUG"] = "WARN"                    # keep RCCL's version banner off stdout: this process prints ONE JSON line
+        os.environ["NCCL_DEBUG"] = "WARN"
     os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
-    s = __import__("socket").socket()
+    s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
-    # whatever RCCL still writes to the C-level stdout (it has printed its banner there on some boxes) goes to stderr for the duration of the leg
     sys.stdout.flush()
-    saved_fd = os.dup(1)
+    saved_fd = os.dup(1)                       # whatever RCCL writes to the C-level stdout goes to stderr: this process prints ONE JSON line
     os.dup2(2, 1)
+    res, red, model = None, None, None
     try:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
-    except Exception:
-        os.dup2(saved_fd, 1)
-        os.close(saved_fd)
-        raise
-    try:
+        torch.manual_seed(0)
+        model = yolo(synthetic.VOC_CONFIG).to(device).train()
+        x, tg = make_batch(a.batch, 0, device, a.size)
+
+        def step():
+            for p in model.parameters():
+                p.grad = None
+            out = model(x, tg)
+            (out[0][0] + out[1][0]).backward()
+
+        def timed(k):
+            for _ in range(3):
+                step()
+            if red is not None:
+                red.wait()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(k):
+                step()
+            if red is not None:
+                red.wait()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / k * 1e3
+
+        k = max(5, min(a.steps, 10))
+        plain1 = timed(k)
+        dist.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(seconds=90))
         red = attach_data_parallel(model)
-        for _ in range(3):
-            step()
-        red.wait()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        red.wait()
-        torch.cuda.synchronize()
-        dp_ms = (time.perf_counter() - t0) / steps * 1e3
+        dp_ms = timed(k)
         plan = next(iter(model._plans.values()))
         nb = len(red.for_plan(plan).buckets)
         payload = plan.gflat.numel() * 4
         red.detach()
         del model.dp_reducer
-        plan.reducer = None
-        # the plain step again, right after, so both numbers see the same clocks / box state
-        for _ in range(2):
-            step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        torch.cuda.synchronize()
-        plain2 = (time.perf_counter() - t0) / steps * 1e3
+        plan._dp = None
+        red = None
+        plain2 = timed(k)                     # the plain step again, right after, so both numbers see the same clocks / box state
+        res = {"one_rank_rccl_ms_per_step": round(dp_ms, 3), "plain_ms_per_step": round(plain2, 3), "plain_before_ms_per_step": round(plain1, 3),
+               "overhead_frac": round(dp_ms / plain2 - 1.0, 4), "buckets": nb,
+               "note": "1-rank RCCL group on this GPU, own child process with a hard timeout: segmented backward replay + %d all-reduce launches per step; "
+                       "not part of `value`" % nb,
+               "allreduce_model": allreduce_model(payload, nb)}
     finally:
         try:
-            dist.destroy_process_group()
+            if red is not None:
+                red.detach()
+            if model is not None and hasattr(model, "dp_reducer"):
+                del model.dp_reducer
+            if dist.is_initialized():
+                dist.destroy_process_group()
         finally:
             sys.stdout.flush()
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
-    return {"one_rank_rccl_ms_per_step": round(dp_ms, 3), "plain_ms_per_step": round(plain2, 3), "timed_region_ms_per_step": round(plain_ms, 3),
-            "overhead_frac": round(dp_ms / plain2 - 1.0, 4), "buckets": nb,
-            "note": "1-rank RCCL group on this GPU: segmented backward replay + %d all-reduce launches per step; not part of `value`" % nb,
-            "allreduce_model": allreduce_model(payload, nb)}
+    print(json.dumps({"dp_overhead": res}))
+
+
+def dp_overhead_leg(a, timeout_s=240):
+    """Run dp_overhead_child in a fresh child process (this process keeps its plans; HBM holds both) and merge its JSON line in."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--dp-overhead-child", "--steps", str(a.steps), "--batch", str(a.batch), "--size", str(a.size)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {"error": "child exceeded its %d s limit and was killed (RCCL / rendezvous stall?)" % timeout_s}
+    for line in reversed(r.stdout.splitlines()):
+        if line.startswith("{"):
+            return json.loads(line)["dp_overhead"]
+    return {"error": "child exit %d: %s" % (r.returncode, r.stderr[-300:])}
+
+
+def dp_evidence_after_warmup(plan, reducer, out, world, rank, device):
+    """N > 1 (or MNY_FORCE_DP=1): what shows on the line that RCCL really ran with N ranks and that the reduced arena is the same
+    everywhere.  Called after the warm-up steps (>= 1 reduced step), before the timed region."""
+    import torch.distributed as dist
+    reducer.wait()
+    torch.cuda.synchronize()
+    g = plan.gflat.double()
+    mine = torch.stack([g.sum(), g.abs().sum(), (out[0][0].detach() + out[1][0].detach()).double().reshape(())]).to(device)
+    allr = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    allr = torch.stack(allr).cpu()
+    same = bool((allr[:, :2].view(torch.int64) == allr[0, :2].view(torch.int64)).all())
+    return {"rccl_ranks": dist.get_world_size(), "backend": str(dist.get_backend()), "grad_checksum_equal_across_ranks": same,
+            "grad_checksum_fp64": [float(allr[0, 0]), float(allr[0, 1])], "finite": bool(torch.isfinite(allr).all()),
+            "rank_losses": [round(float(v), 5) for v in allr[:, 2]],
+            "note": "after the warm-up steps: fp64 sum and abs-sum of the all-reduced gradient arena, all-gathered and compared bit for bit; "
+                    "rank_losses differ because every rank runs its own shard (per-rank BN statistics, SURVEY 8e)"}
+
+
+def measure_allreduce(plan, reducer, world, reps=15):
+    """Measured time of each gradient bucket's all-reduce, in isolation, after the timed region: HIP events on the launch stream
+    around a blocking (async_op=False) collective on a scratch copy of the arena — the launch stream waits for RCCL's stream, so
+    the bracket spans the collective end to end.  MAX over ranks of each rank's median."""
+    import statistics
+    import torch.distributed as dist
+    scratch = plan.gflat.clone()
+    r = reducer.for_plan(plan)
+    per = []
+    for b, e, _ in r.buckets:
+        view, ms = scratch[b:e], []
+        for _ in range(reps):
+            dist.barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dist.all_reduce(view, op=dist.ReduceOp.AVG)
+            e1.record()
+            e1.synchronize()
+            ms.append(e0.elapsed_time(e1))
+        per.append(statistics.median(ms[3:]))
+    t = torch.tensor(per, device=scratch.device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return {"per_bucket_ms": [round(float(v), 4) for v in t.cpu()], "bucket_mb": [round((e - b) * 4 / 1e6, 2) for b, e, _ in r.buckets],
+            "sum_ms": round(float(t.sum()), 4), "reps": reps - 3,
+            "note": "isolated (nothing overlapping), blocking collectives on a copy of the arena; inside a step all but the last bucket ride under backward"}
 
 
 def main():
@@ -609,10 +736,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1 and a.gpus > 1 and "RANK" not in os.environ:
-        # `python bench.py --gpus N` without a launcher: start the N ranks as CHILD processes (one per GPU, RCCL over xGMI) before this
-        # process has made any GPU call, hand their output through (rank 0 prints the one JSON line) and exit with their code
-        sys.exit(self_launch(a.gpus))
+    if a.dp_overhead_child:
+        return dp_overhead_child(a)
     if world != a.gpus:
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, a.gpus))
     if a.launch_check:
@@ -622,7 +747,8 @@ def main():
         dist.all_reduce(t)
         dist.barrier()
         if rank == 0:
-            print(json.dumps({"launch_check": True, "n_gpus": world, "rank_sum": float(t.item())}))
+            print(json.dumps({"launch_check": True, "n_gpus": world, "rank_sum": float(t.item()),
+                              "parent_clean": os.environ.get("MNY_LAUNCHER_PARENT_CLEAN") == "1", "rank_cuda_initialized": bool(torch.cuda.is_initialized())}))
         dist.destroy_process_group()
         return
     torch.cuda.set_device(local)
@@ -663,6 +789,7 @@ def main():
         out = step()
     torch.cuda.synchronize()
     plan = model._plans[(a.batch, a.size, a.size, True) + (("bf16",) if a.dtype == "bf16" else ())]
+    dp_info = dp_evidence_after_warmup(plan, reducer, out, world, rank, device) if use_dp else None
 
     # timed region: K steps, barrier + sync on both sides; the dominant kernels are bracketed by HIP events
     inline = a.roofline_pass == "inline" or a.breakdown
@@ -719,6 +846,12 @@ def main():
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    if use_dp:
+        try:
+            dp_info["allreduce_measured"] = measure_allreduce(plan, reducer, world)
+        except Exception as e:                                                  # noqa: BLE001 — evidence, never the headline
+            dp_info["allreduce_measured"] = {"error": repr(e)[:300]}
+        dp_info["allreduce_model"] = allreduce_model(plan.gflat.numel() * 4, len(reducer.for_plan(plan).buckets))
 
     if rank == 0:
         if a.breakdown:
@@ -780,6 +913,8 @@ def main():
                        "loss": round(loss, 5)},
             "roofline": roof,
         }
+        if dp_info is not None:
+            res["data_parallel"] = dp_info
         res["plan_signatures"] = {e: list(plan_signature(plan, e)) for e in [dom] + sorted(SECOND_PASS) if plan_signature(plan, e)[0]}
         res["plan_signatures"]["__step__"] = list(step_signature(plan))
         alg = {}
@@ -797,7 +932,8 @@ def main():
             res["cpu_baseline"] = cpu_baseline()
         if world == 1 and not a.no_nms and headline and not use_dp:
             try:
-                res["dp_overhead"] = dp_overhead_leg(model, step, max(5, min(a.steps, 10)), dt / a.steps * 1e3)
+                res["dp_overhead"] = dp_overhead_leg(a)
+                res["dp_overhead"]["timed_region_ms_per_step"] = round(dt / a.steps * 1e3, 3)
             except Exception as e:                                              # noqa: BLE001 — a side leg must never cost the headline line
                 res["dp_overhead"] = {"error": repr(e)[:300]}
         if world == 1 and not a.no_nms and headline:

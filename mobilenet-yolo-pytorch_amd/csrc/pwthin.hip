@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void pw_thin_kernel(ThinArgs p) {
             const raw_t ycur = yq[0], acur = aq[0];
 #pragma unroll
             for (int d = 0; d + 1 < PD; ++d) { yq[d] = yq[d + 1]; aq[d] = aq[d + 1]; }
-            if (PD > 0) {
+            if constexpr (PD > 0) {               // `if constexpr`: a plain `if` still instantiates yq[-1] for PD = 0 (1 536 -Warray-bounds lines per build)
                 yq[PD - 1] = raw_t(); aq[PD - 1] = raw_t();
                 if (j + PD < R) {
                     const bool okn = FULL || rr + (j + PD) * rpb < rows_here;

@@ -15,6 +15,21 @@ def lib_path():
     return b.build()
 
 
+def test_one_translation_unit_really_goes_through_hipcc(tmp_path):
+    """build() is mtime-incremental: on a box that receives prebuilt objects it only links.  Force the smallest source through the
+    compiler with the build's own flags so that "the sources compile for gfx950" is exercised whatever the state of _obj/."""
+    import subprocess
+    import mobilenet_yolo_pytorch_amd.build as b
+    src = os.path.join(b.CSRC, "core.hip")
+    out = str(tmp_path / "core.o")
+    r = subprocess.run([b.HIPCC] + b.BASE_FLAGS + b.EXTRA.get("core.hip", []) + ["-c", src, "-o", out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "warning" not in r.stderr, r.stderr[-2000:]
+    assert os.path.getsize(out) > 1000
+    sym = subprocess.run(["nm", out], capture_output=True, text=True).stdout
+    assert " T mny_version" in sym and " T mny_last_error" in sym
+
+
 def _declared():
     src = open(os.path.join(REPO, "include", "mnyolo.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)

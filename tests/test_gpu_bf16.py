@@ -240,7 +240,7 @@ def test_whole_net_bf16_tracks_fp32(arch, size):
         assert rms < 3.0 * prev + 2e-2, (uid, rms, prev)
         prev = max(prev, rms)
     for i in range(2):
-        l32, l16 = float(r32[i][0]), float(r16[i][0])
+        l32, l16 = float(r32[i][0].detach()), float(r16[i][0].detach())
         assert abs(l32 - l16) <= 0.05 * abs(l32) + 1e-3, (i, l32, l16)
     g32, g16 = dict(m32.named_parameters()), dict(m16.named_parameters())
     for k, p in g16.items():                            # parameter gradients stay fp32 (the seg branch has none, as in fp32)

@@ -208,7 +208,7 @@ def test_eval_mode_loss_uses_running_statistics_and_leaves_them_alone():
     # and it differs from the batch-statistics loss of train mode (the bug was silently returning that one)
     m.train()
     tr = m(x.cuda(), tg)
-    assert abs(float(tr[0][0]) - float(res[0][0])) > 1e-3 * abs(float(res[0][0]))
+    assert abs(float(tr[0][0].detach()) - float(res[0][0].detach())) > 1e-3 * abs(float(res[0][0].detach()))
     # detections in eval mode still work next to the loss plan
     m.eval()
     assert len(m(x.cuda())) == 4

@@ -60,7 +60,7 @@ def test_step_is_bitwise_deterministic(arch, bf16):
         res = m(x, tg)
         (res[0][0] + res[1][0]).backward()
         torch.cuda.synchronize()
-        snap = [float(res[0][0]), float(res[1][0])] + [p.grad.clone() for p in m.parameters() if p.grad is not None]
+        snap = [float(res[0][0].detach()), float(res[1][0].detach())] + [p.grad.clone() for p in m.parameters() if p.grad is not None]
         if ref is None:
             ref = snap
             continue
