@@ -497,6 +497,32 @@ int mny_cvt_batch_f32_bf16(const mny_cvt_job* jobs, const int32_t* block_job, in
 int mny_cvt_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
 int mny_cvt_bf16_f32(const void* src, float* dst, int64_t n, void* stream);
 
+/* ---- expand + depthwise as one unit (csrc/exdw.hip): the front half of an inverted-residual block whose depthwise conv has
+ * stride 2 — 1x1 conv K -> C = 6K (K in {16, 24, 32}) + BN + ReLU6 + depthwise 3x3 stride 2 (models/mobilenetv2.py:73-85) — with the
+ * 6x-wide expand output and its gradient NEVER materialised: every pass recomputes it from the thin input x[N,H,W,K] (a view:
+ * in_scale / in_shift / in_act as everywhere), bit-identical to what mny_pw_fwd would have stored.  fp32 storage, even H and W.
+ *   mny_exdw_stats : BN batch statistics of the expand output -> partial rows [mny_exdw_stat_parts()][2][C] for mny_bn_finalize
+ *   mny_exdw_fwd   : z[N,H/2,W/2,C] = dw3x3_s2(relu6(e_scale * (x w_exp^T) + e_shift)), z statistics -> [mny_exdw_fwd_parts()][2][C]
+ *   mny_exdw_bwd   : given gz = dL/d act(z_scale z + z_shift) and the depthwise unit's BN-backward coefficients z_coef[3][C]
+ *                    (mny_bn_bwd_finalize): dw_dw[C,3,3] (or, dw_dw == NULL, partial rows [mny_exdw_bwd_parts()][C*9] left in dw_ws),
+ *                    the expand unit's dw_exp[C,K], dgamma_e, dbeta_e, and dx[N,H,W,K] = data gradient wrt the viewed input (+ addend).
+ *                    ws: mny_exdw_bwd_ws_floats() floats; dw_ws: mny_exdw_bwd_parts() * C * 9 floats. */
+int mny_exdw_supported(int N, int H, int W, int K, int C, int stride);
+int mny_exdw_stat_parts(int64_t M, int K, int C);
+int mny_exdw_stats(const float* x, const float* in_scale, const float* in_shift, int in_act, const float* w_exp, float* stats,
+                   int64_t M, int K, int C, void* stream);
+int mny_exdw_fwd_parts(int N, int H, int W, int K, int C, int stride);
+int mny_exdw_fwd(const float* x, const float* in_scale, const float* in_shift, int in_act, const float* w_exp,
+                 const float* e_scale, const float* e_shift, const float* w_dw, float* z, float* z_stats,
+                 int N, int H, int W, int K, int C, int stride, void* stream);
+int mny_exdw_bwd_parts(int N, int H, int W, int K, int C, int stride);
+size_t mny_exdw_bwd_ws_floats(int N, int H, int W, int K, int C, int stride);
+int mny_exdw_bwd(const float* gz, const float* z, const float* z_scale, const float* z_shift, int z_act, const float* z_coef,
+                 const float* x, const float* in_scale, const float* in_shift, int in_act, const float* w_exp,
+                 const float* e_scale, const float* e_shift, const float* e_mean, const float* e_invstd, const float* e_gamma,
+                 const float* w_dw, const float* addend, float* dx, float* dw_exp, float* dgamma_e, float* dbeta_e,
+                 float* dw_dw, float* dw_ws, float* ws, int N, int H, int W, int K, int C, int stride, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,6 +43,15 @@ _SIGS = {
     "mny_dw_bnbwd_s2_parts": (c_int, [c_int] * 4),
     "mny_dw_bnbwd_s2": (c_int, [P, P, P, P, c_int, P, P, P, P, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "mny_dw_bnbwd_red": (c_int, [P, P, P, P, c_int, P, P, P, P, c_int, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "mny_exdw_supported": (c_int, [c_int] * 6),
+    "mny_exdw_stat_parts": (c_int, [c_int64, c_int, c_int]),
+    "mny_exdw_stats": (c_int, [P, P, P, c_int, P, P, c_int64, c_int, c_int, P]),
+    "mny_exdw_fwd_parts": (c_int, [c_int] * 6),
+    "mny_exdw_fwd": (c_int, [P, P, P, c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "mny_exdw_bwd_parts": (c_int, [c_int] * 6),
+    "mny_exdw_bwd_ws_floats": (c_size_t, [c_int] * 6),
+    "mny_exdw_bwd": (c_int, [P, P, P, P, c_int, P, P, P, P, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P,
+                             c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "mny_adamw_step": (c_int, [P, c_int, c_double, c_double, c_double, c_double, c_double, c_int64, P]),
     "mny_pw_fwd": (c_int, [P, P, P, c_int, P, P, P, P, P, c_int64, c_int, c_int, P]),
     "mny_pw_stat_parts": (c_int, [c_int64, c_int, c_int]),
