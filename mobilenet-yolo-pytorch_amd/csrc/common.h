@@ -235,4 +235,11 @@ int pw_wgs_splits(int64_t M, int K, int N);
 int pw_wgs_launch(const float* x, const float* in_scale, const float* in_shift, int in_act, const float* dy, float* partial,
                   int64_t M, int K, int N, hipStream_t st);
 
+// fused BN-backward of a thin expand unit (pwgemm.hip): partial row layout  P1[N*K] | Gram[K*K] | s1[N] | s2[N] | s3[K]  and its fp64 finalize
+// (-> dW, dgamma, dbeta and the data-gradient operands B1[K][N] = ca o W^T, Q[K][K] = W^T diag(cb) W, bias[K] = cc . W)
+__host__ __device__ inline int64_t bnw_stride(int N, int K) { return (int64_t)N * K + (int64_t)K * K + 2 * N + K; }
+int pw_bnbwd_finalize_launch(const float* partials, int nparts, float* red, const float* w, const float* gamma, const float* mean,
+                             const float* invstd, int64_t M, int Nc, int K, float* dw, float* dgamma, float* dbeta, float* B1, float* Q,
+                             float* bias, hipStream_t st);
+
 }  // namespace mny

@@ -1886,8 +1886,7 @@ struct BnwArgs {
     int tiles_total;    // ceil(N/32); blockIdx.y selects a slice of TI column tiles (wide units run as two slices: occupancy)
 };
 
-// partial layout per split: P1[N*K] | Gram[K*K] | s1[N] | s2[N] | s3[K]
-__host__ __device__ inline int64_t bnw_stride(int N, int K) { return (int64_t)N * K + (int64_t)K * K + 2 * N + K; }
+// partial layout per split: P1[N*K] | Gram[K*K] | s1[N] | s2[N] | s3[K]   (bnw_stride: common.h — exdw.hip writes the same rows)
 
 template <int TI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) void pw_bnbwd_stage1_kernel(BnwArgs p) {
@@ -2770,6 +2769,17 @@ static BnwPlan bnw_plan(int64_t M, int K, int N) {
     pl.tiles_per_block = (int)cdiv(pl.m_tiles, gx);
     pl.gx2 = (int)cdiv(pl.m_tiles, pl.tiles_per_block);
     return pl;
+}
+
+// combine + finalize of the fused expand-unit backward for a producer outside this file (exdw.hip): partial rows in the layout above
+int pw_bnbwd_finalize_launch(const float* partials, int nparts, float* red, const float* w, const float* gamma, const float* mean,
+                             const float* invstd, int64_t M, int Nc, int K, float* dw, float* dgamma, float* dbeta, float* B1, float* Q,
+                             float* bias, hipStream_t st) {
+    const int64_t stride = bnw_stride(Nc, K);
+    hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(stride, 32)), dim3(256), 0, st, partials, nparts, stride, red);
+    hipLaunchKernelGGL(pw_bnbwd_finalize_kernel, dim3((unsigned)cdiv((int64_t)Nc * K, 256)), dim3(256), (size_t)3 * Nc * sizeof(double), st, red, w, gamma,
+                       mean, invstd, (double)M, Nc, K, dw, dgamma, dbeta, B1, Q, bias);
+    return check_launch("pw_bnbwd_finalize_kernel");
 }
 
 }  // namespace mny

@@ -125,3 +125,83 @@ def test_forward_is_bitwise_the_materialised_path(K, N, H, W):
     yd = y.double()
     assert torch.allclose(s[0], yd.sum(dim=(0, 1, 2)), rtol=1e-6, atol=1e-3)
     assert torch.allclose(s[1], (yd * yd).sum(dim=(0, 1, 2)), rtol=1e-6, atol=1e-3)
+
+
+def ref_backward(x, w, wd, gam, bet, zgam, zbet, isc, ish, gz):
+    """autograd (fp64, CPU) of  X -> Y = X W^T -> BN(batch) -> ReLU6 -> dw3x3 s2 -> BN(batch) -> ReLU6, given gz = dL/d(output).
+    -> dict of gradients wrt the VIEWED input X (what the unit's dx is), w, gamma/beta of the expand BN, wd, plus the forward tensors"""
+    dt = torch.float64
+    X = x.to(dt)
+    if isc is not None:
+        X = X * isc.to(dt) + ish.to(dt)
+    X = X.clone().requires_grad_(True)
+    W_, Wd_, G_, Bt_ = (t.to(dt).clone().requires_grad_(True) for t in (w, wd, gam, bet))
+    Y = X @ W_.t()
+    mean, var = Y.mean(dim=(0, 1, 2)), Y.var(dim=(0, 1, 2), unbiased=False)
+    a = torch.clamp((Y - mean) / torch.sqrt(var + EPS) * G_ + Bt_, 0.0, 6.0)
+    Z = F.conv2d(a.permute(0, 3, 1, 2), Wd_[:, None], stride=2, padding=1, groups=a.shape[-1]).permute(0, 2, 3, 1)
+    zm, zv = Z.mean(dim=(0, 1, 2)), Z.var(dim=(0, 1, 2), unbiased=False)
+    out = torch.clamp((Z - zm) / torch.sqrt(zv + EPS) * zgam.to(dt) + zbet.to(dt), 0.0, 6.0)
+    out.backward(gz.to(dt))
+    return dict(dx=X.grad, dw=W_.grad, dgamma=G_.grad, dbeta=Bt_.grad, dwd=Wd_.grad, Z=Z.detach(), zmean=zm.detach(), zvar=zv.detach(),
+                mean=mean.detach(), var=var.detach())
+
+
+@pytest.mark.parametrize("K,N,H,W,affine,addend", [(16, 2, 20, 20, True, False), (16, 3, 36, 44, False, True), (24, 2, 28, 36, True, True),
+                                                   (32, 2, 20, 24, False, False), (16, 12, 64, 48, True, False)])
+def test_backward_matches_autograd(K, N, H, W, affine, addend):
+    dev = torch.device("cuda:0")
+    x, w, wd, gam, bet, isc, ish = make_case(N, H, W, K, seed=7 * K + N + W, affine_in=affine)
+    C, M, Ho, Wo = 6 * K, N * H * W, H // 2, W // 2
+    g = torch.Generator().manual_seed(K + H)
+    zgam, zbet = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.5 + 1.0
+    gz = torch.randn(N, Ho, Wo, C, generator=g)
+    add = torch.randn(N, H, W, K, generator=g) if addend else None
+    R = ref_backward(x, w, wd, gam, bet, zgam, zbet, isc, ish, gz)
+    st = stream()
+    d = lambda t: t.to(dev).contiguous() if t is not None else None  # noqa: E731
+    xd, wv, wdd, gamd, betd, iscd, ishd, zgd, zbd, gzd, addd = (d(t) for t in (x, w, wd, gam, bet, isc, ish, zgam, zbet, gz, add))
+    # forward through the unit (its own statistics)
+    parts = _lib.query("mny_exdw_stat_parts", M, K, C)
+    stats = torch.zeros(2048 * 2 * C, device=dev)
+    _lib.call("mny_exdw_stats", ptr(xd), ptr(iscd), ptr(ishd), 0, ptr(wv), ptr(stats), M, K, C, st)
+    ec = torch.zeros(4, C, device=dev)
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    _lib.call("mny_bn_finalize", ptr(stats), parts, M, ptr(gamd), ptr(betd), EPS, 0.1, ptr(rm), ptr(rv), ptr(ec[0]), ptr(ec[1]), ptr(ec[2]), ptr(ec[3]), C, st)
+    z = torch.empty(N, Ho, Wo, C, device=dev)
+    zparts = _lib.query("mny_exdw_fwd_parts", N, H, W, K, C, 2)
+    _lib.call("mny_exdw_fwd", ptr(xd), ptr(iscd), ptr(ishd), 0, ptr(wv), ptr(ec[0]), ptr(ec[1]), ptr(wdd), ptr(z), ptr(stats), N, H, W, K, C, 2, st)
+    zc = torch.zeros(4, C, device=dev)
+    Mz = N * Ho * Wo
+    _lib.call("mny_bn_finalize", ptr(stats), zparts, Mz, ptr(zgd), ptr(zbd), EPS, 0.1, ptr(rm), ptr(rv), ptr(zc[0]), ptr(zc[1]), ptr(zc[2]), ptr(zc[3]), C, st)
+    # the depthwise unit's BN backward coefficients
+    red = torch.zeros(2048 * 2 * C, device=dev)
+    rparts = _lib.query("mny_bn_bwd_parts", Mz, C)
+    zcoef = torch.zeros(3, C, device=dev)
+    dgz, dbz = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    _lib.call("mny_bn_bwd_reduce", ptr(gzd), ptr(z), ptr(zc[0]), ptr(zc[1]), 1, ptr(zc[2]), ptr(zc[3]), ptr(red), Mz, C, st)
+    _lib.call("mny_bn_bwd_finalize", ptr(red), rparts, Mz, ptr(zgd), ptr(zc[2]), ptr(zc[3]), ptr(dgz), ptr(dbz), ptr(zcoef), C, st)
+    ws = torch.zeros(int(_lib.query("mny_exdw_bwd_ws_floats", N, H, W, K, C, 2)), device=dev)
+    bparts = _lib.query("mny_exdw_bwd_parts", N, H, W, K, C, 2)
+    dws = torch.zeros(bparts * C * 9, device=dev)
+    dx = torch.full((N, H, W, K), float("nan"), device=dev)
+    dwe, dge, dbe, dwd = torch.zeros(C, K, device=dev), torch.zeros(C, device=dev), torch.zeros(C, device=dev), torch.zeros(C, 3, 3, device=dev)
+    _lib.call("mny_exdw_bwd", ptr(gzd), ptr(z), ptr(zc[0]), ptr(zc[1]), 1, ptr(zcoef), ptr(xd), ptr(iscd), ptr(ishd), 0, ptr(wv),
+              ptr(ec[0]), ptr(ec[1]), ptr(ec[2]), ptr(ec[3]), ptr(gamd), ptr(wdd), ptr(addd), ptr(dx), ptr(dwe), ptr(dge), ptr(dbe),
+              ptr(dwd), ptr(dws), ptr(ws), N, H, W, K, C, 2, st)
+    torch.cuda.synchronize()
+
+    def close(name, got, want, rtol):
+        got, want = got.cpu().double(), want.double()
+        assert torch.isfinite(got).all(), name
+        err = (got - want).abs().max().item()
+        assert err <= rtol * want.abs().max().item() + 1e-6, (name, err, want.abs().max().item())
+
+    want_dx = R["dx"] + (add.double() if add is not None else 0.0)
+    close("dx", dx, want_dx, 2e-4)
+    close("dw_exp", dwe, R["dw"], 2e-4)
+    close("dgamma", dge, R["dgamma"], 2e-4)
+    close("dbeta", dbe, R["dbeta"], 2e-4)
+    close("dw_dw", dwd, R["dwd"], 2e-4)
+    # partial rows of the depthwise weight gradient (the engine's deferred combine reads these)
+    close("dw_dw partial rows", dws.view(bparts, C, 3, 3).double().sum(0), R["dwd"], 2e-4)
