@@ -259,18 +259,41 @@ class NetPlan:
         def view(v):
             if v.kind == "unit":
                 u = self.units[v.id]
+                assert u.Y is not None, "%s is the un-materialised expand output of an exdw unit" % v.name
                 return (u.Y, u.scale, u.shift, v.act)
             return (self.reals[v.id], None, None, ACT_NONE)
 
         self._view = view
         self._shape = shape
+        # expand + depthwise units (csrc/exdw.hip): a thin expand conv (16 / 24 / 32 -> 6x channels, ReLU6) whose ONLY consumer is a 3x3
+        # stride-2 depthwise conv (ReLU6) runs as one unit that never writes the 6x-wide tensor or its gradient: every pass recomputes it
+        # from the thin input.  exdw_pw[expand node out id] = depthwise node, exdw_dw[depthwise node out id] = expand node.
+        self.exdw_pw, self.exdw_dw = {}, {}
+        if not self.bf16:
+            ks = set(int(v) for v in os.environ.get("MNY_EXDW_K", "16").split(",") if v)
+            cons = {}
+            for nd in g.nodes:
+                for v in nd.ins:
+                    cons.setdefault(v.id, []).append(nd)
+            out_ids = {v.id for v in list(g.outputs) + ([g.seg_out] if g.seg_out is not None else [])}
+            for nd in g.nodes:
+                if nd.op != "pw" or nd.out.id in out_ids or len(cons.get(nd.out.id, ())) != 1:
+                    continue
+                d = cons[nd.out.id][0]
+                i = nd.ins[0]
+                ish = shape(i)
+                if (d.op == "dw" and d.k == 3 and d.stride == 2 and nd.out.act == _lib.ACT_RELU6 and d.out.act == _lib.ACT_RELU6 and not nd.bias
+                        and i.act in (ACT_NONE, _lib.ACT_RELU6, _lib.ACT_LEAKY, _lib.ACT_RELU) and i.C in ks
+                        and _lib.query("mny_exdw_supported", N, ish[1], ish[2], i.C, nd.out.C, 2) == 1):
+                    self.exdw_pw[nd.out.id] = d
+                    self.exdw_dw[d.out.id] = nd
         for nd in g.nodes:
             o = nd.out
             shp = shape(o)
             M = shp[0] * shp[1] * shp[2]
             if nd.op in ("stem", "dw", "pw"):
                 u = _Unit()
-                u.Y = torch.empty(shp, **act)
+                u.Y = torch.empty(shp, **act) if o.id not in self.exdw_pw else None      # the expand output of an exdw unit is never materialised
                 u.coef4 = torch.empty(4, o.C, **f32)
                 u.scale, u.shift, u.mean, u.invstd = u.coef4[0], u.coef4[1], u.coef4[2], u.coef4[3]
                 u.act, u.C, u.M, u.shape = o.act, o.C, M, shp
@@ -281,6 +304,16 @@ class NetPlan:
                     parts = _lib.query("mny_stem_stat_parts", N, H, W, o.C)
                     self.fwd.add(K("mny_stem_fwd"), self.x_ptr, w, u.Y, stats, N, H, W, o.C, self.stream,
                                  meta=dict(flops=2 * M * o.C * 27, bytes=4 * N * 3 * H * W + eb * M * o.C))
+                elif nd.op == "dw" and o.id in self.exdw_dw:
+                    pn = self.exdw_dw[o.id]                  # the expand node: x = its input (a view), e = its BN coefficients
+                    pi, pu = pn.ins[0], self.units[pn.out.id]
+                    psh = shape(pi)
+                    xv = view(pi)
+                    parts = _lib.query("mny_exdw_fwd_parts", N, psh[1], psh[2], pi.C, o.C, 2)
+                    Mx = N * psh[1] * psh[2]
+                    self.fwd.add("mny_exdw_fwd", xv[0], xv[1], xv[2], xv[3], P[pn.conv + ".weight"], pu.scale, pu.shift, w, u.Y, stats,
+                                 N, psh[1], psh[2], pi.C, o.C, 2, self.stream,
+                                 meta=dict(flops=2 * Mx * pi.C * o.C + 2 * M * o.C * 9, bytes=eb * (Mx * pi.C + M * o.C), shape="exdw K%d C%d H%d" % (pi.C, o.C, psh[1])))
                 elif nd.op == "dw":
                     i = nd.ins[0]
                     ish = shape(i)
@@ -289,6 +322,13 @@ class NetPlan:
                     self.fwd.add(K("mny_dw_fwd"), xv[0], xv[1], xv[2], xv[3], w, u.Y, stats, N, ish[1], ish[2], o.C, nd.k, nd.stride, self.stream,
                                  meta=dict(flops=2 * M * o.C * nd.k * nd.k, bytes=eb * (N * ish[1] * ish[2] * o.C + M * o.C) + 4 * o.C * nd.k * nd.k,
                                            shape="C%d H%d s%d" % (o.C, ish[1], nd.stride)))
+                elif o.id in self.exdw_pw:
+                    i = nd.ins[0]
+                    xv = view(i)
+                    parts = _lib.query("mny_exdw_stat_parts", M, i.C, o.C)
+                    if bn_batch:                             # batch statistics of the un-materialised expand output (eval plans use the running ones)
+                        self.fwd.add("mny_exdw_stats", xv[0], xv[1], xv[2], xv[3], w, stats, M, i.C, o.C, self.stream,
+                                     meta=dict(flops=2 * M * i.C * o.C, bytes=eb * M * i.C, shape="exdw stats M%d K%d N%d" % (M, i.C, o.C)))
                 else:
                     i = nd.ins[0]
                     xv = view(i)
@@ -654,8 +694,45 @@ class NetPlan:
             shp = shape(o)
             M = shp[0] * shp[1] * shp[2]
             s = gs[o.id]
+            if o.id in self.exdw_pw:
+                continue                                   # handled with its depthwise consumer (mny_exdw_bwd below)
             assert s.buf is not None, "no gradient reached %s" % o.name
             G = s.buf
+            if nd.op == "dw" and o.id in self.exdw_dw:
+                # expand + depthwise unit: the depthwise unit's BN-backward sums as usual, then ONE entry point yields the depthwise and the
+                # expand unit's parameter gradients and the data gradient wrt the thin input; neither the expand output nor its gradient exists
+                u = self.units[o.id]
+                pn = self.exdw_dw[o.id]
+                pi, pu = pn.ins[0], self.units[pn.out.id]
+                psh = shape(pi)
+                xv = view(pi)
+                gam = P[nd.bn + ".weight"]
+                red_buf, red_parts = self.fused_red.get(o.id, (None, 0))
+                if red_buf is None:
+                    red_buf, red_parts = self.red_ws, _lib.query("mny_bn_bwd_parts", M, o.C)
+                    bwd.add(K("mny_bn_bwd_reduce"), G, u.Y, u.scale, u.shift, o.act, u.mean, u.invstd, self.red_ws, M, o.C, self.stream,
+                            meta=dict(flops=0, bytes=2 * eb * M * o.C, shape="M%d C%d" % (M, o.C)))
+                bwd.add("mny_bn_bwd_finalize", red_buf, red_parts, M, gam, u.mean, u.invstd, gv(nd.bn + ".weight"), gv(nd.bn + ".bias"),
+                        self.coef_ws, o.C, self.stream)
+                dparts = _lib.query("mny_exdw_bwd_parts", N, psh[1], psh[2], pi.C, o.C, 2)
+                dwv = gv(nd.conv + ".weight")
+                if self.defer and single(nd):
+                    dwv_k, dws_k = None, defer_job(dparts * o.C * 9, dwv, dparts, o.C * 9)
+                else:
+                    dwv_k, dws_k = dwv, torch.empty(dparts * o.C * 9, **f32)
+                xws = torch.empty(max(int(_lib.query("mny_exdw_bwd_ws_floats", N, psh[1], psh[2], pi.C, o.C, 2)), 4), **f32)
+                dwe, dge, dbe = gv(pn.conv + ".weight"), gv(pn.bn + ".weight"), gv(pn.bn + ".bias")
+                Mx = N * psh[1] * psh[2]
+                contribute_kernel(pi, lambda out, addend, G=G, u=u, xv=xv, pu=pu, pn=pn, nd=nd, dwe=dwe, dge=dge, dbe=dbe, dwv_k=dwv_k, dws_k=dws_k, xws=xws,
+                                  psh=psh, Kc=pi.C, C=o.C, M=M, Mx=Mx, act=o.act: bwd.add(
+                    "mny_exdw_bwd", G, u.Y, u.scale, u.shift, act, self.coef_ws, xv[0], xv[1], xv[2], xv[3], P[pn.conv + ".weight"],
+                    pu.scale, pu.shift, pu.mean, pu.invstd, P[pn.bn + ".weight"], P[nd.conv + ".weight"], addend, out, dwe, dge, dbe,
+                    dwv_k, dws_k, xws, N, psh[1], psh[2], Kc, C, 2, self.stream,
+                    meta=dict(flops=8 * Mx * Kc * C + 4 * M * C * 9, bytes=self.eb * (3 * Mx * Kc + 4 * M * C), shape="exdw K%d C%d H%d" % (Kc, C, psh[1]))))    # algorithmic: X twice + dX once, G_z and Z twice
+                flush_shared()
+                flush_reduce()
+                bwd.marks[o.name] = len(bwd.calls)
+                continue
             if nd.op == "add":
                 has_b, has_up = nd.k & 1, nd.k & 2
                 contribute_alias(nd.ins[0], G)
