@@ -29,6 +29,7 @@
 namespace mny {
 
 constexpr int kExTH = 8;            // output rows (= input row pairs) per work item
+constexpr int kExTHB = 4;           // backward: input row PAIRS per work item (LDS: three y / dz row-pair buffers next to the X tile)
 constexpr int kExNS = 7;            // staging chunks per thread and item, upper bound (17 x 21 pixels x K/4 chunks over >= 252 threads)
 
 struct ExGeom {
@@ -42,11 +43,11 @@ static bool ex_shape_ok(int N, int H, int W, int K, int C, int stride) {
     return N > 0 && stride == 2 && (K == 16 || K == 24 || K == 32) && C == 6 * K && H >= 4 && W >= 4 && (H & 1) == 0 && (W & 1) == 0;
 }
 
-static ExGeom ex_geom(int N, int H, int W, int K, int C) {
+static ExGeom ex_geom(int N, int H, int W, int K, int C, int th = kExTH) {
     ExGeom g;
     g.N = N; g.H = H; g.W = W; g.K = K; g.C = C; g.Ho = H / 2; g.Wo = W / 2;
     g.nq = C / 4; g.ppb = 256 / g.nq;
-    g.nHS = (int)cdiv(g.Ho, kExTH); g.nCT = (int)cdiv(g.Wo, g.ppb);
+    g.nHS = (int)cdiv(g.Ho, th); g.nCT = (int)cdiv(g.Wo, g.ppb);
     g.items = N * g.nHS * g.nCT;
     return g;
 }
@@ -58,6 +59,12 @@ static int ex_grid(const ExGeom& g, int per_cu) {
     if (gx > 8) gx &= ~7;           // a multiple of 8: the XCD-contiguous item order below needs it
     return gx;
 }
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a fence + barrier: it waits for EVERY outstanding memory operation
+// of the wave (s_waitcnt vmcnt(0)), i.e. for the round trip of the streaming stores and of the prefetched loads in flight — with one
+// barrier per output row that was ~3 000 cycles per row (forward, 16->96 @176^2: 0.74 ms against a 0.25 ms matrix-pipe bound).  Nothing
+// that crosses waves in these kernels goes through global memory, so the barrier only needs the LDS counter.
+__device__ __forceinline__ void ex_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // Y quad of one pixel: the fmaf chain of pw_thin_kernel::row_step (k ascending, accumulators start at zero)
 template <int K>
@@ -150,7 +157,7 @@ __global__ __launch_bounds__(256) void exdw_stats_kernel(ExStatArgs p) {
     int64_t tile = blockIdx.x;
     int buf = 0;
     if (tile < p.ntiles) { fetch(tile); park(0); }
-    __syncthreads();
+    ex_barrier();
     for (; tile < p.ntiles; tile += gridDim.x) {
         const bool has_next = tile + gridDim.x < p.ntiles;
         if (has_next) fetch(tile + gridDim.x);
@@ -165,12 +172,12 @@ __global__ __launch_bounds__(256) void exdw_stats_kernel(ExStatArgs p) {
             }
         }
         if (has_next) park(buf ^ 1);
-        __syncthreads();
+        ex_barrier();
         buf ^= 1;
     }
     red[tid * 2 + 0] = worker ? f4u(s1) : f4zero();
     red[tid * 2 + 1] = worker ? f4u(s2) : f4zero();
-    __syncthreads();
+    ex_barrier();
     if (pp == 0) {
         float4 a = f4zero(), b = f4zero();
         for (int i = 0; i < p.ppb; ++i) { add4(a, red[(i * p.nq + q) * 2]); add4(b, red[(i * p.nq + q) * 2 + 1]); }
@@ -259,9 +266,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     int item = ex_lb();
     if (item < g.items) fetch(item);
     for (; item < g.items; item += gx) {
-        __syncthreads();                                     // every wave is done with the previous tile
+        ex_barrier();                                     // every wave is done with the previous tile
         park();
-        __syncthreads();
+        ex_barrier();
         if (item + gx < g.items) fetch(item + gx);           // the next tile's loads fly under this tile's arithmetic
         int n, i0, j0;
         decode(item, n, i0, j0);
@@ -311,10 +318,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
         }
     }
     if (p.parts == nullptr) return;
-    __syncthreads();
+    ex_barrier();
     red[tid * 2 + 0] = worker ? f4u(acc1) : f4zero();
     red[tid * 2 + 1] = worker ? f4u(acc2) : f4zero();
-    __syncthreads();
+    ex_barrier();
     if (pp == 0) {
         float4 a = f4zero(), b = f4zero();
         for (int i = 0; i < g.ppb; ++i) { add4(a, red[(i * g.nq + q) * 2]); add4(b, red[(i * g.nq + q) * 2 + 1]); }
@@ -323,6 +330,350 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
         st4(dst + g.C + c, b);
     }
 }
+
+
+// =====================================================================================================================
+// Second generation: the expand output is recomputed on the MATRIX cores (v_mfma_f32_16x16x4_f32: exact fp32, the same fmaf chain).
+// The first-generation kernels above keep the thread's 4 x K expand weights in registers and read every X row from LDS as a wave
+// broadcast: 4 ds_read_b128 per 32 packed FMAs, i.e. the LDS pipe saturates together with the vector ALU and the kernels ran at half
+// their vector-ALU bound (16->96 @176^2: statistics 0.38 ms, forward 0.80 ms).  On the matrix cores a 16-pixel x 16-channel tile of
+// Y costs K/4 instructions whose A operand (one b32 LDS read per lane) is shared by all channel tiles and whose B operand (the
+// weights of one channel tile: K/4 registers) never leaves the register file; the vector ALU only sees the finished tile.
+// =====================================================================================================================
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- statistics ------------------------------------------------------------------------------------------------------
+template <int K, int XF>
+__global__ __launch_bounds__(256) void exdw_stats2_kernel(ExStatArgs p) {
+    constexpr int KQ = K / 4, KP = K + 4, ST = 256 / KQ * KQ, PS = ST / KQ, C = 6 * K, NT = C / 16;
+    constexpr int NS = (kExStatRows * KQ + ST - 1) / ST;
+    __shared__ __attribute__((aligned(16))) float xs[2][kExStatRows * KP];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l16 = lane & 15, lg = lane >> 4;
+    float wb[NT][KQ];                                    // B operands: W[16 t + l16][4 s + lg]
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int sI = 0; sI < KQ; ++sI) wb[t][sI] = p.w[(int64_t)(16 * t + l16) * K + 4 * sI + lg];
+    const int kq_s = tid % KQ, row_s = tid / KQ;
+    const bool stager = tid < ST;
+    float4 xsc = f4one(), xsh = f4zero();
+    if (XF && p.in_scale) { xsc = ld4(p.in_scale + 4 * kq_s); xsh = ld4(p.in_shift + 4 * kq_s); }
+    const float slope = act_slope(p.in_act), hi = act_hi(p.in_act);
+    float4 stg[NS];
+    auto fetch = [&](int64_t tile) {
+        const int64_t base = tile * kExStatRows;
+        const int64_t left = p.M - 1 - base;
+        const int lim = (int)(left < kExStatRows - 1 ? left : kExStatRows - 1);
+        const float* ta = p.x + base * K;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            int tr = row_s + i * PS;
+            tr = tr < lim ? tr : lim;
+            stg[i] = ld4(at_bytes(ta, (unsigned)(tr * K + 4 * kq_s) * 4u));
+        }
+    };
+    auto park = [&](int buf, int64_t tile) {              // rows past M are parked as zeros: they add nothing to either sum
+        const int64_t left = p.M - tile * kExStatRows;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int tr = row_s + i * PS;
+            if (stager && tr < kExStatRows) *reinterpret_cast<float4*>(&xs[buf][tr * KP + 4 * kq_s]) = tr < left ? ex_xf<XF>(stg[i], xsc, xsh, slope, hi) : f4zero();
+        }
+    };
+    float s1[NT], s2[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { s1[t] = 0.f; s2[t] = 0.f; }
+    int64_t tile = blockIdx.x;
+    int buf = 0;
+    if (tile < p.ntiles) { fetch(tile); park(0, tile); }
+    ex_barrier();
+    for (; tile < p.ntiles; tile += gridDim.x) {
+        const bool has_next = tile + gridDim.x < p.ntiles;
+        if (has_next) fetch(tile + gridDim.x);
+#pragma unroll
+        for (int gi = 0; gi < kExStatRows / 64; ++gi) {   // this wave's 16-row groups of the tile
+            const float* xp = &xs[buf][(16 * (wave + 4 * gi) + l16) * KP + lg];
+            float a[KQ];
+#pragma unroll
+            for (int sI = 0; sI < KQ; ++sI) a[sI] = xp[4 * sI];
+            f32x4 acc[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sI = 0; sI < KQ; ++sI)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[sI], wb[t][sI], acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                s1[t] += (acc[t][0] + acc[t][1]) + (acc[t][2] + acc[t][3]);
+                s2[t] = fmaf(acc[t][0], acc[t][0], s2[t]); s2[t] = fmaf(acc[t][1], acc[t][1], s2[t]);
+                s2[t] = fmaf(acc[t][2], acc[t][2], s2[t]); s2[t] = fmaf(acc[t][3], acc[t][3], s2[t]);
+            }
+        }
+        if (has_next) park(buf ^ 1, tile + gridDim.x);
+        ex_barrier();
+        buf ^= 1;
+    }
+    // lane (l16, lg) of wave w holds the sums of channel 16 t + l16 over its pixels: 16 rows per channel -> one partial row per block
+    float* red = &xs[0][0];                               // [16][2][C]
+    ex_barrier();
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        red[((wave * 4 + lg) * 2 + 0) * C + 16 * t + l16] = s1[t];
+        red[((wave * 4 + lg) * 2 + 1) * C + 16 * t + l16] = s2[t];
+    }
+    ex_barrier();
+    for (int e = tid; e < 2 * C; e += 256) {
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a += red[i * 2 * C + e];
+        p.parts[(int64_t)blockIdx.x * 2 * C + e] = a;
+    }
+}
+
+// ---- forward -----------------------------------------------------------------------------------------------------------
+// A workgroup owns TH = 6 output rows x PPB output columns of one image.  The X tile ((2 TH + 1) x (2 PPB + 1) pixels) is staged once;
+// the activated expand output a = relu6(sc * Y + sh) lives in a ring of SIX input rows [slot][column][C], slot(row) = (row + 1) % 6:
+// while the stencil threads (4 channels x one output column, dw3_fwd_kernel's tap order) read rows 2i-1..2i+1 of output row i, the
+// matrix cores fill rows 2i+2, 2i+3 for the next one — one barrier per output row.  A row pair always sits in two ADJACENT slots, so a
+// finished 16 x 16 tile goes to LDS with one address and four immediate offsets.  Matrix work is dealt to the four waves as contiguous
+// runs of (channel tile, 16-pixel group) units: a wave touches at most three channel tiles (3 x K/4 weight registers).  Zero padding of
+// the ACTIVATED tensor (input row / column -1) is applied by the stencil threads as tap masks, the matrix epilogue has no bounds checks.
+template <int K> struct ExF {
+    static constexpr int KQ = K / 4, KP = K + 4, C = 6 * K, CP = C + 4, NQ = C / 4, NT = C / 16, PPB = 256 / NQ, NCOLS = 2 * PPB + 1;
+    static constexpr int TH = 6, ROWS = 2 * TH + 1, XPIX = ROWS * NCOLS;
+    static constexpr int NG = (2 * NCOLS + 15) / 16;                      // 16-pixel groups of a row pair
+    static constexpr int U = NT * NG, SL = 3;                             // units per row pair; channel-tile slots per wave
+    static constexpr int XS_FLOATS = (XPIX + 16) * KP;                    // + the pixels a padded last group reads past the tile
+    static constexpr int RING_FLOATS = 6 * NCOLS * CP;
+    static constexpr size_t LDS = (size_t)(XS_FLOATS + RING_FLOATS) * 4;
+    static constexpr int span(int w) { return (U * (w + 1) / 4 - 1) / NG - (U * w / 4) / NG + 1; }     // channel tiles wave w's run touches
+    static_assert(span(0) <= SL && span(1) <= SL && span(2) <= SL && span(3) <= SL, "a wave's run of units must fit its channel-tile slots");
+    static_assert(XS_FLOATS >= 256 * 8, "the end-of-kernel statistics fold lives in the X tile");
+};
+
+// 512 threads: waves 0-3 drive the matrix cores (producers of ring rows), waves 4-7 are the stencil threads (consumers) — the two
+// kinds of work overlap inside a workgroup instead of waiting for a co-resident one to be in the other phase (the 256-thread form, every
+// wave doing both in turn with two waves per SIMD, was latency-bound: 0.88 ms at 16->96 @176^2 against 0.80 for the first generation).
+template <int K, int XF>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 8))) void exdw_fwd2_s2_kernel(ExFwdArgs p) {
+    using F = ExF<K>;
+    constexpr int KQ = F::KQ, KP = F::KP, C = F::C, CP = F::CP, NQ = F::NQ, PPB = F::PPB, NCOLS = F::NCOLS, NG = F::NG, SL = F::SL, TH = F::TH;
+    constexpr int ST = 512 / KQ * KQ, PS = ST / KQ, NS = (F::XPIX * KQ + ST - 1) / ST;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* xs = lds;                                         // [ROWS][NCOLS][KP]
+    float* ring = lds + F::XS_FLOATS;                        // [6][NCOLS][CP]
+    const ExGeom& g = p.g;
+    const int tid = threadIdx.x, wave = tid >> 6;
+    for (int i = tid; i < F::XS_FLOATS; i += 512) xs[i] = 0.f;           // pads and slack stay zero (finite operands for the padded groups)
+    const int kq_s = tid % KQ, pix_s = tid / KQ;
+    const bool stager = tid < ST;
+    float4 xsc = f4one(), xsh = f4zero();
+    if (XF && p.in_scale) { xsc = ld4(p.in_scale + 4 * kq_s); xsh = ld4(p.in_shift + 4 * kq_s); }
+    const float slope = act_slope(p.in_act), hi = act_hi(p.in_act);
+    float4 stg[NS];
+    auto decode = [&](int item, int& n, int& i0, int& j0) {
+        const int ct = item % g.nCT; const int t = item / g.nCT;
+        const int hs = t % g.nHS; n = t / g.nHS;
+        i0 = hs * TH; j0 = ct * PPB;
+    };
+    auto fetch = [&](int item) {
+        int n, i0, j0;
+        decode(item, n, i0, j0);
+        const int r0 = 2 * i0 - 1, c0 = 2 * j0 - 1;
+        const float* xn = p.x + (int64_t)n * g.H * g.W * K;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int pix = min(pix_s + i * PS, F::XPIX - 1);
+            const int rr = pix / NCOLS, cc = pix - rr * NCOLS;
+            const int gr = min(max(r0 + rr, 0), g.H - 1), gc = min(max(c0 + cc, 0), g.W - 1);
+            stg[i] = ld4(xn + ((int64_t)gr * g.W + gc) * K + 4 * kq_s);
+        }
+    };
+    auto park = [&]() {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int pix = pix_s + i * PS;
+            if (stager && pix < F::XPIX) *reinterpret_cast<float4*>(&xs[pix * KP + 4 * kq_s]) = ex_xf<XF>(stg[i], xsc, xsh, slope, hi);
+        }
+    };
+    const int gx = gridDim.x;
+    int item = ex_lb();
+    if (item < g.items) fetch(item);
+
+    // The two roles run the SAME barrier sequence (item top x 2, prologue, one per output row) in separate loops, so that the register
+    // allocator sees two disjoint live sets (weights + accumulators | taps + window) instead of their union.
+    if (wave < 4) {
+        // ---- producers: wave W's run of units [UB, UE) of u = tile * NG + group, up to SL channel tiles; code specialised per wave so
+        // that no predicate surrounds an MFMA (the first cut chose the units at run time: 49 M branches and 129 M scalar instructions per launch)
+        auto run = [&](auto wtag) {
+            constexpr int W = decltype(wtag)::value;
+            constexpr int UB = F::U * W / 4, UE = F::U * (W + 1) / 4, T0 = UB / NG;
+            const int lane = tid & 63, l16 = lane & 15, lg = lane >> 4;
+            float wb[SL][KQ], esc_s[SL], esh_s[SL];
+#pragma unroll
+            for (int j = 0; j < SL; ++j) {
+                const int ch = min(16 * (T0 + j) + l16, C - 1);
+#pragma unroll
+                for (int sI = 0; sI < KQ; ++sI) wb[j][sI] = p.w[(int64_t)ch * K + 4 * sI + lg];
+                esc_s[j] = p.e_scale[ch]; esh_s[j] = p.e_shift[ch];
+            }
+            auto g0 = [](int j) constexpr { const int t = T0 + j; return (UB > t * NG ? UB : t * NG) - t * NG; };
+            auto g1 = [](int j) constexpr { const int t = T0 + j; return (UE < (t + 1) * NG ? UE : (t + 1) * NG) - t * NG; };
+            // activated expand output of a row PAIR (FULL: 2 NCOLS pixels) or of one row (NCOLS pixels), row-major from X-tile row lr0
+            // -> ring slots s0, s0 + 1 (adjacent).  All A fragments first, then every unit's K/4-deep chain one step at a time, then the
+            // finished tiles are activated and parked.
+            auto mfma_rows = [&](auto full_tag, int lr0, int s0) {
+                constexpr bool FULL = decltype(full_tag)::value;
+                constexpr int COUNT = FULL ? 2 * NCOLS : NCOLS;
+                constexpr int NGC = (COUNT + 15) / 16;                   // groups that hold pixels of this pass
+                const float* xp = xs + (lr0 * NCOLS + l16) * KP + lg;
+                float a[NG][KQ];
+#pragma unroll
+                for (int gi = 0; gi < NGC; ++gi)
+#pragma unroll
+                    for (int sI = 0; sI < KQ; ++sI) a[gi][sI] = xp[16 * gi * KP + 4 * sI];
+                f32x4 acc[SL][NG];
+#pragma unroll
+                for (int sI = 0; sI < KQ; ++sI)
+                    static_for<0, SL>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        static_for<0, NGC>([&](auto gc) {
+                            constexpr int gi = decltype(gc)::value;
+                            if constexpr (gi >= g0(j) && gi < g1(j)) {
+                                if (sI == 0) acc[j][gi] = f32x4{0.f, 0.f, 0.f, 0.f};
+                                acc[j][gi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[gi][sI], wb[j][sI], acc[j][gi], 0, 0, 0);
+                            }
+                        });
+                    });
+                static_for<0, SL>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    float* rp = ring + (s0 * NCOLS + 4 * lg) * CP + 16 * (T0 + j) + l16;
+                    static_for<0, NGC>([&](auto gc) {
+                        constexpr int gi = decltype(gc)::value;
+                        if constexpr (gi >= g0(j) && gi < g1(j)) {
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) {
+                                const float av = __builtin_amdgcn_fmed3f(fmaf(acc[j][gi][v], esc_s[j], esh_s[j]), 0.f, 6.f);
+                                // a pair's last group may run past its pixels (into a slot being read); a single row's spill-over lands on
+                                // the next slot's first pixels, which hold the same values already
+                                if (!FULL || 16 * gi + 15 < COUNT || 16 * gi + 4 * lg + v < COUNT) rp[(16 * gi + v) * CP] = av;
+                            }
+                        }
+                    });
+                });
+            };
+            for (; item < g.items; item += gx) {
+                ex_barrier();                                // every wave is done with the previous tile (X and ring)
+                park();
+                ex_barrier();
+                if (item + gx < g.items) fetch(item + gx);
+                int n, i0, j0;
+                decode(item, n, i0, j0);
+                const int nrows = min(i0 + TH, g.Ho) - i0;
+                mfma_rows(std::true_type{}, 1, 2);           // X-tile rows 1, 2 -> slots 2, 3; row 0 -> slot 1
+                mfma_rows(std::false_type{}, 0, 1);
+                ex_barrier();
+                for (int li = 0; li < nrows; ++li) {
+                    if (li + 1 < nrows) mfma_rows(std::true_type{}, 2 * li + 3, (2 * li + 4) % 6);
+                    ex_barrier();
+                }
+            }
+        };
+        if (wave == 0) run(std::integral_constant<int, 0>{});
+        else if (wave == 1) run(std::integral_constant<int, 1>{});
+        else if (wave == 2) run(std::integral_constant<int, 2>{});
+        else run(std::integral_constant<int, 3>{});
+        if (p.parts == nullptr) return;
+        ex_barrier();
+        ex_barrier();
+        return;
+    }
+    // ---- consumers: stencil thread = 4 channels x one output column
+    const int st = tid - 256;
+    const int q = st % NQ, pp = st / NQ;
+    const bool worker = pp < PPB;
+    const int c = 4 * q;
+    F4P wt[9];
+    {
+        float raw[36];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const float4 v = ld4(p.w_dw + (int64_t)c * 9 + 4 * i);
+            raw[4 * i] = v.x; raw[4 * i + 1] = v.y; raw[4 * i + 2] = v.z; raw[4 * i + 3] = v.w;
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) { wt[t].lo = v2f{raw[t], raw[9 + t]}; wt[t].hi = v2f{raw[18 + t], raw[27 + t]}; }
+    }
+    F4P acc1 = f4p0(), acc2 = f4p0();
+    for (; item < g.items; item += gx) {
+        ex_barrier();
+        park();
+        ex_barrier();
+        if (item + gx < g.items) fetch(item + gx);
+        int n, i0, j0;
+        decode(item, n, i0, j0);
+        const int nrows = min(i0 + TH, g.Ho) - i0;
+        ex_barrier();
+        const int j = j0 + pp;
+        float* zo = p.z + (((int64_t)n * g.Ho + i0) * g.Wo + min(j, g.Wo - 1)) * C + c;
+        const int64_t opitch = (int64_t)g.Wo * C;
+        const float ml = j > 0 ? 1.f : 0.f;                  // input column 2j-1 = -1: zero padding of the activated tensor
+        for (int li = 0; li < nrows; ++li) {
+            if (worker && j < g.Wo) {
+                const float mt = (li > 0 || i0 > 0) ? 1.f : 0.f;         // input row 2i-1 = -1
+                const float* r0p = ring + (((2 * li + 1) % 6) * NCOLS + 2 * pp) * CP + c;
+                const float* r1p = ring + (((2 * li + 2) % 6) * NCOLS + 2 * pp) * CP + c;
+                const float* r2p = ring + (((2 * li + 3) % 6) * NCOLS + 2 * pp) * CP + c;
+                F4P t0[3], t1[3], t2[3];
+#pragma unroll
+                for (int qc = 0; qc < 3; ++qc) { t0[qc] = f4p(ld4(r0p + qc * CP)); t1[qc] = f4p(ld4(r1p + qc * CP)); t2[qc] = f4p(ld4(r2p + qc * CP)); }
+                const v2f mtl = v2f{mt * ml, mt * ml}, mt2 = v2f{mt, mt}, ml2 = v2f{ml, ml};
+                t0[0].lo *= mtl; t0[0].hi *= mtl; t0[1].lo *= mt2; t0[1].hi *= mt2; t0[2].lo *= mt2; t0[2].hi *= mt2;
+                t1[0].lo *= ml2; t1[0].hi *= ml2; t2[0].lo *= ml2; t2[0].hi *= ml2;
+                F4P o = f4p0();
+#pragma unroll
+                for (int qc = 0; qc < 3; ++qc) { pfma(o, t0[qc], wt[qc]); pfma(o, t1[qc], wt[3 + qc]); pfma(o, t2[qc], wt[6 + qc]); }
+                st4_stream(zo, f4u(o));
+                zo += opitch;
+                acc1.lo += o.lo; acc1.hi += o.hi;
+                pfma(acc2, o, o);
+            }
+            ex_barrier();
+        }
+    }
+    if (p.parts == nullptr) return;
+    ex_barrier();
+    float4* red = reinterpret_cast<float4*>(lds);
+    red[st * 2 + 0] = worker ? f4u(acc1) : f4zero();
+    red[st * 2 + 1] = worker ? f4u(acc2) : f4zero();
+    ex_barrier();
+    if (pp == 0) {
+        float4 a = f4zero(), b = f4zero();
+        for (int i = 0; i < PPB; ++i) { add4(a, red[(i * NQ + q) * 2]); add4(b, red[(i * NQ + q) * 2 + 1]); }
+        float* dst = p.parts + (int64_t)blockIdx.x * 2 * C;
+        st4(dst + c, a);
+        st4(dst + C + c, b);
+    }
+}
+
+template <int K>
+static int ex_fwd2_launch(const ExFwdArgs& a, bool xf, int grid, hipStream_t st) {
+    const size_t lds = ExF<K>::LDS;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)exdw_fwd2_s2_kernel<K, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute((const void*)exdw_fwd2_s2_kernel<K, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            set_error("exdw_fwd: hipFuncSetAttribute failed"); return MNY_EHIP;
+        }
+        attr = true;
+    }
+    if (xf) hipLaunchKernelGGL((exdw_fwd2_s2_kernel<K, 1>), dim3(grid), dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((exdw_fwd2_s2_kernel<K, 0>), dim3(grid), dim3(512), lds, st, a);
+    return check_launch("exdw_fwd2_s2_kernel");
+}
+static int ex_fwd_th(int K) { (void)K; return 6; }
+static bool ex_v1() { static const bool v = getenv("MNY_EXDW_V1") != nullptr; return v; }      // A/B: the first-generation kernels
 
 static size_t ex_fwd_lds(const ExGeom& g) {
     const size_t xs = (size_t)(2 * kExTH + 1) * (2 * g.ppb + 1) * (g.K + 4) * sizeof(float);
@@ -354,8 +705,10 @@ extern "C" int mny_exdw_stats(const float* x, const float* in_scale, const float
     ExStatArgs a{x, in_scale, in_shift, in_act, w, stats, M, C, C / 4, 256 / (C / 4), cdiv(M, kExStatRows)};
     const int grid = mny_exdw_stat_parts(M, K, C);
     hipStream_t st = (hipStream_t)stream;
-#define MNY_EXS(K_) do { if (xf) hipLaunchKernelGGL((exdw_stats_kernel<K_, 1>), dim3(grid), dim3(256), 0, st, a); \
-                         else hipLaunchKernelGGL((exdw_stats_kernel<K_, 0>), dim3(grid), dim3(256), 0, st, a); } while (0)
+#define MNY_EXS(K_) do { if (ex_v1()) { if (xf) hipLaunchKernelGGL((exdw_stats_kernel<K_, 1>), dim3(grid), dim3(256), 0, st, a); \
+                                            else hipLaunchKernelGGL((exdw_stats_kernel<K_, 0>), dim3(grid), dim3(256), 0, st, a); } \
+                         else if (xf) hipLaunchKernelGGL((exdw_stats2_kernel<K_, 1>), dim3(grid), dim3(256), 0, st, a); \
+                         else hipLaunchKernelGGL((exdw_stats2_kernel<K_, 0>), dim3(grid), dim3(256), 0, st, a); } while (0)
     if (K == 16) MNY_EXS(16); else if (K == 24) MNY_EXS(24); else MNY_EXS(32);
 #undef MNY_EXS
     return check_launch("exdw_stats_kernel");
@@ -363,7 +716,7 @@ extern "C" int mny_exdw_stats(const float* x, const float* in_scale, const float
 
 extern "C" int mny_exdw_fwd_parts(int N, int H, int W, int K, int C, int stride) {
     if (!ex_shape_ok(N, H, W, K, C, stride)) return MNY_EINVAL;
-    return ex_grid(ex_geom(N, H, W, K, C), 2);
+    return ex_grid(ex_geom(N, H, W, K, C, ex_v1() ? kExTH : ex_fwd_th(K)), 2);
 }
 
 extern "C" int mny_exdw_fwd(const float* x, const float* in_scale, const float* in_shift, int in_act, const float* w_exp,
@@ -373,12 +726,13 @@ extern "C" int mny_exdw_fwd(const float* x, const float* in_scale, const float* 
     MNY_REQUIRE(ex_shape_ok(N, H, W, K, C, stride), "exdw_fwd: N=%d H=%d W=%d K=%d C=%d stride=%d not supported", N, H, W, K, C, stride);
     MNY_REQUIRE(!in_scale == !in_shift, "exdw_fwd: scale and shift come together");
     MNY_REQUIRE(in_act <= MNY_ACT_RELU, "exdw_fwd: unsupported input activation %d", in_act);
-    const ExGeom g = ex_geom(N, H, W, K, C);
+    const ExGeom g = ex_geom(N, H, W, K, C, ex_v1() ? kExTH : ex_fwd_th(K));
     const bool xf = in_scale != nullptr || in_act != MNY_ACT_NONE;
     ExFwdArgs a{x, in_scale, in_shift, in_act, w_exp, e_scale, e_shift, w_dw, z, z_stats, g};
     const int grid = ex_grid(g, 2);
     const size_t lds = ex_fwd_lds(g);
     hipStream_t st = (hipStream_t)stream;
+    if (!ex_v1()) return K == 16 ? ex_fwd2_launch<16>(a, xf, grid, st) : (K == 24 ? ex_fwd2_launch<24>(a, xf, grid, st) : ex_fwd2_launch<32>(a, xf, grid, st));
 #define MNY_EXF(K_) do { if (xf) hipLaunchKernelGGL((exdw_fwd_s2_kernel<K_, 1>), dim3(grid), dim3(256), lds, st, a); \
                          else hipLaunchKernelGGL((exdw_fwd_s2_kernel<K_, 0>), dim3(grid), dim3(256), lds, st, a); } while (0)
     if (K == 16) MNY_EXF(16); else if (K == 24) MNY_EXF(24); else MNY_EXF(32);
@@ -407,12 +761,10 @@ struct ExBwdArgs {
     ExGeom g;
 };
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 template <int K> struct ExB {
     static constexpr int KQ = K / 4, KP = K + 4, C = 6 * K, CP = C + 4, NQ = C / 4, PPB = 256 / NQ, NCOLS = 2 * PPB, NPX = 2 * NCOLS;
     static constexpr int NT = C / 16, KT = (K + 15) / 16;
-    static constexpr int XROWS = 2 * kExTH, XPIX = XROWS * NCOLS;
+    static constexpr int XROWS = 2 * kExTHB, XPIX = XROWS * NCOLS;
     static constexpr int DZPX = (NPX + 15) / 16 * 16;                     // rows of a dz buffer: MODE 2 reads whole 16-pixel tiles
     static constexpr int XS_FLOATS = (XPIX + DZPX - NPX + 2) * KP;        // + the pixels the last padded tile reads past the X tile
     static constexpr int DZ_FLOATS = DZPX * CP;
@@ -497,9 +849,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     for (int item = ex_lb(); item < g.items; item += gridDim.x) {
         const int ct = item % g.nCT; const int tt = item / g.nCT;
         const int hs = tt % g.nHS; const int n = tt / g.nHS;
-        const int i0 = hs * kExTH, j0 = ct * PPB;
-        const int i1 = min(i0 + kExTH, Ho);
-        __syncthreads();                                                 // the previous item's matrix phase is done with xs / dzs
+        const int i0 = hs * kExTHB, j0 = ct * PPB;
+        const int i1 = min(i0 + kExTHB, Ho);
+        ex_barrier();                                                 // the previous item's matrix phase is done with xs / dzs
         {
             const float* xn = p.x + (int64_t)n * g.H * g.W * K;
             float4 stg[NSB];
@@ -518,7 +870,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
                 if (stager && pix < B::XPIX) *reinterpret_cast<float4*>(&xs[pix * KP + 4 * kq_s]) = valid ? ex_xf<XF>(stg[i], xsc, xsh, slope, hi) : f4zero();
             }
         }
-        __syncthreads();
+        ex_barrier();
         const int j = j0 + ppa;
         const bool colv = worker && j < Wo;
         const float am = colv ? 1.f : 0.f;
@@ -553,7 +905,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
             dz_fetch(i0 + 1, rawn);
             dz_finish(i0, r0, d00, d01);
         }
-        unsigned short* mrow = p.mask + ((int64_t)item * kExTH) * 256 + tid;
+        unsigned short* mrow = p.mask + ((int64_t)item * kExTHB) * 256 + tid;
         unsigned bits_next = 0;
         if constexpr (MODE == 2) bits_next = mrow[0];
         for (int i = i0; i < i1; ++i) {
@@ -610,7 +962,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
 #pragma unroll
                 for (int px = 0; px < 4; ++px) *reinterpret_cast<float4*>(&dzb[((px >> 1) * NCOLS + 2 * pp + (px & 1)) * CP + c]) = f4u(o[px]);
             }
-            __syncthreads();
+            ex_barrier();
             if constexpr (MODE == 1) {
                 for (int gq = wave; gq < NPX / 4; gq += 4) {
                     const int px = 4 * gq + lg;
@@ -685,7 +1037,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
         float* dst = p.partial + (int64_t)blockIdx.x * bnw_stride(C, K);
         float* fold = dzs;
         for (int w = 0; w < 4; ++w) {                                    // the four waves' matrix accumulators, added in wave order
-            __syncthreads();
+            ex_barrier();
             if (wave == w) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
@@ -713,7 +1065,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
         red[tid * 2 + 1] = worker ? f4u(s2) : f4zero();
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) s3buf[(wave * 4 + lg) * (16 * KT) + 16 * kt + l16] = s3a[kt];
-        __syncthreads();
+        ex_barrier();
         for (int e = tid; e < C * K + K * K; e += 256) dst[e] = fold[e];
         if (pp == 0) {
             float4 a = f4zero(), b = f4zero();
@@ -728,9 +1080,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
         }
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            __syncthreads();
+            ex_barrier();
             red[tid] = worker ? f4u(wp[t]) : f4zero();
-            __syncthreads();
+            ex_barrier();
             if (pp == 0) {
                 float4 a = f4zero();
                 for (int i = 0; i < PPB; ++i) add4(a, red[i * NQ + q]);
@@ -739,6 +1091,387 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
             }
         }
     }
+}
+
+// ---- backward pass 1, second generation --------------------------------------------------------------------------------------
+// 512 threads.  Waves 0-3 (producers) own the matrix cores: per input row pair s they recompute the raw expand output Y of the pair
+// (K/4-deep chains per 16-pixel x 16-channel tile) into T[s % 3], and — one pair behind — contract the pair's dz (left in T by the
+// consumers) with X: P1 += dz^T X, Gram += X^T X.  Waves 4-7 (consumers, thread = 4 channels x one input-quad column as in the first
+// generation) turn Y into a / relu6' / yhat, rebuild dZ, gather G_a, accumulate dW_dw and the BN sums, and overwrite the Y quad with
+// dz IN PLACE.  Three row-pair buffers rotate (being produced | being consumed | being contracted): one barrier per row pair, and
+// the matrix pipe, the vector ALU and the global-memory latency of (G_z, Z) overlap inside one workgroup.  Work is dealt to the
+// producer waves statically (code specialised per wave: no predicates around the MFMAs, one basic block per row pair).
+template <int K> struct ExB1 {
+    static constexpr int KQ = K / 4, KP = K + 4, C = 6 * K, CP = C + 4, NQ = C / 4, PPB = 256 / NQ, NCOLS = 2 * PPB, NPX = 2 * NCOLS;
+    static constexpr int NT = C / 16, KT = (K + 15) / 16, NG = (NPX + 15) / 16, U = NT * NG, SL = 3;
+    static constexpr int XPIX = 2 * kExTHB * NCOLS;
+    static constexpr int XS_FLOATS = (XPIX + 16) * KP;                    // + the pixels a padded last group reads past the tile
+    static constexpr int T_FLOATS = NPX * CP;
+    static constexpr int CST_F4 = 18 * NQ;
+    static constexpr size_t LDS = (size_t)(XS_FLOATS + 3 * T_FLOATS) * 4 + (size_t)CST_F4 * 16;
+    static constexpr int ub(int w) { return U * w / 4; }
+    static constexpr int ue(int w) { return U * (w + 1) / 4; }
+    static constexpr int span(int w) { return (ue(w) - 1) / NG - ub(w) / NG + 1; }
+    static_assert(span(0) <= SL && span(1) <= SL && span(2) <= SL && span(3) <= SL, "a wave's run of units must fit its channel-tile slots");
+    static_assert(ue(0) >= NG, "wave 0 must own every pixel group of channel tile 0 (it also accumulates Gram and colsum)");
+    static_assert(3 * T_FLOATS >= C * K + K * K, "the end-of-kernel fold of P1 / Gram lives in the row-pair buffers");
+    static_assert(XS_FLOATS >= 256 * 8 + 64 * KT, "the end-of-kernel folds of the per-thread sums live in the X tile");
+};
+
+template <int K, int XF>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 8))) void exdw_bwd1v2_s2_kernel(ExBwdArgs p) {
+    using B = ExB1<K>;
+    constexpr int KQ = B::KQ, KP = B::KP, C = B::C, CP = B::CP, NQ = B::NQ, PPB = B::PPB, NCOLS = B::NCOLS, NPX = B::NPX, KT = B::KT,
+                  NG = B::NG, SL = B::SL;
+    constexpr int ST = 512 / KQ * KQ, PS = ST / KQ, NSB = (B::XPIX * KQ + ST - 1) / ST;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* xs = lds;                                                     // [2 THB][NCOLS][KP] (+ slack)
+    float* T = lds + B::XS_FLOATS;                                       // [3][NPX][CP]
+    float4* cst = reinterpret_cast<float4*>(T + 3 * B::T_FLOATS);        // [18][NQ]: 9 taps, z scale / shift, ca, cb, cc, e scale / shift / mean / invstd
+    const ExGeom& g = p.g;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l16 = lane & 15, lg = lane >> 4;
+    for (int i = tid; i < B::XS_FLOATS + 3 * B::T_FLOATS; i += 512) lds[i] = 0.f;
+    if (tid < NQ) {
+        const int c = 4 * tid;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) cst[t * NQ + tid] = make_float4(p.w_dw[(c + 0) * 9 + t], p.w_dw[(c + 1) * 9 + t], p.w_dw[(c + 2) * 9 + t], p.w_dw[(c + 3) * 9 + t]);
+        cst[9 * NQ + tid] = ld4(p.z_scale + c);   cst[10 * NQ + tid] = ld4(p.z_shift + c);
+        cst[11 * NQ + tid] = ld4(p.z_coef + c);   cst[12 * NQ + tid] = ld4(p.z_coef + C + c);   cst[13 * NQ + tid] = ld4(p.z_coef + 2 * C + c);
+        cst[14 * NQ + tid] = ld4(p.e_scale + c);  cst[15 * NQ + tid] = ld4(p.e_shift + c);
+        cst[16 * NQ + tid] = ld4(p.e_mean + c);   cst[17 * NQ + tid] = ld4(p.e_invstd + c);
+    }
+    const int kq_s = tid % KQ, pix_s = tid / KQ;
+    const bool stager = tid < ST;
+    float4 xsc = f4one(), xsh = f4zero();
+    if (XF && p.in_scale) { xsc = ld4(p.in_scale + 4 * kq_s); xsh = ld4(p.in_shift + 4 * kq_s); }
+    const float slope = act_slope(p.in_act), hi = act_hi(p.in_act);
+    const int Ho = g.Ho, Wo = g.Wo;
+    auto decode = [&](int item, int& n, int& i0, int& j0) {
+        const int ct = item % g.nCT; const int tt = item / g.nCT;
+        const int hs = tt % g.nHS; n = tt / g.nHS;
+        i0 = hs * kExTHB; j0 = ct * PPB;
+    };
+    auto stage = [&](int n, int i0, int j0) {                            // X tile: rows 2 i0 .., columns 2 j0 ..; zeros outside the image
+        const float* xn = p.x + (int64_t)n * g.H * g.W * K;
+        float4 stg[NSB];
+#pragma unroll
+        for (int i = 0; i < NSB; ++i) {
+            const int pix = pix_s + i * PS;
+            const int rr = pix / NCOLS, cc = pix - rr * NCOLS;
+            const int gr = min(2 * i0 + rr, g.H - 1), gc = min(2 * j0 + cc, g.W - 1);
+            stg[i] = ld4(xn + ((int64_t)gr * g.W + gc) * K + 4 * kq_s);
+        }
+#pragma unroll
+        for (int i = 0; i < NSB; ++i) {
+            const int pix = pix_s + i * PS;
+            const int rr = pix / NCOLS, cc = pix - rr * NCOLS;
+            const bool valid = 2 * i0 + rr < g.H && 2 * j0 + cc < g.W;
+            if (stager && pix < B::XPIX) *reinterpret_cast<float4*>(&xs[pix * KP + 4 * kq_s]) = valid ? ex_xf<XF>(stg[i], xsc, xsh, slope, hi) : f4zero();
+        }
+    };
+    float* dst = p.partial + (int64_t)blockIdx.x * bnw_stride(C, K);
+    float* fold = T;
+    float4* red = reinterpret_cast<float4*>(xs);
+    float* s3buf = xs + 256 * 8;
+
+    if (wave < 4) {
+        // ================================================= producers =================================================
+        auto run = [&](auto wtag) {
+            constexpr int W = decltype(wtag)::value;
+            constexpr int UB = B::ub(W), UE = B::ue(W), T0 = UB / NG;
+            float wb[SL][KQ];
+            f32x4 accP[SL][KT], accG[KT][KT];
+            float s3a[KT];
+#pragma unroll
+            for (int j = 0; j < SL; ++j) {
+                const int ch = min(16 * (T0 + j) + l16, C - 1);
+#pragma unroll
+                for (int sI = 0; sI < KQ; ++sI) wb[j][sI] = p.w[(int64_t)ch * K + 4 * sI + lg];
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) accP[j][kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int a = 0; a < KT; ++a) {
+                s3a[a] = 0.f;
+#pragma unroll
+                for (int b = 0; b < KT; ++b) accG[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            auto g0 = [](int j) constexpr { const int t = T0 + j; return (UB > t * NG ? UB : t * NG) - t * NG; };
+            auto g1 = [](int j) constexpr { const int t = T0 + j; return (UE < (t + 1) * NG ? UE : (t + 1) * NG) - t * NG; };
+            // raw expand output of row pair s -> T[s % 3]
+            auto make_y = [&](int sp) {
+                const float* xp = xs + (2 * sp * NCOLS + l16) * KP + lg;
+                float* tp = T + (sp % 3) * B::T_FLOATS + (4 * lg) * CP + l16;
+                float a[NG][KQ];
+#pragma unroll
+                for (int gi = 0; gi < NG; ++gi)
+#pragma unroll
+                    for (int sI = 0; sI < KQ; ++sI) a[gi][sI] = xp[16 * gi * KP + 4 * sI];
+                f32x4 acc[SL][NG];
+                static_for<0, SL>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    static_for<0, NG>([&](auto gc) {
+                        constexpr int gi = decltype(gc)::value;
+                        if constexpr (gi >= g0(j) && gi < g1(j)) acc[j][gi] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    });
+                });
+#pragma unroll
+                for (int sI = 0; sI < KQ; ++sI)
+                    static_for<0, SL>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        static_for<0, NG>([&](auto gc) {
+                            constexpr int gi = decltype(gc)::value;
+                            if constexpr (gi >= g0(j) && gi < g1(j)) acc[j][gi] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[gi][sI], wb[j][sI], acc[j][gi], 0, 0, 0);
+                        });
+                    });
+                static_for<0, SL>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    static_for<0, NG>([&](auto gc) {
+                        constexpr int gi = decltype(gc)::value;
+                        if constexpr (gi >= g0(j) && gi < g1(j)) {
+#pragma unroll
+                            for (int v = 0; v < 4; ++v)
+                                if (16 * gi + 12 + 3 < NPX || 16 * gi + 4 * lg + v < NPX) tp[(16 * gi + v) * CP + 16 * (T0 + j)] = acc[j][gi][v];
+                        }
+                    });
+                });
+            };
+            // P1 += dz^T X over row pair s (dz in T[s % 3]); wave 0 also Gram += X^T X and the column sums of X
+            auto contract = [&](int sp) {
+                const float* dzb = T + (sp % 3) * B::T_FLOATS + lg * CP + l16;
+                const float* xb = xs + (2 * sp * NCOLS + lg) * KP + l16;
+                static_for<0, NG>([&](auto gc) {
+                    constexpr int gi = decltype(gc)::value;
+                    static_for<0, 4>([&](auto pc) {
+                        constexpr int pg = decltype(pc)::value;
+                        constexpr int px0 = 16 * gi + 4 * pg;
+                        constexpr bool mine = (gi >= g0(0) && gi < g1(0)) || (SL > 1 && gi >= g0(1) && gi < g1(1)) || (SL > 2 && gi >= g0(2) && gi < g1(2));
+                        if constexpr (px0 < NPX && mine) {
+                            float b[KT];
+#pragma unroll
+                            for (int kt = 0; kt < KT; ++kt) b[kt] = xb[px0 * KP + 16 * kt];
+                            static_for<0, SL>([&](auto jc) {
+                                constexpr int j = decltype(jc)::value;
+                                if constexpr (gi >= g0(j) && gi < g1(j)) {
+                                    const float a = dzb[px0 * CP + 16 * (T0 + j)];
+#pragma unroll
+                                    for (int kt = 0; kt < KT; ++kt) accP[j][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[kt], accP[j][kt], 0, 0, 0);
+                                }
+                            });
+                            if constexpr (W == 0) {
+#pragma unroll
+                                for (int ka = 0; ka < KT; ++ka) {
+                                    s3a[ka] += b[ka];
+#pragma unroll
+                                    for (int kb = 0; kb < KT; ++kb) accG[ka][kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[ka], b[kb], accG[ka][kb], 0, 0, 0);
+                                }
+                            }
+                        }
+                    });
+                });
+            };
+            for (int item = ex_lb(); item < g.items; item += gridDim.x) {
+                int n, i0, j0;
+                decode(item, n, i0, j0);
+                const int nq = min(i0 + kExTHB, Ho) - i0;
+                ex_barrier();
+                stage(n, i0, j0);
+                ex_barrier();
+                make_y(0);
+                ex_barrier();
+                for (int sp = 0; sp < nq; ++sp) {
+                    if (sp + 1 < nq) make_y(sp + 1);
+                    if (sp >= 1) contract(sp - 1);
+                    ex_barrier();
+                }
+                contract(nq - 1);
+            }
+            // tail (same barrier sequence as the consumers'): fold the matrix accumulators in wave order
+            ex_barrier();
+            for (int i = tid; i < C * K + K * K; i += 256) fold[i] = 0.f;
+            if constexpr (W == 0) {
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) s3buf[lg * (16 * KT) + 16 * kt + l16] = s3a[kt];
+            }
+            ex_barrier();
+            for (int w = 0; w < 4; ++w) {
+                if (w == W) {
+                    static_for<0, SL>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        if constexpr (g0(j) < g1(j)) {
+#pragma unroll
+                            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                                for (int v = 0; v < 4; ++v) {
+                                    const int nn = 16 * (T0 + j) + 4 * lg + v, k = 16 * kt + l16;
+                                    if (k < K) fold[nn * K + k] += accP[j][kt][v];
+                                }
+                        }
+                    });
+                    if constexpr (W == 0) {
+#pragma unroll
+                        for (int ka = 0; ka < KT; ++ka)
+#pragma unroll
+                            for (int kb = 0; kb < KT; ++kb)
+#pragma unroll
+                                for (int v = 0; v < 4; ++v) {
+                                    const int r = 16 * ka + 4 * lg + v, k = 16 * kb + l16;
+                                    if (r < K && k < K) fold[C * K + r * K + k] = accG[ka][kb][v];
+                                }
+                    }
+                }
+                ex_barrier();
+            }
+            for (int t = 0; t < 9; ++t) { ex_barrier(); ex_barrier(); }
+        };
+        if (wave == 0) run(std::integral_constant<int, 0>{});
+        else if (wave == 1) run(std::integral_constant<int, 1>{});
+        else if (wave == 2) run(std::integral_constant<int, 2>{});
+        else run(std::integral_constant<int, 3>{});
+        return;
+    }
+    // ===================================================== consumers =====================================================
+    const int st = tid - 256;
+    const int q = st % NQ, pp = st / NQ;
+    const bool worker = pp < PPB;
+    const int ppa = worker ? pp : 0;
+    const int c = 4 * q;
+    F4P wp[9], s1 = f4p0(), s2 = f4p0();
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wp[t] = f4p0();
+    for (int item = ex_lb(); item < g.items; item += gridDim.x) {
+        int n, i0, j0;
+        decode(item, n, i0, j0);
+        const int nq = min(i0 + kExTHB, Ho) - i0;
+        ex_barrier();
+        stage(n, i0, j0);
+        ex_barrier();
+        const int j = j0 + ppa;
+        const bool colv = worker && j < Wo;
+        const float am = colv ? 1.f : 0.f;
+        const float jm1 = (j + 1 < Wo) ? am : 0.f;
+        const int jc0 = min(j, Wo - 1), jc1 = min(j + 1, Wo - 1);
+        int lo = q;
+        asm volatile("" : "+v"(lo));
+        const float4* my = cst + lo;
+        auto dz_fetch = [&](int ho, float4 (&r)[4]) {
+            const int64_t ro = ((int64_t)n * Ho + min(ho, Ho - 1)) * Wo;
+            r[0] = ld4(p.gz + (ro + jc0) * C + c); r[1] = ld4(p.z + (ro + jc0) * C + c);
+            r[2] = ld4(p.gz + (ro + jc1) * C + c); r[3] = ld4(p.z + (ro + jc1) * C + c);
+        };
+        auto dz2 = [&](v2f gv, v2f zv, v2f s, v2f h, v2f a, v2f b, v2f cterm) {
+            const v2f t = __builtin_elementwise_fma(zv, s, h);
+            const v2f d = gv * v2f{(t.x > 0.f ? 1.f : 0.f) * (t.x < 6.f ? 1.f : 0.f), (t.y > 0.f ? 1.f : 0.f) * (t.y < 6.f ? 1.f : 0.f)};
+            return __builtin_elementwise_fma(a, d, __builtin_elementwise_fma(b, zv, cterm));
+        };
+        auto dz_finish = [&](int ho, const float4 (&r)[4], F4P& d0, F4P& d1) {
+            const float rm = (ho < Ho) ? 1.f : 0.f;
+            const F4P zs = f4p(my[9 * NQ]), zh = f4p(my[10 * NQ]), ca = f4p(my[11 * NQ]), cb = f4p(my[12 * NQ]), cc = f4p(my[13 * NQ]);
+            const F4P G0 = f4p(r[0]), Z0 = f4p(r[1]), G1 = f4p(r[2]), Z1 = f4p(r[3]);
+            const v2f m0 = v2f{rm * am, rm * am}, m1 = v2f{rm * jm1, rm * jm1};
+            d0.lo = dz2(G0.lo, Z0.lo, zs.lo, zh.lo, ca.lo, cb.lo, cc.lo) * m0; d0.hi = dz2(G0.hi, Z0.hi, zs.hi, zh.hi, ca.hi, cb.hi, cc.hi) * m0;
+            d1.lo = dz2(G1.lo, Z1.lo, zs.lo, zh.lo, ca.lo, cb.lo, cc.lo) * m1; d1.hi = dz2(G1.hi, Z1.hi, zs.hi, zh.hi, ca.hi, cb.hi, cc.hi) * m1;
+        };
+        float4 rawn[4];
+        F4P d00, d01;
+        {
+            float4 r0[4];
+            dz_fetch(i0, r0);
+            dz_fetch(i0 + 1, rawn);
+            dz_finish(i0, r0, d00, d01);
+        }
+        unsigned short* mrow = p.mask + ((int64_t)item * kExTHB) * 256 + st;
+        ex_barrier();                                                    // row pair 0's Y is in T[0]
+        for (int sp = 0; sp < nq; ++sp) {
+            const int i = i0 + sp;
+            float* tb = T + (sp % 3) * B::T_FLOATS + (2 * ppa) * CP + c;
+            F4P d10, d11;
+            dz_finish(i + 1, rawn, d10, d11);
+            if (sp + 1 < nq) dz_fetch(i + 2, rawn);
+            // one pixel of the quad at a time (register budget: 128 with four waves per SIMD): gather G_a with the statically known taps,
+            // read the pixel's Y quad, mask, sums, the depthwise weight gradient's terms of this pixel, dz back in place
+            unsigned bits = 0;
+#define WG(t) f4p(my[(t) * NQ])
+            static_for<0, 4>([&](auto pc) {
+                constexpr int px = decltype(pc)::value;
+                F4P o = f4p0();
+                if constexpr (px == 0) { pfma(o, d00, WG(4)); }
+                if constexpr (px == 1) { pfma(o, d00, WG(5)); pfma(o, d01, WG(3)); }
+                if constexpr (px == 2) { pfma(o, d00, WG(7)); pfma(o, d10, WG(1)); }
+                if constexpr (px == 3) { pfma(o, d00, WG(8)); pfma(o, d01, WG(6)); pfma(o, d10, WG(2)); pfma(o, d11, WG(0)); }
+                float* yp = tb + ((px >> 1) * NCOLS + (px & 1)) * CP;
+                const F4P y = f4p(ld4(yp));
+                const F4P esc = f4p(my[14 * NQ]), esh = f4p(my[15 * NQ]);
+                const v2f z0 = __builtin_elementwise_fma(y.lo, esc.lo, esh.lo), z1 = __builtin_elementwise_fma(y.hi, esc.hi, esh.hi);
+                F4P a;
+                a.lo = v2f{__builtin_amdgcn_fmed3f(z0.x, 0.f, 6.f), __builtin_amdgcn_fmed3f(z0.y, 0.f, 6.f)};
+                a.hi = v2f{__builtin_amdgcn_fmed3f(z1.x, 0.f, 6.f), __builtin_amdgcn_fmed3f(z1.y, 0.f, 6.f)};
+                const bool m0 = z0.x > 0.f && z0.x < 6.f, m1 = z0.y > 0.f && z0.y < 6.f, m2 = z1.x > 0.f && z1.x < 6.f, m3 = z1.y > 0.f && z1.y < 6.f;
+                bits |= ((m0 ? 1u : 0u) | (m1 ? 2u : 0u) | (m2 ? 4u : 0u) | (m3 ? 8u : 0u)) << (4 * px);
+                o.lo = v2f{m0 ? o.lo.x : 0.f, m1 ? o.lo.y : 0.f};
+                o.hi = v2f{m2 ? o.hi.x : 0.f, m3 ? o.hi.y : 0.f};
+                s1.lo += o.lo; s1.hi += o.hi;
+                const F4P emu = f4p(my[16 * NQ]), eis = f4p(my[17 * NQ]);
+                const v2f h0 = (y.lo - emu.lo) * eis.lo, h1 = (y.hi - emu.hi) * eis.hi;
+                s2.lo = __builtin_elementwise_fma(o.lo, h0, s2.lo); s2.hi = __builtin_elementwise_fma(o.hi, h1, s2.hi);
+                if constexpr (px == 0) { pfma(wp[4], a, d00); }
+                if constexpr (px == 1) { pfma(wp[5], a, d00); pfma(wp[3], a, d01); }
+                if constexpr (px == 2) { pfma(wp[7], a, d00); pfma(wp[1], a, d10); }
+                if constexpr (px == 3) { pfma(wp[8], a, d00); pfma(wp[6], a, d01); pfma(wp[2], a, d10); pfma(wp[0], a, d11); }
+                if (worker) *reinterpret_cast<float4*>(yp) = f4u(o);
+            });
+#undef WG
+            mrow[sp * 256] = (unsigned short)bits;
+            ex_barrier();
+            d00 = d10; d01 = d11;
+        }
+    }
+    // tail: the producers fold their accumulators (6 barriers), then this half writes the block's partial rows
+    ex_barrier();
+    red[st * 2 + 0] = worker ? f4u(s1) : f4zero();
+    red[st * 2 + 1] = worker ? f4u(s2) : f4zero();
+    ex_barrier();
+    for (int w = 0; w < 4; ++w) ex_barrier();
+    for (int e = st; e < C * K + K * K; e += 256) dst[e] = fold[e];
+    if (pp == 0) {
+        float4 a = f4zero(), b = f4zero();
+        for (int i = 0; i < PPB; ++i) { add4(a, red[(i * NQ + q) * 2]); add4(b, red[(i * NQ + q) * 2 + 1]); }
+        st4(dst + C * K + K * K + c, a);
+        st4(dst + C * K + K * K + C + c, b);
+    }
+    if (st < K) {
+        float a = 0.f;
+        for (int i = 0; i < 4; ++i) a += s3buf[i * (16 * KT) + st];
+        dst[C * K + K * K + 2 * C + st] = a;
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        ex_barrier();
+        red[st] = worker ? f4u(wp[t]) : f4zero();
+        ex_barrier();
+        if (pp == 0) {
+            float4 a = f4zero();
+            for (int i = 0; i < PPB; ++i) add4(a, red[i * NQ + q]);
+            float* dd = p.dw_parts + (int64_t)blockIdx.x * C * 9;
+            dd[(c + 0) * 9 + t] = a.x; dd[(c + 1) * 9 + t] = a.y; dd[(c + 2) * 9 + t] = a.z; dd[(c + 3) * 9 + t] = a.w;
+        }
+    }
+}
+
+template <int K>
+static int ex_bwd1v2_launch(const ExBwdArgs& a, bool xf, int grid, hipStream_t st) {
+    const size_t lds = ExB1<K>::LDS;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)exdw_bwd1v2_s2_kernel<K, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute((const void*)exdw_bwd1v2_s2_kernel<K, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+            set_error("exdw_bwd: hipFuncSetAttribute failed"); return MNY_EHIP;
+        }
+        attr = true;
+    }
+    if (xf) hipLaunchKernelGGL((exdw_bwd1v2_s2_kernel<K, 1>), dim3(grid), dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((exdw_bwd1v2_s2_kernel<K, 0>), dim3(grid), dim3(512), lds, st, a);
+    return check_launch("exdw_bwd1v2_s2_kernel");
 }
 
 struct ExWs { size_t partials, red, B1, Q, bias, mask, total; };
@@ -751,7 +1484,7 @@ static ExWs ex_ws(const ExGeom& g, int grid) {
     w.Q = w.B1 + (size_t)g.C * g.K;
     w.bias = w.Q + (size_t)g.K * g.K;
     w.mask = (w.bias + 64 + 3) / 4 * 4;
-    w.total = w.mask + (size_t)g.items * kExTH * 128;          // 256 x 16-bit mask words per quad row = 128 floats
+    w.total = w.mask + (size_t)g.items * kExTHB * 128;          // 256 x 16-bit mask words per quad row = 128 floats
     return w;
 }
 
@@ -778,15 +1511,19 @@ static int ex_bwd_launch(const ExBwdArgs& a, bool xf, int grid, hipStream_t st, 
 
 }  // namespace mny
 
+// workgroups (= partial rows) of the first backward pass: second generation one 512-thread workgroup per CU (its stencil half needs
+// ~210 VGPRs: accumulators of the depthwise weight gradient, the BN sums, two dZ rows, the prefetched (G_z, Z) row), first generation two
+static int ex_bwd1_grid(const ExGeom& g) { return ex_grid(g, ex_v1() ? 2 : 1); }
+
 extern "C" int mny_exdw_bwd_parts(int N, int H, int W, int K, int C, int stride) {
     if (!ex_shape_ok(N, H, W, K, C, stride)) return MNY_EINVAL;
-    return ex_grid(ex_geom(N, H, W, K, C), 2);
+    return ex_bwd1_grid(ex_geom(N, H, W, K, C, kExTHB));
 }
 
 extern "C" size_t mny_exdw_bwd_ws_floats(int N, int H, int W, int K, int C, int stride) {
     if (!ex_shape_ok(N, H, W, K, C, stride)) return 0;
-    const ExGeom g = ex_geom(N, H, W, K, C);
-    return ex_ws(g, ex_grid(g, 2)).total;
+    const ExGeom g = ex_geom(N, H, W, K, C, kExTHB);
+    return ex_ws(g, ex_bwd1_grid(g)).total;
 }
 
 extern "C" int mny_exdw_bwd(const float* gz, const float* z, const float* z_scale, const float* z_shift, int z_act, const float* z_coef,
@@ -800,18 +1537,24 @@ extern "C" int mny_exdw_bwd(const float* gz, const float* z, const float* z_scal
     MNY_REQUIRE(z_act == MNY_ACT_RELU6, "exdw_bwd: the depthwise unit's activation must be ReLU6 (got %d)", z_act);
     MNY_REQUIRE(!in_scale == !in_shift, "exdw_bwd: scale and shift come together");
     MNY_REQUIRE(in_act <= MNY_ACT_RELU, "exdw_bwd: unsupported input activation %d", in_act);
-    const ExGeom g = ex_geom(N, H, W, K, C);
-    const int grid = ex_grid(g, 2);
+    const ExGeom g = ex_geom(N, H, W, K, C, kExTHB);
+    const int grid = ex_bwd1_grid(g), grid2 = ex_grid(g, 2);
     const ExWs o = ex_ws(g, grid);
     const bool xf = in_scale != nullptr || in_act != MNY_ACT_NONE;
     hipStream_t st = (hipStream_t)stream;
     ExBwdArgs a{gz, z, z_scale, z_shift, z_coef, x, in_scale, in_shift, in_act, w_exp, e_scale, e_shift, e_mean, e_invstd, w_dw,
                 ws + o.partials, dw_ws, reinterpret_cast<unsigned short*>(ws + o.mask), ws + o.B1, ws + o.Q, ws + o.bias, addend, dx, g};
-    int rc = K == 16 ? ex_bwd_launch<16>(a, xf, grid, st, 1) : (K == 24 ? ex_bwd_launch<24>(a, xf, grid, st, 1) : ex_bwd_launch<32>(a, xf, grid, st, 1));
+    int rc = 0;
+    static const int only = getenv("MNY_EXDW_ONLY") ? atoi(getenv("MNY_EXDW_ONLY")) : 0;       // timing aid: 1 = first pass only, 2 = second pass only (stale operands)
+    if (only == 2) goto pass2;
+    if (ex_v1()) rc = K == 16 ? ex_bwd_launch<16>(a, xf, grid, st, 1) : (K == 24 ? ex_bwd_launch<24>(a, xf, grid, st, 1) : ex_bwd_launch<32>(a, xf, grid, st, 1));
+    else rc = K == 16 ? ex_bwd1v2_launch<16>(a, xf, grid, st) : (K == 24 ? ex_bwd1v2_launch<24>(a, xf, grid, st) : ex_bwd1v2_launch<32>(a, xf, grid, st));
     if (rc) return rc;
     rc = pw_bnbwd_finalize_launch(ws + o.partials, grid, ws + o.red, w_exp, e_gamma, e_mean, e_invstd, (int64_t)N * H * W, C, K, dw_exp, dgamma_e, dbeta_e,
                                   ws + o.B1, ws + o.Q, ws + o.bias, st);
     if (rc) return rc;
     if (dw_dw) { rc = launch_reduce_parts(dw_ws, grid, C * 9, dw_dw, st); if (rc) return rc; }
-    return K == 16 ? ex_bwd_launch<16>(a, xf, grid, st, 2) : (K == 24 ? ex_bwd_launch<24>(a, xf, grid, st, 2) : ex_bwd_launch<32>(a, xf, grid, st, 2));
+    if (only == 1) return MNY_OK;
+pass2:
+    return K == 16 ? ex_bwd_launch<16>(a, xf, grid2, st, 2) : (K == 24 ? ex_bwd_launch<24>(a, xf, grid2, st, 2) : ex_bwd_launch<32>(a, xf, grid2, st, 2));
 }

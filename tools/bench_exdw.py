@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Same-box timing of the expand + depthwise unit (csrc/exdw.hip) against the materialised kernels it replaces, at the three
-stride-2 shapes of the bs-256 / 352x352 plan.  usage: python tools/bench_exdw.py [fwd|bwd|all] [bs]"""
+stride-2 shapes of the bs-256 / 352x352 plan.  usage: python tools/bench_exdw.py [fwd|bwd|all] [bs] [K]"""
 import ctypes
 import os
 import sys
@@ -14,7 +14,7 @@ P = ctypes.c_void_p
 ptr = lambda t: P(t.data_ptr()) if t is not None else None  # noqa: E731
 
 
-def timeit(fn, reps=10):
+def timeit(fn, reps=int(os.environ.get('EXDW_REPS', '10'))):
     for _ in range(2):
         fn()
     torch.cuda.synchronize()
@@ -32,7 +32,10 @@ def main():
     bs = int(sys.argv[2]) if len(sys.argv) > 2 else 256
     dev = torch.device("cuda:0")
     st = P(torch.cuda.current_stream().cuda_stream)
+    only_k = int(sys.argv[3]) if len(sys.argv) > 3 else 0
     for K, H in ((16, 176), (24, 88), (32, 44)):
+        if only_k and K != only_k:
+            continue
         N, W, C = bs, H, 6 * K
         M = N * H * W
         Ho, Wo = H // 2, W // 2
