@@ -302,3 +302,71 @@ def test_nms_reference_shaped_batch_256_images_x_1815_candidates(ops):
         assert oc[s] == len(ref_idx), s
         assert np.array_equal(out_idx[off[s]:off[s] + oc[s]] - off[s], ref_idx.numpy()), s
         assert np.array_equal(out_rows[prefix[s]:prefix[s + 1]], ref_rows.numpy()), s
+
+
+def _gpu_nms_single(ops, rows, C, thr):
+    """One image's rows through mny_nms_per_class -> kept original indices (class-major, as utils/box.py:20-29 emits them)."""
+    n = rows.shape[0]
+    beg, cnt = torch.tensor([0], dtype=torch.int32).cuda(), torch.tensor([n], dtype=torch.int32).cuda()
+    out_idx, out_counts, out_rows, prefix, status = ops.nms_per_class(rows.cuda(), beg, cnt, C, thr)
+    assert int(status.cpu()) == 0
+    return out_idx[:int(out_counts.cpu()[0])].cpu().tolist()
+
+
+def _rows(boxes, scores, cls=0):
+    b = torch.tensor(boxes, dtype=torch.float32)
+    s = torch.tensor(scores, dtype=torch.float32)
+    return torch.cat((b, torch.ones(len(s), 1), s[:, None], torch.full((len(s), 1), float(cls))), 1)
+
+
+def test_nms_threshold_edges_known_answers_on_the_gpu(ops):
+    """the strict `>` against a DOUBLE threshold of a FLOAT IoU (torchvision's CPU kernel, utils/box.py:27-28) through
+    mny_nms_per_class itself, not only through the oracle: IoU exactly 0.5 against thr 0.5 / 0.4999999 / 0.5000000001 (the cases of
+    tests/test_oracle_nms.py:22), and each answer equal to the CPU restatement's."""
+    rows = _rows([[0, 0, 2, 1], [1, 0, 3, 1], [0, 0, 1, 1.0]], [0.9, 0.8, 0.7])      # iou(0,1) = 1/3, iou(0,2) = 0.5 exactly
+    for thr, want in ((0.5, [0, 1, 2]), (0.4999999, [0, 1]), (0.5000000001, [0, 1, 2])):
+        assert _gpu_nms_single(ops, rows, 1, thr) == want, thr
+        assert nms_ref.nms_rows(rows, 1, thr)[1].tolist() == want
+    # duplicates and exact ties: stable descending order keeps the earlier index (torchvision sorts stably)
+    rows = _rows([[0, 0, 10, 10], [1, 1, 11, 11], [20, 20, 30, 30], [0, 0, 10, 10.0]], [0.9, 0.8, 0.7, 0.9])
+    assert _gpu_nms_single(ops, rows, 1, 0.45) == [0, 2] == nms_ref.nms_rows(rows, 1, 0.45)[1].tolist()
+    assert _gpu_nms_single(ops, rows, 1, 0.7) == [0, 1, 2] == nms_ref.nms_rows(rows, 1, 0.7)[1].tolist()
+
+
+def test_nms_float_iou_rounding_across_the_045_threshold(ops):
+    """A pair whose IoU, computed in float as torchvision computes it (inter / (a + b - inter)), lands within a few ulps of float32(0.45):
+    whether it is suppressed depends on the float rounding of `ovr` against the DOUBLE 0.45.  Sweep the second box's width through
+    that neighbourhood one float at a time: every case must agree with the CPU restatement, and both outcomes must occur."""
+    import struct
+    outcomes = set()
+    w0 = np.float32(0.45 * 2 / 1.45)                    # second box [0, 0, w, 1] inside the unit box: IoU = w, need w around 0.45... use widths near 0.45
+    for k in range(-6, 7):
+        w = np.float32(0.45)
+        bits = struct.unpack("I", struct.pack("f", float(w)))[0] + k
+        w = np.float32(struct.unpack("f", struct.pack("I", bits))[0])
+        rows = _rows([[0, 0, 1, 1], [0, 0, float(w), 1.0]], [0.9, 0.8])              # IoU = w / 1 (contained box): float ovr == w exactly
+        got = _gpu_nms_single(ops, rows, 1, 0.45)
+        assert got == nms_ref.nms_rows(rows, 1, 0.45)[1].tolist(), (k, float(w))
+        assert got == ([0] if float(w) > 0.45 else [0, 1]), (k, float(w))             # float -> double promotion, strict >
+        outcomes.add(len(got))
+    assert outcomes == {1, 2}
+    del w0
+
+
+def test_nms_score_ties_across_the_64_candidate_tile_boundary(ops):
+    """130 boxes of ONE score in one class, laid out so that suppression depends on stable order across the 64-candidate tiles of the
+    greedy loop: box 2m+1 duplicates box 2m (IoU 1) -> exactly the even indices survive, in index order; then the same with the pairs
+    straddling tile boundaries (offset by one)."""
+    n = 130
+    for shift in (0, 1):
+        boxes = []
+        for i in range(n):
+            m = (i + shift) // 2
+            boxes.append([3.0 * m, 0.0, 3.0 * m + 2.0, 2.0])
+        rows = _rows(boxes, [0.5] * n)
+        want = nms_ref.nms_rows(rows, 1, 0.45)[1].tolist()
+        assert _gpu_nms_single(ops, rows, 1, 0.45) == want
+        first = {}
+        for i in range(n):
+            first.setdefault((i + shift) // 2, i)
+        assert want == sorted(first.values())
