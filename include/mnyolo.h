@@ -497,6 +497,14 @@ int mny_cvt_batch_f32_bf16(const mny_cvt_job* jobs, const int32_t* block_job, in
 int mny_cvt_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
 int mny_cvt_bf16_f32(const void* src, float* dst, int64_t n, void* stream);
 
+/* ---- frozen BatchNorm: a module in eval() whose losses are differentiated (models/mbv2_yolo.py:157 returns losses with a graph under
+ * model.eval(); nn.BatchNorm2d then normalises with the running statistics, which are constants of the step).  mny_bn_eval_stats fills
+ * the mean / invstd the backward kernels read (mean = running_mean, invstd = 1 / sqrt(running_var + eps)); mny_bn_bwd_finalize_frozen
+ * has mny_bn_bwd_finalize's argument list and yields dgamma = sum dz * yhat, dbeta = sum dz, coef = (gamma * invstd, 0, 0). */
+int mny_bn_eval_stats(const float* running_mean, const float* running_var, float eps, float* mean_out, float* invstd_out, int C,
+                      void* stream);
+int mny_bn_bwd_finalize_frozen(const float* red, int parts, int64_t count, const float* gamma, const float* mean, const float* invstd,
+                               float* dgamma, float* dbeta, float* coef, int C, void* stream);
 /* ---- expand + depthwise as one unit (csrc/exdw.hip): the front half of an inverted-residual block whose depthwise conv has
  * stride 2 — 1x1 conv K -> C = 6K (K in {16, 24, 32}) + BN + ReLU6 + depthwise 3x3 stride 2 (models/mobilenetv2.py:73-85) — with the
  * 6x-wide expand output and its gradient NEVER materialised: every pass recomputes it from the thin input x[N,H,W,K] (a view:

@@ -82,6 +82,8 @@ _SIGS = {
     "mny_bn_bwd_reduce": (c_int, [P, P, P, P, c_int, P, P, P, c_int64, c_int, P]),
     "mny_bn_bwd_parts": (c_int, [c_int64, c_int]),
     "mny_bn_bwd_finalize": (c_int, [P, c_int, c_int64, P, P, P, P, P, P, c_int, P]),
+    "mny_bn_eval_stats": (c_int, [P, P, c_float, P, P, c_int, P]),
+    "mny_bn_bwd_finalize_frozen": (c_int, [P, c_int, c_int64, P, P, P, P, P, P, c_int, P]),
     "mny_bn_bwd_apply": (c_int, [P, P, P, P, c_int, P, P, c_int64, c_int, P]),
     "mny_add_views": (c_int, [P, P, P, c_int, P, P, P, c_int, P, P, c_int, c_int, c_int, c_int, P]),
     "mny_mul_views": (c_int, [P, P, P, c_int, P, P, P, c_int, P, c_int64, c_int, P]),

@@ -404,6 +404,25 @@ extern "C" int mny_bn_eval_coeffs(const float* gamma, const float* beta, const f
     return check_launch("bn_eval_coeffs_kernel");
 }
 
+// frozen BatchNorm (module in eval mode, gradients wanted: mbv2_yolo.py:157 returns differentiable losses under model.eval()):
+// the statistics are the running ones, constants of the step — mean / invstd for the backward kernels' yhat, and a finalize whose
+// data-gradient coefficients are (gamma * invstd, 0, 0): dgamma = sum dz * yhat, dbeta = sum dz as in training.
+__global__ void bn_eval_stats_kernel(const float* rm, const float* rv, float eps, float* mean_out, float* invstd_out, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        mean_out[c] = rm[c];
+        invstd_out[c] = 1.f / sqrtf(rv[c] + eps);            // the denominator bn_eval_coeffs_kernel divides gamma by
+    }
+}
+
+extern "C" int mny_bn_eval_stats(const float* running_mean, const float* running_var, float eps, float* mean_out, float* invstd_out, int C,
+                                 void* stream) {
+    MNY_REQUIRE(running_mean && running_var && mean_out && invstd_out && C > 0, "bn_eval_stats: bad arguments");
+    hipLaunchKernelGGL(bn_eval_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, running_mean, running_var, eps, mean_out,
+                       invstd_out, C);
+    return check_launch("bn_eval_stats_kernel");
+}
+
 static void c1_layout(int64_t M, int C, int& cb, int& chunks, int& gx) {
     chunks = (int)cdiv(C, 256);
     cb = (int)cdiv(C, chunks);
@@ -449,6 +468,15 @@ extern "C" int mny_bn_bwd_finalize(const float* red, int parts, int64_t count, c
     MNY_REQUIRE(red && gamma && mean && invstd && dgamma && dbeta && coef && parts > 0 && C > 0, "bn_bwd_finalize: bad arguments");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, red, parts, (double)count,
                        gamma, mean, invstd, dgamma, dbeta, coef, C);
+    return check_launch("bn_bwd_finalize_kernel");
+}
+
+extern "C" int mny_bn_bwd_finalize_frozen(const float* red, int parts, int64_t count, const float* gamma, const float* mean,
+                                          const float* invstd, float* dgamma, float* dbeta, float* coef, int C, void* stream) {
+    (void)count;                                   // same argument list as mny_bn_bwd_finalize; the statistics do not depend on the batch
+    MNY_REQUIRE(red && gamma && mean && invstd && dgamma && dbeta && coef && parts > 0 && C > 0, "bn_bwd_finalize_frozen: bad arguments");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 31) / 32), dim3(1024), 0, (hipStream_t)stream, red, parts, (double)INFINITY,
+                       gamma, mean, invstd, dgamma, dbeta, coef, C);              // count = inf: cb = -0, cc = -0 exactly
     return check_launch("bn_bwd_finalize_kernel");
 }
 

@@ -192,13 +192,15 @@ class _Unit:
 
 
 class NetPlan:
-    def __init__(self, net, N, H, W, training, act_dtype=torch.float32, bn_batch=None):
+    def __init__(self, net, N, H, W, training, act_dtype=torch.float32, bn_batch=None, frozen_bwd=False):
         """training: build the loss calls (else decode + NMS).  bn_batch (default = training): BatchNorm on batch statistics
         with the running-statistics update, and the backward list; False with training=True is the "validation loss" plan
-        (running statistics, buffers untouched, forward only)."""
+        (running statistics, buffers untouched) — forward only, or with frozen_bwd the backward list of frozen BatchNorm
+        (the statistics are constants of the step: mbv2_yolo.py:157 under model.eval() with gradients)."""
         self.net, self.N, self.H, self.W, self.training = net, N, H, W, training
         bn_batch = training if bn_batch is None else (bn_batch and training)
         self.bn_batch = bn_batch
+        self.frozen = bool(training and not bn_batch and frozen_bwd)
         self.fwd_gen = 0
         self.resident_bytes = 0
         dev = net.device
@@ -269,7 +271,7 @@ class NetPlan:
         # stride-2 depthwise conv (ReLU6) runs as one unit that never writes the 6x-wide tensor or its gradient: every pass recomputes it
         # from the thin input.  exdw_pw[expand node out id] = depthwise node, exdw_dw[depthwise node out id] = expand node.
         self.exdw_pw, self.exdw_dw = {}, {}
-        if not self.bf16:
+        if not self.bf16 and not self.frozen:           # (the frozen-BatchNorm backward runs on the generic, materialised kernels)
             ks = set(int(v) for v in os.environ.get("MNY_EXDW_K", "16").split(",") if v)
             cons = {}
             for nd in g.nodes:
@@ -344,6 +346,8 @@ class NetPlan:
                                  u.scale, u.shift, u.mean, u.invstd, o.C, self.stream)
                 else:
                     self.fwd.add("mny_bn_eval_coeffs", gam, bet, rm, rv, BN_EPS, u.scale, u.shift, o.C, self.stream)
+                    if self.frozen:                          # the backward kernels' yhat = (y - running_mean) * invstd
+                        self.fwd.add("mny_bn_eval_stats", rm, rv, BN_EPS, u.mean, u.invstd, o.C, self.stream)
             elif nd.op == "pwb":
                 i = nd.ins[0]
                 xv = view(i)
@@ -388,7 +392,7 @@ class NetPlan:
         self.seg_head = self.head32.get(g.seg_out.id, self.reals[g.seg_out.id]) if g.seg_out is not None else None
         self.loss_outputs = list(g.outputs) + ([g.seg_out] if g.seg_out is not None else [])     # values a loss reads
         self._build_detection()
-        if training and bn_batch:
+        if training and (bn_batch or self.frozen):
             self._build_backward()
 
     # ------------------------------------------------------------------------------------------
@@ -510,6 +514,7 @@ class NetPlan:
 
         written = set()
         self.shared_tmp = []
+        fin_name = "mny_bn_bwd_finalize_frozen" if self.frozen else "mny_bn_bwd_finalize"
 
         def gv(nm):
             """Destination of a parameter gradient.  The first contribution writes the arena slot; a later one (shared
@@ -652,8 +657,8 @@ class NetPlan:
 
         def takes_own_sums(pn):
             """True for the thin expand units handled by mny_pw_bnbwd (their stage 1 forms the BN sums itself)."""
-            if pn.op != "pw" or os.environ.get("MNY_NO_BNFUSE") == "1" or (self.bf16 and os.environ.get("MNY_BNFUSE_BF16") == "0"):
-                return False
+            if pn.op != "pw" or self.frozen or os.environ.get("MNY_NO_BNFUSE") == "1" or (self.bf16 and os.environ.get("MNY_BNFUSE_BF16") == "0"):
+                return False                     # (frozen BatchNorm: that unit's own finalize assumes batch statistics)
             po, pi = pn.out, pn.ins[0]
             if pi.act in (_lib.ACT_HSWISH, _lib.ACT_HSIGMOID) or po.act in (_lib.ACT_HSWISH, _lib.ACT_HSIGMOID):
                 return False
@@ -712,7 +717,7 @@ class NetPlan:
                     red_buf, red_parts = self.red_ws, _lib.query("mny_bn_bwd_parts", M, o.C)
                     bwd.add(K("mny_bn_bwd_reduce"), G, u.Y, u.scale, u.shift, o.act, u.mean, u.invstd, self.red_ws, M, o.C, self.stream,
                             meta=dict(flops=0, bytes=2 * eb * M * o.C, shape="M%d C%d" % (M, o.C)))
-                bwd.add("mny_bn_bwd_finalize", red_buf, red_parts, M, gam, u.mean, u.invstd, gv(nd.bn + ".weight"), gv(nd.bn + ".bias"),
+                bwd.add(fin_name, red_buf, red_parts, M, gam, u.mean, u.invstd, gv(nd.bn + ".weight"), gv(nd.bn + ".bias"),
                         self.coef_ws, o.C, self.stream)
                 dparts = _lib.query("mny_exdw_bwd_parts", N, psh[1], psh[2], pi.C, o.C, 2)
                 dwv = gv(nd.conv + ".weight")
@@ -810,7 +815,7 @@ class NetPlan:
                         red_buf, red_parts = self.red_ws, parts
                         bwd.add(K("mny_bn_bwd_reduce"), G, u.Y, u.scale, u.shift, o.act, u.mean, u.invstd, self.red_ws, M, o.C, self.stream,
                                 meta=dict(flops=0, bytes=2 * eb * M * o.C, shape="M%d C%d" % (M, o.C)))
-                    bwd.add("mny_bn_bwd_finalize", red_buf, red_parts, M, gam, u.mean, u.invstd, gv(nd.bn + ".weight"), gv(nd.bn + ".bias"),
+                    bwd.add(fin_name, red_buf, red_parts, M, gam, u.mean, u.invstd, gv(nd.bn + ".weight"), gv(nd.bn + ".bias"),
                             self.coef_ws, o.C, self.stream)
                     n_sh = len(self.shared_tmp)
                     dwv = gv(nd.conv + ".weight")
@@ -854,7 +859,7 @@ class NetPlan:
                         red_buf, red_parts = self.red_ws, parts
                         bwd.add(K("mny_bn_bwd_reduce"), G, u.Y, u.scale, u.shift, o.act, u.mean, u.invstd, self.red_ws, M, o.C, self.stream,
                                 meta=dict(flops=0, bytes=2 * eb * M * o.C, shape="M%d C%d" % (M, o.C)))
-                    bwd.add("mny_bn_bwd_finalize", red_buf, red_parts, M, gam, u.mean, u.invstd, gv(nd.bn + ".weight"), gv(nd.bn + ".bias"),
+                    bwd.add(fin_name, red_buf, red_parts, M, gam, u.mean, u.invstd, gv(nd.bn + ".weight"), gv(nd.bn + ".bias"),
                             self.coef_ws, o.C, self.stream)
                     dwv = gv(nd.conv + ".weight")
                     wt = P[nd.conv + ".weight"]
@@ -876,7 +881,7 @@ class NetPlan:
                     red_buf, red_parts = self.red_ws, parts
                     bwd.add(K("mny_bn_bwd_reduce"), G, u.Y, u.scale, u.shift, o.act, u.mean, u.invstd, self.red_ws, M, o.C, self.stream,
                             meta=dict(flops=0, bytes=2 * eb * M * o.C, shape="M%d C%d" % (M, o.C)))
-                bwd.add("mny_bn_bwd_finalize", red_buf, red_parts, M, gam, u.mean, u.invstd, gv(nd.bn + ".weight"), gv(nd.bn + ".bias"),
+                bwd.add(fin_name, red_buf, red_parts, M, gam, u.mean, u.invstd, gv(nd.bn + ".weight"), gv(nd.bn + ".bias"),
                         self.coef_ws, o.C, self.stream)
                 stem_fused = (nd.op == "stem" and os.environ.get("MNY_NO_STEMFUSE") != "1" and _lib.query("mny_stem_bnwgrad_supported", o.C) == 1)
                 if not stem_fused:

@@ -81,21 +81,6 @@ class _TrainStep(torch.autograd.Function):
         return None, None, None, None, None, None
 
 
-class _EvalLossEdge(torch.autograd.Function):
-    """Graph edge of the validation loss (`model.eval()(images, targets)` with grad mode on): the reference's eval-mode losses are
-    differentiable (mbv2_yolo.py:157 — frozen-BatchNorm fine-tuning works there); this build has no backward list for the
-    running-statistics plan, and says so when backward() reaches it instead of failing with a generic 'does not require grad'."""
-
-    @staticmethod
-    def forward(ctx, losses, anchor):
-        return losses.clone()
-
-    @staticmethod
-    def backward(ctx, _g):
-        raise _lib.MnyError("backward() through model.eval()(images, targets): the eval-mode (running-statistics) plan is forward only — "
-                            "frozen-BatchNorm fine-tuning is not implemented; call model.train() for gradients, or wrap validation in torch.no_grad()")
-
-
 class yolo(nn.Module):
     ARCH = "mbv2"
 
@@ -204,8 +189,9 @@ class yolo(nn.Module):
     PLAN_BUDGET_FRAC = 0.6        # share of the device's HBM the cached plans may keep resident
 
     def _plan(self, N, H, W, training):
-        """`training`: True (loss + backward, batch statistics), False (decode + NMS, running statistics) or "evalloss"
-        (loss on running statistics, no statistics update, no backward: `model.eval()(images, targets)`)."""
+        """`training`: True (loss + backward, batch statistics), False (decode + NMS, running statistics), "evalloss" (loss on running
+        statistics, no statistics update, forward only: `model.eval()(images, targets)` under no_grad) or "evalgrad" (the same with the
+        backward list of frozen BatchNorm: `model.eval()(images, targets)` with gradients, mbv2_yolo.py:157)."""
         key = (N, H, W, training) if self.act_dtype == torch.float32 else (N, H, W, training, "bf16")
         p = self._plans.get(key)
         if p is None or p.stale():
@@ -215,7 +201,7 @@ class yolo(nn.Module):
             _lib.load()
             self._plans.pop(key, None)
             before = torch.cuda.memory_allocated(self.device)
-            p = NetPlan(self, N, H, W, bool(training), self.act_dtype, bn_batch=(training is True))
+            p = NetPlan(self, N, H, W, bool(training), self.act_dtype, bn_batch=(training is True), frozen_bwd=(training == "evalgrad"))
             p.resident_bytes = max(torch.cuda.memory_allocated(self.device) - before, 0)
             self._plans[key] = p
             # multi-scale training keeps one plan per size: bound them by resident BYTES (a bs=256/352x352 training plan holds
@@ -256,9 +242,16 @@ class yolo(nn.Module):
             nbt = [b for k, b in self.named_buffers() if k.endswith("num_batches_tracked")]
             torch._foreach_add_(nbt, 1)
             losses, metrics = _TrainStep.apply(x, self._anchor, self, plan, targets, seg_maps if self.has_seg else None)
+        elif torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # model.eval()(images, targets) with gradients — frozen-BatchNorm fine-tuning (mbv2_yolo.py:157 returns differentiable losses in
+            # eval mode): running statistics in the forward, untouched buffers, and a backward in which they are constants
+            plan = self._plan(N, H, W, "evalgrad")
+            if self._anchor is None or self._anchor.device != x.device:
+                self._anchor = torch.zeros((), device=x.device, requires_grad=True)
+            losses, metrics = _TrainStep.apply(x, self._anchor, self, plan, targets, seg_maps if self.has_seg else None)
         else:
-            # model.eval()(images, targets) — a validation loss: nn.BatchNorm2d normalises with the running statistics and leaves
-            # them untouched (mobilenetv2.py:41-84 in eval mode).  Forward only: backward() through it raises an explicit MnyError.
+            # model.eval()(images, targets) under no_grad — a validation loss: nn.BatchNorm2d normalises with the running statistics and
+            # leaves them untouched (mobilenetv2.py:41-84 in eval mode); forward-only plan
             plan = self._plan(N, H, W, "evalloss")
             with torch.no_grad():
                 res = plan.forward_train(x, targets, seg_maps if self.has_seg else None).clone()
@@ -267,10 +260,6 @@ class yolo(nn.Module):
                     seg3 = plan.seg_out3.clone()
                     losses = torch.cat((losses, seg3[:1]))
                     metrics = torch.cat((metrics.reshape(-1), seg3[1:]))
-            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-                if self._anchor is None or self._anchor.device != x.device:
-                    self._anchor = torch.zeros((), device=x.device, requires_grad=True)
-                losses = _EvalLossEdge.apply(losses, self._anchor)             # backward() raises an explicit MnyError
         seg_metrics = None
         if self.has_seg:
             seg_metrics, metrics = metrics[12:], metrics[:12].view(2, 6)
