@@ -148,3 +148,42 @@ def test_mbv3_512_matches_oracle():
     for k, p in m.named_parameters():
         a, b = p.grad.double().norm().item(), rp[k].grad.double().norm().item()
         assert abs(a - b) <= 3e-2 * b + 5e-5, (k, a, b)
+
+
+def test_mbv3_eval_mode_losses_are_differentiable_frozen_batchnorm():
+    """models/mbv3_yolo.py under model.eval() with gradients (frozen BatchNorm: running statistics, constants of the step) — the
+    shared `connect_for_S16` module (two contributions), the squeeze-excite gates and the h-swish units all through the generic
+    backward kernels with mny_bn_bwd_finalize_frozen; losses and every gradient norm against the oracle in .eval()."""
+    ref = procedural.fill_state_dict_(net_ref_v3.RefYoloV3(procedural.VOC_CONFIG)).train()
+    x = procedural.images(2, 256, 256, seed=7)
+    tg = procedural.targets(2, seed=8, empty_every=0)
+    # running statistics that fit the weights (the procedural ones send the eval-mode activations to inf): one train-mode pass at momentum 1
+    bns = [mod for mod in ref.modules() if isinstance(mod, torch.nn.BatchNorm2d)]
+    for mod in bns:
+        mod.momentum = 1.0
+    with torch.no_grad():
+        ref(procedural.images(4, 256, 256, seed=9), procedural.targets(4, seed=10, empty_every=0))
+    for mod in bns:
+        mod.momentum = 0.1
+    ref.eval()
+    m = _model(False)
+    m.load_state_dict(ref.state_dict())
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    rr = ref(x, tg)
+    (rr[0][0] + rr[1][0]).backward()
+    res = m(x.cuda(), tg)
+    (res[0][0] + res[1][0]).backward()
+    for i in range(2):
+        np.testing.assert_allclose(np.array([float(torch.as_tensor(v).detach()) for v in res[i]]), np.array([float(torch.as_tensor(v).detach()) for v in rr[i]]), rtol=3e-3, atol=1e-5)
+    rp = dict(ref.named_parameters())
+    n_cmp = 0
+    for k, p in m.named_parameters():
+        if rp[k].grad is None:
+            assert p.grad is None, k
+            continue
+        a, b = p.grad.double().norm().item(), rp[k].grad.double().norm().item()
+        assert abs(a - b) <= 3e-2 * b + 5e-5, (k, a, b)
+        n_cmp += 1
+    assert n_cmp > 200
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, before[k]), k
