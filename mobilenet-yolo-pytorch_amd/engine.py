@@ -733,7 +733,7 @@ class NetPlan:
                     "mny_exdw_bwd", G, u.Y, u.scale, u.shift, act, self.coef_ws, xv[0], xv[1], xv[2], xv[3], P[pn.conv + ".weight"],
                     pu.scale, pu.shift, pu.mean, pu.invstd, P[pn.bn + ".weight"], P[nd.conv + ".weight"], addend, out, dwe, dge, dbe,
                     dwv_k, dws_k, xws, N, psh[1], psh[2], Kc, C, 2, self.stream,
-                    meta=dict(flops=8 * Mx * Kc * C + 4 * M * C * 9, bytes=self.eb * (3 * Mx * Kc + 4 * M * C), shape="exdw K%d C%d H%d" % (Kc, C, psh[1]))))    # algorithmic: X twice + dX once, G_z and Z twice
+                    meta=dict(flops=6 * Mx * Kc * C + 6 * M * C * 9, bytes=self.eb * (3 * Mx * Kc + 4 * M * C), shape="exdw K%d C%d H%d" % (Kc, C, psh[1]))))    # algorithmic: the expand output once per pass + P1 + dX; the transposed stencil per pass + dW_dw; X twice + dX once, G_z and Z twice
                 flush_shared()
                 flush_reduce()
                 bwd.marks[o.name] = len(bwd.calls)

@@ -124,6 +124,14 @@ def main():
         "mny_dw_fwd": lambda k: k.startswith("dw3_fwd_kernel") or bool(re.match(r"dw_slide_kernel<f32, \d, \d, 0,", k)),
         # the fused backward of the thin expand units: stage 1 + finalize + stage 2 (the entry point's own partial combine rides along)
         "mny_pw_bnbwd": lambda k: k.startswith("pw_bnbwd_"),
+        # the fused depthwise backward (round 4: priced) and the expand + depthwise unit (exdw.hip; its backward = pass 1 + 2; the shared
+        # finalize / combine kernels of pwgemm.hip it launches are counted under mny_pw_bnbwd's name filter when that entry point also runs)
+        "mny_dw_bnbwd": lambda k: bool(re.match(r"dw_bnbwd_s1k3_kernel<.*, false>$", k)),
+        "mny_dw_bnbwd_red": lambda k: bool(re.match(r"dw_bnbwd_s1k3_kernel<.*, true>$", k)),
+        "mny_dw_bnbwd_s2": lambda k: k.startswith("dw_bnbwd_s2k3_kernel"),
+        "mny_exdw_stats": lambda k: k.startswith("exdw_stats"),
+        "mny_exdw_fwd": lambda k: k.startswith("exdw_fwd"),
+        "mny_exdw_bwd": lambda k: k.startswith("exdw_bwd"),
     }
     for entry, pred in groups.items():
         g = [(ms, n, f_gb, w_gb) for ms, k, n, f_gb, w_gb in rows if pred(k)]
