@@ -350,7 +350,10 @@ enum {
     MNY_ROUTE_WIDE = 4,         /* barrier-free wide-output kernel (pwwide.hip) */
     MNY_ROUTE_WGRAD_STREAM = 5  /* barrier-free stream weight-gradient kernel (pwwgs.hip) */
 };
-int mny_pw_route(int op, int bf16, int64_t M, int K, int Nc);
+int mny_pw_route(int op, int bf16, int64_t M, int K, int Nc);   /* PREDICTION for a plain view (no h-swish input, no bias gradient) */
+/* the family the LAST pointwise-conv call of the calling thread actually took (recorded by the dispatchers where they decide; -1 before
+ * the first call).  engine.py records it for every call of a plan's first replay: NetPlan.kernel_routes() reports what ran. */
+int mny_pw_last_route(void);
 
 /* ---- evaluation consumer: VOC07 11-point mAP on the device -----------------------------
  * Replaces utils/eval_mAP.py:134-187 (calculate_mAP), :69-132 (eval_class_ap), :8-65

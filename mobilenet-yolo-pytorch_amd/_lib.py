@@ -66,6 +66,7 @@ _SIGS = {
     "mny_pw_dgrad_bnred_add_supported": (c_int, [c_int64, c_int, c_int, c_int]),
     "mny_pw_dgrad_bnred_add": (c_int, [P, P, P, P, P, P, P, c_int, P, P, P, c_int64, c_int, c_int, P]),
     "mny_pw_route": (c_int, [c_int, c_int, c_int64, c_int, c_int]),
+    "mny_pw_last_route": (c_int, []),
     "mny_pw_w6_supported": (c_int, [c_int64, c_int, c_int]),
     "mny_pw_w6_bytes": (c_size_t, [c_int, c_int]),
     "mny_cut3_batch": (c_int, [P, P, c_int, P]),

@@ -2785,6 +2785,7 @@ int pw_bnbwd_finalize_launch(const float* partials, int nparts, float* red, cons
 }  // namespace mny
 
 using namespace mny;
+static thread_local int g_pw_route = -1;        // kernel family of this thread's last pointwise-conv call (mny_pw_last_route below)
 
 extern "C" int mny_pw_stat_parts(int64_t M, int K, int Nc) {
     if (M <= 0 || K <= 0 || Nc <= 0) return MNY_EINVAL;
@@ -2838,11 +2839,16 @@ extern "C" int mny_pw_fwd(const float* x, const float* in_scale, const float* in
     hipStream_t st = (hipStream_t)stream;
     const bool xf = in_scale != nullptr || in_act != MNY_ACT_NONE;
     static const bool force_v1 = getenv("MNY_GEMM_V1") != nullptr;   // A/B switch for profiling
-    if (pw_thin_ok(0, 0, M, K, Nc))                        // short reduction: vector-ALU stream kernel (pwthin.hip)
+    if (pw_thin_ok(0, 0, M, K, Nc)) {                      // short reduction: vector-ALU stream kernel (pwthin.hip)
+        g_pw_route = MNY_ROUTE_THIN;
         return pw_thin_launch(0, x, in_scale, in_shift, in_act, w, bias, addend, y, stats, M, K, Nc, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, st);
+    }
+    bool took_wide = false;
     if (pw_wide_ok(M, K, Nc, false)) {              // short reduction, wide output: barrier-free matrix-core kernel (pwwide.hip)
         if (!bias && !addend && in_act != MNY_ACT_HSIGMOID) {
             const int64_t Mf = M & ~(int64_t)31;    // it takes whole 32-row tiles; the last M % 32 rows follow below (one more partial row)
+            g_pw_route = MNY_ROUTE_WIDE;
+            took_wide = true;
             const int rc = pw_wide_launch(x, in_scale, in_shift, in_act, w, y, stats, Mf, K, Nc, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, st);
             if (rc != 0 || Mf == M) return rc;
             if (stats) stats += (int64_t)pw_wide_parts(M, K, Nc, false) * 2 * Nc;
@@ -2858,9 +2864,11 @@ extern "C" int mny_pw_fwd(const float* x, const float* in_scale, const float* in
                     nullptr, nullptr, nullptr, nullptr, nullptr, 0};
         dim3 grid2(p2.grid), block2(256);
         const int XF = !xf ? 0 : (in_act == MNY_ACT_HSWISH ? 2 : 1);
+        if (!took_wide) g_pw_route = nt_x6(M, K, Nc) ? MNY_ROUTE_DMA_X6 : MNY_ROUTE_DMA_F32;     // (the last M % 32 rows of a wide-kernel call stay "wide")
         hipLaunchKernelGGL(nt2_kernel(p2.TN, XF, 0, nt_x6(M, K, Nc)), grid2, block2, p2.lds, st, g);
         return check_launch("pw_gemm_nt_dma_kernel");
     }
+    if (!took_wide) g_pw_route = MNY_ROUTE_TILE_V1;
     return pw_fwd_v1<float>(x, in_scale, in_shift, in_act, w, bias, addend, y, stats, M, K, Nc, st);
 }
 
@@ -2889,10 +2897,14 @@ static int pw_dgrad_bnred_impl(const void* dy, const void* wT, void* dx, const v
     MNY_REQUIRE(dy && wT && dx && y && scale && shift && mean && invstd && red, "pw_dgrad_bnred: null pointer");
     MNY_REQUIRE(dgrad_bnred_ok(M, K, Nc, act) && (!BF || (K & 7) == 0), "pw_dgrad_bnred: unsupported problem M=%lld K=%d N=%d act=%d (see mny_pw_dgrad_bnred_supported)",
                 (long long)M, K, Nc, act);
+    if (pw_thin_ok(BF, 1, M, K, Nc)) g_pw_route = MNY_ROUTE_THIN;
     if (pw_thin_ok(BF, 1, M, K, Nc))
         return pw_thin_launch(BF, dy, nullptr, nullptr, MNY_ACT_NONE, wT, nullptr, addend, dx, red, M, K, Nc, addend ? 2 : 1, y, scale, shift, mean, invstd, act,
                               (hipStream_t)stream);
+    bool took_wide = false;
     if (!BF && pw_wide_ok(M, K, Nc, true)) {        // whole 32-row tiles on the barrier-free kernel, the last M % 32 rows below (one more partial row)
+        g_pw_route = MNY_ROUTE_WIDE;
+        took_wide = true;
         const int64_t Mf = M & ~(int64_t)31;
         const int rc = pw_wide_launch((const float*)dy, nullptr, nullptr, MNY_ACT_NONE, (const float*)wT, (float*)dx, red, Mf, K, Nc, (const float*)y, scale, shift,
                                       mean, invstd, act, (const float*)addend, (hipStream_t)stream);
@@ -2909,6 +2921,7 @@ static int pw_dgrad_bnred_impl(const void* dy, const void* wT, void* dx, const v
     Nt2Kernel k;
     constexpr int X = BF ? 0 : 1;                   // the six-product bf16 form exists for fp32 operands only
     const bool x6 = !BF && nt_x6(M, K, Nc);
+    if (!took_wide) g_pw_route = x6 ? MNY_ROUTE_DMA_X6 : MNY_ROUTE_DMA_F32;
     if (addend) switch (p2.TN) {                    // RED = 2: with an addend (own instantiations: the addend loads cost the TN = 4 variant registers)
         case 1: k = x6 ? (Nt2Kernel)pw_gemm_nt_dma_kernel<1, 0, BF, 2, X> : (Nt2Kernel)pw_gemm_nt_dma_kernel<1, 0, BF, 2>; break;
         case 2: k = x6 ? (Nt2Kernel)pw_gemm_nt_dma_kernel<2, 0, BF, 2, X> : (Nt2Kernel)pw_gemm_nt_dma_kernel<2, 0, BF, 2>; break;
@@ -2997,6 +3010,7 @@ extern "C" int mny_pw_fwd_w6(const float* x, const float* in_scale, const float*
                 nullptr, nullptr, nullptr, nullptr, nullptr, 0};
     const int XF = !xf ? 0 : (in_act == MNY_ACT_HSWISH ? 2 : 1);
     const Nt2Kernel k = nt2_kernel(p2.TN, XF, 0, 3);
+    g_pw_route = MNY_ROUTE_DMA_X6;
     nt2_allow_lds(k, lds);
     hipLaunchKernelGGL(k, dim3(p2.grid), dim3(256), lds, (hipStream_t)stream, g);
     return check_launch("pw_gemm_nt_dma_kernel<w6>");
@@ -3022,6 +3036,7 @@ extern "C" int mny_pw_dgrad_bnred_w6(const float* dy, const void* wT6, const flo
         case 1: k = (Nt2Kernel)pw_gemm_nt_dma_kernel<1, 0, 0, 1, 3>; break; case 2: k = (Nt2Kernel)pw_gemm_nt_dma_kernel<2, 0, 0, 1, 3>; break;
         case 3: k = (Nt2Kernel)pw_gemm_nt_dma_kernel<3, 0, 0, 1, 3>; break; default: k = (Nt2Kernel)pw_gemm_nt_dma_kernel<4, 0, 0, 1, 3>; break;
     }
+    g_pw_route = MNY_ROUTE_DMA_X6;
     nt2_allow_lds(k, lds);
     hipLaunchKernelGGL(k, dim3(p2.grid), dim3(256), lds, (hipStream_t)stream, g);
     return check_launch("pw_gemm_nt_dma_kernel<RED, w6>");
@@ -3037,21 +3052,29 @@ extern "C" int mny_pw_fwd_bf16(const void* x, const float* in_scale, const float
     const bool xf = in_scale != nullptr || in_act != MNY_ACT_NONE;
     static const bool force_v1 = getenv("MNY_GEMM_V1") != nullptr;
     if (pw_thin_ok(1, 0, M, K, Nc))
-        return pw_thin_launch(1, x, in_scale, in_shift, in_act, w, bias, addend, y, stats, M, K, Nc, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, st);
+        return (g_pw_route = MNY_ROUTE_THIN, pw_thin_launch(1, x, in_scale, in_shift, in_act, w, bias, addend, y, stats, M, K, Nc, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, st));
     if ((K & 7) == 0 && !force_v1) {                // LDS-DMA pipeline on the bf16 matrix cores (16-B aligned bf16 rows)
         Nt2Plan p2 = nt2_plan(M, K, Nc, xf, 1);
         MNY_REQUIRE(p2.lds <= 64 * 1024, "pw_fwd: K=%d too large for the LDS scale cache", K);
         Gemm2Args g{x, in_scale, in_shift, in_act, w, bias, addend, y, stats, M, K, Nc, p2.m_tiles, p2.tiles_per_block, p2.gx, p2.n_tiles,
                     nullptr, nullptr, nullptr, nullptr, nullptr, 0};
         const int XF = !xf ? 0 : (in_act == MNY_ACT_HSWISH ? 2 : 1);
+        g_pw_route = MNY_ROUTE_DMA_F32;
         hipLaunchKernelGGL(nt2_kernel(p2.TN, XF, 1), dim3(p2.grid), dim3(256), p2.lds, st, g);
         return check_launch("pw_gemm_nt_dma_kernel<bf16>");
     }
+    g_pw_route = MNY_ROUTE_TILE_V1;
     return pw_fwd_v1<bf16_t>((const bf16_t*)x, in_scale, in_shift, in_act, (const bf16_t*)w, bias, (const bf16_t*)addend, (bf16_t*)y, stats,
                              M, K, Nc, st);
 }
 
-// which kernel family a call takes: the same predicates, in the same order, as the three dispatchers (tests prove plan coverage with it)
+// which kernel family the LAST pointwise-conv call of this thread took — set by the dispatchers themselves where they decide, so it cannot
+// drift from them (the predictor below ignores h-swish views / bias gradients).  engine.py records it for every call of a plan's
+// first replay; NetPlan.kernel_routes() reports those.
+extern "C" int mny_pw_last_route(void) { return g_pw_route; }
+
+// PREDICTED kernel family of a call with a plain view (no h-swish input, no bias gradient): the predicates of the three dispatchers in
+// their order.  For shapes no plan at hand launches (tests ask it about the bs-256 shapes while running a bs-64 plan).
 extern "C" int mny_pw_route(int op, int bf16, int64_t M, int K, int Nc) {
     if (M <= 0 || K <= 0 || Nc <= 0 || op < 0 || op > 2) return MNY_EINVAL;
     static const bool gemm_v1 = getenv("MNY_GEMM_V1") != nullptr, wgrad_v1 = getenv("MNY_WGRAD_V1") != nullptr;
@@ -3090,6 +3113,7 @@ static int pw_wgrad_impl(const T* x, const float* in_scale, const float* in_shif
     MNY_REQUIRE(M > 0 && K > 0 && Nc > 0, "pw_wgrad: empty problem");
     constexpr bool is_f32 = sizeof(T) == 4;
     if (is_f32 && pw_wgs_ok(M, K, Nc) && !dbias) {              // narrow-sided shape: barrier-free stream kernel (pwwgs.hip), partial rows [pw_wgs_splits][Nc][K]
+        g_pw_route = MNY_ROUTE_WGRAD_STREAM;
         int rc = pw_wgs_launch((const float*)x, in_scale, in_shift, in_act, (const float*)dy, ws, M, K, Nc, (hipStream_t)stream);
         if (rc || !dw) return rc;
         const int64_t n = (int64_t)Nc * K;
@@ -3126,6 +3150,7 @@ static int pw_wgrad_impl(const T* x, const float* in_scale, const float* in_shif
         }
     }
     const int key = dk ? -1 : pl.mode * 100 + pl.TI * 10 + pl.TJ;
+    g_pw_route = !dk ? MNY_ROUTE_TILE_V1 : ((is_f32 && nt_x6(M, K, Nc)) ? MNY_ROUTE_DMA_X6 : MNY_ROUTE_DMA_F32);
     if (dk) hipLaunchKernelGGL(dk, grid_dma, block, pl.lds_dma, st, a_dma);
 #define MNY_WG(MD, I, J) hipLaunchKernelGGL((pw_wgrad_kernel<T, MD, I, J>), grid, block, pl.lds, st, a)
     switch (key) {
@@ -3316,7 +3341,9 @@ extern "C" int mny_pw_bnbwd(const float* g, const float* y, const float* scale, 
 // Shapes: K in {8, 16, 24, 32}, N in {64, 72, 96, 144, 192} (the expand units of MobileNetV3 / MobileNetV2), M >= 4096.  Same three steps:
 // second-generation stage 1 on a bf16 LDS image, the fp32 finalize, the barrier-free data-gradient stage with widened 8-byte loads.
 static bool bnw_supported_bf16(int64_t M, int K, int N) {
-    return bnw_supported(M, K, N) && (K & 7) == 0 && (N == 64 || N == 72 || N == 96 || N == 144 || N == 192);
+    // (stage 1 is instantiated for up to three column tiles per slice: with MNY_BNW_NOSLICE set the 144 / 192-column units would need
+    // five / six and every replay would fail — they are then not offered at all)
+    return bnw_supported(M, K, N) && (K & 7) == 0 && (N == 64 || N == 72 || N == 96 || N == 144 || N == 192) && bnw_plan(M, K, N).TIs <= 3;
 }
 extern "C" int mny_pw_bnbwd_supported_bf16(int64_t M, int K, int Nc) { return bnw_supported_bf16(M, K, Nc) ? 1 : 0; }
 extern "C" int mny_pw_bnbwd_bf16(const void* g, const void* y, const float* scale, const float* shift, int act,

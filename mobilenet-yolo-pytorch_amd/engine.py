@@ -62,6 +62,18 @@ class CallList:
             if rc:
                 raise MnyError("%s failed (%d): %s" % (name, rc, lib.mny_last_error().decode()))
 
+    def run_recording(self, routes, begin=0, end=None):
+        """run(), and for every pointwise-conv call note the kernel family its dispatcher took (mny_pw_last_route) in routes[call index]."""
+        lib = _lib.load()
+        end = len(self.calls) if end is None else end
+        for idx in range(begin, end):
+            fn, args, name, _ = self.calls[idx]
+            rc = fn(*args)
+            if rc:
+                raise MnyError("%s failed (%d): %s" % (name, rc, lib.mny_last_error().decode()))
+            if name.startswith(("mny_pw_fwd", "mny_pw_dgrad_bnred", "mny_pw_wgrad")):
+                routes[idx] = lib.mny_pw_last_route()
+
     def run_timed(self, events, only=None, begin=0, end=None):
         """Like run(), bracketing each call (or only the entry points named in `only`) with HIP events
         recorded on torch's current stream — the stream the kernels are launched on.
@@ -217,6 +229,7 @@ class NetPlan:
         self.stream = _vp(0)
         self.x_ptr = _vp(0)
         self.timing = None
+        self.routes = {"fwd": {}, "bwd": {}}     # call index -> kernel family the dispatcher actually took (recorded at the first replay)
         self.reducer = None
         # optional hipGraph replay (MNY_HIPGRAPH=1): after two eager steps (which also run every one-time HIP attribute /
         # occupancy query) the call lists are captured once per segment and replayed.  Measured on MI355X: no gain
@@ -1063,16 +1076,19 @@ class NetPlan:
         runs; tools/plan_stats.py prints the table)."""
         import re
         out = []
-        lists = [self.fwd.calls] + ([self.bwd.calls] if getattr(self, "bwd", None) is not None else [])
-        for calls in lists:
-            for fn, _args, label, meta in calls:
+        lists = [("fwd", self.fwd.calls)] + ([("bwd", self.bwd.calls)] if getattr(self, "bwd", None) is not None else [])
+        for which, calls in lists:
+            for idx, (fn, _args, label, meta) in enumerate(calls):
                 base = label[:-5] if label.endswith("_bf16") else label
                 op = {"mny_pw_fwd": 0, "mny_pw_dgrad_bnred": 1, "mny_pw_dgrad_bnred_add": 1, "mny_pw_wgrad": 2}.get(base)
                 m = re.search(r"M(\d+) K(\d+) N(\d+)", (meta or {}).get("shape", ""))
                 if op is None or m is None:
                     continue
                 M, K, N = (int(v) for v in m.groups())
-                out.append((getattr(fn, "__name__", label), label, (M, K, N), _lib.query("mny_pw_route", op, int(self.bf16), M, K, N)))
+                fam = self.routes[which].get(idx)             # what the dispatcher did; the predictor only before the first replay
+                if fam is None:
+                    fam = _lib.query("mny_pw_route", op, int(self.bf16), M, K, N)
+                out.append((getattr(fn, "__name__", label), label, (M, K, N), fam))
         return out
 
     def stale(self):
@@ -1096,7 +1112,11 @@ class NetPlan:
             calls.run_timed(self.timing[which], self.timing["only"], begin, end)
             return
         if not (self.use_graphs and self.eager_steps >= 2):
-            calls.run(begin, end)
+            rec = self.routes[which]
+            if rec is not None and not all(i in rec for i in range(begin, len(calls.calls) if end is None else end)):
+                calls.run_recording(rec, begin, end)          # the first replay of every call: which kernel family its dispatcher took
+            else:
+                calls.run(begin, end)
             return
         key = (which, begin, end)
         g = self.graphs.get(key)

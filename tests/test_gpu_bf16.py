@@ -274,7 +274,7 @@ def test_bf16_training_reduces_loss():
         loss = res[0][0] + res[1][0]
         loss.backward()
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     assert np.isfinite(losses).all()
     assert np.mean(losses[-5:]) < 0.7 * np.mean(losses[:3]), losses
     m.eval()

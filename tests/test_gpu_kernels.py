@@ -281,11 +281,15 @@ def test_fused_bn_backward_expand_unit_bf16_storage(ops, M, K, Nc, act, xact):
     assert torch.equal(dwn, dw)
 
 
-@pytest.mark.parametrize("M,K,Nc,bf", [(262144, 24, 72, True), (262144, 32, 64, True), (262144, 16, 64, True), (524288, 16, 96, False)])
+@pytest.mark.parametrize("M,K,Nc,bf", [(262144, 24, 72, True), (262144, 32, 64, True), (262144, 16, 64, True), (524288, 16, 96, False),
+                                       # every bf16 instantiation of the stage-2 kernel (N = 64, 72, 96, 144, 192) with K = 24 and K = 32
+                                       (262144, 24, 64, True), (262144, 32, 72, True), (262144, 24, 96, True), (262144, 32, 96, True),
+                                       (131072, 24, 144, True), (131072, 32, 144, True), (131072, 24, 192, True), (131072, 32, 192, True)])
 def test_fused_bn_backward_expand_unit_is_run_to_run_deterministic(ops, M, K, Nc, bf):
     """Round 3: the first bf16 build of this unit dropped the addend from a few output quads per launch, differently each launch
-    (a compiler-chosen v_pk_add_f32 with swapped source halves in the epilogue).  Twelve launches on the same inputs
-    with allocator churn in between: every output bit for bit the same, and dX within bf16 rounding of the fp32 kernel's."""
+    (a compiler-chosen v_pk_add_f32 with swapped source halves in the epilogue; DESIGN.md — an open correctness risk with a guard, not
+    an explained bug).  Thirty launches on the same inputs with allocator churn in between (the original failure hit a few waves per
+    launch and needed a 30-launch run to show): every output bit for bit the same, and dX within bf16 rounding of the fp32 kernel's."""
     dt = torch.bfloat16 if bf else torch.float32
     x = rnd(M, K, seed=1).view(1, 1, M, K).cuda().to(dt)
     w = rnd(Nc, K, seed=2, scale=K ** -0.5).cuda()
@@ -295,7 +299,7 @@ def test_fused_bn_backward_expand_unit_is_run_to_run_deterministic(ops, M, K, Nc
     scale, shift, mean, invstd = ops.bn_finalize(st, M, gamma, beta)
     gd, ad = rnd(M, Nc, seed=7).view(1, 1, M, Nc).cuda().to(dt), rnd(M, K, seed=8).view(1, 1, M, K).cuda().to(dt)
     first = None
-    for it in range(12):
+    for it in range(30):
         junk = torch.full((1 << 22,), float("nan"), device="cuda")
         out = ops.pw_bnbwd(gd, y, scale, shift, 3, mean, invstd, gamma, (x, xs, xh, 0), w, addend=ad)
         torch.cuda.synchronize()

@@ -187,3 +187,25 @@ def test_mbv3_eval_mode_losses_are_differentiable_frozen_batchnorm():
     assert n_cmp > 200
     for k, v in m.state_dict().items():
         assert torch.equal(v, before[k]), k
+
+
+def test_recorded_kernel_routes_are_what_the_dispatchers_did():
+    """NetPlan.kernel_routes() reports the family each pointwise-conv call's dispatcher TOOK at the plan's first replay
+    (mny_pw_last_route), not a prediction: MobileNetV3's weight gradients over h-swish views run the register-staged kernel in fp32
+    (pw_wgrad_impl keeps them off the LDS-DMA kernels) although the plain-view predictor mny_pw_route says otherwise."""
+    from mobilenet_yolo_pytorch_amd import _lib
+    m = _model(True)
+    x = procedural.images(2, 256, 256, seed=3).cuda()
+    tg = procedural.targets(2, seed=4, empty_every=0)
+    res = m(x, tg)
+    (res[0][0] + res[1][0]).backward()
+    plan = m._plans[(2, 256, 256, True)]
+    assert plan.routes["fwd"] and plan.routes["bwd"]
+    rec = plan.kernel_routes()
+    n_diff = 0
+    for fn, label, (M, K, N), fam in rec:
+        op = {"mny_pw_fwd": 0, "mny_pw_wgrad": 2}.get(label, 1)
+        n_diff += int(fam != _lib.query("mny_pw_route", op, 0, M, K, N))
+        assert 0 <= fam <= 5
+    hsw = [nd for nd in m.graph.nodes if nd.op == "pw" and nd.ins[0].act == _lib.ACT_HSWISH]
+    assert hsw and n_diff > 0           # at least the h-swish-view weight gradients differ from the plain-view prediction

@@ -1,5 +1,5 @@
 # configs[3] (MobileNetV3-YOLO 512x512 bs 64, bf16 storage): kernel stats + HBM counters, each in its own run (program directly after `--`)
-#   then, in the build container:  python tools/prof_c3_summary.py gpurun_out/prof_c3 gpurun_out/prof_c3_fetch gpurun_out/prof_c3_write 13 6 r03
+#   then, in the build container:  python tools/prof_c3_summary.py gpurun_out/prof_c3 gpurun_out/prof_c3_fetch gpurun_out/prof_c3_write 23 6 r04   (3 warm-up + 10 timed + 10 second-pass steps = 23; 1 + 2 + 3 = 6)
 set -e
 REPO=$GRAFT_REPO_ROOT
 C3="--arch mbv3 --size 512 --batch 64 --dtype bf16 --no-cpu-baseline --no-nms"
