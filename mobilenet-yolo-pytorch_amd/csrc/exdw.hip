@@ -759,6 +759,7 @@ struct ExBwdArgs {
     float* partial; float* dw_parts; unsigned short* mask;
     const float* B1; const float* Q; const float* bias; const float* addend; float* dx;
     ExGeom g;
+    const float* e_gamma;
 };
 
 template <int K> struct ExB {
@@ -1122,7 +1123,7 @@ template <int K, int XF>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 8))) void exdw_bwd1v2_s2_kernel(ExBwdArgs p) {
     using B = ExB1<K>;
     constexpr int KQ = B::KQ, KP = B::KP, C = B::C, CP = B::CP, NQ = B::NQ, PPB = B::PPB, NCOLS = B::NCOLS, NPX = B::NPX, KT = B::KT,
-                  NG = B::NG, SL = B::SL;
+                  NG = B::NG, SL = B::SL, NT = B::NT;
     constexpr int ST = 512 / KQ * KQ, PS = ST / KQ, NSB = (B::XPIX * KQ + ST - 1) / ST;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* xs = lds;                                                     // [2 THB][NCOLS][KP] (+ slack)
@@ -1182,6 +1183,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
             float wb[SL][KQ];
             f32x4 accP[SL][KT], accG[KT][KT];
             float s3a[KT];
+            // B operand of the data gradient's first term dz (ca o W): ca = gamma * invstd is known BEFORE the BN-backward sums, so that
+            // term (the contraction over the C channels) is formed here, from the dz tile this pass holds anyway; what depends on the sums
+            // (X Q^T + bias) is thin and follows in exdw_dxfix_kernel.  breg[kt][s][v] = ca[n] W[n][k], n = 16 s + 4 lg + v, k = 16 kt + l16
+            float breg[KT][NT][4];
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int sI = 0; sI < NT; ++sI)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int n = 16 * sI + 4 * lg + v, k = 16 * kt + l16;
+                        breg[kt][sI][v] = k < K ? (float)((double)p.e_gamma[n] * (double)p.e_invstd[n] * (double)p.w[(int64_t)n * K + k]) : 0.f;
+                    }
 #pragma unroll
             for (int j = 0; j < SL; ++j) {
                 const int ch = min(16 * (T0 + j) + l16, C - 1);
@@ -1270,6 +1284,42 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
                     });
                 });
             };
+            // first term of the data gradient for row pair sp: 16-pixel tiles of dz (T[sp % 3]) against breg, reduction over the C channels;
+            // the tiles of a pair go to the waves in rotation (tile counter modulo 4)
+            int tile_ctr = 0;
+            auto dx_tiles = [&](int sp, int n, int i, int j0) {
+                const float* dzb = T + (sp % 3) * B::T_FLOATS;
+#pragma unroll
+                for (int tI = 0; tI < NG; ++tI) {
+                    if (((tile_ctr + tI) & 3) != W) continue;
+                    f32x4 accD[KT];
+#pragma unroll
+                    for (int kt = 0; kt < KT; ++kt) accD[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    const float* dzp = dzb + (16 * tI + l16) * CP + 4 * lg;    // (a padded last tile reads the next buffer's rows: finite, discarded)
+#pragma unroll
+                    for (int sI = 0; sI < NT; ++sI) {
+                        const float4 a4 = *reinterpret_cast<const float4*>(dzp + 16 * sI);
+                        const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                        for (int v = 0; v < 4; ++v)
+#pragma unroll
+                            for (int kt = 0; kt < KT; ++kt) accD[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[v], breg[kt][sI][v], accD[kt], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int px = 16 * tI + 4 * lg + v;
+                        const int rr = px >= NCOLS ? 1 : 0, cc = px - rr * NCOLS;
+                        const int gc = 2 * j0 + cc;
+                        if (px < NPX && gc < g.W) {
+                            float* dp = p.dx + (((int64_t)n * g.H + 2 * i + rr) * g.W + gc) * K;
+#pragma unroll
+                            for (int kt = 0; kt < KT; ++kt)
+                                if (16 * kt + l16 < K) dp[16 * kt + l16] = accD[kt][v];
+                        }
+                    }
+                }
+                tile_ctr += NG;
+            };
             for (int item = ex_lb(); item < g.items; item += gridDim.x) {
                 int n, i0, j0;
                 decode(item, n, i0, j0);
@@ -1281,10 +1331,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
                 ex_barrier();
                 for (int sp = 0; sp < nq; ++sp) {
                     if (sp + 1 < nq) make_y(sp + 1);
-                    if (sp >= 1) contract(sp - 1);
+                    if (sp >= 1) { contract(sp - 1); dx_tiles(sp - 1, n, i0 + sp - 1, j0); }
                     ex_barrier();
                 }
                 contract(nq - 1);
+                dx_tiles(nq - 1, n, i0 + nq - 1, j0);
             }
             // tail (same barrier sequence as the consumers'): fold the matrix accumulators in wave order
             ex_barrier();
@@ -1380,7 +1431,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
             dz_fetch(i0 + 1, rawn);
             dz_finish(i0, r0, d00, d01);
         }
-        unsigned short* mrow = p.mask + ((int64_t)item * kExTHB) * 256 + st;
         ex_barrier();                                                    // row pair 0's Y is in T[0]
         for (int sp = 0; sp < nq; ++sp) {
             const int i = i0 + sp;
@@ -1390,7 +1440,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
             if (sp + 1 < nq) dz_fetch(i + 2, rawn);
             // one pixel of the quad at a time (register budget: 128 with four waves per SIMD): gather G_a with the statically known taps,
             // read the pixel's Y quad, mask, sums, the depthwise weight gradient's terms of this pixel, dz back in place
-            unsigned bits = 0;
 #define WG(t) f4p(my[(t) * NQ])
             static_for<0, 4>([&](auto pc) {
                 constexpr int px = decltype(pc)::value;
@@ -1407,7 +1456,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
                 a.lo = v2f{__builtin_amdgcn_fmed3f(z0.x, 0.f, 6.f), __builtin_amdgcn_fmed3f(z0.y, 0.f, 6.f)};
                 a.hi = v2f{__builtin_amdgcn_fmed3f(z1.x, 0.f, 6.f), __builtin_amdgcn_fmed3f(z1.y, 0.f, 6.f)};
                 const bool m0 = z0.x > 0.f && z0.x < 6.f, m1 = z0.y > 0.f && z0.y < 6.f, m2 = z1.x > 0.f && z1.x < 6.f, m3 = z1.y > 0.f && z1.y < 6.f;
-                bits |= ((m0 ? 1u : 0u) | (m1 ? 2u : 0u) | (m2 ? 4u : 0u) | (m3 ? 8u : 0u)) << (4 * px);
                 o.lo = v2f{m0 ? o.lo.x : 0.f, m1 ? o.lo.y : 0.f};
                 o.hi = v2f{m2 ? o.hi.x : 0.f, m3 ? o.hi.y : 0.f};
                 s1.lo += o.lo; s1.hi += o.hi;
@@ -1421,7 +1469,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
                 if (worker) *reinterpret_cast<float4*>(yp) = f4u(o);
             });
 #undef WG
-            mrow[sp * 256] = (unsigned short)bits;
             ex_barrier();
             d00 = d10; d01 = d11;
         }
@@ -1472,6 +1519,47 @@ static int ex_bwd1v2_launch(const ExBwdArgs& a, bool xf, int grid, hipStream_t s
     if (xf) hipLaunchKernelGGL((exdw_bwd1v2_s2_kernel<K, 1>), dim3(grid), dim3(512), lds, st, a);
     else hipLaunchKernelGGL((exdw_bwd1v2_s2_kernel<K, 0>), dim3(grid), dim3(512), lds, st, a);
     return check_launch("exdw_bwd1v2_s2_kernel");
+}
+
+// ---- the thin remainder of the data gradient: dx += view(X) Q^T + bias (+ addend) -------------------------------------------------
+// Q[K][K] = W^T diag(cb) W and bias[K] = cc . W depend on the BN-backward sums (fp64 finalize, pwgemm.hip); X and dx are K channels wide.
+// Thread = one pixel x 4 output channels; the pixel's K inputs arrive as 16-B loads shared by its K/4 threads (adjacent lanes).
+struct ExFixArgs { float* dx; const float* x; const float* in_scale; const float* in_shift; int in_act; const float* Q; const float* bias;
+                   const float* addend; int64_t M; };
+template <int K, int XF>
+__global__ __launch_bounds__(256) void exdw_dxfix_kernel(ExFixArgs p) {
+    constexpr int KQ = K / 4;
+    const int kq = threadIdx.x % KQ;
+    float4 qrow[K];                                   // Q[4 kq + e][k'] as qrow[k'].{x,y,z,w}
+#pragma unroll
+    for (int k2 = 0; k2 < K; ++k2)
+        qrow[k2] = make_float4(p.Q[(4 * kq + 0) * K + k2], p.Q[(4 * kq + 1) * K + k2], p.Q[(4 * kq + 2) * K + k2], p.Q[(4 * kq + 3) * K + k2]);
+    const float4 b4 = ld4(p.bias + 4 * kq);
+    const float slope = act_slope(p.in_act), hi = act_hi(p.in_act);
+    const int64_t stride = (int64_t)gridDim.x * (256 / KQ);
+    for (int64_t m = (int64_t)blockIdx.x * (256 / KQ) + threadIdx.x / KQ; m < p.M; m += stride) {
+        float4 acc = ld4(p.dx + m * K + 4 * kq);
+        acc.x += b4.x; acc.y += b4.y; acc.z += b4.z; acc.w += b4.w;
+        if (p.addend) add4(acc, ld4(p.addend + m * K + 4 * kq));
+#pragma unroll
+        for (int j = 0; j < KQ; ++j) {
+            float4 xv = ld4(p.x + m * K + 4 * j);
+            if (XF) xv = ex_xf<1>(xv, ld4(p.in_scale + 4 * j), ld4(p.in_shift + 4 * j), slope, hi);
+            fma4(acc, make_float4(xv.x, xv.x, xv.x, xv.x), qrow[4 * j + 0]); fma4(acc, make_float4(xv.y, xv.y, xv.y, xv.y), qrow[4 * j + 1]);
+            fma4(acc, make_float4(xv.z, xv.z, xv.z, xv.z), qrow[4 * j + 2]); fma4(acc, make_float4(xv.w, xv.w, xv.w, xv.w), qrow[4 * j + 3]);
+        }
+        st4_stream(p.dx + m * K + 4 * kq, acc);
+    }
+}
+
+template <int K>
+static int ex_dxfix_launch(const ExFixArgs& a, bool xf, hipStream_t st) {
+    const int64_t rows_per_block = 256 / (K / 4);
+    const int64_t want = cdiv(a.M, rows_per_block);
+    const int grid = (int)(want < 2048 ? want : 2048);
+    if (xf) hipLaunchKernelGGL((exdw_dxfix_kernel<K, 1>), dim3(grid), dim3(256 / (K / 4) * (K / 4)), 0, st, a);
+    else hipLaunchKernelGGL((exdw_dxfix_kernel<K, 0>), dim3(grid), dim3(256 / (K / 4) * (K / 4)), 0, st, a);
+    return check_launch("exdw_dxfix_kernel");
 }
 
 struct ExWs { size_t partials, red, B1, Q, bias, mask, total; };
@@ -1543,7 +1631,7 @@ extern "C" int mny_exdw_bwd(const float* gz, const float* z, const float* z_scal
     const bool xf = in_scale != nullptr || in_act != MNY_ACT_NONE;
     hipStream_t st = (hipStream_t)stream;
     ExBwdArgs a{gz, z, z_scale, z_shift, z_coef, x, in_scale, in_shift, in_act, w_exp, e_scale, e_shift, e_mean, e_invstd, w_dw,
-                ws + o.partials, dw_ws, reinterpret_cast<unsigned short*>(ws + o.mask), ws + o.B1, ws + o.Q, ws + o.bias, addend, dx, g};
+                ws + o.partials, dw_ws, reinterpret_cast<unsigned short*>(ws + o.mask), ws + o.B1, ws + o.Q, ws + o.bias, addend, dx, g, e_gamma};
     int rc = 0;
     static const int only = getenv("MNY_EXDW_ONLY") ? atoi(getenv("MNY_EXDW_ONLY")) : 0;       // timing aid: 1 = first pass only, 2 = second pass only (stale operands)
     if (only == 2) goto pass2;
@@ -1555,6 +1643,11 @@ extern "C" int mny_exdw_bwd(const float* gz, const float* z, const float* z_scal
     if (rc) return rc;
     if (dw_dw) { rc = launch_reduce_parts(dw_ws, grid, C * 9, dw_dw, st); if (rc) return rc; }
     if (only == 1) return MNY_OK;
+    if (!ex_v1()) {                                  // second generation: pass 1 left dz (ca o W) in dx; the thin remainder follows
+        MNY_REQUIRE(!in_scale || in_act <= MNY_ACT_RELU, "exdw_bwd: view");
+        ExFixArgs f{dx, x, in_scale, in_shift, in_act, ws + o.Q, ws + o.bias, addend, (int64_t)N * H * W};
+        return K == 16 ? ex_dxfix_launch<16>(f, xf, st) : (K == 24 ? ex_dxfix_launch<24>(f, xf, st) : ex_dxfix_launch<32>(f, xf, st));
+    }
 pass2:
     return K == 16 ? ex_bwd_launch<16>(a, xf, grid2, st, 2) : (K == 24 ? ex_bwd_launch<24>(a, xf, grid2, st, 2) : ex_bwd_launch<32>(a, xf, grid2, st, 2));
 }

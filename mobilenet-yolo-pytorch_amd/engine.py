@@ -285,7 +285,7 @@ class NetPlan:
         # from the thin input.  exdw_pw[expand node out id] = depthwise node, exdw_dw[depthwise node out id] = expand node.
         self.exdw_pw, self.exdw_dw = {}, {}
         if not self.bf16 and not self.frozen:           # (the frozen-BatchNorm backward runs on the generic, materialised kernels)
-            ks = set(int(v) for v in os.environ.get("MNY_EXDW_K", "16").split(",") if v)
+            ks = set(int(v) for v in os.environ.get("MNY_EXDW_K", "16,24").split(",") if v)
             cons = {}
             for nd in g.nodes:
                 for v in nd.ins:
