@@ -533,6 +533,16 @@ int mny_exdw_bwd(const float* gz, const float* z, const float* z_scale, const fl
                  const float* e_scale, const float* e_shift, const float* e_mean, const float* e_invstd, const float* e_gamma,
                  const float* w_dw, const float* addend, float* dx, float* dw_exp, float* dgamma_e, float* dbeta_e,
                  float* dw_dw, float* dw_ws, float* ws, int N, int H, int W, int K, int C, int stride, void* stream);
+/* the same where x is the RAW output of a conv+BN(+act) unit consumed only by this one (view in_scale / in_shift / in_act, statistics
+ * in_mean / in_invstd): dx is then that unit's complete output gradient, and its BN-backward sums (mny_bn_bwd_reduce's: sum dz, sum dz*yhat)
+ * are left in in_red as partial rows [mny_exdw_bwd_red_parts()][2][K] for mny_bn_bwd_finalize — no separate reduce pass over dx and x
+ * (the project conv in front of the first expand unit, models/mobilenetv2.py:69-85).  Like mny_dw_bnbwd_red. */
+int mny_exdw_bwd_red_parts(int N, int H, int W, int K, int C, int stride);
+int mny_exdw_bwd_red(const float* gz, const float* z, const float* z_scale, const float* z_shift, int z_act, const float* z_coef,
+                     const float* x, const float* in_scale, const float* in_shift, int in_act, const float* in_mean, const float* in_invstd,
+                     const float* w_exp, const float* e_scale, const float* e_shift, const float* e_mean, const float* e_invstd,
+                     const float* e_gamma, const float* w_dw, const float* addend, float* dx, float* dw_exp, float* dgamma_e, float* dbeta_e,
+                     float* dw_dw, float* dw_ws, float* ws, float* in_red, int N, int H, int W, int K, int C, int stride, void* stream);
 
 #ifdef __cplusplus
 }

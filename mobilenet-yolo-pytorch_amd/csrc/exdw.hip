@@ -1524,12 +1524,21 @@ static int ex_bwd1v2_launch(const ExBwdArgs& a, bool xf, int grid, hipStream_t s
 // ---- the thin remainder of the data gradient: dx += view(X) Q^T + bias (+ addend) -------------------------------------------------
 // Q[K][K] = W^T diag(cb) W and bias[K] = cc . W depend on the BN-backward sums (fp64 finalize, pwgemm.hip); X and dx are K channels wide.
 // Thread = one pixel x 4 output channels; the pixel's K inputs arrive as 16-B loads shared by its K/4 threads (adjacent lanes).
+// RED: x is the raw output of a conv+BN(+act) unit consumed only here, so the finished dx IS that unit's complete output gradient: its
+// BN-backward sums (sum dz, sum dz * yhat; mny_bn_bwd_reduce's arithmetic) leave with it as partial rows [gridDim.x][2][K] and the
+// unit's separate reduce pass — a re-read of dx and x — disappears (the project conv 32->16 @176^2 in front of the first expand unit).
 struct ExFixArgs { float* dx; const float* x; const float* in_scale; const float* in_shift; int in_act; const float* Q; const float* bias;
-                   const float* addend; int64_t M; };
-template <int K, int XF>
+                   const float* addend; int64_t M; const float* in_mean; const float* in_invstd; float* in_red; };
+template <int K, int XF, bool RED>
 __global__ __launch_bounds__(256) void exdw_dxfix_kernel(ExFixArgs p) {
     constexpr int KQ = K / 4;
+    __shared__ float4 red[RED ? 256 * 2 : 1];
     const int kq = threadIdx.x % KQ;
+    float4 s1 = f4zero(), s2 = f4zero(), rsc = f4one(), rsh = f4zero(), rmu = f4zero(), ris = f4zero();
+    if (RED) {
+        if (p.in_scale) { rsc = ld4(p.in_scale + 4 * kq); rsh = ld4(p.in_shift + 4 * kq); }
+        rmu = ld4(p.in_mean + 4 * kq); ris = ld4(p.in_invstd + 4 * kq);
+    }
     float4 qrow[K];                                   // Q[4 kq + e][k'] as qrow[k'].{x,y,z,w}
 #pragma unroll
     for (int k2 = 0; k2 < K; ++k2)
@@ -1541,24 +1550,51 @@ __global__ __launch_bounds__(256) void exdw_dxfix_kernel(ExFixArgs p) {
         float4 acc = ld4(p.dx + m * K + 4 * kq);
         acc.x += b4.x; acc.y += b4.y; acc.z += b4.z; acc.w += b4.w;
         if (p.addend) add4(acc, ld4(p.addend + m * K + 4 * kq));
+        float4 yraw = f4zero();
 #pragma unroll
         for (int j = 0; j < KQ; ++j) {
             float4 xv = ld4(p.x + m * K + 4 * j);
+            if (RED && j == kq) yraw = xv;
             if (XF) xv = ex_xf<1>(xv, ld4(p.in_scale + 4 * j), ld4(p.in_shift + 4 * j), slope, hi);
             fma4(acc, make_float4(xv.x, xv.x, xv.x, xv.x), qrow[4 * j + 0]); fma4(acc, make_float4(xv.y, xv.y, xv.y, xv.y), qrow[4 * j + 1]);
             fma4(acc, make_float4(xv.z, xv.z, xv.z, xv.z), qrow[4 * j + 2]); fma4(acc, make_float4(xv.w, xv.w, xv.w, xv.w), qrow[4 * j + 3]);
         }
         st4_stream(p.dx + m * K + 4 * kq, acc);
+        if (RED) {
+            float4 dz;
+            dz.x = acc.x * act_bwd(fmaf(yraw.x, rsc.x, rsh.x), p.in_act); dz.y = acc.y * act_bwd(fmaf(yraw.y, rsc.y, rsh.y), p.in_act);
+            dz.z = acc.z * act_bwd(fmaf(yraw.z, rsc.z, rsh.z), p.in_act); dz.w = acc.w * act_bwd(fmaf(yraw.w, rsc.w, rsh.w), p.in_act);
+            add4(s1, dz);
+            s2.x = fmaf(dz.x, (yraw.x - rmu.x) * ris.x, s2.x); s2.y = fmaf(dz.y, (yraw.y - rmu.y) * ris.y, s2.y);
+            s2.z = fmaf(dz.z, (yraw.z - rmu.z) * ris.z, s2.z); s2.w = fmaf(dz.w, (yraw.w - rmu.w) * ris.w, s2.w);
+        }
+    }
+    if (RED) {
+        red[threadIdx.x * 2] = s1;
+        red[threadIdx.x * 2 + 1] = s2;
+        __syncthreads();
+        if (threadIdx.x < KQ) {
+            float4 a = f4zero(), b = f4zero();
+            for (int r = 0; r < (int)blockDim.x / KQ; ++r) { add4(a, red[(r * KQ + kq) * 2]); add4(b, red[(r * KQ + kq) * 2 + 1]); }
+            st4(p.in_red + (int64_t)blockIdx.x * 2 * K + 4 * kq, a);
+            st4(p.in_red + (int64_t)blockIdx.x * 2 * K + K + 4 * kq, b);
+        }
     }
 }
 
+static int ex_dxfix_grid(int64_t M, int K) {
+    const int64_t want = cdiv(M, 256 / (K / 4));
+    return (int)(want < 1024 ? want : 1024);          // (= partial rows of the RED form: mny_max_parts bounds them)
+}
 template <int K>
 static int ex_dxfix_launch(const ExFixArgs& a, bool xf, hipStream_t st) {
-    const int64_t rows_per_block = 256 / (K / 4);
-    const int64_t want = cdiv(a.M, rows_per_block);
-    const int grid = (int)(want < 2048 ? want : 2048);
-    if (xf) hipLaunchKernelGGL((exdw_dxfix_kernel<K, 1>), dim3(grid), dim3(256 / (K / 4) * (K / 4)), 0, st, a);
-    else hipLaunchKernelGGL((exdw_dxfix_kernel<K, 0>), dim3(grid), dim3(256 / (K / 4) * (K / 4)), 0, st, a);
+    const int grid = ex_dxfix_grid(a.M, K);
+    const dim3 block(256 / (K / 4) * (K / 4));
+    if (a.in_red) {
+        if (xf) hipLaunchKernelGGL((exdw_dxfix_kernel<K, 1, true>), dim3(grid), block, 0, st, a);
+        else hipLaunchKernelGGL((exdw_dxfix_kernel<K, 0, true>), dim3(grid), block, 0, st, a);
+    } else if (xf) hipLaunchKernelGGL((exdw_dxfix_kernel<K, 1, false>), dim3(grid), block, 0, st, a);
+    else hipLaunchKernelGGL((exdw_dxfix_kernel<K, 0, false>), dim3(grid), block, 0, st, a);
     return check_launch("exdw_dxfix_kernel");
 }
 
@@ -1614,11 +1650,12 @@ extern "C" size_t mny_exdw_bwd_ws_floats(int N, int H, int W, int K, int C, int 
     return ex_ws(g, ex_bwd1_grid(g)).total;
 }
 
-extern "C" int mny_exdw_bwd(const float* gz, const float* z, const float* z_scale, const float* z_shift, int z_act, const float* z_coef,
-                            const float* x, const float* in_scale, const float* in_shift, int in_act, const float* w_exp,
-                            const float* e_scale, const float* e_shift, const float* e_mean, const float* e_invstd, const float* e_gamma,
-                            const float* w_dw, const float* addend, float* dx, float* dw_exp, float* dgamma_e, float* dbeta_e,
-                            float* dw_dw, float* dw_ws, float* ws, int N, int H, int W, int K, int C, int stride, void* stream) {
+static int exdw_bwd_impl(const float* gz, const float* z, const float* z_scale, const float* z_shift, int z_act, const float* z_coef,
+                         const float* x, const float* in_scale, const float* in_shift, int in_act, const float* w_exp,
+                         const float* e_scale, const float* e_shift, const float* e_mean, const float* e_invstd, const float* e_gamma,
+                         const float* w_dw, const float* addend, float* dx, float* dw_exp, float* dgamma_e, float* dbeta_e,
+                         float* dw_dw, float* dw_ws, float* ws, int N, int H, int W, int K, int C, int stride, void* stream,
+                         const float* in_mean, const float* in_invstd, float* in_red) {
     MNY_REQUIRE(gz && z && z_scale && z_shift && z_coef && x && w_exp && e_scale && e_shift && e_mean && e_invstd && e_gamma && w_dw && dx && dw_exp &&
                     dgamma_e && dbeta_e && dw_ws && ws, "exdw_bwd: null pointer");
     MNY_REQUIRE(ex_shape_ok(N, H, W, K, C, stride), "exdw_bwd: N=%d H=%d W=%d K=%d C=%d stride=%d not supported", N, H, W, K, C, stride);
@@ -1645,9 +1682,35 @@ extern "C" int mny_exdw_bwd(const float* gz, const float* z, const float* z_scal
     if (only == 1) return MNY_OK;
     if (!ex_v1()) {                                  // second generation: pass 1 left dz (ca o W) in dx; the thin remainder follows
         MNY_REQUIRE(!in_scale || in_act <= MNY_ACT_RELU, "exdw_bwd: view");
-        ExFixArgs f{dx, x, in_scale, in_shift, in_act, ws + o.Q, ws + o.bias, addend, (int64_t)N * H * W};
+        ExFixArgs f{dx, x, in_scale, in_shift, in_act, ws + o.Q, ws + o.bias, addend, (int64_t)N * H * W, in_mean, in_invstd, in_red};
         return K == 16 ? ex_dxfix_launch<16>(f, xf, st) : (K == 24 ? ex_dxfix_launch<24>(f, xf, st) : ex_dxfix_launch<32>(f, xf, st));
     }
 pass2:
     return K == 16 ? ex_bwd_launch<16>(a, xf, grid2, st, 2) : (K == 24 ? ex_bwd_launch<24>(a, xf, grid2, st, 2) : ex_bwd_launch<32>(a, xf, grid2, st, 2));
+}
+
+extern "C" int mny_exdw_bwd(const float* gz, const float* z, const float* z_scale, const float* z_shift, int z_act, const float* z_coef,
+                            const float* x, const float* in_scale, const float* in_shift, int in_act, const float* w_exp,
+                            const float* e_scale, const float* e_shift, const float* e_mean, const float* e_invstd, const float* e_gamma,
+                            const float* w_dw, const float* addend, float* dx, float* dw_exp, float* dgamma_e, float* dbeta_e,
+                            float* dw_dw, float* dw_ws, float* ws, int N, int H, int W, int K, int C, int stride, void* stream) {
+    return exdw_bwd_impl(gz, z, z_scale, z_shift, z_act, z_coef, x, in_scale, in_shift, in_act, w_exp, e_scale, e_shift, e_mean, e_invstd, e_gamma, w_dw,
+                         addend, dx, dw_exp, dgamma_e, dbeta_e, dw_dw, dw_ws, ws, N, H, W, K, C, stride, stream, nullptr, nullptr, nullptr);
+}
+
+extern "C" int mny_exdw_bwd_red_parts(int N, int H, int W, int K, int C, int stride) {
+    if (!ex_shape_ok(N, H, W, K, C, stride) || ex_v1()) return MNY_EINVAL;
+    return ex_dxfix_grid((int64_t)N * H * W, K);
+}
+
+extern "C" int mny_exdw_bwd_red(const float* gz, const float* z, const float* z_scale, const float* z_shift, int z_act, const float* z_coef,
+                                const float* x, const float* in_scale, const float* in_shift, int in_act, const float* in_mean,
+                                const float* in_invstd, const float* w_exp, const float* e_scale, const float* e_shift, const float* e_mean,
+                                const float* e_invstd, const float* e_gamma, const float* w_dw, const float* addend, float* dx, float* dw_exp,
+                                float* dgamma_e, float* dbeta_e, float* dw_dw, float* dw_ws, float* ws, float* in_red, int N, int H, int W, int K, int C,
+                                int stride, void* stream) {
+    MNY_REQUIRE(in_mean && in_invstd && in_red, "exdw_bwd_red: null pointer");
+    MNY_REQUIRE(!ex_v1(), "exdw_bwd_red: not available with MNY_EXDW_V1 (first-generation kernels)");
+    return exdw_bwd_impl(gz, z, z_scale, z_shift, z_act, z_coef, x, in_scale, in_shift, in_act, w_exp, e_scale, e_shift, e_mean, e_invstd, e_gamma, w_dw,
+                         addend, dx, dw_exp, dgamma_e, dbeta_e, dw_dw, dw_ws, ws, N, H, W, K, C, stride, stream, in_mean, in_invstd, in_red);
 }

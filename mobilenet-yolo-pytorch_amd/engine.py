@@ -741,6 +741,26 @@ class NetPlan:
                 xws = torch.empty(max(int(_lib.query("mny_exdw_bwd_ws_floats", N, psh[1], psh[2], pi.C, o.C, 2)), 4), **f32)
                 dwe, dge, dbe = gv(pn.conv + ".weight"), gv(pn.bn + ".weight"), gv(pn.bn + ".bias")
                 Mx = N * psh[1] * psh[2]
+                prod = pi.node
+                # the thin input is the raw output of a conv+BN unit consumed only here (the project conv in front of the first expand unit):
+                # the finished dX is that unit's complete output gradient -> its BN-backward sums leave with it, no separate reduce pass
+                if (os.environ.get("MNY_NO_EXRED") != "1" and pi.kind == "unit" and prod is not None and prod.op in ("pw", "dw", "stem") and gs[pi.id].buf is None
+                        and n_consumers[pi.id] == 1 and not takes_own_sums(prod) and xv[1] is not None and pi.act not in (_lib.ACT_HSWISH, _lib.ACT_HSIGMOID)
+                        and _lib.query("mny_exdw_bwd_red_parts", N, psh[1], psh[2], pi.C, o.C, 2) > 0):
+                    ppu = self.units[pi.id]
+                    rparts = _lib.query("mny_exdw_bwd_red_parts", N, psh[1], psh[2], pi.C, o.C, 2)
+                    rbuf = torch.empty(rparts * 2 * pi.C, **f32)
+                    self.fused_red[pi.id] = (rbuf, rparts)
+                    contribute_kernel(pi, lambda out, addend, G=G, u=u, xv=xv, pu=pu, ppu=ppu, pn=pn, nd=nd, dwe=dwe, dge=dge, dbe=dbe, dwv_k=dwv_k, dws_k=dws_k,
+                                      xws=xws, rbuf=rbuf, psh=psh, Kc=pi.C, C=o.C, M=M, Mx=Mx, act=o.act: bwd.add(
+                        "mny_exdw_bwd_red", G, u.Y, u.scale, u.shift, act, self.coef_ws, xv[0], xv[1], xv[2], xv[3], ppu.mean, ppu.invstd, P[pn.conv + ".weight"],
+                        pu.scale, pu.shift, pu.mean, pu.invstd, P[pn.bn + ".weight"], P[nd.conv + ".weight"], addend, out, dwe, dge, dbe,
+                        dwv_k, dws_k, xws, rbuf, N, psh[1], psh[2], Kc, C, 2, self.stream, label="mny_exdw_bwd",
+                        meta=dict(flops=6 * Mx * Kc * C + 6 * M * C * 9, bytes=self.eb * (3 * Mx * Kc + 4 * M * C), shape="exdw K%d C%d H%d +red" % (Kc, C, psh[1]))))
+                    flush_shared()
+                    flush_reduce()
+                    bwd.marks[o.name] = len(bwd.calls)
+                    continue
                 contribute_kernel(pi, lambda out, addend, G=G, u=u, xv=xv, pu=pu, pn=pn, nd=nd, dwe=dwe, dge=dge, dbe=dbe, dwv_k=dwv_k, dws_k=dws_k, xws=xws,
                                   psh=psh, Kc=pi.C, C=o.C, M=M, Mx=Mx, act=o.act: bwd.add(
                     "mny_exdw_bwd", G, u.Y, u.scale, u.shift, act, self.coef_ws, xv[0], xv[1], xv[2], xv[3], P[pn.conv + ".weight"],

@@ -205,3 +205,63 @@ def test_backward_matches_autograd(K, N, H, W, affine, addend):
     close("dw_dw", dwd, R["dwd"], 2e-4)
     # partial rows of the depthwise weight gradient (the engine's deferred combine reads these)
     close("dw_dw partial rows", dws.view(bparts, C, 3, 3).double().sum(0), R["dwd"], 2e-4)
+
+
+@pytest.mark.parametrize("K,N,H,W", [(16, 6, 40, 36), (24, 3, 28, 44), (32, 2, 20, 24)])
+def test_backward_with_the_input_units_bn_sums_equals_a_separate_reduce_pass(K, N, H, W):
+    """mny_exdw_bwd_red: same dx / parameter gradients as mny_exdw_bwd, and its partial rows sum to what mny_bn_bwd_reduce computes over
+    the finished dx and the raw input (the unit in front: sum dz, sum dz * yhat)."""
+    dev = torch.device("cuda:0")
+    x, w, wd, gam, bet, isc, ish = make_case(N, H, W, K, seed=5 * K + H, affine_in=True)
+    C, M, Ho, Wo = 6 * K, N * H * W, H // 2, W // 2
+    g = torch.Generator().manual_seed(K + W)
+    zgam, zbet = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.5 + 1.0
+    gz = torch.randn(N, Ho, Wo, C, generator=g)
+    imean, iinv = torch.randn(K, generator=g) * 0.2, torch.rand(K, generator=g) + 0.5
+    st = stream()
+    xd, wv, wdd, gamd, betd, iscd, ishd, zgd, zbd, gzd, imd, iid = (t.to(dev).contiguous() for t in (x, w, wd, gam, bet, isc, ish, zgam, zbet, gz, imean, iinv))
+    parts = _lib.query("mny_exdw_stat_parts", M, K, C)
+    stats = torch.zeros(2048 * 2 * C, device=dev)
+    _lib.call("mny_exdw_stats", ptr(xd), ptr(iscd), ptr(ishd), 0, ptr(wv), ptr(stats), M, K, C, st)
+    ec = torch.zeros(4, C, device=dev)
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    _lib.call("mny_bn_finalize", ptr(stats), parts, M, ptr(gamd), ptr(betd), EPS, 0.1, ptr(rm), ptr(rv), ptr(ec[0]), ptr(ec[1]), ptr(ec[2]), ptr(ec[3]), C, st)
+    z = torch.empty(N, Ho, Wo, C, device=dev)
+    zparts = _lib.query("mny_exdw_fwd_parts", N, H, W, K, C, 2)
+    _lib.call("mny_exdw_fwd", ptr(xd), ptr(iscd), ptr(ishd), 0, ptr(wv), ptr(ec[0]), ptr(ec[1]), ptr(wdd), ptr(z), ptr(stats), N, H, W, K, C, 2, st)
+    zc = torch.zeros(4, C, device=dev)
+    Mz = N * Ho * Wo
+    _lib.call("mny_bn_finalize", ptr(stats), zparts, Mz, ptr(zgd), ptr(zbd), EPS, 0.1, ptr(rm), ptr(rv), ptr(zc[0]), ptr(zc[1]), ptr(zc[2]), ptr(zc[3]), C, st)
+    red = torch.zeros(2048 * 2 * C, device=dev)
+    zcoef = torch.zeros(3, C, device=dev)
+    dgz, dbz = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    _lib.call("mny_bn_bwd_reduce", ptr(gzd), ptr(z), ptr(zc[0]), ptr(zc[1]), 1, ptr(zc[2]), ptr(zc[3]), ptr(red), Mz, C, st)
+    _lib.call("mny_bn_bwd_finalize", ptr(red), _lib.query("mny_bn_bwd_parts", Mz, C), Mz, ptr(zgd), ptr(zc[2]), ptr(zc[3]), ptr(dgz), ptr(dbz), ptr(zcoef), C, st)
+    ws = torch.zeros(int(_lib.query("mny_exdw_bwd_ws_floats", N, H, W, K, C, 2)), device=dev)
+    bparts = _lib.query("mny_exdw_bwd_parts", N, H, W, K, C, 2)
+    outs = []
+    for with_red in (False, True):
+        dws = torch.zeros(bparts * C * 9, device=dev)
+        dx = torch.full((N, H, W, K), float("nan"), device=dev)
+        dwe, dge, dbe, dwd = torch.zeros(C, K, device=dev), torch.zeros(C, device=dev), torch.zeros(C, device=dev), torch.zeros(C, 3, 3, device=dev)
+        if with_red:
+            rparts = _lib.query("mny_exdw_bwd_red_parts", N, H, W, K, C, 2)
+            ired = torch.full((rparts, 2, K), float("nan"), device=dev)
+            _lib.call("mny_exdw_bwd_red", ptr(gzd), ptr(z), ptr(zc[0]), ptr(zc[1]), 1, ptr(zcoef), ptr(xd), ptr(iscd), ptr(ishd), 0, ptr(imd), ptr(iid), ptr(wv),
+                      ptr(ec[0]), ptr(ec[1]), ptr(ec[2]), ptr(ec[3]), ptr(gamd), ptr(wdd), None, ptr(dx), ptr(dwe), ptr(dge), ptr(dbe),
+                      ptr(dwd), ptr(dws), ptr(ws), ptr(ired), N, H, W, K, C, 2, st)
+        else:
+            _lib.call("mny_exdw_bwd", ptr(gzd), ptr(z), ptr(zc[0]), ptr(zc[1]), 1, ptr(zcoef), ptr(xd), ptr(iscd), ptr(ishd), 0, ptr(wv),
+                      ptr(ec[0]), ptr(ec[1]), ptr(ec[2]), ptr(ec[3]), ptr(gamd), ptr(wdd), None, ptr(dx), ptr(dwe), ptr(dge), ptr(dbe),
+                      ptr(dwd), ptr(dws), ptr(ws), N, H, W, K, C, 2, st)
+        torch.cuda.synchronize()
+        outs.append((dx, dwe, dge, dbe, dwd))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    # a separate reduce pass over (dx, raw x) with the same view and statistics
+    rparts2 = _lib.query("mny_bn_bwd_parts", M, K)
+    red2 = torch.zeros(rparts2, 2, K, device=dev)
+    _lib.call("mny_bn_bwd_reduce", ptr(outs[1][0]), ptr(xd), ptr(iscd), ptr(ishd), 0, ptr(imd), ptr(iid), ptr(red2), M, K, st)
+    torch.cuda.synchronize()
+    got, want = ired.double().sum(0).cpu(), red2.double().sum(0).cpu()
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-3 * float(want.abs().max())), (got, want)
