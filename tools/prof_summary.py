@@ -131,7 +131,7 @@ def main():
         "mny_dw_bnbwd_s2": lambda k: k.startswith("dw_bnbwd_s2k3_kernel"),
         "mny_exdw_stats": lambda k: k.startswith("exdw_stats"),
         "mny_exdw_fwd": lambda k: k.startswith("exdw_fwd"),
-        "mny_exdw_bwd": lambda k: k.startswith("exdw_bwd"),
+        "mny_exdw_bwd": lambda k: k.startswith("exdw_bwd") or k.startswith("exdw_dxfix"),
     }
     for entry, pred in groups.items():
         g = [(ms, n, f_gb, w_gb) for ms, k, n, f_gb, w_gb in rows if pred(k)]
