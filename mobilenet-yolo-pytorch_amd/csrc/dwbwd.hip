@@ -414,7 +414,8 @@ static int dwb2_geom(DwbGeom& g, CgLayout& L, int& gx, int N, int H, int W, int 
     L = make_stencil_layout(C);
     g.cg_total = L.cg_total; g.cgb = L.cgb;
     int64_t want = cdiv(g.nstrips, L.ppb);
-    int cap = 768 / L.chunks > 0 ? 768 / L.chunks : 1;
+    static const int res2 = getenv("MNY_DWB_RES") ? atoi(getenv("MNY_DWB_RES")) : 768;       // resident workgroups (3 per CU at <= 168 VGPRs)
+    int cap = res2 / L.chunks > 0 ? res2 / L.chunks : 1;
     g.xcd = 1;
     if (cap > 8) cap &= ~7;
     if (want > 8) want = (want + 7) & ~(int64_t)7;
@@ -461,7 +462,8 @@ static int dwb_geom(DwbGeom& g, CgLayout& L, int& gx, int N, int H, int W, int C
     L = make_stencil_layout(C);                            // <= 64 channel groups per block: >= 4 columns, <= 16 KB of LDS constants
     g.cg_total = L.cg_total; g.cgb = L.cgb;
     int64_t want = cdiv(g.nstrips, L.ppb);
-    int cap = 768 / L.chunks > 0 ? 768 / L.chunks : 1;         // 3 resident workgroups per CU (<= 168 VGPRs): one full wave of blocks
+    static const int res1 = getenv("MNY_DWB_RES") ? atoi(getenv("MNY_DWB_RES")) : 768;
+    int cap = res1 / L.chunks > 0 ? res1 / L.chunks : 1;       // 3 resident workgroups per CU (<= 168 VGPRs): one full wave of blocks
     static const int xcd_env = getenv("MNY_DWB_XCD") ? atoi(getenv("MNY_DWB_XCD")) : 1;
     g.xcd = xcd_env;
     if (cap > 8) cap &= ~7;

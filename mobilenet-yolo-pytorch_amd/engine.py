@@ -239,9 +239,12 @@ class NetPlan:
         # kernels of the following layers.  Fork = the side stream waits for what the main stream has enqueued (dY ready); join
         # before every batched combine and at the end of every replayed segment.  Measured (same-box A/B): no gain at
         # bs=256/352x352, where every kernel fills the chip (49.4 vs 49.5-49.8 ms), +3 % on MobileNetV3 512x512 bs=64 bf16, whose
-        # 10-100 us kernels leave CUs idle (17.7 -> 17.2 ms) -> on by default for plans below 24 M input pixels; MNY_SIDE_STREAM=0/1 forces.
+        # 10-100 us kernels leave CUs idle (17.7 -> 17.2 ms).  Round 4 (same-box, un-bracketed steps): bs 256 / 352x352 38.19 -> 37.98 and
+        # 38.07 -> 37.91 ms, so it is on up to 48 M input pixels; fewer resident depthwise-backward workgroups to make room for the side
+        # kernels lose more than the overlap gains (MNY_DWB_RES=512: +0.3 ms).  bench.py's timed region brackets its dominant kernels with
+        # HIP events and therefore runs single-stream: its `value` does not contain this.  MNY_SIDE_STREAM=0/1 forces.
         env_side = os.environ.get("MNY_SIDE_STREAM")
-        auto_side = N * H * W <= 24 * 1000 * 1000
+        auto_side = N * H * W <= 48 * 1000 * 1000
         self.side_on = training and not self.use_graphs and (env_side == "1" or (env_side is None and auto_side))
         self.stream_side = _vp(0)
         self._side_stream = torch.cuda.Stream(dev) if self.side_on else None
