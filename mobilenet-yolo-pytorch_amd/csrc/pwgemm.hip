@@ -282,7 +282,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((X6 == 3 &&
     // [half][column] and lane (column, half) reads back ITS OWN 16 bytes: consecutive lanes, consecutive chunks, no bank conflict.
     // (Round 2 laid the image out [column][half]: the lanes of a half then read every OTHER chunk — SQ_LDS_BANK_CONFLICT was 40 % of
     // the LDS-active cycles of every planes kernel, profiles/r03_pmc_step_lds.txt.)
-    constexpr int A_ST = BM * BKD, B_ST = X6 == 3 ? BN * 24 : BN * BKD, STAGE = A_ST + B_ST;     // floats
+    constexpr int A_ST = BM * BKD, B_ST = X6 == 3 ? BN * 24 : BN * BKD;                          // floats
     constexpr int NA = BM / 16, NB = X6 == 3 ? 3 * TN : BN / 16, NL = NA + NB;                   // 1-KiB DMA instructions per stage
     constexpr int LPW = (NL + 3) / 4;                                         // per wave (surplus ones duplicate the last)
     // Ring layout: [S slots of A][SB slots of B][scale / shift cache].  Planes mode (round 3): the pre-cut weight planes are L2-resident
@@ -2258,6 +2258,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     }
 }
 
+static inline size_t bnw_finalize_lds(int N, int K) { return (size_t)3 * N * sizeof(double) + ((size_t)N * K + (size_t)K * K) * sizeof(float); }   // <= 33 KB (N <= 192, K <= 32)
+
 // finalize.  red = [P1 | Gram | s1 | s2 | s3] summed over splits.  Every block recomputes the N coefficient triples (cheap) and
 // takes a grid-stride share of the fp64 element loops (one block took 80 us per unit).
 __global__ __launch_bounds__(256) void pw_bnbwd_finalize_kernel(const float* __restrict__ red, const float* __restrict__ W,
@@ -2265,8 +2267,11 @@ __global__ __launch_bounds__(256) void pw_bnbwd_finalize_kernel(const float* __r
                                                                 const float* __restrict__ invstd, double count, int N, int K,
                                                                 float* __restrict__ dW, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                 float* __restrict__ B1, float* __restrict__ Q, float* __restrict__ bias) {
-    extern __shared__ double sd[];             // ca[N] cb[N] cc[N]
-    double* ca = sd; double* cb = sd + N; double* cc = sd + 2 * N;
+    extern __shared__ double sd[];             // ca[N] cb[N] cc[N] | W[N][K] | Gram[K][K] (floats): the element loops below are serial
+    double* ca = sd; double* cb = sd + N; double* cc = sd + 2 * N;          // fp64 chains over W and the Gram matrix; out of L2 they took 25 us per launch
+    float* sW = reinterpret_cast<float*>(sd + 3 * N); float* sG = sW + N * K;
+    for (int e = threadIdx.x; e < N * K; e += blockDim.x) sW[e] = W[e];
+    for (int e = threadIdx.x; e < K * K; e += blockDim.x) sG[e] = red[(int64_t)N * K + e];
     const float* P1 = red; const float* Gm = red + (int64_t)N * K; const float* s1 = Gm + (int64_t)K * K;
     const float* s2 = s1 + N; const float* s3 = s2 + N;
     const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
@@ -2280,19 +2285,19 @@ __global__ __launch_bounds__(256) void pw_bnbwd_finalize_kernel(const float* __r
     for (int e = gtid; e < N * K; e += gsz) {
         const int n = e / K, k = e % K;
         double wg = 0.0;
-        for (int j = 0; j < K; ++j) wg += (double)W[(int64_t)n * K + j] * (double)Gm[j * K + k];
+        for (int j = 0; j < K; ++j) wg += (double)sW[n * K + j] * (double)sG[j * K + k];
         dW[e] = (float)(ca[n] * (double)P1[e] + cb[n] * wg + cc[n] * (double)s3[k]);
-        B1[(int64_t)k * N + n] = (float)(ca[n] * (double)W[e]);      // [K][N]: rows = dX columns, contraction over n
+        B1[(int64_t)k * N + n] = (float)(ca[n] * (double)sW[e]);     // [K][N]: rows = dX columns, contraction over n
     }
     for (int e = gtid; e < K * K; e += gsz) {                         // Y (cb o W) = X (W^T diag(cb) W): Q[kc][k], symmetric
         const int kc = e / K, k = e % K;
         double a = 0.0;
-        for (int n = 0; n < N; ++n) a += cb[n] * (double)W[(int64_t)n * K + kc] * (double)W[(int64_t)n * K + k];
+        for (int n = 0; n < N; ++n) a += cb[n] * (double)sW[n * K + kc] * (double)sW[n * K + k];
         Q[e] = (float)a;
     }
     for (int k = gtid; k < K; k += gsz) {
         double a = 0.0;
-        for (int n = 0; n < N; ++n) a += cc[n] * (double)W[(int64_t)n * K + k];
+        for (int n = 0; n < N; ++n) a += cc[n] * (double)sW[n * K + k];
         bias[k] = (float)a;
     }
 }
@@ -2777,7 +2782,7 @@ int pw_bnbwd_finalize_launch(const float* partials, int nparts, float* red, cons
                              float* bias, hipStream_t st) {
     const int64_t stride = bnw_stride(Nc, K);
     hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(stride, 32)), dim3(256), 0, st, partials, nparts, stride, red);
-    hipLaunchKernelGGL(pw_bnbwd_finalize_kernel, dim3((unsigned)cdiv((int64_t)Nc * K, 256)), dim3(256), (size_t)3 * Nc * sizeof(double), st, red, w, gamma,
+    hipLaunchKernelGGL(pw_bnbwd_finalize_kernel, dim3((unsigned)cdiv((int64_t)Nc * K, 256)), dim3(256), bnw_finalize_lds(Nc, K), st, red, w, gamma,
                        mean, invstd, (double)M, Nc, K, dw, dgamma, dbeta, B1, Q, bias);
     return check_launch("pw_bnbwd_finalize_kernel");
 }
@@ -3311,7 +3316,7 @@ extern "C" int mny_pw_bnbwd(const float* g, const float* y, const float* scale, 
     int rc = check_launch("pw_bnbwd_stage1_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(stride, 32)), dim3(256), 0, st, ws, pl.splits, stride, red);
-    hipLaunchKernelGGL(pw_bnbwd_finalize_kernel, dim3((unsigned)cdiv((int64_t)Nc * K, 256)), dim3(256), (size_t)3 * Nc * sizeof(double), st, red, w, gamma, mean, invstd,
+    hipLaunchKernelGGL(pw_bnbwd_finalize_kernel, dim3((unsigned)cdiv((int64_t)Nc * K, 256)), dim3(256), bnw_finalize_lds(Nc, K), st, red, w, gamma, mean, invstd,
                        (double)M, Nc, K, dw, dgamma, dbeta, B1, Q, bias);
     rc = check_launch("pw_bnbwd_finalize_kernel");
     if (rc || !dx) return rc;
@@ -3382,7 +3387,7 @@ extern "C" int mny_pw_bnbwd_bf16(const void* g, const void* y, const float* scal
     int rc = check_launch("pw_bnbwd_stage1b_kernel<bf16>");
     if (rc) return rc;
     hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(stride, 32)), dim3(256), 0, st, ws, pl.splits, stride, red);
-    hipLaunchKernelGGL(pw_bnbwd_finalize_kernel, dim3((unsigned)cdiv((int64_t)Nc * K, 256)), dim3(256), (size_t)3 * Nc * sizeof(double), st, red, w, gamma, mean, invstd,
+    hipLaunchKernelGGL(pw_bnbwd_finalize_kernel, dim3((unsigned)cdiv((int64_t)Nc * K, 256)), dim3(256), bnw_finalize_lds(Nc, K), st, red, w, gamma, mean, invstd,
                        (double)M, Nc, K, dw, dgamma, dbeta, B1, Q, bias);
     rc = check_launch("pw_bnbwd_finalize_kernel");
     if (rc || !dx) return rc;

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Timing of the fused depthwise 3x3 stride-1 backward (csrc/dwbwd.hip) at the shapes of the bs-256 / 352x352 plan.  The knobs of
+that file (MNY_DWB_TH, MNY_DWB_RES, MNY_DWB_XCD, MNY_STENCIL_CGB) are read once per process, so run it once per setting:
+    python tools/bench_dwbwd.py [bs]          prints ms, algorithmic GB/s and fp64 checksums of dX / dW / producer sums per shape"""
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from mobilenet_yolo_pytorch_amd import _lib  # noqa: E402
+
+P = ctypes.c_void_p
+ptr = lambda t: P(t.data_ptr()) if t is not None else None  # noqa: E731
+
+
+def timeit(fn, reps):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+def main():
+    bs = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    dev = torch.device("cuda:0")
+    st = P(torch.cuda.current_stream().cuda_stream)
+    total = 0.0
+    for C, H, red, count in ((32, 176, 0, 1), (144, 88, 1, 1), (192, 44, 1, 2), (384, 22, 1, 4), (576, 22, 1, 3), (960, 11, 1, 3)):
+        N, W = bs, H
+        torch.manual_seed(C)
+        g, y, x = (torch.randn(N, H, W, C, device=dev) for _ in range(3))
+        add = torch.randn(N, H, W, C, device=dev)
+        mk = lambda a, b: (a + b * torch.randn(C, device=dev))  # noqa: E731
+        scale, shift = mk(1.0, 0.2), mk(0.0, 0.3)
+        coef = torch.stack((mk(1.0, 0.2), mk(0.0, 0.05), mk(0.0, 0.05))).contiguous()
+        xs, xh, xm, xi = mk(1.0, 0.2), mk(0.0, 0.3), mk(0.0, 0.2), mk(1.0, 0.1).abs()
+        w = torch.randn(C, 3, 3, device=dev) * 0.4
+        parts = _lib.query("mny_dw_bnbwd_parts", N, H, W, C)
+        ws = torch.zeros(parts * C * 9, device=dev)
+        inred = torch.zeros(parts * 2 * C, device=dev)
+        dx, dw = torch.empty_like(x), torch.zeros(C, 3, 3, device=dev)
+
+        def plain():
+            _lib.call("mny_dw_bnbwd", ptr(g), ptr(y), ptr(scale), ptr(shift), 1, ptr(coef), ptr(x), ptr(xs), ptr(xh), 1, ptr(w), ptr(add), ptr(dx), ptr(dw),
+                      ptr(ws), N, H, W, C, 3, 1, st)
+
+        def withred():
+            _lib.call("mny_dw_bnbwd_red", ptr(g), ptr(y), ptr(scale), ptr(shift), 1, ptr(coef), ptr(x), ptr(xs), ptr(xh), 1, ptr(xm), ptr(xi), ptr(w), ptr(add),
+                      ptr(dx), ptr(dw), ptr(ws), ptr(inred), N, H, W, C, 3, 1, st)
+
+        t0 = timeit(plain, 10)
+        cs = (dx.double().sum().item(), dx.double().abs().sum().item(), (dw.double() * torch.arange(9, device=dev).view(1, 3, 3)).sum().item())
+        t1 = timeit(withred, 10)
+        rs = inred.view(parts, 2, C).double().sum(0)
+        gb = 5 * N * H * W * C * 4 / 1e9
+        print("C%-4d %3dx%-3d parts %4d: plain %.3f ms (%.0f GB/s)  with producer sums %.3f ms (%.0f GB/s) | dx %.9e %.9e dw %.9e red %.9e %.9e" % (
+            C, H, W, parts, t0, gb / t0 * 1e3, t1, gb / t1 * 1e3, cs[0], cs[1], cs[2], rs[0].sum().item(), rs[1].sum().item()), flush=True)
+        total += count * (t1 if red else t0)
+    print("step share (plan's launch counts): %.3f ms" % total)
+
+
+if __name__ == "__main__":
+    main()
