@@ -957,36 +957,50 @@ __global__ __launch_bounds__(256) void exdw_dxfix_kernel(ExFixArgs p) {
     // A lane loads ITS quarter of the pixel's input row (one coalesced 16-byte load) and the K/4 lanes of a pixel trade quarters through
     // LDS (double-buffered, one barrier per pixel group); every lane loading the whole row itself was K/4 loads of which the lanes of a
     // pixel fetched the same 16 bytes — 3.1 TB/s on a stream that is three tensor passes.
-    __shared__ float4 xs[2][256];
+    __shared__ float4 xs[2][2][256];
     float4 xsc = f4one(), xsh = f4zero();
     if (XF) { xsc = ld4(p.in_scale + 4 * kq); xsh = ld4(p.in_shift + 4 * kq); }
     const int pix0 = (threadIdx.x / KQ) * KQ;
-    const int64_t stride = (int64_t)gridDim.x * (256 / KQ);
+    constexpr int PPB = 256 / KQ;
+    const int64_t stride = (int64_t)gridDim.x * (2 * PPB);
     int buf = 0;
-    for (int64_t base = (int64_t)blockIdx.x * (256 / KQ); base < p.M; base += stride, buf ^= 1) {      // workgroup-uniform trip count
-        const int64_t m = base + threadIdx.x / KQ;
-        const bool live = m < p.M;
-        float4 yraw = live ? ld4(p.x + m * K + 4 * kq) : f4zero();
-        xs[buf][threadIdx.x] = XF ? ex_xf<1>(yraw, xsc, xsh, slope, hi) : yraw;
-        float4 acc = live ? ld4(p.dx + m * K + 4 * kq) : f4zero();
-        acc.x += b4.x; acc.y += b4.y; acc.z += b4.z; acc.w += b4.w;
-        if (p.addend && live) add4(acc, ld4(p.addend + m * K + 4 * kq));
+    // two pixel groups per trip: both groups' loads are in the air before the barrier (a lane has 2 x 32 bytes in flight; with one group
+    // the 146-register producer-sums form ran 3 waves per SIMD at 3.4 TB/s)
+    for (int64_t base = (int64_t)blockIdx.x * (2 * PPB); base < p.M; base += stride, buf ^= 1) {      // workgroup-uniform trip count
+        int64_t m[2]; bool live[2]; float4 yraw[2], acc[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            m[u] = base + u * PPB + threadIdx.x / KQ;
+            live[u] = m[u] < p.M;
+            yraw[u] = live[u] ? ld4(p.x + m[u] * K + 4 * kq) : f4zero();
+            acc[u] = live[u] ? ld4(p.dx + m[u] * K + 4 * kq) : f4zero();
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            xs[buf][u][threadIdx.x] = XF ? ex_xf<1>(yraw[u], xsc, xsh, slope, hi) : yraw[u];
+            acc[u].x += b4.x; acc[u].y += b4.y; acc[u].z += b4.z; acc[u].w += b4.w;
+            if (p.addend && live[u]) add4(acc[u], ld4(p.addend + m[u] * K + 4 * kq));
+        }
         __syncthreads();                                  // the other buffer is rewritten after the NEXT barrier only
 #pragma unroll
-        for (int j = 0; j < KQ; ++j) {
-            const float4 xv = xs[buf][pix0 + j];
-            fma4(acc, make_float4(xv.x, xv.x, xv.x, xv.x), qrow[4 * j + 0]); fma4(acc, make_float4(xv.y, xv.y, xv.y, xv.y), qrow[4 * j + 1]);
-            fma4(acc, make_float4(xv.z, xv.z, xv.z, xv.z), qrow[4 * j + 2]); fma4(acc, make_float4(xv.w, xv.w, xv.w, xv.w), qrow[4 * j + 3]);
-        }
-        if (!live) continue;
-        st4_stream(p.dx + m * K + 4 * kq, acc);
-        if (RED) {
-            float4 dz;
-            dz.x = acc.x * act_bwd(fmaf(yraw.x, rsc.x, rsh.x), p.in_act); dz.y = acc.y * act_bwd(fmaf(yraw.y, rsc.y, rsh.y), p.in_act);
-            dz.z = acc.z * act_bwd(fmaf(yraw.z, rsc.z, rsh.z), p.in_act); dz.w = acc.w * act_bwd(fmaf(yraw.w, rsc.w, rsh.w), p.in_act);
-            add4(s1, dz);
-            s2.x = fmaf(dz.x, (yraw.x - rmu.x) * ris.x, s2.x); s2.y = fmaf(dz.y, (yraw.y - rmu.y) * ris.y, s2.y);
-            s2.z = fmaf(dz.z, (yraw.z - rmu.z) * ris.z, s2.z); s2.w = fmaf(dz.w, (yraw.w - rmu.w) * ris.w, s2.w);
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int j = 0; j < KQ; ++j) {
+                const float4 xv = xs[buf][u][pix0 + j];
+                fma4(acc[u], make_float4(xv.x, xv.x, xv.x, xv.x), qrow[4 * j + 0]); fma4(acc[u], make_float4(xv.y, xv.y, xv.y, xv.y), qrow[4 * j + 1]);
+                fma4(acc[u], make_float4(xv.z, xv.z, xv.z, xv.z), qrow[4 * j + 2]); fma4(acc[u], make_float4(xv.w, xv.w, xv.w, xv.w), qrow[4 * j + 3]);
+            }
+            if (!live[u]) continue;
+            st4_stream(p.dx + m[u] * K + 4 * kq, acc[u]);
+            if (RED) {
+                const float4 yr = yraw[u], ac = acc[u];
+                float4 dz;
+                dz.x = ac.x * act_bwd(fmaf(yr.x, rsc.x, rsh.x), p.in_act); dz.y = ac.y * act_bwd(fmaf(yr.y, rsc.y, rsh.y), p.in_act);
+                dz.z = ac.z * act_bwd(fmaf(yr.z, rsc.z, rsh.z), p.in_act); dz.w = ac.w * act_bwd(fmaf(yr.w, rsc.w, rsh.w), p.in_act);
+                add4(s1, dz);
+                s2.x = fmaf(dz.x, (yr.x - rmu.x) * ris.x, s2.x); s2.y = fmaf(dz.y, (yr.y - rmu.y) * ris.y, s2.y);
+                s2.z = fmaf(dz.z, (yr.z - rmu.z) * ris.z, s2.z); s2.w = fmaf(dz.w, (yr.w - rmu.w) * ris.w, s2.w);
+            }
         }
     }
     if (RED) {
@@ -1003,7 +1017,7 @@ __global__ __launch_bounds__(256) void exdw_dxfix_kernel(ExFixArgs p) {
 }
 
 static int ex_dxfix_grid(int64_t M, int K) {
-    const int64_t want = cdiv(M, 256 / (K / 4));
+    const int64_t want = cdiv(M, 2 * (256 / (K / 4)));      // two pixel groups per workgroup trip
     return (int)(want < 1024 ? want : 1024);          // (= partial rows of the RED form: mny_max_parts bounds them)
 }
 template <int K>
