@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ x, 
 constexpr int ST_TH = 8, ST_TW = 32, ST_IH = 2 * ST_TH + 1, ST_IW = 2 * ST_TW + 1, ST_IWP = 72, ST_C0 = 3;
 
 template <typename T, int MODE>
-__global__ __launch_bounds__(256) void stem_tile_kernel(const float* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void stem_tile_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         T* __restrict__ y, const T* __restrict__ dy,
                                                         float* __restrict__ parts, StemGeom g, int tiles_h, int tiles_w,
                                                         const T* __restrict__ yraw = nullptr, const float* __restrict__ scale = nullptr,
@@ -161,9 +161,28 @@ __global__ __launch_bounds__(256) void stem_tile_kernel(const float* __restrict_
             }
         }
         __syncthreads();
+        // weight-gradient modes: the (dY, Y) rows of the NEXT pixel pass are requested before this pass's 108 FMAs (one pass of loads in
+        // flight per lane while it computes; fetched right where they are used, a lane idled a full round trip per pass)
+        float4 d_nx = f4zero(), y_nx = f4zero();
+        auto pass_off = [&](int pp, bool& ok) {
+            const int pr = pp / ST_TW, pc = pp % ST_TW;
+            ok = pp < ST_TH * ST_TW && ho0 + pr < g.Ho && wo0 + pc < g.Wo;
+            return ((n * g.Ho + ho0 + pr) * g.Wo + wo0 + pc) * g.Cout + c;
+        };
+        if (MODE != 0) {
+            bool ok;
+            const int64_t o0 = pass_off(tid / cgn, ok);
+            if (ok) { d_nx = ld4(dy + o0); if (MODE == 2) y_nx = ld4(yraw + o0); }
+        }
         for (int pp = tid / cgn; pp < ST_TH * ST_TW; pp += ppi) {
             const int pr = pp / ST_TW, pc = pp % ST_TW;
             const int ho = ho0 + pr, wo = wo0 + pc;
+            float4 d_cur = d_nx, y_cur = y_nx;
+            if (MODE != 0) {
+                bool ok;
+                const int64_t o1 = pass_off(pp + ppi, ok);
+                if (ok) { d_nx = ld4(dy + o1); if (MODE == 2) y_nx = ld4(yraw + o1); }
+            }
             if (ho >= g.Ho || wo >= g.Wo) continue;
             const int64_t o = ((n * g.Ho + ho) * g.Wo + wo) * g.Cout + c;
             const float* tp = tile + (2 * pr) * ST_IWP + ST_C0 + 2 * pc;
@@ -184,9 +203,9 @@ __global__ __launch_bounds__(256) void stem_tile_kernel(const float* __restrict_
                 add4(s1, acc);
                 fma4(s2, acc, acc);
             } else {
-                float4 d = ld4(dy + o);
+                float4 d = d_cur;
                 if (MODE == 2) {
-                    const float4 yv = ld4(yraw + o);
+                    const float4 yv = y_cur;
                     const float4 sc = cst[cgl], sh = cst[64 + cgl], ca = cst[128 + cgl], cb = cst[192 + cgl], cc = cst[256 + cgl];
                     d.x = fmaf(ca.x, d.x * act_bwd(fmaf(yv.x, sc.x, sh.x), act), fmaf(cb.x, yv.x, cc.x));
                     d.y = fmaf(ca.y, d.y * act_bwd(fmaf(yv.y, sc.y, sh.y), act), fmaf(cb.y, yv.y, cc.y));

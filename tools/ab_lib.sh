@@ -1,6 +1,6 @@
 # same-box A/B of two builds of the library: tools/ab/libmnyolo_prev.so (MNY_LIB) against the in-tree one; alternating runs
 R=$GRAFT_REPO_ROOT/gpurun_out
-B="python bench.py --steps 15 --warmup 4 --no-cpu-baseline --no-nms"
+B="python bench.py --steps 15 --warmup 4 --no-cpu-baseline --no-nms --roofline-pass after"
 for i in 1 2; do
   $B > $R/ab_new_$i.json 2> /dev/null
   MNY_LIB=$GRAFT_REPO_ROOT/tools/ab/libmnyolo_prev.so $B > $R/ab_prev_$i.json 2> /dev/null
