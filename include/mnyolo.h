@@ -512,7 +512,9 @@ int mny_bn_bwd_finalize_frozen(const float* red, int parts, int64_t count, const
  * stride 2 — 1x1 conv K -> C = 6K (K in {16, 24, 32}) + BN + ReLU6 + depthwise 3x3 stride 2 (models/mobilenetv2.py:73-85) — with the
  * 6x-wide expand output and its gradient NEVER materialised: every pass recomputes it from the thin input x[N,H,W,K] (a view:
  * in_scale / in_shift / in_act as everywhere), bit-identical to what mny_pw_fwd would have stored.  fp32 storage, even H and W.
- *   mny_exdw_stats : BN batch statistics of the expand output -> partial rows [mny_exdw_stat_parts()][2][C] for mny_bn_finalize
+ *   mny_exdw_stats : BN batch statistics of the expand output -> partial rows [mny_exdw_stat_parts()][2][C] for mny_bn_finalize;
+ *                    derived from the K x K second-moment matrix and the column sums of the viewed input (sum y^2 = w^T (x^T x) w, fp64
+ *                    per workgroup): one read of x, no recomputation of y.  MNY_EXDW_STATS=direct sums the recomputed y instead.
  *   mny_exdw_fwd   : z[N,H/2,W/2,C] = dw3x3_s2(relu6(e_scale * (x w_exp^T) + e_shift)), z statistics -> [mny_exdw_fwd_parts()][2][C]
  *   mny_exdw_bwd   : given gz = dL/d act(z_scale z + z_shift) and the depthwise unit's BN-backward coefficients z_coef[3][C]
  *                    (mny_bn_bwd_finalize): dw_dw[C,3,3] (or, dw_dw == NULL, partial rows [mny_exdw_bwd_parts()][C*9] left in dw_ws),

@@ -193,6 +193,116 @@ __global__ __launch_bounds__(256) void exdw_stats2_kernel(ExStatArgs p) {
     }
 }
 
+// ---- statistics, Gram form ----------------------------------------------------------------------------------------------
+// sum_c = w_c . colsum(X) and sum_c^2 = w_c^T (X^T X) w_c: the statistics of Y need the K x K second-moment matrix of the (viewed) input
+// and its column sums, not Y — M K^2 products instead of M K C, and the pass becomes a plain read of the thin X.  Lane (l16, lg) of a wave
+// loads X[pixel 4u + lg][channel 16a + l16] as a dword (a wave instruction = 4 pixels x 64 contiguous bytes at K = 16): that register IS
+// both operands of v_mfma_f32_16x16x4_f32 for the block (a, b) of X^T X (A[i][k] = X[k][i], B[k][j] = X[k][j], k = the pixel), so a
+// 64-pixel chunk is 16 KT loads (all in flight before the first use), the view transform, 16 column-sum adds and 16 KT(KT+1)/2 MFMAs.
+// A workgroup folds its four waves' matrices in fp64, forms its partial (sum, sum of squares) per output channel in fp64 and writes ONE
+// partial row [2][C] like every other statistics producer — mny_bn_finalize does not know the difference.
+template <int K, int XF>
+__global__ __launch_bounds__(256) void exdw_gram_stats_kernel(ExStatArgs p) {
+    constexpr int KT = (K + 15) / 16, KP = 16 * KT, C = 6 * K, NB = KT * (KT + 1) / 2, NE = KP * KP + KP;
+    __shared__ float sG[4][NE];
+    __shared__ double sD[NE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, lg = lane >> 4;
+    float sc[KT], sh[KT];
+    bool chok[KT];
+    int chc[KT];
+#pragma unroll
+    for (int a = 0; a < KT; ++a) {
+        const int ch = 16 * a + l16;
+        chok[a] = ch < K;
+        chc[a] = chok[a] ? ch : K - 1;
+        sc[a] = (XF && p.in_scale) ? p.in_scale[chc[a]] : 1.f;
+        sh[a] = (XF && p.in_scale) ? p.in_shift[chc[a]] : 0.f;
+    }
+    const float slope = act_slope(p.in_act), hi = act_hi(p.in_act);
+    f32x4 acc[NB];
+    float cs[KT];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < KT; ++a) cs[a] = 0.f;
+    const int64_t nchunks = cdiv(p.M, 64);
+    const int64_t per = cdiv(nchunks, (int64_t)gridDim.x);
+    const int64_t c_begin = (int64_t)ex_lb() * per;
+    const int64_t c_end = c_begin + per < nchunks ? c_begin + per : nchunks;
+    for (int64_t c = c_begin + wave; c < c_end; c += 4) {
+        float v[16][KT];
+        const int64_t pix0 = c * 64 + lg;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int64_t pix = pix0 + 4 * u;
+            const float* row = p.x + (pix < p.M ? pix : p.M - 1) * K;
+#pragma unroll
+            for (int a = 0; a < KT; ++a) v[u][a] = row[chc[a]];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const bool ok = pix0 + 4 * u < p.M;
+#pragma unroll
+            for (int a = 0; a < KT; ++a) {
+                float t = v[u][a];
+                if (XF) { t = fmaf(t, sc[a], sh[a]); t = fminf(fmaxf(t, slope * t), hi); }
+                t = (ok && chok[a]) ? t : 0.f;
+                v[u][a] = t;
+                cs[a] += t;
+            }
+            int blk = 0;
+#pragma unroll
+            for (int a = 0; a < KT; ++a)
+#pragma unroll
+                for (int b = a; b < KT; ++b, ++blk) acc[blk] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[u][a], v[u][b], acc[blk], 0, 0, 0);
+        }
+    }
+    // accumulator of block (a, b): lane (l16, lg), element r = (X^T X)[16 a + 4 lg + r][16 b + l16]
+    float* gw = sG[wave];
+    {
+        int blk = 0;
+#pragma unroll
+        for (int a = 0; a < KT; ++a)
+#pragma unroll
+            for (int b = a; b < KT; ++b, ++blk)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gw[(16 * a + 4 * lg + r) * KP + 16 * b + l16] = acc[blk][r];
+    }
+#pragma unroll
+    for (int a = 0; a < KT; ++a) {
+        float t = cs[a];
+        t += __shfl_xor(t, 16);
+        t += __shfl_xor(t, 32);
+        if (lg == 0) gw[KP * KP + 16 * a + l16] = t;
+    }
+    __syncthreads();
+    for (int e = tid; e < NE; e += 256) {                  // the four waves in fixed order; blocks below the diagonal mirror the ones above
+        int src = e;
+        if (e < KP * KP) {
+            const int i = e / KP, j = e % KP;
+            if (i / 16 > j / 16) src = j * KP + i;
+        }
+        sD[e] = ((double)sG[0][src] + (double)sG[1][src]) + ((double)sG[2][src] + (double)sG[3][src]);
+    }
+    __syncthreads();
+    for (int ch = tid; ch < C; ch += 256) {
+        float wr[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) wr[k] = p.w[(int64_t)ch * K + k];
+        double s = 0.0, q = 0.0;
+#pragma unroll 4
+        for (int i = 0; i < K; ++i) {
+            double gi = 0.0;
+#pragma unroll
+            for (int j = 0; j < K; ++j) gi += sD[i * KP + j] * (double)wr[j];
+            q += (double)wr[i] * gi;
+            s += (double)wr[i] * sD[KP * KP + i];
+        }
+        p.parts[((int64_t)blockIdx.x * 2 + 0) * C + ch] = (float)s;
+        p.parts[((int64_t)blockIdx.x * 2 + 1) * C + ch] = (float)q;
+    }
+}
+
 // ---- forward -----------------------------------------------------------------------------------------------------------
 // A workgroup owns TH = 6 output rows x PPB output columns of one image.  The X tile ((2 TH + 1) x (2 PPB + 1) pixels) is staged once;
 // the activated expand output a = relu6(sc * Y + sh) lives in a ring of SIX input rows [slot][column][C], slot(row) = (row + 1) % 6:
@@ -444,10 +554,12 @@ extern "C" int mny_exdw_supported(int N, int H, int W, int K, int C, int stride)
     return (!off && ex_shape_ok(N, H, W, K, C, stride)) ? 1 : 0;
 }
 
+// MNY_EXDW_STATS=direct (read at every call: a test switches it): the first form, which recomputes Y on the matrix cores and sums it
+static bool ex_stats_gram() { const char* e = getenv("MNY_EXDW_STATS"); return !(e && e[0] == 'd'); }
 extern "C" int mny_exdw_stat_parts(int64_t M, int K, int C) {
     (void)K; (void)C;
     const int64_t tiles = cdiv(M, kExStatRows);
-    return (int)(tiles < 768 ? tiles : 768);
+    return (int)(tiles < 768 ? tiles : 768);               // both forms run this many workgroups, one partial row each
 }
 
 extern "C" int mny_exdw_stats(const float* x, const float* in_scale, const float* in_shift, int in_act, const float* w, float* stats,
@@ -462,8 +574,15 @@ extern "C" int mny_exdw_stats(const float* x, const float* in_scale, const float
     hipStream_t st = (hipStream_t)stream;
 #define MNY_EXS(K_) do { if (xf) hipLaunchKernelGGL((exdw_stats2_kernel<K_, 1>), dim3(grid), dim3(256), 0, st, a); \
                          else hipLaunchKernelGGL((exdw_stats2_kernel<K_, 0>), dim3(grid), dim3(256), 0, st, a); } while (0)
+#define MNY_EXG(K_) do { if (xf) hipLaunchKernelGGL((exdw_gram_stats_kernel<K_, 1>), dim3(grid), dim3(256), 0, st, a); \
+                         else hipLaunchKernelGGL((exdw_gram_stats_kernel<K_, 0>), dim3(grid), dim3(256), 0, st, a); } while (0)
+    if (ex_stats_gram()) {
+        if (K == 16) MNY_EXG(16); else if (K == 24) MNY_EXG(24); else MNY_EXG(32);
+        return check_launch("exdw_gram_stats_kernel");
+    }
     if (K == 16) MNY_EXS(16); else if (K == 24) MNY_EXS(24); else MNY_EXS(32);
 #undef MNY_EXS
+#undef MNY_EXG
     return check_launch("exdw_stats2_kernel");
 }
 

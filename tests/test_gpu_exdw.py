@@ -127,6 +127,32 @@ def test_forward_is_bitwise_the_materialised_path(K, N, H, W):
     assert torch.allclose(s[1], (yd * yd).sum(dim=(0, 1, 2)), rtol=1e-6, atol=1e-3)
 
 
+@pytest.mark.parametrize("K,N,H,W,shift", [(16, 8, 64, 64, 0.3), (24, 5, 44, 88, 0.0), (32, 3, 40, 36, 0.3), (16, 6, 48, 48, 4.0), (24, 3, 36, 44, 4.0),
+                                           (16, 1, 6, 10, 0.3)])
+def test_gram_form_statistics_equal_the_summed_expand_output(K, N, H, W, shift, monkeypatch):
+    """mny_exdw_stats derives (sum y, sum y^2) per output channel from the K x K second-moment matrix of the viewed input
+    (sum y^2 = w^T (X^T X) w); MNY_EXDW_STATS=direct is the first form, which recomputes Y and sums it.  Same partial-row contract, same
+    values: both against the fp64 reference, including inputs whose mean is 4 standard deviations away from zero (the variance is then
+    the difference of two sums 17 times its size)."""
+    dev = torch.device("cuda:0")
+    x, w, wd, gam, bet, isc, ish = make_case(N, H, W, K, seed=7 * K + H, affine_in=True)
+    ish = ish + shift
+    X, Y, mean, var, sc, sh, a, Z = ref_forward(x, w, wd, gam, bet, isc, ish)
+    xd, wv, iscd, ishd = (t.to(dev).contiguous() for t in (x, w, isc, ish))
+    M = N * H * W
+    got = {}
+    for form in ("gram", "direct"):
+        monkeypatch.setenv("MNY_EXDW_STATS", form)
+        s = gpu_stats(xd, iscd, ishd, wv, dev).cpu()
+        got[form] = s
+        m = s[0] / M
+        v = s[1] / M - m * m
+        assert torch.allclose(m, mean, rtol=1e-5, atol=2e-6), (form, (m - mean).abs().max().item())
+        assert torch.allclose(v, var, rtol=1e-4 if shift > 1 else 2e-5, atol=1e-6), (form, ((v - var) / var).abs().max().item())
+    assert torch.allclose(got["gram"][0], got["direct"][0], rtol=2e-6, atol=1e-3 * M ** 0.5)
+    assert torch.allclose(got["gram"][1], got["direct"][1], rtol=2e-6, atol=1e-3 * M ** 0.5)
+
+
 def ref_backward(x, w, wd, gam, bet, zgam, zbet, isc, ish, gz):
     """autograd (fp64, CPU) of  X -> Y = X W^T -> BN(batch) -> ReLU6 -> dw3x3 s2 -> BN(batch) -> ReLU6, given gz = dL/d(output).
     -> dict of gradients wrt the VIEWED input X (what the unit's dx is), w, gamma/beta of the expand BN, wd, plus the forward tensors"""
