@@ -114,10 +114,11 @@ MFMA_KERNELS = {"mny_pw_fwd", "mny_pw_fwd_bf16"}
 # priced in a SECOND, untimed pass of K event-bracketed steps (brackets cost the GPU its back-to-back dispatch, so they stay out
 # of the timed region): the depthwise forward against HBM (north-star target >= 60 %), the other two GEMM entry points against MFMA
 # round 4: the fused depthwise backward (three entry points, 7.3 ms of the round-3 step, priced nowhere before) against HBM, and the expand +
-# depthwise unit (csrc/exdw.hip: instruction-bound recomputation, no longer an HBM stream) against the fp32 matrix / vector peak
+# depthwise unit (csrc/exdw.hip: instruction-bound recomputation, no longer an HBM stream) against the fp32 matrix / vector peak; its
+# statistics pass reads the thin input once (second-moment matrix, no recomputation of the expand output) and is priced against HBM
 SECOND_PASS = {"mny_dw_fwd": "hbm", "mny_pw_wgrad": "mfma", "mny_pw_dgrad_bnred": "mfma", "mny_pw_bnbwd": "hbm",
                "mny_dw_bnbwd": "hbm", "mny_dw_bnbwd_red": "hbm", "mny_dw_bnbwd_s2": "hbm",
-               "mny_exdw_stats": "mfma", "mny_exdw_fwd": "mfma", "mny_exdw_bwd": "mfma",
+               "mny_exdw_stats": "hbm", "mny_exdw_fwd": "mfma", "mny_exdw_bwd": "mfma",
                "mny_dw_fwd_bf16": "hbm", "mny_pw_wgrad_bf16": "mfma", "mny_pw_dgrad_bnred_bf16": "mfma"}
 
 

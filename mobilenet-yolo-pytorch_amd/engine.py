@@ -346,7 +346,8 @@ class NetPlan:
                     parts = _lib.query("mny_exdw_stat_parts", M, i.C, o.C)
                     if bn_batch:                             # batch statistics of the un-materialised expand output (eval plans use the running ones)
                         self.fwd.add("mny_exdw_stats", xv[0], xv[1], xv[2], xv[3], w, stats, M, i.C, o.C, self.stream,
-                                     meta=dict(flops=2 * M * i.C * o.C, bytes=eb * M * i.C, shape="exdw stats M%d K%d N%d" % (M, i.C, o.C)))
+                                     meta=dict(flops=2 * M * i.C * (i.C + 1), bytes=eb * M * i.C,      # X^T X and colsum(X): one read of the thin X
+                                               shape="exdw stats M%d K%d N%d" % (M, i.C, o.C)))
                 else:
                     i = nd.ins[0]
                     xv = view(i)

@@ -129,7 +129,7 @@ def main():
         "mny_dw_bnbwd": lambda k: bool(re.match(r"dw_bnbwd_s1k3_kernel<.*, false>$", k)),
         "mny_dw_bnbwd_red": lambda k: bool(re.match(r"dw_bnbwd_s1k3_kernel<.*, true>$", k)),
         "mny_dw_bnbwd_s2": lambda k: k.startswith("dw_bnbwd_s2k3_kernel"),
-        "mny_exdw_stats": lambda k: k.startswith("exdw_stats"),
+        "mny_exdw_stats": lambda k: k.startswith("exdw_stats") or k.startswith("exdw_gram_stats"),
         "mny_exdw_fwd": lambda k: k.startswith("exdw_fwd"),
         "mny_exdw_bwd": lambda k: k.startswith("exdw_bwd") or k.startswith("exdw_dxfix"),
     }
