@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Timing of the fused depthwise 3x3 stride-1 backward (csrc/dwbwd.hip) at the shapes of the bs-256 / 352x352 plan.  The knobs of
 that file (MNY_DWB_TH, MNY_DWB_RES, MNY_DWB_XCD, MNY_STENCIL_CGB) are read once per process, so run it once per setting:
-    python tools/bench_dwbwd.py [bs]          prints ms, algorithmic GB/s and fp64 checksums of dX / dW / producer sums per shape"""
+    python tools/bench_dwbwd.py [bs] [f32|bf16]   prints ms, algorithmic GB/s and fp64 checksums of dX / dW / producer sums per shape
+bf16: the shapes of the MobileNetV3-YOLO 512x512 bs-64 plan."""
 import ctypes
 import os
 import sys
@@ -30,14 +31,19 @@ def timeit(fn, reps):
 
 def main():
     bs = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+    bf = len(sys.argv) > 2 and sys.argv[2] == "bf16"
+    dt = torch.bfloat16 if bf else torch.float32
+    sfx = "_bf16" if bf else ""
+    shapes = ((16, 256, 1, 1), (72, 128, 0, 1), (120, 64, 1, 2), (200, 32, 1, 1), (184, 32, 1, 2), (480, 32, 1, 1), (672, 32, 1, 1), (960, 16, 1, 2), (160, 32, 0, 2),
+              (320, 32, 0, 1), (320, 16, 0, 2)) if bf else ((32, 176, 0, 1), (144, 88, 1, 1), (192, 44, 1, 2), (384, 22, 1, 4), (576, 22, 1, 3), (960, 11, 1, 3))
     dev = torch.device("cuda:0")
     st = P(torch.cuda.current_stream().cuda_stream)
     total = 0.0
-    for C, H, red, count in ((32, 176, 0, 1), (144, 88, 1, 1), (192, 44, 1, 2), (384, 22, 1, 4), (576, 22, 1, 3), (960, 11, 1, 3)):
+    for C, H, red, count in shapes:
         N, W = bs, H
         torch.manual_seed(C)
-        g, y, x = (torch.randn(N, H, W, C, device=dev) for _ in range(3))
-        add = torch.randn(N, H, W, C, device=dev)
+        g, y, x = (torch.randn(N, H, W, C, device=dev).to(dt) for _ in range(3))
+        add = torch.randn(N, H, W, C, device=dev).to(dt)
         mk = lambda a, b: (a + b * torch.randn(C, device=dev))  # noqa: E731
         scale, shift = mk(1.0, 0.2), mk(0.0, 0.3)
         coef = torch.stack((mk(1.0, 0.2), mk(0.0, 0.05), mk(0.0, 0.05))).contiguous()
@@ -49,18 +55,18 @@ def main():
         dx, dw = torch.empty_like(x), torch.zeros(C, 3, 3, device=dev)
 
         def plain():
-            _lib.call("mny_dw_bnbwd", ptr(g), ptr(y), ptr(scale), ptr(shift), 1, ptr(coef), ptr(x), ptr(xs), ptr(xh), 1, ptr(w), ptr(add), ptr(dx), ptr(dw),
+            _lib.call("mny_dw_bnbwd" + sfx, ptr(g), ptr(y), ptr(scale), ptr(shift), 1, ptr(coef), ptr(x), ptr(xs), ptr(xh), 1, ptr(w), ptr(add), ptr(dx), ptr(dw),
                       ptr(ws), N, H, W, C, 3, 1, st)
 
         def withred():
-            _lib.call("mny_dw_bnbwd_red", ptr(g), ptr(y), ptr(scale), ptr(shift), 1, ptr(coef), ptr(x), ptr(xs), ptr(xh), 1, ptr(xm), ptr(xi), ptr(w), ptr(add),
+            _lib.call("mny_dw_bnbwd_red" + sfx, ptr(g), ptr(y), ptr(scale), ptr(shift), 1, ptr(coef), ptr(x), ptr(xs), ptr(xh), 1, ptr(xm), ptr(xi), ptr(w), ptr(add),
                       ptr(dx), ptr(dw), ptr(ws), ptr(inred), N, H, W, C, 3, 1, st)
 
         t0 = timeit(plain, 10)
         cs = (dx.double().sum().item(), dx.double().abs().sum().item(), (dw.double() * torch.arange(9, device=dev).view(1, 3, 3)).sum().item())
         t1 = timeit(withred, 10)
         rs = inred.view(parts, 2, C).double().sum(0)
-        gb = 5 * N * H * W * C * 4 / 1e9
+        gb = 5 * N * H * W * C * (2 if bf else 4) / 1e9
         print("C%-4d %3dx%-3d parts %4d: plain %.3f ms (%.0f GB/s)  with producer sums %.3f ms (%.0f GB/s) | dx %.9e %.9e dw %.9e red %.9e %.9e" % (
             C, H, W, parts, t0, gb / t0 * 1e3, t1, gb / t1 * 1e3, cs[0], cs[1], cs[2], rs[0].sum().item(), rs[1].sum().item()), flush=True)
         total += count * (t1 if red else t0)
