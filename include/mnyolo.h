@@ -546,6 +546,24 @@ int mny_exdw_bwd_red(const float* gz, const float* z, const float* z_scale, cons
                      const float* e_gamma, const float* w_dw, const float* addend, float* dx, float* dw_exp, float* dgamma_e, float* dbeta_e,
                      float* dw_dw, float* dw_ws, float* ws, float* in_red, int N, int H, int W, int K, int C, int stride, void* stream);
 
+/* ---- stem + first depthwise unit, backward as one pass (csrc/stemdw.hip): the autograd of nn.Conv2d(3,32,3,2,1) + BN + ReLU6
+ * (models/mobilenetv2.py:40,113) followed by the depthwise nn.Conv2d(32,32,3,1,1,groups=32) + BN + ReLU6 of the first InvertedResidual
+ * (:65-67), given gd = dL/d act(d_scale d + d_shift) (the depthwise unit's output gradient), the depthwise unit's BN-backward
+ * coefficients d_coef[3][32] (mny_bn_bwd_finalize), the raw outputs d (depthwise) and s (stem) with their BN coefficients, and the
+ * NCHW fp32 image.  Replaces mny_dw_bnbwd_red + mny_bn_bwd_finalize + mny_stem_bnwgrad for that pair: the stem's output gradient is
+ * never written (dW_stem = ca o (dz^T P) + cb o (W P^T P) + cc (x) colsum(P), P = the 27-value image patches; fp64 finalize).
+ * Outputs: dw_stem[32,3,3,3], dgamma_s[32], dbeta_s[32], dw_dw[32,3,3] (or, dw_dw == NULL, partial rows
+ * [mny_stemdw_bwd_parts()][32*9] left in dw_ws for mny_reduce_batch).  ws: mny_stemdw_bwd_ws_floats() floats; dw_ws:
+ * mny_stemdw_bwd_parts() * 288 floats.  fp32 storage, Cout = 32, activations of the ReLU / ReLU6 / leaky family. */
+int mny_stemdw_supported(int N, int H, int W, int Cout, int s_act, int d_act);
+int mny_stemdw_bwd_parts(int N, int H, int W, int Cout);
+size_t mny_stemdw_bwd_ws_floats(int N, int H, int W, int Cout);
+int mny_stemdw_bwd(const float* gd, const float* d, const float* d_scale, const float* d_shift, int d_act, const float* d_coef,
+                   const float* s, const float* s_scale, const float* s_shift, const float* s_mean, const float* s_invstd,
+                   const float* s_gamma, int s_act, const float* x_nchw, const float* w_stem, const float* w_dw,
+                   float* dw_stem, float* dgamma_s, float* dbeta_s, float* dw_dw, float* dw_ws, float* ws,
+                   int N, int H, int W, int Cout, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

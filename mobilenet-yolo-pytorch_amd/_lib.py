@@ -55,6 +55,10 @@ _SIGS = {
     "mny_exdw_bwd_red_parts": (c_int, [c_int] * 6),
     "mny_exdw_bwd_red": (c_int, [P, P, P, P, c_int, P, P, P, P, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P,
                                  c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "mny_stemdw_supported": (c_int, [c_int] * 6),
+    "mny_stemdw_bwd_parts": (c_int, [c_int] * 4),
+    "mny_stemdw_bwd_ws_floats": (c_size_t, [c_int] * 4),
+    "mny_stemdw_bwd": (c_int, [P, P, P, P, c_int, P, P, P, P, P, P, P, c_int, P, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "mny_adamw_step": (c_int, [P, c_int, c_double, c_double, c_double, c_double, c_double, c_int64, P]),
     "mny_pw_fwd": (c_int, [P, P, P, c_int, P, P, P, P, P, c_int64, c_int, c_int, P]),
     "mny_pw_stat_parts": (c_int, [c_int64, c_int, c_int]),

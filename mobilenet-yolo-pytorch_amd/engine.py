@@ -666,6 +666,7 @@ class NetPlan:
         for v in outs:
             n_consumers[v.id] += 1
         self.fused_red = {}      # value id -> (partial-sum buffer, rows) written by the data-gradient GEMM that produced the value's gradient
+        self.stemdw_done = set() # stem output ids whose whole backward (BN sums, weight gradient) left with the depthwise consumer's (mny_stemdw_bwd)
         last_consumer = {}       # value id -> the consumer node whose backward runs LAST (order = reverse topological)
         for nd_ in order:
             for v_ in nd_.ins:
@@ -716,8 +717,8 @@ class NetPlan:
             shp = shape(o)
             M = shp[0] * shp[1] * shp[2]
             s = gs[o.id]
-            if o.id in self.exdw_pw:
-                continue                                   # handled with its depthwise consumer (mny_exdw_bwd below)
+            if o.id in self.exdw_pw or o.id in self.stemdw_done:
+                continue                                   # handled with its depthwise consumer (mny_exdw_bwd / mny_stemdw_bwd below)
             assert s.buf is not None, "no gradient reached %s" % o.name
             G = s.buf
             if nd.op == "dw" and o.id in self.exdw_dw:
@@ -862,6 +863,29 @@ class NetPlan:
                         dparts = _lib.query("mny_dw_bnbwd_parts", N, ish[1], ish[2], o.C)
                         dwv_k, ws_k = None, defer_job(dparts * o.C * 9, dwv, dparts, o.C * 9)
                     prod = i.node
+                    # stem -> this depthwise unit (MobileNetV2's first two units): ONE pass yields both units' parameter gradients; the stem's
+                    # output gradient (its only consumer is the stem's weight gradient) is never written (csrc/stemdw.hip)
+                    if (not self.bf16 and not self.frozen and i.kind == "unit" and prod is not None and prod.op == "stem" and gs[i.id].buf is None
+                            and n_consumers[i.id] == 1 and not takes_own_sums(prod) and xv[1] is not None and single(nd) and single(prod)
+                            and _lib.query("mny_stemdw_supported", N, self.H, self.W, i.C, i.act, o.act) == 1):
+                        pu = self.units[i.id]
+                        sparts = _lib.query("mny_stemdw_bwd_parts", N, self.H, self.W, i.C)
+                        xws = torch.empty(max(int(_lib.query("mny_stemdw_bwd_ws_floats", N, self.H, self.W, i.C)), 4), **f32)
+                        if self.defer:
+                            self._red_jobs.pop()            # the job registered above counts the rows of mny_dw_bnbwd's partial buffer
+                            dwv_k, ws_k = None, defer_job(sparts * o.C * 9, dwv, sparts, o.C * 9)
+                        else:
+                            dwv_k, ws_k = dwv, torch.empty(sparts * o.C * 9, **f32)
+                        bwd.add("mny_stemdw_bwd", G, u.Y, u.scale, u.shift, o.act, self.coef_ws, pu.Y, pu.scale, pu.shift, pu.mean, pu.invstd,
+                                P[prod.bn + ".weight"], i.act, self.x_ptr, P[prod.conv + ".weight"], wt,
+                                gv(prod.conv + ".weight"), gv(prod.bn + ".weight"), gv(prod.bn + ".bias"), dwv_k, ws_k, xws,
+                                N, self.H, self.W, i.C, self.stream,
+                                meta=dict(flops=2 * M * o.C * (2 * 9 + 27), bytes=4 * (3 * M * o.C + N * 3 * self.H * self.W), shape="stem+dw C%d H%d" % (o.C, ish[1])))
+                        self.stemdw_done.add(i.id)
+                        flush_shared()
+                        flush_reduce()
+                        bwd.marks[o.name] = len(bwd.calls)
+                        continue
                     # the input is the raw output of a conv+BN+act unit consumed ONLY here: this kernel's dX is that unit's complete
                     # output gradient, so it also leaves the unit's BN-backward sums (mny_dw_bnbwd_red) and the unit's separate
                     # bn_bwd_reduce pass — a re-read of dX and X — disappears (wide expand units, the stem, the neck's pointwise units)
