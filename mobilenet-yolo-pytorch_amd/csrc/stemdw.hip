@@ -24,6 +24,11 @@ namespace mny {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Workgroup barrier that orders LDS traffic only (exdw.hip's): __syncthreads() also waits for every outstanding global load of the wave
+// (s_waitcnt vmcnt(0)) — here that is the rows requested two iterations ahead, i.e. the prefetch would be drained at every row.
+// Nothing crosses waves through global memory inside the row loop.
+__device__ __forceinline__ void sd_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 constexpr int SD_C = 32, SD_CG = 8, SD_SLOTS = 32, SD_OWN = 30, SD_K = 27, SD_DZS = 48;     // SD_DZS: floats per pixel row of the dz_s tile (bank-conflict-free MFMA reads)
 constexpr int SD_IMGW = 68;                                                                 // staged image row: 2 * 32 + 1 columns, padded
 
@@ -42,8 +47,8 @@ struct SdArgs {
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) void stemdw_bwd_kernel(SdArgs p) {
     __shared__ float4 cst[18 * SD_CG];                       // 9 taps, d scale / shift, ca, cb, cc, s scale / shift / mean / invstd, (pad)
     __shared__ float4 ring[4][256];                          // dY rows of the depthwise unit
-    __shared__ __attribute__((aligned(16))) float dzs[SD_SLOTS * SD_DZS];   // the finished row of dz_s: [slot][channel]
-    __shared__ float img[3 * 3 * SD_IMGW];                   // image rows of that row's patches: [ci][kh][column]
+    __shared__ __attribute__((aligned(16))) float dzs[2][SD_SLOTS * SD_DZS];   // the finished row of dz_s: [slot][channel], double-buffered:
+    __shared__ float img[2][3 * 3 * SD_IMGW];                // image rows of that row's patches: [ci][kh][column]    its sums run one row behind
     __shared__ float4 red[256 * 2];
     const SdGeom& g = p.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, lg = lane >> 4;
@@ -96,6 +101,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     const int lb = ((gxd & 7) == 0) ? (int)(blockIdx.x & 7) * (gxd >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     const int64_t rowpitch = (int64_t)g.Wo * SD_C;
     const int64_t plane = (int64_t)g.H * g.W;
+    // image staging: element e = tid + 256 u of the 9 x 65 block (row rr = ci * 3 + kh, column col) — all of it thread-constant
+    int st_off[3], st_col[3], st_kh[3], st_lds[3];
+    bool st_ok[3];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+        const int e = tid + 256 * u;
+        const int rr = e / 65, col = e - rr * 65;
+        st_ok[u] = rr < 9;
+        st_kh[u] = rr % 3;
+        st_col[u] = col;
+        st_off[u] = (int)((rr / 3) * plane) + st_kh[u] * g.W + col;       // + (2 hp - 1) * W + wi0: the (row, tile) part
+        st_lds[u] = rr * SD_IMGW + col;
+    }
+    // this wave's eight pixels (slots 8 wave .. 8 wave + 7) of a finished row: two k-steps of four
+    auto mma_row = [&](int buf, int w0) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int px = 8 * wave + 4 * ks + lg;
+            const bool owned = px >= 1 && px <= SD_OWN && w0 + px - 1 < g.Wo;
+            const float a0 = dzs[buf][px * SD_DZS + l16], a1 = dzs[buf][px * SD_DZS + 16 + l16];
+            float b0 = img[buf][poff[0] + 2 * px], b1 = img[buf][poff[1] + 2 * px];
+            b0 = (owned && pok[0]) ? b0 : 0.f;
+            b1 = (owned && pok[1]) ? b1 : 0.f;
+            cs[0] += b0; cs[1] += b1;
+            accP[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, accP[0][0], 0, 0, 0);
+            accP[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, accP[0][1], 0, 0, 0);
+            accP[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, accP[1][0], 0, 0, 0);
+            accP[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, accP[1][1], 0, 0, 0);
+            accG[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0, b0, accG[0], 0, 0, 0);
+            accG[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0, b1, accG[1], 0, 0, 0);
+            accG[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1, b1, accG[2], 0, 0, 0);
+        }
+    };
     for (int64_t tile = lb; tile < g.ntiles; tile += gxd) {                     // workgroup-uniform: every thread meets every barrier
         const int wt = (int)(tile % g.nWT);
         const int hs = (int)((tile / g.nWT) % g.nHS);
@@ -134,12 +172,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
             const bool mrow = hp >= h0;                         // row r-1 is a finished, owned row of dz_s (hp < h1 by the loop bound)
             float iv[3];
             if (mrow) {
+                const float* xr = xn + (int64_t)(2 * hp - 1) * g.W + wi0;
 #pragma unroll
                 for (int u = 0; u < 3; ++u) {
-                    const int e = tid + 256 * u;                // (ci, kh, column) = e / 65 / 3 ...
-                    const int col = e % 65, rr = e / 65;        // rr = ci * 3 + kh < 9
-                    const int hi = 2 * hp - 1 + rr % 3, wi = wi0 + col;
-                    iv[u] = (rr < 9 && hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) ? xn[(rr / 3) * plane + (int64_t)hi * g.W + wi] : 0.f;
+                    const int hi = 2 * hp - 1 + st_kh[u], wi = wi0 + st_col[u];
+                    iv[u] = (st_ok[u] && hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) ? xr[st_off[u]] : 0.f;
                 }
             }
             const float rokf = (r >= 0 && r < g.Ho) ? 1.f : 0.f;
@@ -154,7 +191,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
             }
             float4* row = &ring[r & 3][0];
             row[tid] = f4u(dyo);
-            __syncthreads();
+            sd_barrier();
+            if (r - 2 >= h0) mma_row((r - 1) & 1, w0);          // the bilinear sums of the row finished one iteration ago (buffers written before this barrier)
             float4 dz4 = f4zero();
             if (inter) {
                 F4P dyr[3];
@@ -211,33 +249,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
                 aprev = ar;
             }
             if (mrow) {                                         // workgroup-uniform
-                *reinterpret_cast<float4*>(&dzs[slot * SD_DZS + c]) = dz4;       // zeros from the halo / past-the-edge slots
+                *reinterpret_cast<float4*>(&dzs[r & 1][slot * SD_DZS + c]) = dz4;    // zeros from the halo / past-the-edge slots
 #pragma unroll
-                for (int u = 0; u < 3; ++u) {
-                    const int e = tid + 256 * u;
-                    if (e < 9 * 65) img[(e / 65) * SD_IMGW + e % 65] = iv[u];
-                }
-                __syncthreads();
-                // this wave's eight pixels (slots 8 wave .. 8 wave + 7): two k-steps of four
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const int px = 8 * wave + 4 * ks + lg;
-                    const bool owned = px >= 1 && px <= SD_OWN && w0 + px - 1 < g.Wo;
-                    const float a0 = dzs[px * SD_DZS + l16], a1 = dzs[px * SD_DZS + 16 + l16];
-                    float b0 = img[poff[0] + 2 * px], b1 = img[poff[1] + 2 * px];
-                    b0 = (owned && pok[0]) ? b0 : 0.f;
-                    b1 = (owned && pok[1]) ? b1 : 0.f;
-                    cs[0] += b0; cs[1] += b1;
-                    accP[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, accP[0][0], 0, 0, 0);
-                    accP[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, accP[0][1], 0, 0, 0);
-                    accP[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, accP[1][0], 0, 0, 0);
-                    accP[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, accP[1][1], 0, 0, 0);
-                    accG[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0, b0, accG[0], 0, 0, 0);
-                    accG[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(b0, b1, accG[1], 0, 0, 0);
-                    accG[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(b1, b1, accG[2], 0, 0, 0);
-                }
+                for (int u = 0; u < 3; ++u)
+                    if (st_ok[u]) img[r & 1][st_lds[u]] = iv[u];
             }
         }
+        sd_barrier();                                           // the last row of the strip
+        mma_row(h1 & 1, w0);
     }
 
     // ---- the block's partial rows ------------------------------------------------------------------------------------------------
