@@ -564,6 +564,20 @@ int mny_stemdw_bwd(const float* gd, const float* d, const float* d_scale, const 
                    float* dw_stem, float* dgamma_s, float* dbeta_s, float* dw_dw, float* dw_ws, float* ws,
                    int N, int H, int W, int Cout, void* stream);
 
+/* ---- project-conv unit, backward as one pass (csrc/pjbwd.hip): the autograd of the linear bottleneck nn.Conv2d(Ki,No,1) + BN that
+ * closes an inverted-residual block (models/mobilenetv2.py:69-70,83-84), given g = dL/d(BN output) [M,No], the unit's raw conv output
+ * y [M,No], its BN-backward coefficients coef[3][No] (mny_bn_bwd_finalize), and the raw output d [M,Ki] of the unit in front (the
+ * depthwise unit; its view = d_scale / d_shift / d_act, its statistics d_mean / d_invstd), consumed only here.  Replaces
+ * mny_bn_bwd_apply + mny_pw_dgrad_bnred + mny_pw_wgrad for that unit: gd[M,Ki] = dY W (the gradient wrt the activated d), the
+ * BN-backward sums of the unit in front as partial rows red[mny_pj_bwd_parts()][2][Ki] (for mny_bn_bwd_finalize), and
+ * dw[No,Ki] = dY^T act(BN(d)) (or, dw == NULL, partial rows [mny_pj_bwd_parts()][No*Ki] left in dw_ws).  d is read once, dY never
+ * touches HBM.  No in {16,24,32}, Ki in {32,96,144,192}, fp32 storage. */
+int mny_pj_bwd_supported(int64_t M, int Ki, int No, int d_act);
+int mny_pj_bwd_parts(int64_t M, int Ki, int No);
+int mny_pj_bwd(const float* g, const float* y, const float* coef, const float* d, const float* d_scale, const float* d_shift,
+               const float* d_mean, const float* d_invstd, int d_act, const float* w, float* gd, float* dw, float* dw_ws, float* red,
+               int64_t M, int Ki, int No, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

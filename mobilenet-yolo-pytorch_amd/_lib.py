@@ -55,6 +55,9 @@ _SIGS = {
     "mny_exdw_bwd_red_parts": (c_int, [c_int] * 6),
     "mny_exdw_bwd_red": (c_int, [P, P, P, P, c_int, P, P, P, P, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P,
                                  c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "mny_pj_bwd_supported": (c_int, [c_int64, c_int, c_int, c_int]),
+    "mny_pj_bwd_parts": (c_int, [c_int64, c_int, c_int]),
+    "mny_pj_bwd": (c_int, [P, P, P, P, P, P, P, P, c_int, P, P, P, P, P, c_int64, c_int, c_int, P]),
     "mny_stemdw_supported": (c_int, [c_int] * 6),
     "mny_stemdw_bwd_parts": (c_int, [c_int] * 4),
     "mny_stemdw_bwd_ws_floats": (c_size_t, [c_int] * 4),
