@@ -118,7 +118,7 @@ MFMA_KERNELS = {"mny_pw_fwd", "mny_pw_fwd_bf16"}
 # statistics pass reads the thin input once (second-moment matrix, no recomputation of the expand output) and is priced against HBM
 SECOND_PASS = {"mny_dw_fwd": "hbm", "mny_pw_wgrad": "mfma", "mny_pw_dgrad_bnred": "mfma", "mny_pw_bnbwd": "hbm",
                "mny_dw_bnbwd": "hbm", "mny_dw_bnbwd_red": "hbm", "mny_dw_bnbwd_s2": "hbm",
-               "mny_exdw_stats": "hbm", "mny_exdw_fwd": "mfma", "mny_exdw_bwd": "mfma", "mny_stemdw_bwd": "hbm",
+               "mny_exdw_stats": "hbm", "mny_exdw_fwd": "mfma", "mny_exdw_bwd": "mfma", "mny_stemdw_bwd": "hbm", "mny_pj_bwd": "hbm",
                "mny_dw_fwd_bf16": "hbm", "mny_pw_wgrad_bf16": "mfma", "mny_pw_dgrad_bnred_bf16": "mfma"}
 
 

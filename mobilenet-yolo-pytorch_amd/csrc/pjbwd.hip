@@ -172,9 +172,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
 static bool pj_shape_ok(int64_t M, int Ki, int No) {
     return M >= 16 && (No == 16 || No == 24 || No == 32) && (Ki == 32 || Ki == 96 || Ki == 144 || Ki == 192);
 }
-static int pj_grid(int64_t M) {
+static int pj_grid(int64_t M, int Ki) {
     const int64_t want = cdiv(cdiv(M, 16), 4);
-    int gx = (int)(want < 512 ? want : 512);           // two workgroups per CU
+    const int cap = Ki == 32 ? 1024 : 512;             // resident workgroups: 88 VGPRs at Ki = 32 (four per CU), 160-250 above (two per CU)
+    int gx = (int)(want < cap ? want : cap);
     return gx < 1 ? 1 : gx;
 }
 
@@ -194,7 +195,7 @@ extern "C" int mny_pj_bwd_supported(int64_t M, int Ki, int No, int d_act) {
     return (!off && pj_shape_ok(M, Ki, No) && d_act != MNY_ACT_HSWISH && d_act != MNY_ACT_HSIGMOID) ? 1 : 0;
 }
 
-extern "C" int mny_pj_bwd_parts(int64_t M, int Ki, int No) { return pj_shape_ok(M, Ki, No) ? pj_grid(M) : MNY_EINVAL; }
+extern "C" int mny_pj_bwd_parts(int64_t M, int Ki, int No) { return pj_shape_ok(M, Ki, No) ? pj_grid(M, Ki) : MNY_EINVAL; }
 
 extern "C" int mny_pj_bwd(const float* g, const float* y, const float* coef, const float* d, const float* d_scale, const float* d_shift,
                           const float* d_mean, const float* d_invstd, int d_act, const float* w, float* gd, float* dw, float* dw_ws, float* red,
@@ -203,7 +204,7 @@ extern "C" int mny_pj_bwd(const float* g, const float* y, const float* coef, con
     MNY_REQUIRE(pj_shape_ok(M, Ki, No) && d_act != MNY_ACT_HSWISH && d_act != MNY_ACT_HSIGMOID, "pj_bwd: M=%lld Ki=%d No=%d act %d not supported",
                 (long long)M, Ki, No, d_act);
     PjArgs a{g, y, coef, d, d_scale, d_shift, d_mean, d_invstd, d_act, w, gd, dw_ws, red, M};
-    const int grid = pj_grid(M);
+    const int grid = pj_grid(M, Ki);
     hipStream_t st = (hipStream_t)stream;
     int rc;
 #define MNY_PJ(NO_, KI_) rc = pj_launch<NO_, KI_>(a, grid, st)

@@ -350,6 +350,8 @@ def test_headline_plan_bs256_352_is_bit_deterministic_and_gives_the_bench_loss()
         assert names.count("mny_exdw_fwd") >= 1 and names.count("mny_exdw_bwd") == names.count("mny_exdw_fwd") == names.count("mny_exdw_stats")
     if os.environ.get("MNY_NO_STEMDW") is None:
         assert names.count("mny_stemdw_bwd") == 1 and "mny_stem_bnwgrad" not in names      # stem + first depthwise unit: one backward pass
+    if os.environ.get("MNY_NO_PJBWD") is None:
+        assert names.count("mny_pj_bwd") == 6                                              # the six thin project units (32->16 ... 192->32)
 
 
 @pytest.mark.skipif(_mem_available_gb() < 96.0, reason="the CPU oracle at bs 256 needs ~60 GB of host memory")

@@ -133,6 +133,7 @@ def main():
         "mny_exdw_fwd": lambda k: k.startswith("exdw_fwd"),
         "mny_exdw_bwd": lambda k: k.startswith("exdw_bwd") or k.startswith("exdw_dxfix"),
         "mny_stemdw_bwd": lambda k: k.startswith("stemdw_bwd"),
+        "mny_pj_bwd": lambda k: k.startswith("pj_bwd"),
     }
     for entry, pred in groups.items():
         g = [(ms, n, f_gb, w_gb) for ms, k, n, f_gb, w_gb in rows if pred(k)]
