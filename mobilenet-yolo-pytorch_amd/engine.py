@@ -947,8 +947,8 @@ class NetPlan:
                 # linear project unit behind a conv+BN+act unit it alone consumes (the thin bottleneck that closes an inverted-residual block):
                 # ONE pass rebuilds dY in LDS, reads the wide input once and yields the data gradient, the input unit's BN-backward sums and the
                 # weight gradient (csrc/pjbwd.hip) — instead of bn_bwd_apply + pw_dgrad_bnred + pw_wgrad
-                if (nd.op == "pw" and not self.bf16 and not self.frozen and o.act == ACT_NONE and not nd.bias and single(nd) and o.id not in self.head_cp
-                        and not s.shared):
+                if nd.op == "pw" and not self.bf16 and not self.frozen and o.act == ACT_NONE and not nd.bias and single(nd) and o.id not in self.head_cp:
+                    # (G is only read here: a gradient buffer shared with the residual path is fine)
                     i = nd.ins[0]
                     prod = i.node
                     if (prod is not None and prod.op in ("dw", "pw") and i.kind == "unit" and gs[i.id].buf is None and n_consumers[i.id] == 1
