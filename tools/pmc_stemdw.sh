@@ -15,7 +15,7 @@ for d in ('pmc_sd1', 'pmc_sd2', 'pmc_sd3'):
     for f in glob.glob('gpurun_out/%s/**/run_counter_collection.csv' % d, recursive=True):
         for r in csv.DictReader(open(f)):
             k = short(r['Kernel_Name'])
-            if 'exdw' in k or 'dw_bnbwd_s2' in k or 'pw_bnbwd' in k or 'pw_thin' in k or 'dw3_fwd' in k:
+            if 'stemdw' in k or 'dw_bnbwd_s1k3' in k or 'stem_tile' in k or 'pj_bwd' in k:
                 tot[k][r['Counter_Name']] += float(r['Counter_Value']); cnt[k][r['Counter_Name']] += 1
 for k in sorted(tot):
     c = {n: v / cnt[k][n] for n, v in tot[k].items()}
@@ -29,5 +29,5 @@ for k in sorted(tot):
         c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / (c.get('SQ_BUSY_CYCLES', 1) or 1) / 4, c.get('SQ_LDS_BANK_CONFLICT', 0) / wc))
 for f in glob.glob('gpurun_out/pmc_sd4/**/run_kernel_stats.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        if any(t in r['Name'] for t in ('exdw', 'dw_bnbwd_s2', 'pw_bnbwd', 'pw_thin', 'dw3_fwd')): print("%-60s calls %s avg %.1f us" % (short(r['Name']), r['Calls'], float(r['AverageNs']) / 1e3))
+        if any(t in r['Name'] for t in ('stemdw', 'dw_bnbwd_s1k3', 'stem_tile', 'pj_bwd')): print("%-60s calls %s avg %.1f us" % (short(r['Name']), r['Calls'], float(r['AverageNs']) / 1e3))
 PY
