@@ -71,6 +71,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
     for (int b = 0; b < NB; ++b) { s1[b] = 0.f; s2[b] = 0.f; }
 
     const int64_t ntiles = (p.M + 15) / 16;
+    constexpr bool PF = NB <= 6;                       // narrow inputs: the NEXT tile's D is requested while this one is processed (4 NB more registers)
+    float dnext[PF ? NB : 1][4];
+    auto load_d = [&](int64_t tt, float (&dst)[PF ? NB : 1][4]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t m = tt * 16 + 4 * r + lg;
+            const float* row = p.d + (m < p.M ? m : p.M - 1) * KI + l16;
+#pragma unroll
+            for (int b = 0; b < (PF ? NB : 1); ++b) dst[b][r] = row[16 * b];
+        }
+    };
+    if (PF && (int64_t)blockIdx.x * 4 + wave < ntiles) load_d((int64_t)blockIdx.x * 4 + wave, dnext);
     for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < ntiles; t += (int64_t)gridDim.x * 4) {
         const int64_t m0 = t * 16;
         // ---- D in the shared register layout (requested first: the long loads) ----
@@ -80,9 +92,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
         for (int r = 0; r < 4; ++r) {
             const int64_t m = m0 + 4 * r + lg;
             pv[r] = m < p.M;
-            const float* row = p.d + (pv[r] ? m : p.M - 1) * KI + l16;
+            if (!PF) {
+                const float* row = p.d + (pv[r] ? m : p.M - 1) * KI + l16;
 #pragma unroll
-            for (int b = 0; b < NB; ++b) dreg[b][r] = row[16 * b];
+                for (int b = 0; b < NB; ++b) dreg[b][r] = row[16 * b];
+            }
+        }
+        if (PF) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dreg[b][r] = dnext[PF ? b : 0][r];
+            const int64_t tn = t + (int64_t)gridDim.x * 4;
+            if (tn < ntiles) load_d(tn, dnext);
         }
         // ---- dY tile -> LDS ----
 #pragma unroll
