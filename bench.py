@@ -143,7 +143,7 @@ def parse():
     ap.add_argument("--launch-check", action="store_true",
                     help="CPU-only self-test of the N-rank launch path: the ranks meet over gloo, rank 0 prints one JSON line (tests/test_host_logic_cpu.py)")
     ap.add_argument("--dp-overhead-child", action="store_true", help="internal: the 1-rank RCCL leg of the default run, in its own process")
-    ap.add_argument("--detail", default="", help="comma list of entry points: print their per-call table to stderr")
+    ap.add_argument("--detail", default="", help="comma list of entry points (or `all`): print their per-call table to stderr")
     return ap.parse_args()
 
 
@@ -842,11 +842,11 @@ def main():
     agg = roofline_from({"fwd": timing["fwd"], "bwd": timing["bwd"]}, {"fwd": plan.fwd.calls, "bwd": plan.bwd.calls}) if rank == 0 else None
     per = {}
     if rank == 0 and a.breakdown and a.detail:
-        want = set(a.detail.split(","))
+        want = None if a.detail == "all" else set(a.detail.split(","))
         for which in ("fwd", "bwd"):
             calls = plan.fwd.calls if which == "fwd" else plan.bwd.calls
             for idx, name, e0, e1 in timing[which]:
-                if name in want:
+                if want is None or name in want:
                     k = (which, idx)
                     per.setdefault(k, [name, calls[idx][3] or {}, 0.0])[2] += e0.elapsed_time(e1)
     second = None
@@ -883,8 +883,11 @@ def main():
             print("sum of bracketed kernels %.3f ms/step; wall %.3f ms/step" % (tot, dt / a.steps * 1e3), file=sys.stderr)
             for (which, idx), (name, meta, ms) in sorted(per.items(), key=lambda kv: -kv[1][2]):
                 ms /= a.steps
-                print("%s %-18s %-28s %8.3f ms  %7.1f TF/s %7.1f GB/s" % (which, name, meta.get("shape", ""), ms,
-                      meta.get("flops", 0) / ms / 1e9 if ms else 0, meta.get("bytes", 0) / ms / 1e6 if ms else 0), file=sys.stderr)
+                print("%s %-18s %-28s %8.3f ms  %7.1f TF/s %7.1f GB/s  #%d" % (which, name, meta.get("shape", ""), ms,
+                      meta.get("flops", 0) / ms / 1e9 if ms else 0, meta.get("bytes", 0) / ms / 1e6 if ms else 0, idx), file=sys.stderr)
+            if os.environ.get("MNY_PRINT_MARKS") and getattr(plan, "bwd", None) is not None:
+                for nm, ci in sorted(plan.bwd.marks.items(), key=lambda kv: kv[1]):
+                    print("mark bwd %-40s ends before call #%d" % (nm, ci), file=sys.stderr)
         dom = max((n for n in agg if n in MFMA_KERNELS), key=lambda n: agg[n]["ms"])
         headline = (a.arch, a.size, a.batch, a.dtype, world) == ("mbv2", SIZE, BATCH, "f32", 1)
         bf16 = a.dtype == "bf16"
@@ -950,23 +953,56 @@ def main():
         if others:
             res["roofline_more"] = [o for o in others if not o["kernel"].startswith("mny_dw_fwd")]   # wgrad, dgrad+reduce (MFMA) and the fused expand-unit backward (HBM)
         if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline()
+            try:
+                res["cpu_baseline"] = cpu_baseline()
+            except Exception as e:                                              # noqa: BLE001 — reported, never at the cost of the line
+                res["cpu_baseline"] = {"error": repr(e)[:300]}
         if world == 1 and not a.no_nms and headline and not use_dp:
             try:
                 res["dp_overhead"] = dp_overhead_leg(a)
                 res["dp_overhead"]["timed_region_ms_per_step"] = round(dt / a.steps * 1e3, 3)
             except Exception as e:                                              # noqa: BLE001 — a side leg must never cost the headline line
                 res["dp_overhead"] = {"error": repr(e)[:300]}
-        if world == 1 and not a.no_nms and headline:
-            del out
-            res["config3"] = config3_leg(device)
-        if world == 1 and not a.no_nms:
-            res["nms"] = nms_bench(device)
-            res["map"] = map_bench(device)
-            res["prep"] = prep_bench(device)
-            res["optimizer"] = optimizer_bench(model)
-            res["pcie_inclusive"] = h2d_bench(step, x)
-        print(json.dumps(res))
+        # The headline object is complete here.  Every side leg below is evidence, never the headline: each runs under try/except (its
+        # object becomes {"error": ...}), config3 additionally under a wall budget, and the ONE json line is printed whatever they do.
+        def side(name, fn, *fargs):
+            t_leg = time.perf_counter()
+            try:
+                res[name] = fn(*fargs)
+            except BaseException as e:                                          # noqa: BLE001 — incl. KeyboardInterrupt from the budget alarm
+                res[name] = {"error": repr(e)[:300]}
+                try:
+                    torch.cuda.synchronize()
+                except Exception:                                               # noqa: BLE001
+                    pass
+            print("bench: side leg %s %.1f s" % (name, time.perf_counter() - t_leg), file=sys.stderr)
+
+        def with_budget(seconds, fn, *fargs):
+            """fn(*fargs) under a SIGALRM wall budget (main thread only; a leg stuck inside one HIP call is not interruptible — the
+            driver's own timeout covers that — but a leg that merely runs long is cut here and the headline still prints)."""
+            import signal
+
+            def on_alarm(_sig, _frm):
+                raise TimeoutError("side leg exceeded its %d s wall budget" % seconds)
+            old = signal.signal(signal.SIGALRM, on_alarm)
+            signal.alarm(seconds)
+            try:
+                return fn(*fargs)
+            finally:
+                signal.alarm(0)
+                signal.signal(signal.SIGALRM, old)
+        try:
+            if world == 1 and not a.no_nms and headline:
+                del out
+                side("config3", with_budget, 240, config3_leg, device)
+            if world == 1 and not a.no_nms:
+                side("nms", nms_bench, device)
+                side("map", map_bench, device)
+                side("prep", prep_bench, device)
+                side("optimizer", optimizer_bench, model)
+                side("pcie_inclusive", h2d_bench, step, x)
+        finally:
+            print(json.dumps(res), flush=True)
     if use_dp:
         dist.destroy_process_group()
 

@@ -519,7 +519,8 @@ int mny_bn_bwd_finalize_frozen(const float* red, int parts, int64_t count, const
  *   mny_exdw_bwd   : given gz = dL/d act(z_scale z + z_shift) and the depthwise unit's BN-backward coefficients z_coef[3][C]
  *                    (mny_bn_bwd_finalize): dw_dw[C,3,3] (or, dw_dw == NULL, partial rows [mny_exdw_bwd_parts()][C*9] left in dw_ws),
  *                    the expand unit's dw_exp[C,K], dgamma_e, dbeta_e, and dx[N,H,W,K] = data gradient wrt the viewed input (+ addend).
- *                    ws: mny_exdw_bwd_ws_floats() floats; dw_ws: mny_exdw_bwd_parts() * C * 9 floats. */
+ *                    ws: mny_exdw_bwd_ws_floats() floats; dw_ws: mny_exdw_bwd_parts() * C * 9 floats.  addend must NOT alias dx
+ *                    (two passes: dx is overwritten before the addend is read) — MNY_EINVAL. */
 int mny_exdw_supported(int N, int H, int W, int K, int C, int stride);
 int mny_exdw_stat_parts(int64_t M, int K, int C);
 int mny_exdw_stats(const float* x, const float* in_scale, const float* in_shift, int in_act, const float* w_exp, float* stats,

@@ -12,6 +12,7 @@ namespace mny {
 
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
+bool allow_lds(const void* kernel, size_t bytes);     // opt a kernel in to > 64 KB of dynamic LDS, once per (kernel, device)
 
 #define MNY_REQUIRE(cond, ...)                 \
     do {                                       \

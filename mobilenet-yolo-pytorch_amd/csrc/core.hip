@@ -2,6 +2,10 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "common.h"
 
 namespace mny {
@@ -22,6 +26,23 @@ int check_launch(const char* what) {
     }
     return MNY_OK;
 }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE property of a kernel: the opt-in is remembered per (kernel, device) so a
+// process that builds plans on a second GPU sets it there too, under a mutex (entry points may be called from several threads).
+bool allow_lds(const void* kernel, size_t bytes) {
+    static std::map<std::pair<const void*, int>, size_t> done;
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lock(mu);
+    auto key = std::make_pair(kernel, dev);
+    auto it = done.find(key);
+    if (it != done.end() && it->second >= bytes) return true;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return false;
+    done[key] = bytes;
+    return true;
+}
+
 __global__ __launch_bounds__(256) void reduce_parts_f64_kernel(const float* __restrict__ parts, int nparts, int n, float* __restrict__ out) {
     __shared__ double red[8][32];
     const int ol = threadIdx.x & 31, slice = threadIdx.x >> 5;

@@ -950,12 +950,8 @@ extern "C" int mny_nms_per_class(const float* rows, const int32_t* seg_begin, co
     hipStream_t st = (hipStream_t)stream;
     const int cap = nms_cap_for(max_seg_rows > 0 && max_seg_rows < capacity ? max_seg_rows : capacity);
     const size_t lds = (size_t)cap * (8 + 4 + 1);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)nms_bucket_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, NMS_CAP * 13);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)nms_bucket_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, NMS_CAP * 13);
-        if (e != hipSuccess) { set_error("nms: hipFuncSetAttribute: %s", hipGetErrorString(e)); return MNY_EHIP; }
-        attr_set = true;
+    if (!allow_lds((const void*)nms_bucket_kernel<false>, NMS_CAP * 13) || !allow_lds((const void*)nms_bucket_kernel<true>, NMS_CAP * 13)) {
+        set_error("nms: hipFuncSetAttribute failed"); return MNY_EHIP;
     }
     if (hipMemsetAsync(status, 0, 4, st) != hipSuccess) { set_error("nms: memset failed"); return MNY_EHIP; }
     char* after = (char*)kbox + align256((size_t)(capacity > 0 ? capacity : 1) * 16);

@@ -192,6 +192,20 @@ __global__ __launch_bounds__(256) void dw_slide_kernel(
 // ~60 VALU per row.  Strips are handed to workgroups XCD-contiguously (workgroup i lands on XCD i % 8): the column / row halo
 // a workgroup shares with its neighbours is then in the same 4-MB L2 instead of going out to the fabric again.
 
+// A row can be REQUESTED one step before it is used (template parameter PF of the forward kernels): the request keeps the bytes as
+// loaded (`raw`: 16 B fp32 / 8 B bf16 per lane) and the widening shifts of bf16 storage run only when the row is consumed, so nothing
+// in the requesting step waits for it.  Why: a thread keeps one row of loads (3 or 5 x 16 B / 8 B) in flight and 3 workgroups per CU
+// are resident — with 8-B lanes that is ~4.7 MB in flight over the chip, i.e. ~2.3 TB/s at the ~2 us a dependent row takes on the
+// short strips of the 16^2 / 32^2 / 64^2 layers (MobileNetV3 512^2 bs 64 measured 1.1-2.6 TB/s); two rows in flight double it.
+template <typename T> struct dw_raw { typedef float4 type; };
+template <> struct dw_raw<bf16_t> { typedef uint2 type; };
+__device__ __forceinline__ float4 dw_ldraw(const float* p) { return ld4(p); }
+__device__ __forceinline__ uint2 dw_ldraw(const bf16_t* p) { return *reinterpret_cast<const uint2*>(p); }
+__device__ __forceinline__ float4 dw_widen(float4 v) { return v; }
+__device__ __forceinline__ float4 dw_widen(uint2 u) {
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+
 // XF: 0 none (value used as is), 1 ReLU6, 2 h-swish, 4 max(z, slope*z) = leaky / relu / scale-only (no upper clip)
 template <int XF>
 __device__ __forceinline__ F4P dw_xf(float4 v, v2f sc_lo, v2f sc_hi, v2f sh_lo, v2f sh_hi, float slope, float hi_clip) {
@@ -218,7 +232,7 @@ __device__ __forceinline__ F4P dw_xf(float4 v, v2f sc_lo, v2f sc_hi, v2f sh_lo, 
     return z;
 }
 
-template <typename T, int S, int XF, bool ADD, bool NT>
+template <typename T, int S, int XF, bool ADD, bool NT, int PF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void dw3_fwd_kernel(
     const T* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift, int in_act,
     const float* __restrict__ w, int flip, const T* __restrict__ addend, T* __restrict__ y, float* __restrict__ parts, DwGeom g) {
@@ -278,30 +292,54 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
 
             // load + transform one input row into r[3]; rows outside the image come out as zeros
             // fetch = the three 16-B loads of one input row (+ pointer bump); finish = view transform, zero if the row is outside
-            auto fetch = [&](float4 (&raw)[3], float& m) {
+            typedef typename dw_raw<T>::type RW;
+            int nfl = (ho1 - ho0) * S + (3 - S);                 // input rows this strip still has to request: TH + 2 (stride 1), 2 TH + 1 (stride 2)
+            auto fetch = [&](RW (&raw)[3], float& m) {
                 m = (hi_next >= 0 && hi_next < g.H) ? 1.f : 0.f;
-                raw[0] = ld4(pl); raw[1] = ld4(pm); raw[2] = ld4(pr);
-                // advance unless the next row would leave the image (the clamped re-read is zeroed by its own `m`)
-                const int64_t step = (hi_next >= 0 && hi_next + 1 < g.H) ? pitch : 0;
+                raw[0] = dw_ldraw(pl); raw[1] = dw_ldraw(pm); raw[2] = dw_ldraw(pr);
+                // advance unless the next row would leave the image (the clamped re-read is zeroed by its own `m`) or, PF = 1, the strip
+                // needs no further row: the look-ahead request past the strip's end then re-reads the line it just loaded (a cache hit that
+                // is never consumed) — a branch around it would put a wait for the newest row in front of the branch (measured in the ISA)
+                --nfl;
+                const int64_t step = (hi_next >= 0 && hi_next + 1 < g.H && (PF == 0 || nfl > 0)) ? pitch : 0;
                 pl += step; pm += step; pr += step;
                 ++hi_next;
             };
-            auto finish = [&](const float4 (&raw)[3], float m, F4P (&r)[3]) {
+            auto finish = [&](const RW (&raw)[3], float m, F4P (&r)[3]) {
                 const float mq[3] = {m * ml, m, m * mr};          // row outside the image / column outside the image -> zeros
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     const v2f m2 = v2f{mq[q], mq[q]};
-                    r[q] = dw_xf<XF>(raw[q], sc_lo, sc_hi, sh_lo, sh_hi, slope, hi_clip);
+                    r[q] = dw_xf<XF>(dw_widen(raw[q]), sc_lo, sc_hi, sh_lo, sh_hi, slope, hi_clip);
                     r[q].lo *= m2; r[q].hi *= m2;
                 }
             };
-            auto load_row = [&](F4P (&r)[3]) { float4 raw[3]; float m; fetch(raw, m); finish(raw, m, r); };
+            // PF = 1: the row(s) of the NEXT step are requested before this step's row is transformed (pa / pb hold them raw)
+            RW pa[3], pb[3];
+            float pma = 0.f, pmb = 0.f;
+            auto load_row = [&](F4P (&r)[3]) {
+                if constexpr (PF == 0) { RW raw[3]; float m; fetch(raw, m); finish(raw, m, r); }
+                else {
+                    RW c[3] = {pa[0], pa[1], pa[2]};
+                    const float cm = pma;
+                    fetch(pa, pma);
+                    finish(c, cm, r);
+                }
+            };
             // stride 2: both rows' loads are issued before either is transformed (6 x 16 B in flight per thread)
             auto load_rows2 = [&](F4P (&ra)[3], F4P (&rb)[3]) {
-                float4 wa[3], wb[3]; float ma, mb;
-                fetch(wa, ma); fetch(wb, mb);
-                __builtin_amdgcn_sched_barrier(0);
-                finish(wa, ma, ra); finish(wb, mb, rb);
+                if constexpr (PF == 0) {
+                    RW wa[3], wb[3]; float ma, mb;
+                    fetch(wa, ma); fetch(wb, mb);
+                    __builtin_amdgcn_sched_barrier(0);
+                    finish(wa, ma, ra); finish(wb, mb, rb);
+                } else {
+                    RW ca[3] = {pa[0], pa[1], pa[2]}, cb[3] = {pb[0], pb[1], pb[2]};
+                    const float cma = pma, cmb = pmb;
+                    fetch(pa, pma); fetch(pb, pmb);
+                    __builtin_amdgcn_sched_barrier(0);
+                    finish(ca, cma, ra); finish(cb, cmb, rb);
+                }
             };
             auto emit = [&](const F4P (&top)[3], const F4P (&mid)[3], const F4P (&bot)[3]) {
                 F4P o = f4p0();
@@ -323,6 +361,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
             };
             F4P r0[3], r1[3], r2[3];
             int left = ho1 - ho0;
+            if constexpr (PF != 0) {
+                fetch(pa, pma);               // the strip's first row; every load_row / load_rows2 below requests the one(s) after its own
+                if (S == 2) {                 // (stride 2: the single leading row is consumed alone, then pairs)
+                    RW c[3] = {pa[0], pa[1], pa[2]};
+                    const float cm = pma;
+                    fetch(pa, pma); fetch(pb, pmb);
+                    finish(c, cm, r0);
+                }
+            }
             if (S == 1) {
                 load_row(r0);                 // row ho0-1
                 load_row(r1);                 // row ho0
@@ -336,7 +383,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                 if (left >= 1) { load_row(r2); emit(r0, r1, r2); }
                 if (left >= 2) { load_row(r0); emit(r1, r2, r0); }
             } else {
-                load_row(r0);                 // row 2*ho0-1
+                if constexpr (PF == 0) load_row(r0);                 // row 2*ho0-1
 #pragma clang loop unroll(disable)
                 for (; left >= 3; left -= 3) {
                     load_rows2(r1, r2); emit(r0, r1, r2);
@@ -818,8 +865,12 @@ static int dw_launch(const T* x, const float* sc, const float* sh, int act, cons
     }
     if (MODE == 0 && dw_use_v2(K, MODE) && (addend == nullptr || (sc == nullptr && act == MNY_ACT_NONE))) {     // an addend only occurs without a view (backward-data)
         const int xf2 = (sc == nullptr && act == MNY_ACT_NONE) ? 0 : (act == MNY_ACT_RELU6 ? 1 : (act == MNY_ACT_HSWISH ? 2 : 4));
-#define MNY_DW2(S_, X_, A_) do { if (g.nt) hipLaunchKernelGGL((dw3_fwd_kernel<T, S_, X_, A_, true>), grid, block, 0, st, x, sc, sh, act, w, flip, addend, y, parts, g); \
-        else hipLaunchKernelGGL((dw3_fwd_kernel<T, S_, X_, A_, false>), grid, block, 0, st, x, sc, sh, act, w, flip, addend, y, parts, g); } while (0)
+        // rows requested one step ahead (PF = 1): default for bf16 storage (8-B lanes: see dw_raw); MNY_DW_PF=0/1 forces it for both storage types
+        static const int pf_env = getenv("MNY_DW_PF") ? atoi(getenv("MNY_DW_PF")) : -1;
+        const int pf = pf_env >= 0 ? (pf_env != 0) : (std::is_same<T, bf16_t>::value ? 1 : 0);
+#define MNY_DW2P(S_, X_, A_, N_) do { if (pf) hipLaunchKernelGGL((dw3_fwd_kernel<T, S_, X_, A_, N_, 1>), grid, block, 0, st, x, sc, sh, act, w, flip, addend, y, parts, g); \
+        else hipLaunchKernelGGL((dw3_fwd_kernel<T, S_, X_, A_, N_, 0>), grid, block, 0, st, x, sc, sh, act, w, flip, addend, y, parts, g); } while (0)
+#define MNY_DW2(S_, X_, A_) do { if (g.nt) MNY_DW2P(S_, X_, A_, true); else MNY_DW2P(S_, X_, A_, false); } while (0)
 #define MNY_DW2S(S_) do { if (xf2 == 0) { if (addend) MNY_DW2(S_, 0, true); else MNY_DW2(S_, 0, false); } else if (xf2 == 1) MNY_DW2(S_, 1, false); \
         else if (xf2 == 2) MNY_DW2(S_, 2, false); else MNY_DW2(S_, 4, false); } while (0)
         if (K == 3) { if (stride == 1) MNY_DW2S(1); else MNY_DW2S(2); }

@@ -532,13 +532,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 template <int K>
 static int ex_fwd2_launch(const ExFwdArgs& a, bool xf, int grid, hipStream_t st) {
     const size_t lds = ExF<K>::LDS;
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute((const void*)exdw_fwd2_s2_kernel<K, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute((const void*)exdw_fwd2_s2_kernel<K, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            set_error("exdw_fwd: hipFuncSetAttribute failed"); return MNY_EHIP;
-        }
-        attr = true;
+    if (!allow_lds((const void*)exdw_fwd2_s2_kernel<K, 0>, lds) || !allow_lds((const void*)exdw_fwd2_s2_kernel<K, 1>, lds)) {
+        set_error("exdw_fwd: hipFuncSetAttribute failed"); return MNY_EHIP;
     }
     if (xf) hipLaunchKernelGGL((exdw_fwd2_s2_kernel<K, 1>), dim3(grid), dim3(512), lds, st, a);
     else hipLaunchKernelGGL((exdw_fwd2_s2_kernel<K, 0>), dim3(grid), dim3(512), lds, st, a);
@@ -1036,13 +1031,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
 template <int K>
 static int ex_bwd1v2_launch(const ExBwdArgs& a, bool xf, int grid, hipStream_t st) {
     const size_t lds = ExB1<K>::LDS;
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute((const void*)exdw_bwd1v2_s2_kernel<K, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute((const void*)exdw_bwd1v2_s2_kernel<K, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-            set_error("exdw_bwd: hipFuncSetAttribute failed"); return MNY_EHIP;
-        }
-        attr = true;
+    if (!allow_lds((const void*)exdw_bwd1v2_s2_kernel<K, 0>, lds) || !allow_lds((const void*)exdw_bwd1v2_s2_kernel<K, 1>, lds)) {
+        set_error("exdw_bwd: hipFuncSetAttribute failed"); return MNY_EHIP;
     }
     if (xf) hipLaunchKernelGGL((exdw_bwd1v2_s2_kernel<K, 1>), dim3(grid), dim3(512), lds, st, a);
     else hipLaunchKernelGGL((exdw_bwd1v2_s2_kernel<K, 0>), dim3(grid), dim3(512), lds, st, a);
@@ -1193,6 +1183,8 @@ static int exdw_bwd_impl(const float* gz, const float* z, const float* z_scale, 
     MNY_REQUIRE(z_act == MNY_ACT_RELU6, "exdw_bwd: the depthwise unit's activation must be ReLU6 (got %d)", z_act);
     MNY_REQUIRE(!in_scale == !in_shift, "exdw_bwd: scale and shift come together");
     MNY_REQUIRE(in_act <= MNY_ACT_RELU, "exdw_bwd: unsupported input activation %d", in_act);
+    // two passes: the first OVERWRITES dx with dz (ca o W)^T, only the remainder kernel reads the addend -> an addend aliased to dx would be lost
+    MNY_REQUIRE(addend != dx, "exdw_bwd: addend must not alias dx (the first pass overwrites dx before the addend is read)");
     const ExGeom g = ex_geom(N, H, W, K, C, kExTHB);
     const int grid = ex_bwd1_grid(g);
     const ExWs o = ex_ws(g, grid);

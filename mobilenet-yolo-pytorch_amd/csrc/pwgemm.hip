@@ -1013,13 +1013,7 @@ static size_t nt2_lds(int TN, int K, bool xf, int BF = 0) {
 // kernels whose dynamic LDS exceeds the 64 KB default need the opt-in once (the pre-cut planes mode at TN >= 4 with a deep scale cache)
 static void nt2_allow_lds(Nt2Kernel k, size_t lds) {
     if (lds <= 64 * 1024) return;
-    static std::map<const void*, size_t> done;
-    static std::mutex mu;
-    std::lock_guard<std::mutex> lock(mu);
-    auto it = done.find((const void*)k);
-    if (it != done.end() && it->second >= lds) return;
-    (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    done[(const void*)k] = lds;
+    (void)allow_lds((const void*)k, lds);
 }
 
 // ---- pre-cut weight planes for the six-product form --------------------------------------------------------------------------
@@ -2815,16 +2809,14 @@ static int pw_fwd_v1(const T* x, const float* in_scale, const float* in_shift, i
     MNY_REQUIRE(pl.lds <= 160 * 1024, "pw_fwd: K=%d too large for the LDS scale cache", K);
     GemmArgs a{x, in_scale, in_shift, in_act, w, bias, addend, y, stats, M, K, Nc, pl.m_tiles, pl.tiles_per_block};
     dim3 grid(pl.gx, pl.n_tiles), block(256);
-    static bool attr_done = false;
-    if (!attr_done) {                             // > 64 KB of dynamic LDS needs an explicit opt-in per kernel
+    {                             // > 64 KB of dynamic LDS needs an explicit opt-in per kernel
         const void* ks[] = {(const void*)pw_gemm_nt_kernel<T, 1, 16>, (const void*)pw_gemm_nt_kernel<T, 2, 16>, (const void*)pw_gemm_nt_kernel<T, 3, 16>,
                             (const void*)pw_gemm_nt_kernel<T, 4, 16>, (const void*)pw_gemm_nt_kernel<T, 1, 32>, (const void*)pw_gemm_nt_kernel<T, 2, 32>,
                             (const void*)pw_gemm_nt_kernel<T, 3, 32>, (const void*)pw_gemm_nt_kernel<T, 4, 32>};
         for (const void* k : ks)
-            if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+            if (!allow_lds(k, 160 * 1024)) {
                 set_error("pw_fwd: hipFuncSetAttribute failed"); return MNY_EHIP;
             }
-        attr_done = true;
     }
 #define MNY_NT(TN_, B) hipLaunchKernelGGL((pw_gemm_nt_kernel<T, TN_, B>), grid, block, pl.lds, st, a)
     switch (pl.TN * 100 + pl.BK) {
@@ -3143,14 +3135,8 @@ static int pw_wgrad_impl(const T* x, const float* in_scale, const float* in_shif
         const int XF = (in_scale == nullptr && in_act == MNY_ACT_NONE) ? 0 : (in_act == MNY_ACT_HSWISH ? 2 : 1);
         dk = wg_bf16_kernel(pl.mode, pl.TI, pl.TJ, XF);
         if (dk && pl.lds_dma > 64 * 1024) {      // > 64 KB of dynamic LDS needs a per-kernel opt-in (once)
-            static std::map<const void*, bool> done;
-            static std::mutex mu;
-            std::lock_guard<std::mutex> lock(mu);
-            if (!done[(const void*)dk]) {
-                if (hipFuncSetAttribute((const void*)dk, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-                    set_error("pw_wgrad: hipFuncSetAttribute failed"); return MNY_EHIP;
-                }
-                done[(const void*)dk] = true;
+            if (!allow_lds((const void*)dk, 160 * 1024)) {
+                set_error("pw_wgrad: hipFuncSetAttribute failed"); return MNY_EHIP;
             }
         }
     }
@@ -3279,23 +3265,13 @@ extern "C" int mny_pw_bnbwd(const float* g, const float* y, const float* scale, 
     const int64_t npairs = (M / 2 + 66) / 2 * 2;                      // even (16-B aligned rows of words) + a tile of slack
     BnwArgs a{g, y, scale, shift, act, mean, invstd, x, in_scale, in_shift, in_act, ws, mask, npairs, M, K, Nc, pl.rows_per_block, pl.TI};
     dim3 grid(pl.splits, pl.nsl), block(256);
-    static bool attr1 = false;
-    if (!attr1) {                                   // TI >= 5 needs more than 64 KB of dynamic LDS
-        if (hipFuncSetAttribute((const void*)pw_bnbwd_stage1_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void*)pw_bnbwd_stage1_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) {
-            set_error("pw_bnbwd: hipFuncSetAttribute failed"); return MNY_EHIP;
-        }
-        attr1 = true;
+    if (!allow_lds((const void*)pw_bnbwd_stage1_kernel<5>, 96 * 1024) || !allow_lds((const void*)pw_bnbwd_stage1_kernel<6>, 96 * 1024)) {     // TI >= 5 needs more than 64 KB of dynamic LDS
+        set_error("pw_bnbwd: hipFuncSetAttribute failed"); return MNY_EHIP;
     }
     static const bool s1v2 = getenv("MNY_BNW_S1V2") == nullptr || atoi(getenv("MNY_BNW_S1V2")) != 0;     // (=0: first-generation stage 1, A/B)
     if (s1v2) {
-        static bool attr1b = false;
-        if (!attr1b) {
-            if (hipFuncSetAttribute((const void*)pw_bnbwd_stage1b_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess ||
-                hipFuncSetAttribute((const void*)pw_bnbwd_stage1b_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) {
-                set_error("pw_bnbwd: hipFuncSetAttribute failed"); return MNY_EHIP;
-            }
-            attr1b = true;
+        if (!allow_lds((const void*)pw_bnbwd_stage1b_kernel<5>, 96 * 1024) || !allow_lds((const void*)pw_bnbwd_stage1b_kernel<6>, 96 * 1024)) {
+            set_error("pw_bnbwd: hipFuncSetAttribute failed"); return MNY_EHIP;
         }
         switch (pl.TIs) {
             case 1: hipLaunchKernelGGL((pw_bnbwd_stage1b_kernel<1>), grid, block, pl.lds1, st, a); break;
@@ -3320,12 +3296,8 @@ extern "C" int mny_pw_bnbwd(const float* g, const float* y, const float* scale, 
                        (double)M, Nc, K, dw, dgamma, dbeta, B1, Q, bias);
     rc = check_launch("pw_bnbwd_finalize_kernel");
     if (rc || !dx) return rc;
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute((const void*)pw_bnbwd_dgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess) {
-            set_error("pw_bnbwd: hipFuncSetAttribute failed"); return MNY_EHIP;
-        }
-        attr = true;
+    if (!allow_lds((const void*)pw_bnbwd_dgrad_kernel, 96 * 1024)) {
+        set_error("pw_bnbwd: hipFuncSetAttribute failed"); return MNY_EHIP;
     }
     BndArgs d{g, mask, act, x, in_scale, in_shift, in_act, B1, Q, bias, addend, dx, npairs, M, Nc, K, pl.TI, pl.m_tiles, pl.tiles_per_block};
     static const int v2 = getenv("MNY_BND_V2") ? atoi(getenv("MNY_BND_V2")) : 1;

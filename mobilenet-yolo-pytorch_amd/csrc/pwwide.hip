@@ -368,18 +368,8 @@ int pw_wide_launch(const float* A, const float* in_scale, const float* in_shift,
     MNY_REQUIRE(in_act != MNY_ACT_HSIGMOID, "pw_wide: h-sigmoid input transform is not supported");
     WideArgs a{A, in_scale, in_shift, in_act, W, C, stats, M, K, N, pl.gx, pl.n_blocks, pl.ntiles, rY, r_scale, r_shift, r_mean, r_invstd, r_act, addend};
     const WideKernel k = wide_pick(pl.KS, pl.TNB, XF, mode);
-    static std::mutex mu;
-    static std::vector<const void*> allowed;
-    {
-        std::lock_guard<std::mutex> lock(mu);
-        bool seen = false;
-        for (const void* q : allowed) seen |= q == (const void*)k;
-        if (!seen) {                                  // > 64 KB of dynamic LDS needs an explicit opt-in per kernel
-            if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) {
-                set_error("pw_wide: hipFuncSetAttribute failed"); return MNY_EHIP;
-            }
-            allowed.push_back((const void*)k);
-        }
+    if (!allow_lds((const void*)k, 80 * 1024)) {      // > 64 KB of dynamic LDS needs an explicit opt-in per kernel (and device)
+        set_error("pw_wide: hipFuncSetAttribute failed"); return MNY_EHIP;
     }
     hipLaunchKernelGGL(k, dim3(pl.grid), dim3(256), pl.lds, st, a);
     return check_launch("pw_wide_kernel");

@@ -210,7 +210,7 @@ class NetPlan:
         (running statistics, buffers untouched) — forward only, or with frozen_bwd the backward list of frozen BatchNorm
         (the statistics are constants of the step: mbv2_yolo.py:157 under model.eval() with gradients)."""
         self.net, self.N, self.H, self.W, self.training = net, N, H, W, training
-        bn_batch = training if bn_batch is None else (bn_batch and training)
+        bn_batch = training if bn_batch is None else bool(bn_batch)      # (bn_batch without training: decode + NMS on batch statistics, model.train()(images))
         self.bn_batch = bn_batch
         self.frozen = bool(training and not bn_batch and frozen_bwd)
         self.fwd_gen = 0
@@ -230,6 +230,7 @@ class NetPlan:
         self.x_ptr = _vp(0)
         self.timing = None
         self.routes = {"fwd": {}, "bwd": {}}     # call index -> kernel family the dispatcher actually took (recorded at the first replay)
+        self._recorded = set()                   # (which, begin, end) segments whose first replay has been recorded
         self.reducer = None
         # optional hipGraph replay (MNY_HIPGRAPH=1): after two eager steps (which also run every one-time HIP attribute /
         # occupancy query) the call lists are captured once per segment and replayed.  Measured on MI355X: no gain
@@ -241,8 +242,9 @@ class NetPlan:
         # bs=256/352x352, where every kernel fills the chip (49.4 vs 49.5-49.8 ms), +3 % on MobileNetV3 512x512 bs=64 bf16, whose
         # 10-100 us kernels leave CUs idle (17.7 -> 17.2 ms).  Round 4 (same-box, un-bracketed steps): bs 256 / 352x352 38.19 -> 37.98 and
         # 38.07 -> 37.91 ms, so it is on up to 48 M input pixels; fewer resident depthwise-backward workgroups to make room for the side
-        # kernels lose more than the overlap gains (MNY_DWB_RES=512: +0.3 ms).  bench.py's timed region brackets its dominant kernels with
-        # HIP events and therefore runs single-stream: its `value` does not contain this.  MNY_SIDE_STREAM=0/1 forces.
+        # kernels lose more than the overlap gains (MNY_DWB_RES=512: +0.3 ms).  A step whose launches are bracketed with HIP events runs
+        # single-stream (the brackets must mean something): bench.py brackets every 4th timed step (--bracket-every), so three quarters of
+        # the steps behind its `value` run with the side stream, one quarter without.  MNY_SIDE_STREAM=0/1 forces.
         env_side = os.environ.get("MNY_SIDE_STREAM")
         auto_side = N * H * W <= 48 * 1000 * 1000
         self.side_on = training and not self.use_graphs and (env_side == "1" or (env_side is None and auto_side))
@@ -630,13 +632,14 @@ class NetPlan:
                 s.buf, s.shared = nb, False
             bwd.add(K("mny_axpy"), buf, None, s.buf, 1, s.buf.numel(), self.stream)
 
-        def contribute_kernel(v, emit):
-            """emit(out, addend) appends the producing call."""
+        def contribute_kernel(v, emit, inplace_ok=True):
+            """emit(out, addend) appends the producing call.  inplace_ok=False: the kernel cannot take addend == out (the two-pass
+            expand + depthwise backward overwrites `out` before it reads the addend): an existing gradient becomes the addend of a fresh buffer."""
             s = gs[v.id]
             if s.buf is None:
                 s.buf, s.shared = alloc(v), False
                 emit(s.buf, None)
-            elif not s.shared:
+            elif not s.shared and inplace_ok:
                 emit(s.buf, s.buf)
             else:
                 nb = alloc(v)
@@ -761,7 +764,7 @@ class NetPlan:
                         "mny_exdw_bwd_red", G, u.Y, u.scale, u.shift, act, self.coef_ws, xv[0], xv[1], xv[2], xv[3], ppu.mean, ppu.invstd, P[pn.conv + ".weight"],
                         pu.scale, pu.shift, pu.mean, pu.invstd, P[pn.bn + ".weight"], P[nd.conv + ".weight"], addend, out, dwe, dge, dbe,
                         dwv_k, dws_k, xws, rbuf, N, psh[1], psh[2], Kc, C, 2, self.stream, label="mny_exdw_bwd",
-                        meta=dict(flops=6 * Mx * Kc * C + 6 * M * C * 9, bytes=self.eb * (3 * Mx * Kc + 4 * M * C), shape="exdw K%d C%d H%d +red" % (Kc, C, psh[1]))))
+                        meta=dict(flops=6 * Mx * Kc * C + 6 * M * C * 9, bytes=self.eb * (3 * Mx * Kc + 4 * M * C), shape="exdw K%d C%d H%d +red" % (Kc, C, psh[1]))), inplace_ok=False)
                     flush_shared()
                     flush_reduce()
                     bwd.marks[o.name] = len(bwd.calls)
@@ -771,7 +774,7 @@ class NetPlan:
                     "mny_exdw_bwd", G, u.Y, u.scale, u.shift, act, self.coef_ws, xv[0], xv[1], xv[2], xv[3], P[pn.conv + ".weight"],
                     pu.scale, pu.shift, pu.mean, pu.invstd, P[pn.bn + ".weight"], P[nd.conv + ".weight"], addend, out, dwe, dge, dbe,
                     dwv_k, dws_k, xws, N, psh[1], psh[2], Kc, C, 2, self.stream,
-                    meta=dict(flops=6 * Mx * Kc * C + 6 * M * C * 9, bytes=self.eb * (3 * Mx * Kc + 4 * M * C), shape="exdw K%d C%d H%d" % (Kc, C, psh[1]))))    # algorithmic: the expand output once per pass + P1 + dX; the transposed stencil per pass + dW_dw; X twice + dX once, G_z and Z twice
+                    meta=dict(flops=6 * Mx * Kc * C + 6 * M * C * 9, bytes=self.eb * (3 * Mx * Kc + 4 * M * C), shape="exdw K%d C%d H%d" % (Kc, C, psh[1]))), inplace_ok=False)    # algorithmic: the expand output once per pass + P1 + dX; the transposed stencil per pass + dW_dw; X twice + dX once, G_z and Z twice
                 flush_shared()
                 flush_reduce()
                 bwd.marks[o.name] = len(bwd.calls)
@@ -1186,9 +1189,10 @@ class NetPlan:
             calls.run_timed(self.timing[which], self.timing["only"], begin, end)
             return
         if not (self.use_graphs and self.eager_steps >= 2):
-            rec = self.routes[which]
-            if rec is not None and not all(i in rec for i in range(begin, len(calls.calls) if end is None else end)):
-                calls.run_recording(rec, begin, end)          # the first replay of every call: which kernel family its dispatcher took
+            key = (which, begin, end)
+            if key not in self._recorded:
+                calls.run_recording(self.routes[which], begin, end)          # the first replay of every segment: which kernel family each dispatcher took
+                self._recorded.add(key)
             else:
                 calls.run(begin, end)
             return

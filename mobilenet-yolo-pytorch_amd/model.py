@@ -189,7 +189,8 @@ class yolo(nn.Module):
     PLAN_BUDGET_FRAC = 0.6        # share of the device's HBM the cached plans may keep resident
 
     def _plan(self, N, H, W, training):
-        """`training`: True (loss + backward, batch statistics), False (decode + NMS, running statistics), "evalloss" (loss on running
+        """`training`: True (loss + backward, batch statistics), False (decode + NMS, running statistics), "traindet" (decode + NMS on BATCH
+        statistics with the running-statistics update: `model.train()(images)`, mbv2_yolo.py:158-166 in training mode), "evalloss" (loss on running
         statistics, no statistics update, forward only: `model.eval()(images, targets)` under no_grad) or "evalgrad" (the same with the
         backward list of frozen BatchNorm: `model.eval()(images, targets)` with gradients, mbv2_yolo.py:157)."""
         key = (N, H, W, training) if self.act_dtype == torch.float32 else (N, H, W, training, "bf16")
@@ -201,7 +202,8 @@ class yolo(nn.Module):
             _lib.load()
             self._plans.pop(key, None)
             before = torch.cuda.memory_allocated(self.device)
-            p = NetPlan(self, N, H, W, bool(training), self.act_dtype, bn_batch=(training is True), frozen_bwd=(training == "evalgrad"))
+            p = NetPlan(self, N, H, W, training in (True, "evalloss", "evalgrad"), self.act_dtype, bn_batch=(training is True or training == "traindet"),
+                        frozen_bwd=(training == "evalgrad"))
             p.resident_bytes = max(torch.cuda.memory_allocated(self.device) - before, 0)
             self._plans[key] = p
             # multi-scale training keeps one plan per size: bound them by resident BYTES (a bs=256/352x352 training plan holds
@@ -306,8 +308,13 @@ class yolo(nn.Module):
     def _forward_eval(self, x):
         N, _, H, W = x.shape
         if self.training:
-            raise RuntimeError("call model.eval() before inference (the reference's eval path uses running statistics)")
-        plan = self._plan(N, H, W, False)
+            # model.train()(images): the reference decodes + runs NMS in any mode (mbv2_yolo.py:158-166); its BatchNorm layers are then in
+            # training mode — batch statistics, running statistics and num_batches_tracked updated — and so are these
+            plan = self._plan(N, H, W, "traindet")
+            nbt = [b for k, b in self.named_buffers() if k.endswith("num_batches_tracked")]
+            torch._foreach_add_(nbt, 1)
+        else:
+            plan = self._plan(N, H, W, False)
         with torch.no_grad():
             plan.forward_eval(x, [float(h.val_conf) for h in self.yolo_losses])
             counts = plan.out_counts.tolist()                                   # the one host sync of the eval path

@@ -291,3 +291,23 @@ def test_backward_with_the_input_units_bn_sums_equals_a_separate_reduce_pass(K, 
     torch.cuda.synchronize()
     got, want = ired.double().sum(0).cpu(), red2.double().sum(0).cpu()
     assert torch.allclose(got, want, rtol=1e-5, atol=1e-3 * float(want.abs().max())), (got, want)
+
+
+def test_backward_refuses_an_addend_aliased_to_dx():
+    """the backward is two-pass — pass 1 overwrites dx, only the remainder kernel reads the addend — so addend == dx would lose
+    the earlier gradient silently.  The entry point refuses it (and the engine never emits it: contribute_kernel(..., inplace_ok=False))."""
+    dev = torch.device("cuda:0")
+    K, N, H, W = 16, 2, 20, 20
+    C, Ho, Wo = 6 * K, H // 2, W // 2
+    z = lambda *s: torch.zeros(*s, device=dev)  # noqa: E731
+    ws = z(int(_lib.query("mny_exdw_bwd_ws_floats", N, H, W, K, C, 2)))
+    dws = z(_lib.query("mny_exdw_bwd_parts", N, H, W, K, C, 2) * C * 9)
+    dx = z(N, H, W, K)
+    v = [z(C) for _ in range(8)]
+    args = lambda addend: (ptr(z(N, Ho, Wo, C)), ptr(z(N, Ho, Wo, C)), ptr(v[0]), ptr(v[1]), 1, ptr(z(3, C)), ptr(z(N, H, W, K)), None, None, 0,  # noqa: E731
+                           ptr(z(C, K)), ptr(v[2]), ptr(v[3]), ptr(v[4]), ptr(v[5]), ptr(v[6]), ptr(z(C, 3, 3)), ptr(addend), ptr(dx), ptr(z(C, K)),
+                           ptr(v[7]), ptr(z(C)), ptr(z(C, 3, 3)), ptr(dws), ptr(ws), N, H, W, K, C, 2, stream())
+    with pytest.raises(_lib.MnyError, match="alias"):
+        _lib.call("mny_exdw_bwd", *args(dx))
+    _lib.call("mny_exdw_bwd", *args(z(N, H, W, K)))          # a separate addend is fine
+    torch.cuda.synchronize()
