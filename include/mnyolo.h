@@ -579,6 +579,55 @@ int mny_pj_bwd(const float* g, const float* y, const float* coef, const float* d
                const float* d_mean, const float* d_invstd, int d_act, const float* w, float* gd, float* dw, float* dw_ws, float* red,
                int64_t M, int Ki, int No, void* stream);
 
+/* ---- MobileNetV3's per-pixel gate as one unit (csrc/gate.hip), bf16 storage: models/mobilenetv3.py:26-41 (SeModule whose avg_pool is
+ * never called: the gate is per pixel) applied to the project conv's output (:69-71) —
+ *     t = s3 * y3 + b3;  h = relu(BN1(W1 t));  gate = relu6(BN2(W2 h) + 3) / 6;  out = t * gate (+ view(add_x): the residual add of :72)
+ * with the hidden tensors (and, backward, their gradients) never written.  Training-mode BatchNorm needs the batch statistics of W1 t
+ * and of W2 h before they are used, so the forward is three streaming passes over y3 [M,C] with mny_bn_finalize in between:
+ *   mny_gate_stats1_bf16 -> partial rows [mny_gate_parts(M)][2][R] of W1 t   (then mny_bn_finalize(..., R) -> sc1, sh1, mean1, invstd1)
+ *   mny_gate_stats2_bf16 -> partial rows [mny_gate_parts(M)][2][C] of W2 h   (then mny_bn_finalize(..., C) -> sc2, sh2, mean2, invstd2)
+ *   mny_gate_fwd_bf16    -> out [M,C]
+ * and the backward, given dout = dL/d(out) [M,C] (the residual operand's gradient is dout itself), three more with
+ * mny_bn_bwd_finalize in between:
+ *   mny_gate_bwd1_bf16 -> BN2's backward sums, partial rows red2 [mny_gate_bwd_parts(M)][2][C]   (finalize -> dgamma2, dbeta2, coef2[3][C])
+ *   mny_gate_bwd2_bf16 -> BN1's backward sums red1 [..][2][R] (finalize -> dgamma1, dbeta1, coef1[3][R]) and dW2 as partial
+ *                         rows dw2_parts [mny_gate_bwd_parts(M)][C*R] (mny_reduce_batch)
+ *   mny_gate_bwd3_bf16 -> dt [M,C] = dL/d(t) (both uses of t), dW1 as partial rows dw1_parts [..][R*C], and optionally
+ *                         (red3 != NULL, mny_gate_bwd_red3_supported) the project unit's own BN-backward sums red3 [..][2][C] over
+ *                         (dt, y3) — what a separate mny_bn_bwd_reduce pass would compute (mean3 / invstd3: its statistics).
+ * wq: the two 1x1 conv weights (w1 [R,C], w2 [C,R], fp32 masters) cut into bf16 matrix-core operands, mny_gate_wq_bytes(C,R) bytes,
+ * refreshed once per pass for all gates of a plan by mny_gate_cut_batch_bf16 (the gate's counterpart of the GEMM path's bf16 shadows).
+ * (C, R) in {(40,10), (112,28), (160,40)} = MobileNetV3-Large's gates. */
+typedef struct mny_gate_cut_job {
+    const float* w1; /* [R][C] */
+    const float* w2; /* [C][R] */
+    void* wq;        /* mny_gate_wq_bytes(C, R) bytes */
+    int32_t C, R;
+} mny_gate_cut_job;
+int mny_gate_supported(int64_t M, int C, int R);
+int mny_gate_parts(int64_t M);
+int mny_gate_bwd_parts(int64_t M);
+int mny_gate_bwd_red3_supported(int C, int R);
+size_t mny_gate_wq_bytes(int C, int R);
+int mny_gate_cut_batch_bf16(const mny_gate_cut_job* jobs, int njobs, void* stream);
+int mny_gate_stats1_bf16(const void* y3, const float* s3, const float* b3, const void* wq, float* stats, int64_t M, int C, int R,
+                         void* stream);
+int mny_gate_stats2_bf16(const void* y3, const float* s3, const float* b3, const void* wq, const float* sc1, const float* sh1,
+                         float* stats, int64_t M, int C, int R, void* stream);
+int mny_gate_fwd_bf16(const void* y3, const float* s3, const float* b3, const void* wq, const float* sc1, const float* sh1,
+                      const float* sc2, const float* sh2, const void* add_x, const float* add_scale, const float* add_shift,
+                      int add_act, void* out, int64_t M, int C, int R, void* stream);
+int mny_gate_bwd1_bf16(const void* y3, const float* s3, const float* b3, const void* dout, const void* wq, const float* sc1,
+                       const float* sh1, const float* sc2, const float* sh2, const float* mean2, const float* invstd2, float* red2,
+                       int64_t M, int C, int R, void* stream);
+int mny_gate_bwd2_bf16(const void* y3, const float* s3, const float* b3, const void* dout, const void* wq, const float* sc1,
+                       const float* sh1, const float* mean1, const float* invstd1, const float* sc2, const float* sh2,
+                       const float* coef2, float* red1, float* dw2_parts, int64_t M, int C, int R, void* stream);
+int mny_gate_bwd3_bf16(const void* y3, const float* s3, const float* b3, const void* dout, const void* wq, const float* sc1,
+                       const float* sh1, const float* sc2, const float* sh2, const float* coef2, const float* coef1,
+                       const float* mean3, const float* invstd3, void* dt, float* dw1_parts, float* red3, int64_t M, int C, int R,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -125,6 +125,18 @@ BF16_TWINS = ("mny_pw_bnbwd_supported", "mny_pw_bnbwd", "mny_pw_wgrad_splits", "
               "mny_mul_views_bwd", "mny_partadd_up", "mny_slice_channels", "mny_upsample_bwd", "mny_axpy")
 for _n in BF16_TWINS:
     _SIGS[_n + "_bf16"] = _SIGS[_n]
+_SIGS["mny_gate_supported"] = (c_int, [c_int64, c_int, c_int])
+_SIGS["mny_gate_parts"] = (c_int, [c_int64])
+_SIGS["mny_gate_bwd_parts"] = (c_int, [c_int64])
+_SIGS["mny_gate_bwd_red3_supported"] = (c_int, [c_int, c_int])
+_SIGS["mny_gate_wq_bytes"] = (c_size_t, [c_int, c_int])
+_SIGS["mny_gate_cut_batch_bf16"] = (c_int, [P, c_int, P])
+_SIGS["mny_gate_stats1_bf16"] = (c_int, [P, P, P, P, P, c_int64, c_int, c_int, P])
+_SIGS["mny_gate_stats2_bf16"] = (c_int, [P, P, P, P, P, P, P, c_int64, c_int, c_int, P])
+_SIGS["mny_gate_fwd_bf16"] = (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_int, P, c_int64, c_int, c_int, P])
+_SIGS["mny_gate_bwd1_bf16"] = (c_int, [P] * 12 + [c_int64, c_int, c_int, P])
+_SIGS["mny_gate_bwd2_bf16"] = (c_int, [P] * 14 + [c_int64, c_int, c_int, P])
+_SIGS["mny_gate_bwd3_bf16"] = (c_int, [P] * 16 + [c_int64, c_int, c_int, P])
 _SIGS["mny_transpose_bf16"] = _SIGS["mny_transpose"]
 _SIGS["mny_cvt_f32_bf16"] = (c_int, [P, P, c_int64, P])
 _SIGS["mny_cvt_batch_f32_bf16"] = (c_int, [P, P, c_int, P])

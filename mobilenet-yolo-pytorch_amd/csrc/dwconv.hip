@@ -418,7 +418,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
 // is stored as soon as its last input row has passed.  Per thread (4 channels x one output column): 25 taps + 3-5 accumulators
 // + one row, ~170 VGPRs, no spills, two resident workgroups per CU (512 blocks).  Same lane mapping, XCD-contiguous strip order,
 // masks and streaming stores as dw3_fwd_kernel.
-template <typename T, int S, int XF, bool ADD, bool NT>
+template <typename T, int S, int XF, bool ADD, bool NT, int PF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) void dw5_fwd_kernel(
     const T* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift, int in_act,
     const float* __restrict__ w, int flip, const T* __restrict__ addend, T* __restrict__ y, float* __restrict__ parts, DwGeom g) {
@@ -470,18 +470,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
             T* yo = y + (((int64_t)n * g.Ho + ho0) * g.Wo + wo) * g.C + c;
             const T* ad = ADD ? addend + (((int64_t)n * g.Ho + ho0) * g.Wo + wo) * g.C + c : nullptr;
 
-            auto load_row = [&](int hi, F4P (&r)[5]) {             // five columns of input row hi, transformed; zeros outside the image
-                const float rm = (hi >= 0 && hi < g.H) ? 1.f : 0.f;
+            typedef typename dw_raw<T>::type RW;
+            auto request = [&](int hi, RW (&raw)[5], float& rm) {  // the five 16-B / 8-B loads of input row hi (clamped into the image)
+                rm = (hi >= 0 && hi < g.H) ? 1.f : 0.f;
                 const T* p = xn + (int64_t)min(max(hi, 0), g.H - 1) * pitch;
-                float4 raw[5];
 #pragma unroll
-                for (int q = 0; q < 5; ++q) raw[q] = ld4(p + coff[q]);
+                for (int q = 0; q < 5; ++q) raw[q] = dw_ldraw(p + coff[q]);
+            };
+            auto finish = [&](const RW (&raw)[5], float rm, F4P (&r)[5]) {     // transformed; zeros outside the image
 #pragma unroll
                 for (int q = 0; q < 5; ++q) {
                     const float m = rm * cm[q];
                     const v2f m2 = v2f{m, m};
-                    r[q] = dw_xf<XF>(raw[q], sc_lo, sc_hi, sh_lo, sh_hi, slope, hi_clip);
+                    r[q] = dw_xf<XF>(dw_widen(raw[q]), sc_lo, sc_hi, sh_lo, sh_hi, slope, hi_clip);
                     r[q].lo *= m2; r[q].hi *= m2;
+                }
+            };
+            // PF = 1: `pend` holds the raw row requested one step ahead; load_row(hi, next, r) consumes it and requests row `next` (the last
+            // step names its own row again: a cache hit that is never consumed, see dw3_fwd_kernel)
+            RW pend[5];
+            float pend_m = 0.f;
+            auto load_row = [&](int hi, int next, F4P (&r)[5]) {
+                if constexpr (PF == 0) { RW raw[5]; float rm; request(hi, raw, rm); finish(raw, rm, r); }
+                else {
+                    RW c[5] = {pend[0], pend[1], pend[2], pend[3], pend[4]};
+                    const float cmk = pend_m;
+                    request(next, pend, pend_m);
+                    finish(c, cmk, r);
                 }
             };
             auto tap_row = [&](F4P& acc, const F4P (&r)[5], int kr) {
@@ -503,8 +518,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
             if (S == 1) {
                 // accumulator j holds output row (hi - 2 + j) while input row hi is being scattered: kr = 4 - j
                 F4P P0 = f4p0(), P1 = f4p0(), P2 = f4p0(), P3 = f4p0(), P4 = f4p0();
+                if constexpr (PF != 0) request(ho0 - 2, pend, pend_m);
                 for (int hi = ho0 - 2; hi <= ho1 + 1; ++hi) {
-                    load_row(hi, r);
+                    load_row(hi, min(hi + 1, ho1 + 1), r);
                     tap_row(P0, r, 4); tap_row(P1, r, 3); tap_row(P2, r, 2); tap_row(P3, r, 1); tap_row(P4, r, 0);
                     if (hi - 2 >= ho0) emit(P0);                    // output row hi-2 has seen its last input row (hi-2 < ho1 by the loop bound)
                     P0 = P1; P1 = P2; P2 = P3; P3 = P4; P4 = f4p0();
@@ -513,11 +529,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
                 // output row t collects input rows 2t-2 .. 2t+2: an even row 2t feeds outputs t-1, t, t+1 with taps 4, 2, 0, an odd
                 // row 2t+1 feeds t, t+1 with taps 3, 1; output t-1 is complete after row 2t
                 F4P P0 = f4p0(), P1 = f4p0(), P2 = f4p0();
+                if constexpr (PF != 0) request(2 * (ho0 - 1), pend, pend_m);
                 for (int t = ho0 - 1; t <= ho1; ++t) {
-                    load_row(2 * t, r);
+                    load_row(2 * t, 2 * t + 1, r);
                     tap_row(P0, r, 4); tap_row(P1, r, 2); tap_row(P2, r, 0);
                     if (t - 1 >= ho0) emit(P0);                     // (t-1 < ho1 by the loop bound)
-                    load_row(2 * t + 1, r);
+                    load_row(2 * t + 1, min(2 * t + 2, 2 * ho1 + 1), r);
                     tap_row(P1, r, 3); tap_row(P2, r, 1);
                     P0 = P1; P1 = P2; P2 = f4p0();
                 }
@@ -875,11 +892,14 @@ static int dw_launch(const T* x, const float* sc, const float* sh, int act, cons
         else if (xf2 == 2) MNY_DW2(S_, 2, false); else MNY_DW2(S_, 4, false); } while (0)
         if (K == 3) { if (stride == 1) MNY_DW2S(1); else MNY_DW2S(2); }
 #undef MNY_DW2
-#define MNY_DW2(S_, X_, A_) do { if (g.nt) hipLaunchKernelGGL((dw5_fwd_kernel<T, S_, X_, A_, true>), grid, block, 0, st, x, sc, sh, act, w, flip, addend, y, parts, g); \
-        else hipLaunchKernelGGL((dw5_fwd_kernel<T, S_, X_, A_, false>), grid, block, 0, st, x, sc, sh, act, w, flip, addend, y, parts, g); } while (0)
+#undef MNY_DW2P
+#define MNY_DW2P(S_, X_, A_, N_) do { if (pf) hipLaunchKernelGGL((dw5_fwd_kernel<T, S_, X_, A_, N_, 1>), grid, block, 0, st, x, sc, sh, act, w, flip, addend, y, parts, g); \
+        else hipLaunchKernelGGL((dw5_fwd_kernel<T, S_, X_, A_, N_, 0>), grid, block, 0, st, x, sc, sh, act, w, flip, addend, y, parts, g); } while (0)
+#define MNY_DW2(S_, X_, A_) do { if (g.nt) MNY_DW2P(S_, X_, A_, true); else MNY_DW2P(S_, X_, A_, false); } while (0)
         if (K == 5) { if (stride == 1) MNY_DW2S(1); else MNY_DW2S(2); }
 #undef MNY_DW2S
 #undef MNY_DW2
+#undef MNY_DW2P
         return check_launch(K == 3 ? "dw3_fwd_kernel" : "dw5_fwd_kernel");
     }
     const int xf = (sc == nullptr && act == MNY_ACT_NONE) ? 0 : (act == MNY_ACT_HSWISH ? 2 : 1);

@@ -1,0 +1,615 @@
+// MobileNetV3's per-pixel gate ("SeModule", models/mobilenetv3.py:26-41 — its avg_pool is never called, so the module gates every pixel
+// on its own) as ONE unit on bf16 storage:
+//
+//     t = BN3(y3)                       the project conv's output, read through its view (models/mobilenetv3.py:69)
+//     h = relu(BN1(W1 t))               1x1 conv C -> R = C/4, BatchNorm, ReLU                      (:31-34)
+//     gate = hsigmoid(BN2(W2 h))        1x1 conv R -> C, BatchNorm, relu6(x + 3) / 6                 (:35-37)
+//     out = t * gate (+ shortcut)       (:41) and, where the block has one, the residual add of :72
+//
+// Un-fused this is five launches forward (two 1x1 convs with 10 / 28 / 40 hidden channels that fit no GEMM tile: 5 TFLOP/s, two BN
+// finalizes, the multiply) + the add, and eleven backward.  Training-mode BatchNorm needs the batch statistics of W1 t before h exists and
+// those of W2 h before the gate exists (and, backward, the sums of BN2 before those of BN1), so "one kernel" is not available: the unit is
+// three streaming passes over y3 forward (statistics of W1 t, statistics of W2 h, output) and three backward (BN2 sums; BN1 sums + dW2;
+// dt + dW1), with the ordinary finalize launches in between — the hidden tensors h, W2 h and their gradients are never written.
+//
+// Thread mapping (all passes): a WAVE owns 16 consecutive pixels and ALL channels; the products run on the matrix cores as
+// D[out channel][pixel] = W[out channel][k] . X[k][pixel] with v_mfma_f32_16x16x32_bf16:
+//   * lane (px = lane & 15, rg = lane >> 4) holds, of every 16-channel tile T, the four channels 16 T + 4 rg + {0..3} of its pixel — as
+//     loaded (one 8-byte load per tile), as accumulator (the C/D layout: col = lane & 15, row = 4 (lane >> 4) + reg) and as the B
+//     operand of the NEXT product: the matrix core pairs element e of k-group lane >> 4 of A with the same element of B, and k is only a
+//     summation index, so "k-step u, group rg, element e" is DEFINED as channel 32 u + (e < 4 ? 4 rg + e : 16 + 4 rg + e - 4) — the eight
+//     accumulator registers of tiles 2u and 2u+1 ARE the B fragment: no transpose, no LDS round trip for activations, forward or backward;
+//   * the weights are the A operand, cut once per pass (mny_gate_cut_batch_bf16, one launch for all gates) into that k order as bf16
+//     chunks [row tile][k-step][lane]; a workgroup copies its chunk sets into LDS, one ds_read_b128 per MFMA;
+//   * per-channel constants (BN scale / shift / coefficients) sit in LDS as zero-padded rows, read as float4 by (tile, rg);
+//   * weight gradients contract over PIXELS, i.e. need the transposed layout: the 8 waves of a workgroup park their 16-pixel columns of
+//     the two operands as bf16 in LDS ([channel][128 pixels]), and every wave owns a few 16x16 tiles of dW over those 128 pixels.
+// Arithmetic = the bf16-storage GEMM path's: matrix operands rounded to bf16 (RNE), fp32 accumulate, everything else fp32; the hidden
+// tensors are NOT rounded through storage any more (oracle/bf16_storage.py models exactly that).
+#include <stdlib.h>
+
+#include "common.h"
+#include "x6.h"
+
+namespace mny {
+
+typedef float gate_f4 __attribute__((ext_vector_type(4)));
+
+template <int C, int R>
+struct GateDim {
+    static constexpr int CT = (C + 15) / 16, CU = (CT + 1) / 2, CP = CU * 32;      // 16-channel tiles / 32-deep k-steps / padded extent of the wide side
+    static constexpr int RT = (R + 15) / 16, RU = (RT + 1) / 2, RP = RU * 32;      // ... of the hidden side
+    // chunk sets (uint4 units): A1 = W1 (rows r, k = c), A2 = W2 (rows c, k = r), A3 = W2^T (rows r, k = c), A4 = W1^T (rows c, k = r)
+    static constexpr int N1 = RT * CU * 64, N2 = CT * RU * 64, O1 = 0, O2 = N1, O3 = N1 + N2, O4 = 2 * N1 + N2, NQ = 2 * (N1 + N2);
+};
+
+__device__ __forceinline__ uint32_t gate_pack2(float a, float b) { return pack_bf16x2(a, b); }
+
+// one A-operand chunk: row `row` of a [ROWS][COLS] matrix (element (r, k) = w[r * sr + k * sk]), k-step u, lane -> 8 bf16 in the k order above
+__device__ __forceinline__ uint4 gate_chunk(const float* __restrict__ w, int ROWS, int COLS, int sr, int sk, int tr, int u, int lane) {
+    const int row = 16 * tr + (lane & 15), kg = lane >> 4;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = 32 * u + (e < 4 ? 4 * kg + e : 16 + 4 * kg + (e - 4));
+        v[e] = (row < ROWS && k < COLS) ? w[row * sr + k * sk] : 0.f;
+    }
+    return make_uint4(gate_pack2(v[0], v[1]), gate_pack2(v[2], v[3]), gate_pack2(v[4], v[5]), gate_pack2(v[6], v[7]));
+}
+
+// all chunk sets of all gates of a plan in one launch: grid = (16, jobs)
+__global__ __launch_bounds__(256) void gate_cut_kernel(const mny_gate_cut_job* __restrict__ jobs) {
+    const mny_gate_cut_job jb = jobs[blockIdx.y];
+    const int C = jb.C, R = jb.R;
+    const int CT = (C + 15) / 16, CU = (CT + 1) / 2, RT = (R + 15) / 16, RU = (RT + 1) / 2;
+    const int n1 = RT * CU * 64, n2 = CT * RU * 64;
+    uint4* dst = reinterpret_cast<uint4*>(jb.wq);
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < 2 * (n1 + n2); idx += gridDim.x * 256) {
+        int set, i = idx;
+        if (i < n1) set = 0; else if ((i -= n1) < n2) set = 1; else if ((i -= n2) < n1) set = 2; else { i -= n1; set = 3; }
+        const int lane = i & 63;
+        if (set == 0) dst[idx] = gate_chunk(jb.w1, R, C, C, 1, i / (64 * CU), (i >> 6) % CU, lane);          // W1 [R][C]
+        else if (set == 1) dst[idx] = gate_chunk(jb.w2, C, R, R, 1, i / (64 * RU), (i >> 6) % RU, lane);     // W2 [C][R]
+        else if (set == 2) dst[idx] = gate_chunk(jb.w2, R, C, 1, R, i / (64 * CU), (i >> 6) % CU, lane);     // W2^T: (r, c) = W2[c][r]
+        else dst[idx] = gate_chunk(jb.w1, C, R, 1, C, i / (64 * RU), (i >> 6) % RU, lane);                    // W1^T: (c, r) = W1[r][c]
+    }
+}
+
+__device__ __forceinline__ void gate_copy_chunks(uint4* __restrict__ dst, const uint4* __restrict__ src, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+}
+// a zero-padded constant row of n valid floats (`fill` where the source is absent)
+__device__ __forceinline__ void gate_fill_row(float* __restrict__ dst, const float* __restrict__ src, int n, int padded, float fill = 0.f) {
+    for (int i = threadIdx.x; i < padded; i += blockDim.x) dst[i] = i < n ? (src != nullptr ? src[i] : fill) : 0.f;
+}
+__device__ __forceinline__ float4 gate_widen(uint2 u) {
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ bf16x8_t gate_frag(float4 a, float4 b) {
+    const uint4 u = make_uint4(gate_pack2(a.x, a.y), gate_pack2(a.z, a.w), gate_pack2(b.x, b.y), gate_pack2(b.z, b.w));
+    return __builtin_bit_cast(bf16x8_t, u);
+}
+__device__ __forceinline__ float4 gate_fma4(float4 y, float4 s, float4 b) {
+    return make_float4(fmaf(y.x, s.x, b.x), fmaf(y.y, s.y, b.y), fmaf(y.z, s.z, b.z), fmaf(y.w, s.w, b.w));
+}
+__device__ __forceinline__ float4 gate_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 gate_f(gate_f4 a) { return make_float4(a[0], a[1], a[2], a[3]); }
+__device__ __forceinline__ gate_f4 gate_zero() { return gate_f4{0.f, 0.f, 0.f, 0.f}; }
+
+// D[16T .. 16T+15][px] += A-chunks[T][u] . B[u] for all tiles T, k-steps u (NT tiles, NU k-steps; bfrag(u) builds B of k-step u)
+template <int NT, int NU, typename BF>
+__device__ __forceinline__ void gate_product(gate_f4 (&acc)[NT], const uint4* __restrict__ chunks_at_lane, BF&& bfrag) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = gate_zero();
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        const bf16x8_t b = bfrag(u);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, chunks_at_lane[(t * NU + u) * 64]), b, acc[t], 0, 0, 0);
+    }
+}
+
+// per-channel sums held per lane (rows 16 t + 4 rg + i of its pixel) -> one partial row [2][NV] of the workgroup: over the 16 pixel lanes
+// (xor butterflies stay inside the 16-lane group), then the waves in order.  red: [waves][2][NP] floats of LDS.
+template <int NS, int NP, int NV, int NW>
+__device__ __forceinline__ void gate_write_sums(const gate_f4 (&ssum)[NS], const gate_f4 (&qsum)[NS], float* __restrict__ red, float* __restrict__ parts) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, px = lane & 15, rg = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < NS; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float s = ssum[t][i], q = qsum[t][i];
+#pragma unroll
+            for (int k = 1; k < 16; k <<= 1) { s += __shfl_xor(s, k); q += __shfl_xor(q, k); }
+            if (px == 0) { red[(wave * 2 + 0) * NP + 16 * t + 4 * rg + i] = s; red[(wave * 2 + 1) * NP + 16 * t + 4 * rg + i] = q; }
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < NV; c += blockDim.x) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) { s += red[(w * 2 + 0) * NP + c]; q += red[(w * 2 + 1) * NP + c]; }
+        parts[(int64_t)blockIdx.x * 2 * NV + c] = s;
+        parts[(int64_t)blockIdx.x * 2 * NV + NV + c] = q;
+    }
+}
+
+struct GateFwdArgs {
+    const bf16_t* y3; const float* s3; const float* b3;           // the project unit's raw output and BN3 scale / shift
+    const uint4* wq;                                              // chunk sets (mny_gate_cut_batch_bf16)
+    const float* sc1; const float* sh1;                           // BN1 scale / shift (passes 2, 3)
+    const float* sc2; const float* sh2;                           // BN2 scale / shift (pass 3)
+    const bf16_t* add_x; const float* add_scale; const float* add_shift; int add_act;      // pass 3: optional residual operand (a view)
+    bf16_t* out;                                                  // pass 3
+    float* parts;                                                 // passes 1, 2: partial rows [gridDim.x][2][R | C]
+    int64_t M;
+};
+
+// PASS 1: statistics of W1 t;  PASS 2: statistics of W2 h;  PASS 3: out = t * gate (+ residual)
+template <int C, int R, int PASS>
+__global__ __launch_bounds__(256) void gate_fwd_kernel(GateFwdArgs p) {
+    typedef GateDim<C, R> D;
+    constexpr int CT = D::CT, CU = D::CU, CP = D::CP, RT = D::RT, RU = D::RU, RP = D::RP;
+    __shared__ uint4 wa1[D::N1];
+    __shared__ uint4 wa2[PASS >= 2 ? D::N2 : 1];
+    __shared__ __attribute__((aligned(16))) float cs3[CP], cb3[CP], c1s[RP], c1b[RP], c2s[PASS == 3 ? CP : 4], c2b[PASS == 3 ? CP : 4];
+    __shared__ __attribute__((aligned(16))) float cas[PASS == 3 ? CP : 4], cab[PASS == 3 ? CP : 4];
+    __shared__ float red[PASS == 3 ? 1 : 4 * 2 * (PASS == 1 ? RP : CP)];
+
+    gate_copy_chunks(wa1, p.wq + D::O1, D::N1);
+    if (PASS >= 2) gate_copy_chunks(wa2, p.wq + D::O2, D::N2);
+    gate_fill_row(cs3, p.s3, C, CP); gate_fill_row(cb3, p.b3, C, CP);
+    if (PASS >= 2) { gate_fill_row(c1s, p.sc1, R, RP); gate_fill_row(c1b, p.sh1, R, RP); }
+    if (PASS == 3) {
+        gate_fill_row(c2s, p.sc2, C, CP); gate_fill_row(c2b, p.sh2, C, CP);
+        gate_fill_row(cas, p.add_scale, C, CP, 1.f); gate_fill_row(cab, p.add_shift, C, CP, 0.f);
+    }
+    __syncthreads();
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, px = lane & 15, rg = lane >> 4;
+    const int64_t ntiles = (p.M + 15) >> 4;
+    constexpr int NS = PASS == 1 ? RT : (PASS == 2 ? CT : 1);
+    gate_f4 ssum[NS], qsum[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) { ssum[i] = gate_zero(); qsum[i] = gate_zero(); }
+
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+        // opaque per iteration: the LDS reads of weight chunks and constants stay IN the loop (hoisted they are 140+ VGPRs live across it)
+        int lo = lane, cq = 4 * rg;
+        asm volatile("" : "+v"(lo), "+v"(cq));
+        const int64_t m = tile * 16 + px;
+        const bool valid = m < p.M;
+        const float vm = valid ? 1.f : 0.f;
+        const bf16_t* yrow = p.y3 + (valid ? m : 0) * C;
+        uint2 raw[CT];
+#pragma unroll
+        for (int t = 0; t < CT; ++t) raw[t] = (16 * t + 4 * rg < C) ? *reinterpret_cast<const uint2*>(yrow + 16 * t + 4 * rg) : make_uint2(0u, 0u);
+        auto tval = [&](int t) { return gate_fma4(gate_widen(raw[t]), gate_ld4(cs3 + 16 * t + cq), gate_ld4(cb3 + 16 * t + cq)); };
+        // product 1: (W1 t)[r][px]
+        gate_f4 acc1[RT];
+        gate_product<RT, CU>(acc1, wa1 + lo, [&](int u) { return gate_frag(tval(2 * u), 2 * u + 1 < CT ? tval(2 * u + 1 < CT ? 2 * u + 1 : 0) : f4zero()); });
+        if (PASS == 1) {
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                const gate_f4 v = acc1[t] * vm;
+                ssum[t] += v;
+                qsum[t] += v * acc1[t];
+            }
+            continue;
+        }
+        // h = relu(BN1(.)), product 2: (W2 h)[c][px]
+        auto hval = [&](int t) {
+            const float4 s = gate_ld4(c1s + 16 * t + cq), b = gate_ld4(c1b + 16 * t + cq);
+            const gate_f4 a = acc1[t];
+            return make_float4(fmaxf(fmaf(a[0], s.x, b.x), 0.f), fmaxf(fmaf(a[1], s.y, b.y), 0.f), fmaxf(fmaf(a[2], s.z, b.z), 0.f), fmaxf(fmaf(a[3], s.w, b.w), 0.f));
+        };
+        gate_f4 acc2[CT];
+        gate_product<CT, RU>(acc2, wa2 + lo, [&](int u) { return gate_frag(hval(2 * u), 2 * u + 1 < RT ? hval(2 * u + 1 < RT ? 2 * u + 1 : 0) : f4zero()); });
+        if (PASS == 2) {
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                const gate_f4 v = acc2[t] * vm;
+                ssum[t] += v;
+                qsum[t] += v * acc2[t];
+            }
+            continue;
+        }
+        // PASS 3
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const int c0 = 16 * t + 4 * rg;
+            if (c0 >= C || !valid) continue;
+            const int cl = 16 * t + cq;
+            const float4 s2 = gate_ld4(c2s + cl), b2 = gate_ld4(c2b + cl);
+            const float4 tt = tval(t);
+            const gate_f4 a = acc2[t];
+            float4 o;
+            o.x = tt.x * (__builtin_amdgcn_fmed3f(fmaf(a[0], s2.x, b2.x) + 3.f, 0.f, 6.f) / 6.f);
+            o.y = tt.y * (__builtin_amdgcn_fmed3f(fmaf(a[1], s2.y, b2.y) + 3.f, 0.f, 6.f) / 6.f);
+            o.z = tt.z * (__builtin_amdgcn_fmed3f(fmaf(a[2], s2.z, b2.z) + 3.f, 0.f, 6.f) / 6.f);
+            o.w = tt.w * (__builtin_amdgcn_fmed3f(fmaf(a[3], s2.w, b2.w) + 3.f, 0.f, 6.f) / 6.f);
+            if (p.add_x != nullptr) {
+                const float4 av = ld4(p.add_x + m * C + c0);
+                const float4 as = gate_ld4(cas + cl), ab = gate_ld4(cab + cl);
+                o.x += act_fwd(fmaf(av.x, as.x, ab.x), p.add_act); o.y += act_fwd(fmaf(av.y, as.y, ab.y), p.add_act);
+                o.z += act_fwd(fmaf(av.z, as.z, ab.z), p.add_act); o.w += act_fwd(fmaf(av.w, as.w, ab.w), p.add_act);
+            }
+            st4(p.out + m * C + c0, o);
+        }
+    }
+    if (PASS == 1) gate_write_sums<NS, RP, R, 4>(ssum, qsum, red, p.parts);
+    if (PASS == 2) gate_write_sums<NS, CP, C, 4>(ssum, qsum, red, p.parts);
+}
+
+// ---- backward ---------------------------------------------------------------------------------------------------------------------
+// Given dO = dL/d(out) [M,C] (the residual operand's gradient is dO itself: the caller aliases it):
+//   dgate = dO * t;  dz2 = dgate * hsig'(z2), z2 = BN2(g), g = W2 hb;          PASS 1: sum dz2, sum dz2 * ghat  -> mny_bn_bwd_finalize -> coef2
+//   dg = ca2 dz2 + cb2 g + cc2;  dh = W2^T dg;  dz1 = dh * (z1 > 0);           PASS 2: sum dz1, sum dz1 * hhat  -> mny_bn_bwd_finalize -> coef1;  dW2 += dg hb^T
+//   dhr = ca1 dz1 + cb1 hr + cc1;  dt = dO * gate + W1^T dhr                   PASS 3: dt (+ the project unit's BN-backward sums), dW1 += dhr tb^T
+// (hb, tb: the bf16 operand values of the forward products; dg, dhr enter their products as bf16 operands like every stored gradient.)
+struct GateBwdArgs {
+    const bf16_t* y3; const float* s3; const float* b3; const bf16_t* dout;
+    const uint4* wq;
+    const float* sc1; const float* sh1; const float* mean1; const float* invstd1;
+    const float* sc2; const float* sh2; const float* mean2; const float* invstd2;
+    const float* coef2; const float* coef1;                       // [3][C] (passes 2, 3), [3][R] (pass 3)
+    const float* mean3; const float* invstd3;                     // pass 3 with red3: the project unit's statistics
+    float* parts;                                                 // pass 1: [grid][2][C];  pass 2: [grid][2][R]
+    float* dwp;                                                   // pass 2: dW2 partials [grid][C][R];  pass 3: dW1 partials [grid][R][C]
+    bf16_t* dt; float* red3;                                      // pass 3: gradient wrt the project unit's BN output; its BN-backward sums [grid][2][C] (or NULL)
+    int64_t M;
+};
+
+constexpr int kGateBW = 8;                  // waves per workgroup of the backward passes
+constexpr int kGatePitch = 16 * kGateBW + 8; // bf16 elements per row of the transposed operand tiles (272 B: rows 4 banks apart -> conflict-free b128 reads)
+
+template <int C, int R, int PASS>
+struct GateBwdLds {
+    typedef GateDim<C, R> D;
+    static constexpr int NCONST_C = PASS == 1 ? 6 : (PASS == 2 ? 7 : 9), NCONST_R = PASS == 1 ? 2 : (PASS == 2 ? 4 : 5);
+    static constexpr size_t chunks = (size_t)(D::N1 + D::N2 + (PASS >= 2 ? D::N1 : 0) + (PASS == 3 ? D::N2 : 0)) * 16;
+    static constexpr size_t consts = (size_t)(NCONST_C * D::CP + NCONST_R * D::RP) * 4;
+    static constexpr size_t xch = PASS == 1 ? 0 : (size_t)(16 * D::CT + 16 * D::RT) * kGatePitch * 2;
+    static constexpr size_t red = (size_t)kGateBW * 2 * (PASS == 2 ? D::RP : D::CP) * 4;
+    static constexpr size_t total = chunks + consts + xch + red;
+};
+
+template <int C, int R, int PASS, bool RED3>
+__global__ __launch_bounds__(64 * kGateBW) void gate_bwd_kernel(GateBwdArgs p) {
+    typedef GateDim<C, R> D;
+    typedef GateBwdLds<C, R, PASS> L;
+    constexpr int CT = D::CT, CU = D::CU, CP = D::CP, RT = D::RT, RU = D::RU, RP = D::RP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char gate_lds[];
+    uint4* wa1 = reinterpret_cast<uint4*>(gate_lds);
+    uint4* wa2 = wa1 + D::N1;
+    uint4* wa3 = wa2 + D::N2;                                     // PASS >= 2
+    uint4* wa4 = wa3 + D::N1;                                     // PASS == 3
+    float* cst = reinterpret_cast<float*>(gate_lds + L::chunks);
+    // constant rows over the wide side: 0 s3, 1 b3, 2 sc2, 3 sh2, 4 mean2 | ca2, 5 invstd2 | cb2, 6 cc2, 7 mean3, 8 invstd3;  hidden side: 0 sc1, 1 sh1, 2 mean1 | ca1, 3 invstd1 | cb1, 4 cc1
+    float* cr = cst + L::NCONST_C * CP;
+    unsigned short* xa = reinterpret_cast<unsigned short*>(gate_lds + L::chunks + L::consts);        // PASS 2: dg^T [16 CT][pitch];  PASS 3: tb^T
+    unsigned short* xb = xa + 16 * CT * kGatePitch;                                                  // PASS 2: hb^T [16 RT][pitch];  PASS 3: dhr^T
+    float* red = reinterpret_cast<float*>(gate_lds + L::chunks + L::consts + L::xch);
+
+    gate_copy_chunks(wa1, p.wq + D::O1, D::N1);
+    gate_copy_chunks(wa2, p.wq + D::O2, D::N2);
+    if (PASS >= 2) gate_copy_chunks(wa3, p.wq + D::O3, D::N1);
+    if (PASS == 3) gate_copy_chunks(wa4, p.wq + D::O4, D::N2);
+    gate_fill_row(cst + 0 * CP, p.s3, C, CP); gate_fill_row(cst + 1 * CP, p.b3, C, CP);
+    gate_fill_row(cst + 2 * CP, p.sc2, C, CP); gate_fill_row(cst + 3 * CP, p.sh2, C, CP);
+    gate_fill_row(cr + 0 * RP, p.sc1, R, RP); gate_fill_row(cr + 1 * RP, p.sh1, R, RP);
+    if (PASS == 1) { gate_fill_row(cst + 4 * CP, p.mean2, C, CP); gate_fill_row(cst + 5 * CP, p.invstd2, C, CP); }
+    if (PASS >= 2) { gate_fill_row(cst + 4 * CP, p.coef2, C, CP); gate_fill_row(cst + 5 * CP, p.coef2 + C, C, CP); gate_fill_row(cst + 6 * CP, p.coef2 + 2 * C, C, CP); }
+    if (PASS == 2) { gate_fill_row(cr + 2 * RP, p.mean1, R, RP); gate_fill_row(cr + 3 * RP, p.invstd1, R, RP); }
+    if (PASS == 3) {
+        gate_fill_row(cr + 2 * RP, p.coef1, R, RP); gate_fill_row(cr + 3 * RP, p.coef1 + R, R, RP); gate_fill_row(cr + 4 * RP, p.coef1 + 2 * R, R, RP);
+        if (RED3) { gate_fill_row(cst + 7 * CP, p.mean3, C, CP); gate_fill_row(cst + 8 * CP, p.invstd3, C, CP); }
+    }
+    __syncthreads();
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, px = lane & 15, rg = lane >> 4;
+    const int64_t ntiles = (p.M + 15) >> 4;
+    const int64_t niter = (ntiles + kGateBW - 1) / kGateBW;      // workgroup iterations of 8 wave tiles = 128 pixels (uniform: barriers inside)
+    constexpr int NS = PASS == 2 ? RT : ((PASS == 1 || RED3) ? CT : 1);
+    gate_f4 ssum[NS], qsum[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) { ssum[i] = gate_zero(); qsum[i] = gate_zero(); }
+    // weight-gradient tiles of this wave: q = wave + 8 j over the (row tile, column tile) grid — PASS 2: dW2 (CT x RT), PASS 3: dW1 (RT x CT)
+    constexpr int NTILE = CT * RT, JT = PASS == 1 ? 1 : (NTILE + kGateBW - 1) / kGateBW;
+    gate_f4 wacc[JT];
+#pragma unroll
+    for (int j = 0; j < JT; ++j) wacc[j] = gate_zero();
+
+    for (int64_t it = blockIdx.x; it < niter; it += gridDim.x) {
+        int lo = lane, cq = 4 * rg;
+        asm volatile("" : "+v"(lo), "+v"(cq));
+        const int64_t m = (it * kGateBW + wave) * 16 + px;
+        const bool valid = m < p.M;
+        const float vm = valid ? 1.f : 0.f;
+        const int64_t mrow = (valid ? m : 0) * C;
+        uint2 raw[CT], rdo[CT];
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const bool cok = 16 * t + 4 * rg < C;
+            raw[t] = cok ? *reinterpret_cast<const uint2*>(p.y3 + mrow + 16 * t + 4 * rg) : make_uint2(0u, 0u);
+            rdo[t] = cok ? *reinterpret_cast<const uint2*>(p.dout + mrow + 16 * t + 4 * rg) : make_uint2(0u, 0u);
+        }
+        auto tval = [&](int t) { return gate_fma4(gate_widen(raw[t]), gate_ld4(cst + 0 * CP + 16 * t + cq), gate_ld4(cst + 1 * CP + 16 * t + cq)); };
+        gate_f4 acc1[RT];                                         // hr = W1 tb
+        gate_product<RT, CU>(acc1, wa1 + lo, [&](int u) { return gate_frag(tval(2 * u), 2 * u + 1 < CT ? tval(2 * u + 1 < CT ? 2 * u + 1 : 0) : f4zero()); });
+        auto z1val = [&](int t) { return gate_fma4(gate_f(acc1[t]), gate_ld4(cr + 0 * RP + 16 * t + cq), gate_ld4(cr + 1 * RP + 16 * t + cq)); };
+        auto hval = [&](int t) { const float4 z = z1val(t); return make_float4(fmaxf(z.x, 0.f), fmaxf(z.y, 0.f), fmaxf(z.z, 0.f), fmaxf(z.w, 0.f)); };
+        gate_f4 acc2[CT];                                         // g = W2 hb
+        gate_product<CT, RU>(acc2, wa2 + lo, [&](int u) { return gate_frag(hval(2 * u), 2 * u + 1 < RT ? hval(2 * u + 1 < RT ? 2 * u + 1 : 0) : f4zero()); });
+        // dz2 (PASS 1: summed) / dg (PASS >= 2: replaces g in acc2), dO * gate (PASS 3: kept in rdo's place as fp32 -> dog)
+        float4 dog[PASS == 3 ? CT : 1];
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const int cl = 16 * t + cq;
+            const float4 tt = tval(t), dO = gate_widen(rdo[t]);
+            const float4 z2 = gate_fma4(gate_f(acc2[t]), gate_ld4(cst + 2 * CP + cl), gate_ld4(cst + 3 * CP + cl));
+            const float zz[4] = {z2.x, z2.y, z2.z, z2.w}, tv[4] = {tt.x, tt.y, tt.z, tt.w}, dv[4] = {dO.x, dO.y, dO.z, dO.w};
+            float dz[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dz[i] = dv[i] * tv[i] * ((zz[i] > -3.f && zz[i] < 3.f) ? (1.f / 6.f) : 0.f) * vm;
+            if (PASS == 1) {
+                const float4 mu = gate_ld4(cst + 4 * CP + cl), is = gate_ld4(cst + 5 * CP + cl);
+                const float mv[4] = {mu.x, mu.y, mu.z, mu.w}, iv[4] = {is.x, is.y, is.z, is.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { ssum[t][i] += dz[i]; qsum[t][i] = fmaf(dz[i], (acc2[t][i] - mv[i]) * iv[i], qsum[t][i]); }
+            } else {
+                const float4 ca = gate_ld4(cst + 4 * CP + cl), cb = gate_ld4(cst + 5 * CP + cl), cc = gate_ld4(cst + 6 * CP + cl);
+                const float av[4] = {ca.x, ca.y, ca.z, ca.w}, bv[4] = {cb.x, cb.y, cb.z, cb.w}, cv[4] = {cc.x, cc.y, cc.z, cc.w};
+                if (PASS == 3) {
+                    float gt[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) gt[i] = dv[i] * (__builtin_amdgcn_fmed3f(zz[i] + 3.f, 0.f, 6.f) / 6.f);
+                    dog[PASS == 3 ? t : 0] = make_float4(gt[0], gt[1], gt[2], gt[3]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc2[t][i] = fmaf(av[i], dz[i], fmaf(bv[i], acc2[t][i], cv[i])) * vm;      // dg (0 on pixels past M and, through zero constants, on padding channels)
+            }
+        }
+        if (PASS == 1) continue;
+        // dh = W2^T dg (k = wide channels: acc2's tiles ARE the B fragments), dz1 = dh * relu'(z1)
+        gate_f4 acc3[RT];
+        gate_product<RT, CU>(acc3, wa3 + lo, [&](int u) { return gate_frag(gate_f(acc2[2 * u]), 2 * u + 1 < CT ? gate_f(acc2[2 * u + 1 < CT ? 2 * u + 1 : 0]) : f4zero()); });
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            const float4 z1 = z1val(t);
+            const float zz[4] = {z1.x, z1.y, z1.z, z1.w};
+            const int rl = 16 * t + cq;
+            if (PASS == 2) {
+                const float4 mu = gate_ld4(cr + 2 * RP + rl), is = gate_ld4(cr + 3 * RP + rl);
+                const float mv[4] = {mu.x, mu.y, mu.z, mu.w}, iv[4] = {is.x, is.y, is.z, is.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float dz1 = zz[i] > 0.f ? acc3[t][i] : 0.f;            // (dg is already 0 on masked pixels -> so is dh)
+                    ssum[t][i] += dz1;
+                    qsum[t][i] = fmaf(dz1, (acc1[t][i] - mv[i]) * iv[i], qsum[t][i]);
+                }
+            } else {
+                const float4 ca = gate_ld4(cr + 2 * RP + rl), cb = gate_ld4(cr + 3 * RP + rl), cc = gate_ld4(cr + 4 * RP + rl);
+                const float av[4] = {ca.x, ca.y, ca.z, ca.w}, bv[4] = {cb.x, cb.y, cb.z, cb.w}, cv[4] = {cc.x, cc.y, cc.z, cc.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc3[t][i] = fmaf(av[i], zz[i] > 0.f ? acc3[t][i] : 0.f, fmaf(bv[i], acc1[t][i], cv[i])) * vm;     // dhr
+            }
+        }
+        // park the two operands of the weight gradient transposed: [channel][128 pixels] bf16, this wave's 16 columns
+        const int col = 16 * wave + px;
+        if (PASS == 2) {
+#pragma unroll
+            for (int t = 0; t < CT; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xa[(16 * t + 4 * rg + i) * kGatePitch + col] = (unsigned short)(gate_pack2(acc2[t][i], 0.f) & 0xffffu);
+#pragma unroll
+            for (int t = 0; t < RT; ++t) {
+                const float4 hv = hval(t);
+                const float hh[4] = {hv.x, hv.y, hv.z, hv.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xb[(16 * t + 4 * rg + i) * kGatePitch + col] = (unsigned short)(gate_pack2(hh[i] * vm, 0.f) & 0xffffu);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                const float4 tt = tval(t);
+                const float tv[4] = {tt.x, tt.y, tt.z, tt.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xa[(16 * t + 4 * rg + i) * kGatePitch + col] = (unsigned short)(gate_pack2(tv[i] * vm, 0.f) & 0xffffu);
+            }
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xb[(16 * t + 4 * rg + i) * kGatePitch + col] = (unsigned short)(gate_pack2(acc3[t][i], 0.f) & 0xffffu);
+        }
+        if (PASS == 3) {
+            // dt = dO * gate + W1^T dhr (k = hidden channels: acc3's tiles are the B fragments)
+            gate_f4 acc4[CT];
+            gate_product<CT, RU>(acc4, wa4 + lo, [&](int u) { return gate_frag(gate_f(acc3[2 * u]), 2 * u + 1 < RT ? gate_f(acc3[2 * u + 1 < RT ? 2 * u + 1 : 0]) : f4zero()); });
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                const int c0 = 16 * t + 4 * rg;
+                const float4 g = dog[PASS == 3 ? t : 0];
+                const float4 o = make_float4(g.x + acc4[t][0], g.y + acc4[t][1], g.z + acc4[t][2], g.w + acc4[t][3]);
+                if (c0 < C && valid) st4(p.dt + m * C + c0, o);
+                if (RED3) {                                        // the project unit's BN-backward sums over the STORED gradient (its activation is the identity)
+                    const int cl = 16 * t + cq;
+                    const float4 os = stored4<bf16_t>(o), y = gate_widen(raw[t]), mu = gate_ld4(cst + 7 * CP + cl), is = gate_ld4(cst + 8 * CP + cl);
+                    const float ov[4] = {os.x, os.y, os.z, os.w}, yv[4] = {y.x, y.y, y.z, y.w}, mv[4] = {mu.x, mu.y, mu.z, mu.w}, iv[4] = {is.x, is.y, is.z, is.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { const float d = ov[i] * vm; ssum[t][i] += d; qsum[t][i] = fmaf(d, (yv[i] - mv[i]) * iv[i], qsum[t][i]); }
+                }
+            }
+        }
+        __syncthreads();
+        // this wave's tiles of the weight gradient over the 128 parked pixels: A = rows of xa (PASS 2) / xb (PASS 3), B = the other
+        {
+            const unsigned short* ra = PASS == 2 ? xa : xb;       // rows of dW
+            const unsigned short* cb_ = PASS == 2 ? xb : xa;      // columns of dW
+            constexpr int NCOLT = PASS == 2 ? RT : CT;
+#pragma unroll
+            for (int j = 0; j < JT; ++j) {
+                const int q = wave + kGateBW * j;
+                if (q < NTILE) {
+                    const int tr = q / NCOLT, tc = q % NCOLT;
+                    const unsigned short* pa = ra + (16 * tr + px) * kGatePitch + 8 * rg;
+                    const unsigned short* pb = cb_ + (16 * tc + px) * kGatePitch + 8 * rg;
+#pragma unroll
+                    for (int ks = 0; ks < kGateBW / 2; ++ks) {
+                        const uint4 a = *reinterpret_cast<const uint4*>(pa + 32 * ks), b = *reinterpret_cast<const uint4*>(pb + 32 * ks);
+                        wacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), wacc[j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    if (PASS == 1) gate_write_sums<NS, CP, C, kGateBW>(ssum, qsum, red, p.parts);
+    if (PASS == 2) gate_write_sums<NS, RP, R, kGateBW>(ssum, qsum, red, p.parts);
+    if (PASS == 3 && RED3) gate_write_sums<NS, CP, C, kGateBW>(ssum, qsum, red, p.red3);
+    if (PASS >= 2) {
+        constexpr int NROW = PASS == 2 ? C : R, NCOL = PASS == 2 ? R : C, NCOLT = PASS == 2 ? RT : CT;
+        float* dst = p.dwp + (int64_t)blockIdx.x * NROW * NCOL;
+#pragma unroll
+        for (int j = 0; j < JT; ++j) {
+            const int q = wave + kGateBW * j;
+            if (q < NTILE) {
+                const int tr = q / NCOLT, tc = q % NCOLT;
+                const int c = 16 * tc + px;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 16 * tr + 4 * rg + i;
+                    if (r < NROW && c < NCOL) dst[r * NCOL + c] = wacc[j][i];
+                }
+            }
+        }
+    }
+}
+
+static bool gate_shape_ok(int64_t M, int C, int R) {
+    return M > 0 && ((C == 40 && R == 10) || (C == 112 && R == 28) || (C == 160 && R == 40));
+}
+// forward: 4 waves per workgroup, two workgroups' worth of tiles per CU before the grid-stride loop takes over
+static int gate_grid(int64_t M) {
+    const int64_t want = cdiv(cdiv(M, 16), 4);
+    return (int)(want < 512 ? want : 512);
+}
+// backward: 8 waves per workgroup; every workgroup leaves a partial row AND a partial weight gradient, so one resident round is the cap
+static int gate_bwd_grid(int64_t M) {
+    const int64_t want = cdiv(cdiv(M, 16), kGateBW);
+    return (int)(want < 256 ? want : 256);
+}
+
+template <int PASS>
+static int gate_fwd_launch(const GateFwdArgs& a, int C, int R, hipStream_t st) {
+    const dim3 grid(gate_grid(a.M)), block(256);
+    if (C == 40) hipLaunchKernelGGL((gate_fwd_kernel<40, 10, PASS>), grid, block, 0, st, a);
+    else if (C == 112) hipLaunchKernelGGL((gate_fwd_kernel<112, 28, PASS>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((gate_fwd_kernel<160, 40, PASS>), grid, block, 0, st, a);
+    return check_launch("gate_fwd_kernel");
+}
+
+template <int C, int R, int PASS, bool RED3>
+static int gate_bwd_launch_one(const GateBwdArgs& a, hipStream_t st) {
+    constexpr size_t lds = GateBwdLds<C, R, PASS>::total;
+    static_assert(lds <= 160 * 1024, "gate backward: LDS budget");
+    if (lds > 64 * 1024 && !allow_lds((const void*)gate_bwd_kernel<C, R, PASS, RED3>, lds)) { set_error("gate_bwd: hipFuncSetAttribute failed"); return MNY_EHIP; }
+    hipLaunchKernelGGL((gate_bwd_kernel<C, R, PASS, RED3>), dim3(gate_bwd_grid(a.M)), dim3(64 * kGateBW), lds, st, a);
+    return check_launch("gate_bwd_kernel");
+}
+template <int PASS, bool RED3>
+static int gate_bwd_launch(const GateBwdArgs& a, int C, int R, hipStream_t st) {
+    if (C == 40) return gate_bwd_launch_one<40, 10, PASS, RED3>(a, st);
+    if (C == 112) return gate_bwd_launch_one<112, 28, PASS, RED3>(a, st);
+    return gate_bwd_launch_one<160, 40, PASS, false>(a, st);      // (C = 160 has no register room for the 80 extra accumulators: red3 refused below)
+}
+
+}  // namespace mny
+
+using namespace mny;
+
+extern "C" int mny_gate_supported(int64_t M, int C, int R) { return gate_shape_ok(M, C, R) ? 1 : 0; }
+extern "C" int mny_gate_parts(int64_t M) { return M > 0 ? gate_grid(M) : MNY_EINVAL; }
+extern "C" int mny_gate_bwd_parts(int64_t M) { return M > 0 ? gate_bwd_grid(M) : MNY_EINVAL; }
+extern "C" int mny_gate_bwd_red3_supported(int C, int R) { return ((C == 40 && R == 10) || (C == 112 && R == 28)) ? 1 : 0; }
+extern "C" size_t mny_gate_wq_bytes(int C, int R) {
+    if (C <= 0 || R <= 0) return 0;
+    const int CT = (C + 15) / 16, CU = (CT + 1) / 2, RT = (R + 15) / 16, RU = (RT + 1) / 2;
+    return (size_t)2 * (RT * CU + CT * RU) * 64 * 16;
+}
+
+extern "C" int mny_gate_cut_batch_bf16(const mny_gate_cut_job* jobs, int njobs, void* stream) {
+    MNY_REQUIRE(jobs && njobs > 0, "gate_cut_batch: bad arguments");
+    hipLaunchKernelGGL(gate_cut_kernel, dim3(16, (unsigned)njobs), dim3(256), 0, (hipStream_t)stream, jobs);
+    return check_launch("gate_cut_kernel");
+}
+
+extern "C" int mny_gate_stats1_bf16(const void* y3, const float* s3, const float* b3, const void* wq, float* stats, int64_t M, int C, int R, void* stream) {
+    MNY_REQUIRE(y3 && s3 && b3 && wq && stats, "gate_stats1: null pointer");
+    MNY_REQUIRE(gate_shape_ok(M, C, R), "gate_stats1: M=%lld C=%d R=%d not supported", (long long)M, C, R);
+    GateFwdArgs a{};
+    a.y3 = (const bf16_t*)y3; a.s3 = s3; a.b3 = b3; a.wq = (const uint4*)wq; a.parts = stats; a.M = M;
+    return gate_fwd_launch<1>(a, C, R, (hipStream_t)stream);
+}
+
+extern "C" int mny_gate_stats2_bf16(const void* y3, const float* s3, const float* b3, const void* wq, const float* sc1, const float* sh1,
+                                    float* stats, int64_t M, int C, int R, void* stream) {
+    MNY_REQUIRE(y3 && s3 && b3 && wq && sc1 && sh1 && stats, "gate_stats2: null pointer");
+    MNY_REQUIRE(gate_shape_ok(M, C, R), "gate_stats2: M=%lld C=%d R=%d not supported", (long long)M, C, R);
+    GateFwdArgs a{};
+    a.y3 = (const bf16_t*)y3; a.s3 = s3; a.b3 = b3; a.wq = (const uint4*)wq; a.sc1 = sc1; a.sh1 = sh1; a.parts = stats; a.M = M;
+    return gate_fwd_launch<2>(a, C, R, (hipStream_t)stream);
+}
+
+extern "C" int mny_gate_fwd_bf16(const void* y3, const float* s3, const float* b3, const void* wq, const float* sc1, const float* sh1,
+                                 const float* sc2, const float* sh2, const void* add_x, const float* add_scale,
+                                 const float* add_shift, int add_act, void* out, int64_t M, int C, int R, void* stream) {
+    MNY_REQUIRE(y3 && s3 && b3 && wq && sc1 && sh1 && sc2 && sh2 && out, "gate_fwd: null pointer");
+    MNY_REQUIRE(gate_shape_ok(M, C, R), "gate_fwd: M=%lld C=%d R=%d not supported", (long long)M, C, R);
+    MNY_REQUIRE(!add_scale == !add_shift, "gate_fwd: scale and shift of the residual operand come together");
+    GateFwdArgs a{};
+    a.y3 = (const bf16_t*)y3; a.s3 = s3; a.b3 = b3; a.wq = (const uint4*)wq; a.sc1 = sc1; a.sh1 = sh1; a.sc2 = sc2; a.sh2 = sh2;
+    a.add_x = (const bf16_t*)add_x; a.add_scale = add_scale; a.add_shift = add_shift; a.add_act = add_act;
+    a.out = (bf16_t*)out; a.M = M;
+    return gate_fwd_launch<3>(a, C, R, (hipStream_t)stream);
+}
+
+static GateBwdArgs gate_bwd_args(const void* y3, const float* s3, const float* b3, const void* dout, const void* wq, const float* bn1, const float* bn2, int64_t M) {
+    GateBwdArgs a{};
+    a.y3 = (const bf16_t*)y3; a.s3 = s3; a.b3 = b3; a.dout = (const bf16_t*)dout; a.wq = (const uint4*)wq; a.M = M;
+    (void)bn1; (void)bn2;
+    return a;
+}
+
+extern "C" int mny_gate_bwd1_bf16(const void* y3, const float* s3, const float* b3, const void* dout, const void* wq, const float* sc1, const float* sh1,
+                                  const float* sc2, const float* sh2, const float* mean2, const float* invstd2, float* red2, int64_t M, int C, int R,
+                                  void* stream) {
+    MNY_REQUIRE(y3 && s3 && b3 && dout && wq && sc1 && sh1 && sc2 && sh2 && mean2 && invstd2 && red2, "gate_bwd1: null pointer");
+    MNY_REQUIRE(gate_shape_ok(M, C, R), "gate_bwd1: M=%lld C=%d R=%d not supported", (long long)M, C, R);
+    GateBwdArgs a = gate_bwd_args(y3, s3, b3, dout, wq, nullptr, nullptr, M);
+    a.sc1 = sc1; a.sh1 = sh1; a.sc2 = sc2; a.sh2 = sh2; a.mean2 = mean2; a.invstd2 = invstd2; a.parts = red2;
+    return gate_bwd_launch<1, false>(a, C, R, (hipStream_t)stream);
+}
+
+extern "C" int mny_gate_bwd2_bf16(const void* y3, const float* s3, const float* b3, const void* dout, const void* wq, const float* sc1, const float* sh1,
+                                  const float* mean1, const float* invstd1, const float* sc2, const float* sh2, const float* coef2, float* red1,
+                                  float* dw2_parts, int64_t M, int C, int R, void* stream) {
+    MNY_REQUIRE(y3 && s3 && b3 && dout && wq && sc1 && sh1 && mean1 && invstd1 && sc2 && sh2 && coef2 && red1 && dw2_parts, "gate_bwd2: null pointer");
+    MNY_REQUIRE(gate_shape_ok(M, C, R), "gate_bwd2: M=%lld C=%d R=%d not supported", (long long)M, C, R);
+    GateBwdArgs a = gate_bwd_args(y3, s3, b3, dout, wq, nullptr, nullptr, M);
+    a.sc1 = sc1; a.sh1 = sh1; a.mean1 = mean1; a.invstd1 = invstd1; a.sc2 = sc2; a.sh2 = sh2; a.coef2 = coef2; a.parts = red1; a.dwp = dw2_parts;
+    return gate_bwd_launch<2, false>(a, C, R, (hipStream_t)stream);
+}
+
+extern "C" int mny_gate_bwd3_bf16(const void* y3, const float* s3, const float* b3, const void* dout, const void* wq, const float* sc1, const float* sh1,
+                                  const float* sc2, const float* sh2, const float* coef2, const float* coef1, const float* mean3, const float* invstd3,
+                                  void* dt, float* dw1_parts, float* red3, int64_t M, int C, int R, void* stream) {
+    MNY_REQUIRE(y3 && s3 && b3 && dout && wq && sc1 && sh1 && sc2 && sh2 && coef2 && coef1 && dt && dw1_parts, "gate_bwd3: null pointer");
+    MNY_REQUIRE(gate_shape_ok(M, C, R), "gate_bwd3: M=%lld C=%d R=%d not supported", (long long)M, C, R);
+    MNY_REQUIRE(red3 == nullptr || (mean3 && invstd3 && mny_gate_bwd_red3_supported(C, R)), "gate_bwd3: red3 needs mean3 / invstd3 and a shape mny_gate_bwd_red3_supported() accepts");
+    GateBwdArgs a = gate_bwd_args(y3, s3, b3, dout, wq, nullptr, nullptr, M);
+    a.sc1 = sc1; a.sh1 = sh1; a.sc2 = sc2; a.sh2 = sh2; a.coef2 = coef2; a.coef1 = coef1; a.mean3 = mean3; a.invstd3 = invstd3;
+    a.dt = (bf16_t*)dt; a.dwp = dw1_parts; a.red3 = red3;
+    return red3 ? gate_bwd_launch<3, true>(a, C, R, (hipStream_t)stream) : gate_bwd_launch<3, false>(a, C, R, (hipStream_t)stream);
+}

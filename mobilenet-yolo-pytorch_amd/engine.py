@@ -307,10 +307,57 @@ class NetPlan:
                         and _lib.query("mny_exdw_supported", N, ish[1], ish[2], i.C, nd.out.C, 2) == 1):
                     self.exdw_pw[nd.out.id] = d
                     self.exdw_dw[d.out.id] = nd
+        # per-pixel gates as one unit (csrc/gate.hip, bf16 storage): t -> pw(C -> C/4, ReLU) -> pw(C/4 -> C, h-sigmoid) -> t * gate [-> + shortcut]
+        # (mobilenetv3.py:26-41,69-72).  gates[emit node out id] = dict(t, se0, se3, mul, add): the two hidden units are skipped where they stand
+        # and the whole unit is emitted at the multiply (or, when the residual add is its only consumer, at the add, which it absorbs).
+        self.gates, self.gate_units, self.gate_absorbed = {}, {}, set()
+        if self.bf16 and not self.frozen and os.environ.get("MNY_NO_GATE") != "1":
+            cons = {}
+            for nd in g.nodes:
+                for v in nd.ins:
+                    cons.setdefault(v.id, []).append(nd)
+            out_ids = {v.id for v in list(g.outputs) + ([g.seg_out] if g.seg_out is not None else [])}
+            for nd in g.nodes:
+                if nd.op != "mul":
+                    continue
+                tv_, sv = nd.ins
+                se3 = sv.node
+                se0 = se3.ins[0].node if (se3 is not None and se3.op == "pw") else None
+                if (se0 is None or se0.op != "pw" or se0.ins[0] is not tv_ or tv_.kind != "unit" or tv_.act != ACT_NONE or sv.act != _lib.ACT_HSIGMOID
+                        or se0.out.act != _lib.ACT_RELU or se0.bias or se3.bias or len(cons.get(se0.out.id, ())) != 1 or len(cons.get(sv.id, ())) != 1
+                        or len(cons.get(tv_.id, ())) != 2 or tv_.id in out_ids or se0.out.id in out_ids or sv.id in out_ids or nd.out.id in out_ids):
+                    continue                                    # (t feeds the gate and the multiply, nothing else: the unit's backward yields its whole gradient)
+                tsh = shape(tv_)
+                if _lib.query("mny_gate_supported", tsh[0] * tsh[1] * tsh[2], tv_.C, se0.out.C) != 1:
+                    continue
+                gate = dict(t=tv_, se0=se0, se3=se3, mul=nd, add=None,
+                            wq=torch.empty(int(_lib.query("mny_gate_wq_bytes", tv_.C, se0.out.C)), device=dev, dtype=torch.uint8))
+                emit_at = nd
+                mc = cons.get(nd.out.id, [])
+                if len(mc) == 1 and mc[0].op == "add" and mc[0].k == 1 and mc[0].ins[0] is nd.out and os.environ.get("MNY_GATE_NOADD") != "1":
+                    gate["add"] = mc[0]                         # out = t * gate + view(other operand): the add node is absorbed
+                    emit_at = mc[0]
+                    self.gate_absorbed.add(nd.out.id)
+                self.gates[emit_at.out.id] = gate
+                self.gate_units[se0.out.id] = gate
+                self.gate_units[se3.out.id] = gate
         for nd in g.nodes:
             o = nd.out
             shp = shape(o)
             M = shp[0] * shp[1] * shp[2]
+            if nd.op == "pw" and o.id in self.gate_units:
+                u = _Unit()                                   # a hidden unit of a gate: its BN coefficients live here, the calls come with the gate
+                u.Y = None                                    # never materialised
+                u.coef4 = torch.empty(4, o.C, **f32)
+                u.scale, u.shift, u.mean, u.invstd = u.coef4[0], u.coef4[1], u.coef4[2], u.coef4[3]
+                u.act, u.C, u.M, u.shape = o.act, o.C, M, shp
+                self.units[o.id] = u
+                continue
+            if o.id in self.gate_absorbed:
+                continue                                      # the multiply of a gate whose residual add absorbs it
+            if o.id in self.gates:
+                self._emit_gate_forward(self.gates[o.id], nd, bn_batch)
+                continue
             if nd.op in ("stem", "dw", "pw"):
                 u = _Unit()
                 u.Y = torch.empty(shp, **act) if o.id not in self.exdw_pw else None      # the expand output of an exdw unit is never materialised
@@ -407,12 +454,54 @@ class NetPlan:
 
         self._flush_cvt_jobs()
         self._flush_cut_jobs(self.fwd, at_head=True)
+        if self.gates:                                        # the gates' weights as matrix-core operand chunks, one launch per pass for all of them
+            import numpy as np
+            gl = list(self.gates.values())
+            jt = np.array([(P[gt["se0"].conv + ".weight"].data_ptr(), P[gt["se3"].conv + ".weight"].data_ptr(), gt["wq"].data_ptr(), gt["t"].C, gt["se0"].out.C) for gt in gl],
+                          dtype=np.dtype([("w1", np.uint64), ("w2", np.uint64), ("wq", np.uint64), ("C", np.int32), ("R", np.int32)]))
+            self.gate_jobs = torch.from_numpy(jt.view(np.uint8).copy()).to(dev)
+            self.fwd.add("mny_gate_cut_batch_bf16", self.gate_jobs, len(gl), self.stream)
+            self.fwd.calls.insert(0, self.fwd.calls.pop())
         self.heads = [self.head32.get(o.id, self.reals[o.id]) for o in g.outputs]
         self.seg_head = self.head32.get(g.seg_out.id, self.reals[g.seg_out.id]) if g.seg_out is not None else None
         self.loss_outputs = list(g.outputs) + ([g.seg_out] if g.seg_out is not None else [])     # values a loss reads
         self._build_detection()
         if training and (bn_batch or self.frozen):
             self._build_backward()
+
+    # ------------------------------------------------------------------------------------------
+    def _emit_gate_forward(self, gate, nd, bn_batch):
+        """The forward calls of a per-pixel gate (csrc/gate.hip) at node `nd` (the multiply, or the residual add that absorbs it)."""
+        P = self.net.param_tensors
+        t, se0, se3 = gate["t"], gate["se0"], gate["se3"]
+        u1, u2 = self.units[se0.out.id], self.units[se3.out.id]
+        tsh = self._shape(t)
+        M, C, R = tsh[0] * tsh[1] * tsh[2], t.C, se0.out.C
+        tv = self._view(t)
+        wq = gate["wq"]
+        out = torch.empty(self._shape(nd.out), device=self.dev, dtype=self.adt)
+        self.reals[nd.out.id] = out
+        parts = _lib.query("mny_gate_parts", M)
+        eb = self.eb
+        for un, hn, Cn in ((u1, se0, R), (u2, se3, C)):
+            gam, bet = P[hn.bn + ".weight"], P[hn.bn + ".bias"]
+            rm, rv = P[hn.bn + ".running_mean"], P[hn.bn + ".running_var"]
+            if bn_batch:
+                if hn is se0:
+                    self.fwd.add("mny_gate_stats1_bf16", tv[0], tv[1], tv[2], wq, self.stats_ws, M, C, R, self.stream,
+                                 meta=dict(flops=2 * M * C * R, bytes=eb * M * C, shape="gate stats1 M%d C%d R%d" % (M, C, R)))
+                else:
+                    self.fwd.add("mny_gate_stats2_bf16", tv[0], tv[1], tv[2], wq, u1.scale, u1.shift, self.stats_ws, M, C, R, self.stream,
+                                 meta=dict(flops=4 * M * C * R, bytes=eb * M * C, shape="gate stats2 M%d C%d R%d" % (M, C, R)))
+                self.fwd.add("mny_bn_finalize", self.stats_ws, parts, M, gam, bet, BN_EPS, BN_MOMENTUM, rm, rv, un.scale, un.shift, un.mean, un.invstd, Cn, self.stream)
+            else:
+                self.fwd.add("mny_bn_eval_coeffs", gam, bet, rm, rv, BN_EPS, un.scale, un.shift, Cn, self.stream)
+        a = (None, None, None, ACT_NONE)
+        if gate["add"] is not None:
+            a = self._view(gate["add"].ins[1])
+        self.fwd.add("mny_gate_fwd_bf16", tv[0], tv[1], tv[2], wq, u1.scale, u1.shift, u2.scale, u2.shift, a[0], a[1], a[2], a[3], out,
+                     M, C, R, self.stream,
+                     meta=dict(flops=4 * M * C * R, bytes=eb * M * C * (3 if a[0] is not None else 2), shape="gate M%d C%d R%d%s" % (M, C, R, " +add" if a[0] is not None else "")))
 
     # ------------------------------------------------------------------------------------------
     def _build_detection(self):
@@ -722,8 +811,48 @@ class NetPlan:
             s = gs[o.id]
             if o.id in self.exdw_pw or o.id in self.stemdw_done:
                 continue                                   # handled with its depthwise consumer (mny_exdw_bwd / mny_stemdw_bwd below)
+            if o.id in self.gate_units or o.id in self.gate_absorbed:
+                continue                                   # hidden units / absorbed multiply of a per-pixel gate: handled where the gate was emitted
             assert s.buf is not None, "no gradient reached %s" % o.name
             G = s.buf
+            if o.id in self.gates:
+                # per-pixel gate as one unit (csrc/gate.hip): three passes over (y3, dL/d out) with the two BN-backward finalizes in between; the
+                # hidden tensors' gradients are never written.  The residual operand (absorbed add) takes G itself.
+                gate = self.gates[o.id]
+                t, se0, se3 = gate["t"], gate["se0"], gate["se3"]
+                if gate["add"] is not None:
+                    contribute_alias(gate["add"].ins[1], G)
+                u1, u2, u3 = self.units[se0.out.id], self.units[se3.out.id], self.units[t.id]
+                tv = view(t)
+                C, R = t.C, se0.out.C
+                wq = gate["wq"]
+                gparts = _lib.query("mny_gate_bwd_parts", M)
+                coef2, coef1 = torch.empty(3 * C, **f32), torch.empty(3 * R, **f32)
+                gate["coef"] = (coef2, coef1)
+                bwd.add("mny_gate_bwd1_bf16", tv[0], tv[1], tv[2], G, wq, u1.scale, u1.shift, u2.scale, u2.shift, u2.mean, u2.invstd, self.red_ws, M, C, R, self.stream,
+                        meta=dict(flops=4 * M * C * R, bytes=eb * 2 * M * C, shape="gate bwd1 M%d C%d R%d" % (M, C, R)))
+                bwd.add(fin_name, self.red_ws, gparts, M, P[se3.bn + ".weight"], u2.mean, u2.invstd, gv(se3.bn + ".weight"), gv(se3.bn + ".bias"), coef2, C, self.stream)
+                dw2 = gv(se3.conv + ".weight")
+                ws2 = defer_job(gparts * C * R, dw2, gparts, C * R)          # (always through the batched combine, MNY_NO_DEFER or not)
+                bwd.add("mny_gate_bwd2_bf16", tv[0], tv[1], tv[2], G, wq, u1.scale, u1.shift, u1.mean, u1.invstd, u2.scale, u2.shift, coef2, self.red_ws, ws2,
+                        M, C, R, self.stream, meta=dict(flops=8 * M * C * R, bytes=eb * 2 * M * C, shape="gate bwd2 M%d C%d R%d" % (M, C, R)))
+                bwd.add(fin_name, self.red_ws, gparts, M, P[se0.bn + ".weight"], u1.mean, u1.invstd, gv(se0.bn + ".weight"), gv(se0.bn + ".bias"), coef1, R, self.stream)
+                dw1 = gv(se0.conv + ".weight")
+                ws1 = defer_job(gparts * C * R, dw1, gparts, C * R)
+                rbuf = None
+                prod = t.node
+                if (_lib.query("mny_gate_bwd_red3_supported", C, R) == 1 and prod is not None and prod.op == "pw" and not takes_own_sums(prod)
+                        and os.environ.get("MNY_GATE_NORED3") != "1"):
+                    rbuf = torch.empty(gparts * 2 * C, **f32)        # dt is the project unit's complete output gradient: its BN-backward sums leave with it
+                    self.fused_red[t.id] = (rbuf, gparts)
+                assert gs[t.id].buf is None, "the gate's input has another consumer"
+                gs[t.id].buf, gs[t.id].shared = alloc(t), False
+                bwd.add("mny_gate_bwd3_bf16", tv[0], tv[1], tv[2], G, wq, u1.scale, u1.shift, u2.scale, u2.shift, coef2, coef1, u3.mean, u3.invstd, gs[t.id].buf, ws1, rbuf,
+                        M, C, R, self.stream, meta=dict(flops=12 * M * C * R, bytes=eb * 3 * M * C, shape="gate bwd3 M%d C%d R%d" % (M, C, R)))
+                flush_shared()
+                flush_reduce()
+                bwd.marks[o.name] = len(bwd.calls)
+                continue
             if nd.op == "dw" and o.id in self.exdw_dw:
                 # expand + depthwise unit: the depthwise unit's BN-backward sums as usual, then ONE entry point yields the depthwise and the
                 # expand unit's parameter gradients and the data gradient wrt the thin input; neither the expand output nor its gradient exists

@@ -9,7 +9,10 @@ lines it restates) with a straight-through bf16 rounding at exactly the product'
   * the raw output of every convolution (stem, depthwise, pointwise, biased heads — bias added in fp32 first);
   * the A operand of every pointwise GEMM: bf16(act(bn(y))) — the value a materialised bf16 activation would hold — and the
     pointwise weights (bf16 shadow copies of the fp32 masters); depthwise / stem inputs and filters stay fp32;
-  * every materialised sum / product (residual adds, the per-pixel gate multiply, PartAdd) via net_ref.STORE.
+  * every materialised sum / product (residual adds, the per-pixel gate multiply, PartAdd) via net_ref.STORE;
+  * MobileNetV3's per-pixel gates run as one unit (csrc/gate.hip): the operands of their two 1x1 convs are rounded like every GEMM
+    operand (whatever the channel count), their OUTPUTS (the hidden tensors) are never stored, hence not rounded, and where the block's
+    residual add absorbs the multiply only the sum is rounded.
 BatchNorm statistics are then taken over the rounded outputs, as the product does.  Gradients flow straight through the roundings
 (the product additionally rounds activation gradients to bf16: a non-chaotic 2^-9-per-layer effect the tests' bounds absorb).
 """
@@ -37,12 +40,22 @@ def _conv_forward(self, x):
     return q(F.conv2d(x, w, self.bias, self.stride, self.padding, self.dilation, self.groups))
 
 
+def _gate_conv_forward(self, x):
+    return F.conv2d(q(x), q(self.weight), self.bias, self.stride, self.padding, self.dilation, self.groups)      # operands rounded, output kept in fp32
+
+
 @contextlib.contextmanager
 def bf16_storage(model):
     """Inside the context, `model` (a RefYolo / RefYoloV3) computes what the product's bf16-storage plan computes."""
+    from . import net_ref_v3
+    gates = [m for m in model.modules() if isinstance(m, net_ref_v3.PixelGate)]
+    gate_convs = {id(c) for gt in gates for c in gt.modules() if isinstance(c, nn.Conv2d)}
     convs = [m for m in model.modules() if isinstance(m, nn.Conv2d)]
     for m in convs:
-        m.forward = types.MethodType(_conv_forward, m)
+        m.forward = types.MethodType(_gate_conv_forward if id(m) in gate_convs else _conv_forward, m)
+    for blk in model.modules():
+        if isinstance(blk, net_ref_v3.V3Block) and blk.se is not None:
+            blk.se._absorbed_by_add = blk.stride == 1
     old = net_ref.STORE
     net_ref.STORE = q
     try:
@@ -51,3 +64,6 @@ def bf16_storage(model):
         net_ref.STORE = old
         for m in convs:
             del m.forward
+        for gt in gates:
+            if hasattr(gt, "_absorbed_by_add"):
+                del gt._absorbed_by_add

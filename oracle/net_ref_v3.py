@@ -25,7 +25,10 @@ class PixelGate(nn.Module):
                                 nn.Conv2d(c // r, c, 1, bias=False), nn.BatchNorm2d(c), nn.Identity())
 
     def forward(self, x):
-        return _store(x * (F.relu6(self.se(x) + 3) / 6))
+        y = x * (F.relu6(self.se(x) + 3) / 6)
+        # bf16-storage model of the product's fused gate unit (oracle/bf16_storage.py sets the flag): where the block's residual add
+        # absorbs the multiply, the product is not a stored tensor — only the sum is rounded
+        return y if getattr(self, "_absorbed_by_add", False) else _store(y)
 
 
 class V3Block(nn.Module):
