@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         // dY = ca * G * act'(sc*Y + sh) + cb * Y + cc on one register pair (packed fma; the activation derivative is a select)
         // act'(z) as selects between constants (v_cndmask; a select between computed values turned into branches)
         auto dact = [&](float z) {
-            if (AM == 2) return z <= -3.f ? 0.f : (z >= 3.f ? 1.f : (2.f * z + 3.f) / 6.f);
+            if (AM == 2) return z <= -3.f ? 0.f : (z >= 3.f ? 1.f : (2.f * z + 3.f) * (1.f / 6.f));
             return (z > 0.f ? 1.f : slope) * (z < hi ? 1.f : 0.f);
         };
         auto dy2 = [&](v2f gv, v2f yv, v2f s, v2f h, v2f a, v2f b, v2f cterm) {
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                         auto pact = [&](float xv1, float s, float h) {
                             const float z = fmaf(xv1, s, h);
                             if (XF == 1) return (z > 0.f ? 1.f : 0.f) * (z < 6.f ? 1.f : 0.f);
-                            if (XF == 2) return z <= -3.f ? 0.f : (z >= 3.f ? 1.f : (2.f * z + 3.f) / 6.f);
+                            if (XF == 2) return z <= -3.f ? 0.f : (z >= 3.f ? 1.f : (2.f * z + 3.f) * (1.f / 6.f));
                             return z > 0.f ? 1.f : xslope;
                         };
                         float4 dz;
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         const float slope = act_slope(act), hi = act_hi(act);
         const float xslope = act_slope(in_act);
         auto dact = [&](float z) {
-            if (AM == 2) return z <= -3.f ? 0.f : (z >= 3.f ? 1.f : (2.f * z + 3.f) / 6.f);
+            if (AM == 2) return z <= -3.f ? 0.f : (z >= 3.f ? 1.f : (2.f * z + 3.f) * (1.f / 6.f));
             return (z > 0.f ? 1.f : slope) * (z < hi ? 1.f : 0.f);
         };
         auto dy2 = [&](v2f gv, v2f yv, v2f s, v2f h, v2f a, v2f b, v2f cterm) {

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256) void dw_slide_kernel(
                     float z[4] = {fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w)};
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        z[e] = XF == 1 ? fminf(fmaxf(z[e], slope * z[e]), hi_clip) : z[e] * fminf(fmaxf(z[e] + 3.f, 0.f), 6.f) / 6.f;
+                        z[e] = XF == 1 ? fminf(fmaxf(z[e], slope * z[e]), hi_clip) : z[e] * fminf(fmaxf(z[e] + 3.f, 0.f), 6.f) * (1.f / 6.f);
                     v = make_float4(z[0], z[1], z[2], z[3]);
                 }
                 return tap_ok(hi, q) ? v : f4zero();

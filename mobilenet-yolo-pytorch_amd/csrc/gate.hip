@@ -224,10 +224,10 @@ __global__ __launch_bounds__(256) void gate_fwd_kernel(GateFwdArgs p) {
             const float4 tt = tval(t);
             const gate_f4 a = acc2[t];
             float4 o;
-            o.x = tt.x * (__builtin_amdgcn_fmed3f(fmaf(a[0], s2.x, b2.x) + 3.f, 0.f, 6.f) / 6.f);
-            o.y = tt.y * (__builtin_amdgcn_fmed3f(fmaf(a[1], s2.y, b2.y) + 3.f, 0.f, 6.f) / 6.f);
-            o.z = tt.z * (__builtin_amdgcn_fmed3f(fmaf(a[2], s2.z, b2.z) + 3.f, 0.f, 6.f) / 6.f);
-            o.w = tt.w * (__builtin_amdgcn_fmed3f(fmaf(a[3], s2.w, b2.w) + 3.f, 0.f, 6.f) / 6.f);
+            o.x = tt.x * (__builtin_amdgcn_fmed3f(fmaf(a[0], s2.x, b2.x) + 3.f, 0.f, 6.f) * (1.f / 6.f));
+            o.y = tt.y * (__builtin_amdgcn_fmed3f(fmaf(a[1], s2.y, b2.y) + 3.f, 0.f, 6.f) * (1.f / 6.f));
+            o.z = tt.z * (__builtin_amdgcn_fmed3f(fmaf(a[2], s2.z, b2.z) + 3.f, 0.f, 6.f) * (1.f / 6.f));
+            o.w = tt.w * (__builtin_amdgcn_fmed3f(fmaf(a[3], s2.w, b2.w) + 3.f, 0.f, 6.f) * (1.f / 6.f));
             if (p.add_x != nullptr) {
                 const float4 av = ld4(p.add_x + m * C + c0);
                 const float4 as = gate_ld4(cas + cl), ab = gate_ld4(cab + cl);
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(64 * kGateBW) void gate_bwd_kernel(GateBwdArgs p) {
                 if (PASS == 3) {
                     float gt[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) gt[i] = dv[i] * (__builtin_amdgcn_fmed3f(zz[i] + 3.f, 0.f, 6.f) / 6.f);
+                    for (int i = 0; i < 4; ++i) gt[i] = dv[i] * (__builtin_amdgcn_fmed3f(zz[i] + 3.f, 0.f, 6.f) * (1.f / 6.f));
                     dog[PASS == 3 ? t : 0] = make_float4(gt[0], gt[1], gt[2], gt[3]);
                 }
 #pragma unroll

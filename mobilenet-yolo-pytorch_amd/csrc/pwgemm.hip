@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((X6 == 3 &&
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const float zz = fmaf(z[e], scv[e], shv[e]);
-                        z[e] = XF == 1 ? fminf(fmaxf(zz, slope * zz), hi) : zz * fminf(fmaxf(zz + 3.f, 0.f), 6.f) / 6.f;
+                        z[e] = XF == 1 ? fminf(fmaxf(zz, slope * zz), hi) : zz * fminf(fmaxf(zz + 3.f, 0.f), 6.f) * (1.f / 6.f);
                     }
                     au = v4u_t{pack_bf16x2(z[0], z[1]), pack_bf16x2(z[2], z[3]), pack_bf16x2(z[4], z[5]), pack_bf16x2(z[6], z[7])};
                 }
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((X6 == 3 &&
                 float z[8] = {fmaf(a0.x, sc0.x, sh0.x), fmaf(a0.y, sc0.y, sh0.y), fmaf(a0.z, sc0.z, sh0.z), fmaf(a0.w, sc0.w, sh0.w),
                               fmaf(a1.x, sc1.x, sh1.x), fmaf(a1.y, sc1.y, sh1.y), fmaf(a1.z, sc1.z, sh1.z), fmaf(a1.w, sc1.w, sh1.w)};
 #pragma unroll
-                for (int e = 0; e < 8; ++e) z[e] = XF == 1 ? fminf(fmaxf(z[e], slope * z[e]), hi) : z[e] * fminf(fmaxf(z[e] + 3.f, 0.f), 6.f) / 6.f;
+                for (int e = 0; e < 8; ++e) z[e] = XF == 1 ? fminf(fmaxf(z[e], slope * z[e]), hi) : z[e] * fminf(fmaxf(z[e] + 3.f, 0.f), 6.f) * (1.f / 6.f);
                 a0 = v4f_t{z[0], z[1], z[2], z[3]}; a1 = v4f_t{z[4], z[5], z[6], z[7]};
             }
             bf16x8_t ah, am, al;
@@ -534,8 +534,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((X6 == 3 &&
                     af.x = fminf(fmaxf(z0, slope * z0), hi); af.y = fminf(fmaxf(z1, slope * z1), hi);
                     af.z = fminf(fmaxf(z2, slope * z2), hi); af.w = fminf(fmaxf(z3, slope * z3), hi);
                 } else {
-                    af.x = z0 * fminf(fmaxf(z0 + 3.f, 0.f), 6.f) / 6.f; af.y = z1 * fminf(fmaxf(z1 + 3.f, 0.f), 6.f) / 6.f;
-                    af.z = z2 * fminf(fmaxf(z2 + 3.f, 0.f), 6.f) / 6.f; af.w = z3 * fminf(fmaxf(z3 + 3.f, 0.f), 6.f) / 6.f;
+                    af.x = z0 * fminf(fmaxf(z0 + 3.f, 0.f), 6.f) * (1.f / 6.f); af.y = z1 * fminf(fmaxf(z1 + 3.f, 0.f), 6.f) * (1.f / 6.f);
+                    af.z = z2 * fminf(fmaxf(z2 + 3.f, 0.f), 6.f) * (1.f / 6.f); af.w = z3 * fminf(fmaxf(z3 + 3.f, 0.f), 6.f) * (1.f / 6.f);
                 }
             }
             // accumulators interleaved: consecutive MFMAs never depend on each other
@@ -761,7 +761,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((X6 == 3 &&
                         const float av = P < 4 ? a0[P & 3] : a1[P & 3];
                         if constexpr (XF != 0) {
                             const float zz = fmaf(av, P < 4 ? sc0[P & 3] : sc1[P & 3], P < 4 ? sh0[P & 3] : sh1[P & 3]);
-                            z[P] = XF == 1 ? fminf(fmaxf(zz, slope * zz), hi) : zz * fminf(fmaxf(zz + 3.f, 0.f), 6.f) / 6.f;
+                            z[P] = XF == 1 ? fminf(fmaxf(zz, slope * zz), hi) : zz * fminf(fmaxf(zz + 3.f, 0.f), 6.f) * (1.f / 6.f);
                         } else {
                             z[P] = av;
                         }
@@ -1652,7 +1652,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_kernel(WgradArgs p) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float zz = fmaf(z[e], sc[j], sh[j]);
-                    z[e] = XF == 1 ? fminf(fmaxf(zz, slope * zz), hi) : zz * fminf(fmaxf(zz + 3.f, 0.f), 6.f) / 6.f;
+                    z[e] = XF == 1 ? fminf(fmaxf(zz, slope * zz), hi) : zz * fminf(fmaxf(zz + 3.f, 0.f), 6.f) * (1.f / 6.f);
                 }
                 u = make_uint4(pack_bf16x2(z[0], z[1]), pack_bf16x2(z[2], z[3]), pack_bf16x2(z[4], z[5]), pack_bf16x2(z[6], z[7]));
             }

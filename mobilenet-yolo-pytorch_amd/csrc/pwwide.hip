@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float t = fmaf(z[e], sv[e], hv[e]);
-                    z[e] = XF == 1 ? fminf(fmaxf(t, slope * t), hi) : t * fminf(fmaxf(t + 3.f, 0.f), 6.f) / 6.f;
+                    z[e] = XF == 1 ? fminf(fmaxf(t, slope * t), hi) : t * fminf(fmaxf(t + 3.f, 0.f), 6.f) * (1.f / 6.f);
                 }
             }
             x6_split(v4f_t{z[0], z[1], z[2], z[3]}, v4f_t{z[4], z[5], z[6], z[7]}, ah[s], am[s], al[s]);
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     float dact;
                     if (XF == 0) dact = (zz > 0.f ? 1.f : rslope) * (zz < rhi ? 1.f : 0.f);      // clamp family (torch's subgradient choices, act_bwd)
                     else {                                       // h-swish / h-sigmoid: selects, no per-element branch on the wave-uniform kind
-                        const float dsw = zz <= -3.f ? 0.f : (zz >= 3.f ? 1.f : (2.f * zz + 3.f) / 6.f);
+                        const float dsw = zz <= -3.f ? 0.f : (zz >= 3.f ? 1.f : (2.f * zz + 3.f) * (1.f / 6.f));
                         const float dsg = (zz > -3.f && zz < 3.f) ? (1.f / 6.f) : 0.f;
                         dact = rhsig ? dsg : dsw;
                     }

@@ -670,9 +670,18 @@ class NetPlan:
             jdev = torch.from_numpy(jt.view(np.uint8).copy()).to(dev)
             bdev = torch.tensor(block_job, dtype=torch.int32, device=dev)
             self._red_keep += [t for job in self._red_jobs for t in job[:2]]
-            if self.side_on:
-                bwd.add_py(self._join_side, "join")               # the partials of side-stream weight gradients must have landed
-            bwd.add("mny_reduce_batch", jdev, bdev, len(block_job), self.stream, meta=dict(writes=[job[1].data_ptr() for job in self._red_jobs]))
+            # The combine feeds nothing downstream in the backward pass: it runs on the SIDE stream, behind the side-stream weight gradients
+            # whose partial rows it reads (same stream = ordered) and, through the fork, behind everything the main stream has enqueued (the
+            # fused units leave their partial rows there).  Every replayed segment ends with a join (run_bwd_segment), so gradients are
+            # complete before an all-reduce or the optimizer sees them.  (Round 4 joined here and ran the combine on the main stream: 0.3 ms
+            # of 4-5 launches on the critical path of both benchmark configurations.)  MNY_REDUCE_MAIN=1: the round-4 placement.
+            if self.side_on and os.environ.get("MNY_REDUCE_MAIN") != "1":
+                bwd.add_py(self._fork_side, "fork")
+                bwd.add("mny_reduce_batch", jdev, bdev, len(block_job), self.stream_side, meta=dict(writes=[job[1].data_ptr() for job in self._red_jobs]))
+            else:
+                if self.side_on:
+                    bwd.add_py(self._join_side, "join")           # the partials of side-stream weight gradients must have landed
+                bwd.add("mny_reduce_batch", jdev, bdev, len(block_job), self.stream, meta=dict(writes=[job[1].data_ptr() for job in self._red_jobs]))
             self._red_jobs = []
 
         # workspaces shared by all layers (single stream => sequential use)
