@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((X6 == 3 &&
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const float zz = fmaf(z[e], scv[e], shv[e]);
-                        z[e] = XF == 1 ? fminf(fmaxf(zz, slope * zz), hi) : zz * fminf(fmaxf(zz + 3.f, 0.f), 6.f) * (1.f / 6.f);
+                        z[e] = XF == 1 ? __builtin_amdgcn_fmed3f(zz, slope * zz, hi) : zz * __builtin_amdgcn_fmed3f(zz + 3.f, 0.f, 6.f) * (1.f / 6.f);
                     }
                     au = v4u_t{pack_bf16x2(z[0], z[1]), pack_bf16x2(z[2], z[3]), pack_bf16x2(z[4], z[5]), pack_bf16x2(z[6], z[7])};
                 }
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((X6 == 3 &&
                 float z[8] = {fmaf(a0.x, sc0.x, sh0.x), fmaf(a0.y, sc0.y, sh0.y), fmaf(a0.z, sc0.z, sh0.z), fmaf(a0.w, sc0.w, sh0.w),
                               fmaf(a1.x, sc1.x, sh1.x), fmaf(a1.y, sc1.y, sh1.y), fmaf(a1.z, sc1.z, sh1.z), fmaf(a1.w, sc1.w, sh1.w)};
 #pragma unroll
-                for (int e = 0; e < 8; ++e) z[e] = XF == 1 ? fminf(fmaxf(z[e], slope * z[e]), hi) : z[e] * fminf(fmaxf(z[e] + 3.f, 0.f), 6.f) * (1.f / 6.f);
+                for (int e = 0; e < 8; ++e) z[e] = XF == 1 ? __builtin_amdgcn_fmed3f(z[e], slope * z[e], hi) : z[e] * __builtin_amdgcn_fmed3f(z[e] + 3.f, 0.f, 6.f) * (1.f / 6.f);
                 a0 = v4f_t{z[0], z[1], z[2], z[3]}; a1 = v4f_t{z[4], z[5], z[6], z[7]};
             }
             bf16x8_t ah, am, al;
@@ -761,7 +761,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((X6 == 3 &&
                         const float av = P < 4 ? a0[P & 3] : a1[P & 3];
                         if constexpr (XF != 0) {
                             const float zz = fmaf(av, P < 4 ? sc0[P & 3] : sc1[P & 3], P < 4 ? sh0[P & 3] : sh1[P & 3]);
-                            z[P] = XF == 1 ? fminf(fmaxf(zz, slope * zz), hi) : zz * fminf(fmaxf(zz + 3.f, 0.f), 6.f) * (1.f / 6.f);
+                            z[P] = XF == 1 ? __builtin_amdgcn_fmed3f(zz, slope * zz, hi) : zz * __builtin_amdgcn_fmed3f(zz + 3.f, 0.f, 6.f) * (1.f / 6.f);
                         } else {
                             z[P] = av;
                         }
@@ -1652,7 +1652,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_bf16_kernel(WgradArgs p) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float zz = fmaf(z[e], sc[j], sh[j]);
-                    z[e] = XF == 1 ? fminf(fmaxf(zz, slope * zz), hi) : zz * fminf(fmaxf(zz + 3.f, 0.f), 6.f) * (1.f / 6.f);
+                    z[e] = XF == 1 ? __builtin_amdgcn_fmed3f(zz, slope * zz, hi) : zz * __builtin_amdgcn_fmed3f(zz + 3.f, 0.f, 6.f) * (1.f / 6.f);
                 }
                 u = make_uint4(pack_bf16x2(z[0], z[1]), pack_bf16x2(z[2], z[3]), pack_bf16x2(z[4], z[5]), pack_bf16x2(z[6], z[7]));
             }
@@ -2059,9 +2059,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
 // (select, not branch, for the rows past the slice), the Gram MFMA is unconditional (its column-slice twin is simply not stored).
 // T: storage type of G, Y, X (float, or bf16_t for bf16-storage plans: the LDS image holds bf16, a 16-byte DMA chunk is 8 elements, the
 // arithmetic is the same fp32; K % 8 == 0 and N % 8 == 0 there)
-template <int TI, typename T = float>
+// S: ring depth.  A stage is 16 rows whatever the storage type, i.e. HALF the bytes with bf16 storage (2 x 5 KB per workgroup in flight at
+// three stages; the bf16 instantiation runs 2.9 TB/s where the fp32 one runs 4.3-5.2).  Six stages (MNY_BNW_RING=6) were measured in round 5
+// and changed nothing: bytes in flight are not what holds this kernel back.
+template <int TI, typename T = float, int S = 3>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) void pw_bnbwd_stage1b_kernel(BnwArgs p) {
-    constexpr int KC = 16, S = 3, BI = 32 * TI, BJ = 32;
+    constexpr int KC = 16, BI = 32 * TI, BJ = 32;
     constexpr int EPC = 16 / (int)sizeof(T), EPI = 64 * EPC;                  // elements per 16-byte chunk / per 1-KiB DMA instruction
     constexpr int G_ST = KC * BI, X_ST = KC * BJ, STAGE = 2 * G_ST + X_ST;   // elements of T: G | Y | X
     constexpr int NG = (G_ST + EPI - 1) / EPI, NX = (X_ST + EPI - 1) / EPI, NL = 2 * NG + NX;
@@ -3347,13 +3350,17 @@ extern "C" int mny_pw_bnbwd_bf16(const void* g, const void* y, const float* scal
               pl.rows_per_block, pl.TI};
     dim3 grid(pl.splits, pl.nsl), block(256);
     // LDS: the bf16 ring is half the fp32 one, but the block reductions at the end use [3][16][64] + vector scratch in fp32
-    size_t lds1 = (size_t)3 * 16 * (2 * 32 * pl.TIs + 32) * sizeof(bf16_t);
+    static const int deep = getenv("MNY_BNW_RING") ? atoi(getenv("MNY_BNW_RING")) : 3;       // stages of the bf16 ring: MNY_BNW_RING=6 measured round 5, same box: 15.24 / 15.24 vs 15.20 / 15.25 ms — no gain, 3 stays
+    const int S1 = deep == 3 ? 3 : 6;
+    size_t lds1 = (size_t)S1 * 16 * (2 * 32 * pl.TIs + 32) * sizeof(bf16_t);
     const size_t need = (size_t)4 * (2 * pl.TIs + 1) * 32 * sizeof(float);
     if (lds1 < need) lds1 = need;
     if (lds1 < 3 * 16 * 64 * sizeof(float)) lds1 = 3 * 16 * 64 * sizeof(float);
-    switch (pl.TIs) {
-        case 2: hipLaunchKernelGGL((pw_bnbwd_stage1b_kernel<2, bf16_t>), grid, block, lds1, st, a); break;
-        case 3: hipLaunchKernelGGL((pw_bnbwd_stage1b_kernel<3, bf16_t>), grid, block, lds1, st, a); break;
+    switch (pl.TIs * 10 + S1) {
+        case 23: hipLaunchKernelGGL((pw_bnbwd_stage1b_kernel<2, bf16_t, 3>), grid, block, lds1, st, a); break;
+        case 33: hipLaunchKernelGGL((pw_bnbwd_stage1b_kernel<3, bf16_t, 3>), grid, block, lds1, st, a); break;
+        case 26: hipLaunchKernelGGL((pw_bnbwd_stage1b_kernel<2, bf16_t, 6>), grid, block, lds1, st, a); break;
+        case 36: hipLaunchKernelGGL((pw_bnbwd_stage1b_kernel<3, bf16_t, 6>), grid, block, lds1, st, a); break;
         default: set_error("pw_bnbwd_bf16: no stage-1 kernel for %d column tiles", pl.TIs); return MNY_EUNSUPPORTED;
     }
     int rc = check_launch("pw_bnbwd_stage1b_kernel<bf16>");

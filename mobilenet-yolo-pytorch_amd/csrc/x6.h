@@ -19,7 +19,13 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 // poisons in an fp32 FMA chain, but always as NaN — the SIGN of an infinity is lost.  Pinned by tests/test_gpu_kernels.py
 // (test_six_product_form_on_non_finite_...: same non-finite set as MNY_X6=0, finite outputs equal); MNY_X6=0 is the strict-fp32 mode.
 __device__ __forceinline__ void x6_split(v4f_t x0, v4f_t x1, bf16x8_t& h, bf16x8_t& m, bf16x8_t& l) {
-    const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    // The operands are pinned as ROUNDED fp32 values: where x is the result of a multiplication in the caller (the h-swish view's
+    // `z * clamp * (1/6)`), -ffp-contract=fast would fold that multiply into the first subtraction below (fma(t, 1/6, -hi(x))) and cut the
+    // UNROUNDED product — hi + mid + lo would no longer equal the value the other kernels see (round 5: the in-kernel and the pre-cut
+    // forms differed in the last bit behind h-swish views once the division by 6 had become a multiplication).
+#pragma unroll
+    for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(x[e]));
     float r1[8], r2[8];
 #pragma unroll
     for (int e = 0; e < 8; e += 2) {                 // pairs: the subtractions are v_pk_add_f32
