@@ -578,6 +578,15 @@ int mny_pj_bwd_parts(int64_t M, int Ki, int No);
 int mny_pj_bwd(const float* g, const float* y, const float* coef, const float* d, const float* d_scale, const float* d_shift,
                const float* d_mean, const float* d_invstd, int d_act, const float* w, float* gd, float* dw, float* dw_ws, float* red,
                int64_t M, int Ki, int No, void* stream);
+/* the same on bf16 storage (csrc/gate.hip, the wave-per-16-pixels matrix-core machinery of the gate unit): MobileNetV3's thin project
+ * convs (models/mobilenetv3.py:57-58,69), (Ki, No) in {(16,16), (64,24), (72,24), (72,40), (120,40)}, any view activation but h-sigmoid;
+ * the BN-backward sums of the unit in front are taken over the STORED (bf16) gd like mny_pw_dgrad_bnred_bf16's; dw's operands are the
+ * bf16 values the forward GEMM multiplied. */
+int mny_pj_bwd_supported_bf16(int64_t M, int Ki, int No, int d_act);
+int mny_pj_bwd_parts_bf16(int64_t M, int Ki, int No);
+int mny_pj_bwd_bf16(const void* g, const void* y, const float* coef, const void* d, const float* d_scale, const float* d_shift,
+                    const float* d_mean, const float* d_invstd, int d_act, const float* w, void* gd, float* dw, float* dw_ws, float* red,
+                    int64_t M, int Ki, int No, void* stream);
 
 /* ---- MobileNetV3's per-pixel gate as one unit (csrc/gate.hip), bf16 storage: models/mobilenetv3.py:26-41 (SeModule whose avg_pool is
  * never called: the gate is per pixel) applied to the project conv's output (:69-71) —

@@ -120,7 +120,7 @@ _SIGS = {
     "mny_eval_pack": (c_int, [P, c_int64, P, c_int64, P, P, P, P, P, P, P]),
 }
 # bf16-storage twins (activation tensors bf16, everything else as in the fp32 entry point): identical ctypes signature
-BF16_TWINS = ("mny_pw_bnbwd_supported", "mny_pw_bnbwd", "mny_pw_wgrad_splits", "mny_transpose_batch", "mny_pw_dgrad_bnred_supported", "mny_pw_dgrad_bnred_parts", "mny_pw_dgrad_bnred", "mny_pw_dgrad_bnred_add", "mny_pw_dgrad_bnred_add_supported", "mny_stem_bnwgrad", "mny_pad_rows", "mny_transpose_pad", "mny_dw_bnbwd", "mny_dw_bnbwd_s2", "mny_dw_bnbwd_red", "mny_stem_fwd", "mny_stem_wgrad", "mny_dw_fwd", "mny_dw_bwd_data", "mny_dw_bwd_weight", "mny_pw_fwd",
+BF16_TWINS = ("mny_pj_bwd_supported", "mny_pj_bwd_parts", "mny_pj_bwd", "mny_pw_bnbwd_supported", "mny_pw_bnbwd", "mny_pw_wgrad_splits", "mny_transpose_batch", "mny_pw_dgrad_bnred_supported", "mny_pw_dgrad_bnred_parts", "mny_pw_dgrad_bnred", "mny_pw_dgrad_bnred_add", "mny_pw_dgrad_bnred_add_supported", "mny_stem_bnwgrad", "mny_pad_rows", "mny_transpose_pad", "mny_dw_bnbwd", "mny_dw_bnbwd_s2", "mny_dw_bnbwd_red", "mny_stem_fwd", "mny_stem_wgrad", "mny_dw_fwd", "mny_dw_bwd_data", "mny_dw_bwd_weight", "mny_pw_fwd",
               "mny_pw_stat_parts", "mny_pw_wgrad", "mny_bn_bwd_reduce", "mny_bn_bwd_apply", "mny_add_views", "mny_mul_views",
               "mny_mul_views_bwd", "mny_partadd_up", "mny_slice_channels", "mny_upsample_bwd", "mny_axpy")
 for _n in BF16_TWINS:

@@ -487,6 +487,177 @@ __global__ __launch_bounds__(64 * kGateBW) void gate_bwd_kernel(GateBwdArgs p) {
     }
 }
 
+// ---- thin project unit, backward as one pass, bf16 storage (the MobileNetV3 counterpart of csrc/pjbwd.hip) --------------------------------
+// Autograd of the linear bottleneck conv3 + bn3 (models/mobilenetv3.py:57-58,69): given G = dL/d(BN output) [M,No], the unit's raw output
+// Y [M,No], its BN-backward coefficients coef[3][No], and the raw output D [M,Ki] of the depthwise unit in front (view d_scale / d_shift /
+// d_act, statistics d_mean / d_invstd), consumed only here:
+//     dY = ca G + cb Y + cc;   gd = W^T dY  (the gradient wrt the ACTIVATED d, stored);   the depthwise unit's BN-backward sums over
+//     (stored gd * act'(z_d), d);   dW[no][ki] = sum_px dY[no][px] a_d[ki][px],  a_d = bf16(act(z_d)) — the forward GEMM's A operand.
+// One launch instead of mny_bn_bwd_apply + mny_pw_dgrad_bnred + mny_pw_wgrad: G, Y, D are read once, dY never reaches HBM.
+// Same machinery as the gate: a wave owns 16 pixels x all channels, W^T is the A operand (cut once per workgroup), dY in the accumulator
+// layout IS the B fragment; the weight gradient contracts over the 128 pixels the 8 waves of the workgroup park transposed in LDS.
+struct Pj16Args {
+    const bf16_t* g; const bf16_t* y; const float* coef;
+    const bf16_t* d; const float* d_scale; const float* d_shift; const float* d_mean; const float* d_invstd; int d_act;
+    const float* w;                                               // [No][Ki] fp32 master
+    bf16_t* gd; float* dw_parts; float* red;
+    int64_t M;
+};
+template <int KI, int NO>
+struct Pj16Lds {
+    static constexpr int CT = (KI + 15) / 16, CP = ((CT + 1) / 2) * 32, NT = (NO + 15) / 16, NU = (NT + 1) / 2, NP = NU * 32;
+    static constexpr size_t chunks = (size_t)CT * NU * 64 * 16;
+    static constexpr size_t consts = (size_t)(4 * CP + 3 * NP) * 4;
+    static constexpr size_t xch = (size_t)(16 * CT + 16 * NT) * kGatePitch * 2;
+    static constexpr size_t red = (size_t)kGateBW * 2 * CP * 4;
+    static constexpr size_t total = chunks + consts + xch + red;
+};
+
+template <int KI, int NO>
+__global__ __launch_bounds__(64 * kGateBW) void pj16_bwd_kernel(Pj16Args p) {
+    typedef Pj16Lds<KI, NO> L;
+    constexpr int CT = L::CT, CP = L::CP, NT = L::NT, NU = L::NU, NP = L::NP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char pj_lds[];
+    uint4* wa = reinterpret_cast<uint4*>(pj_lds);                  // W^T chunks: rows ki, k = no
+    float* cd = reinterpret_cast<float*>(pj_lds + L::chunks);     // wide side: 0 d_scale, 1 d_shift, 2 d_mean, 3 d_invstd
+    float* cn = cd + 4 * CP;                                      // thin side: 0 ca, 1 cb, 2 cc
+    unsigned short* xa = reinterpret_cast<unsigned short*>(pj_lds + L::chunks + L::consts);       // a_d^T [16 CT][pitch]
+    unsigned short* xb = xa + 16 * CT * kGatePitch;                                               // dY^T  [16 NT][pitch]
+    float* red = reinterpret_cast<float*>(pj_lds + L::chunks + L::consts + L::xch);
+
+    for (int idx = threadIdx.x; idx < CT * NU * 64; idx += blockDim.x)
+        wa[idx] = gate_chunk(p.w, KI, NO, 1, KI, idx / (64 * NU), (idx >> 6) % NU, idx & 63);     // (ki, no) = w[no * KI + ki]
+    gate_fill_row(cd + 0 * CP, p.d_scale, KI, CP); gate_fill_row(cd + 1 * CP, p.d_shift, KI, CP);
+    gate_fill_row(cd + 2 * CP, p.d_mean, KI, CP); gate_fill_row(cd + 3 * CP, p.d_invstd, KI, CP);
+    gate_fill_row(cn + 0 * NP, p.coef, NO, NP); gate_fill_row(cn + 1 * NP, p.coef + NO, NO, NP); gate_fill_row(cn + 2 * NP, p.coef + 2 * NO, NO, NP);
+    __syncthreads();
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, px = lane & 15, rg = lane >> 4;
+    const int64_t ntiles = (p.M + 15) >> 4;
+    const int64_t niter = (ntiles + kGateBW - 1) / kGateBW;
+    gate_f4 ssum[CT], qsum[CT];
+#pragma unroll
+    for (int i = 0; i < CT; ++i) { ssum[i] = gate_zero(); qsum[i] = gate_zero(); }
+    constexpr int NTILE = NT * CT, JT = (NTILE + kGateBW - 1) / kGateBW;
+    gate_f4 wacc[JT];
+#pragma unroll
+    for (int j = 0; j < JT; ++j) wacc[j] = gate_zero();
+
+    // the rows of the NEXT workgroup iteration are requested before this one is processed (one workgroup of 8 waves per CU at ~200 VGPRs:
+    // without it every iteration is a full memory round trip in front of two barriers)
+    uint2 ng[NT], ny[NT], nd_[CT];
+    auto request = [&](int64_t it) {
+        const int64_t m = (it * kGateBW + wave) * 16 + px;
+        const int64_t mr = (it < niter && m < p.M) ? m : 0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const bool ok = 16 * t + 4 * rg < NO;
+            ng[t] = ok ? *reinterpret_cast<const uint2*>(p.g + mr * NO + 16 * t + 4 * rg) : make_uint2(0u, 0u);
+            ny[t] = ok ? *reinterpret_cast<const uint2*>(p.y + mr * NO + 16 * t + 4 * rg) : make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
+            nd_[t] = (16 * t + 4 * rg < KI) ? *reinterpret_cast<const uint2*>(p.d + mr * KI + 16 * t + 4 * rg) : make_uint2(0u, 0u);
+    };
+    request(blockIdx.x);
+    for (int64_t it = blockIdx.x; it < niter; it += gridDim.x) {
+        int lo = lane, cq = 4 * rg;
+        asm volatile("" : "+v"(lo), "+v"(cq));
+        const int64_t m = (it * kGateBW + wave) * 16 + px;
+        const bool valid = m < p.M;
+        const float vm = valid ? 1.f : 0.f;
+        uint2 rg_[NT], ry[NT], rd[CT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { rg_[t] = ng[t]; ry[t] = ny[t]; }
+#pragma unroll
+        for (int t = 0; t < CT; ++t) rd[t] = nd_[t];
+        request(it + gridDim.x);
+        // dY = ca G + cb Y + cc (0 on pixels past M; zero constants on padding channels)
+        auto dyval = [&](int t) {
+            const float4 G = gate_widen(rg_[t]), Y = gate_widen(ry[t]);
+            const float4 ca = gate_ld4(cn + 0 * NP + 16 * t + cq), cb = gate_ld4(cn + 1 * NP + 16 * t + cq), cc = gate_ld4(cn + 2 * NP + 16 * t + cq);
+            return make_float4(fmaf(ca.x, G.x, fmaf(cb.x, Y.x, cc.x)) * vm, fmaf(ca.y, G.y, fmaf(cb.y, Y.y, cc.y)) * vm,
+                               fmaf(ca.z, G.z, fmaf(cb.z, Y.z, cc.z)) * vm, fmaf(ca.w, G.w, fmaf(cb.w, Y.w, cc.w)) * vm);
+        };
+        gate_f4 acc[CT];                                          // gd = W^T dY
+        gate_product<CT, NU>(acc, wa + lo, [&](int u) { return gate_frag(dyval(2 * u), 2 * u + 1 < NT ? dyval(2 * u + 1 < NT ? 2 * u + 1 : 0) : f4zero()); });
+        const int col = 16 * wave + px;
+#pragma unroll
+        for (int t = 0; t < CT; ++t) {
+            const int c0 = 16 * t + 4 * rg, cl = 16 * t + cq;
+            const float4 dv = gate_widen(rd[t]);
+            const float4 z = gate_fma4(dv, gate_ld4(cd + 0 * CP + cl), gate_ld4(cd + 1 * CP + cl));
+            const float4 mu = gate_ld4(cd + 2 * CP + cl), is = gate_ld4(cd + 3 * CP + cl);
+            const float4 o = gate_f(acc[t]);
+            if (c0 < KI && valid) st4_stream(p.gd + m * KI + c0, o);
+            const float4 os = stored4<bf16_t>(o);
+            const float zz[4] = {z.x, z.y, z.z, z.w}, ov[4] = {os.x, os.y, os.z, os.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w};
+            const float mv[4] = {mu.x, mu.y, mu.z, mu.w}, iv[4] = {is.x, is.y, is.z, is.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float dz = ov[i] * act_bwd(zz[i], p.d_act) * vm;
+                ssum[t][i] += dz;
+                qsum[t][i] = fmaf(dz, (dd[i] - mv[i]) * iv[i], qsum[t][i]);
+                xa[(16 * t + 4 * rg + i) * kGatePitch + col] = (unsigned short)(gate_pack2(act_fwd(zz[i], p.d_act) * vm, 0.f) & 0xffffu);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float4 dy = dyval(t);
+            const float dv[4] = {dy.x, dy.y, dy.z, dy.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xb[(16 * t + 4 * rg + i) * kGatePitch + col] = (unsigned short)(gate_pack2(dv[i], 0.f) & 0xffffu);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < JT; ++j) {                             // dW tiles: rows no (xb), columns ki (xa)
+            const int q = wave + kGateBW * j;
+            if (q < NTILE) {
+                const int tr = q / CT, tc = q % CT;
+                const unsigned short* pa = xb + (16 * tr + px) * kGatePitch + 8 * rg;
+                const unsigned short* pb = xa + (16 * tc + px) * kGatePitch + 8 * rg;
+#pragma unroll
+                for (int ks = 0; ks < kGateBW / 2; ++ks) {
+                    const uint4 a = *reinterpret_cast<const uint4*>(pa + 32 * ks), b = *reinterpret_cast<const uint4*>(pb + 32 * ks);
+                    wacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), wacc[j], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    gate_write_sums<CT, CP, KI, kGateBW>(ssum, qsum, red, p.red);
+    float* dst = p.dw_parts + (int64_t)blockIdx.x * NO * KI;
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+        const int q = wave + kGateBW * j;
+        if (q < NTILE) {
+            const int tr = q / CT, tc = q % CT;
+            const int c = 16 * tc + px;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 16 * tr + 4 * rg + i;
+                if (r < NO && c < KI) dst[r * KI + c] = wacc[j][i];
+            }
+        }
+    }
+}
+
+static bool pj16_shape_ok(int64_t M, int Ki, int No) {
+    return M >= 16 && ((Ki == 16 && No == 16) || (Ki == 64 && No == 24) || (Ki == 72 && No == 24) || (Ki == 72 && No == 40) || (Ki == 120 && No == 40));
+}
+static int pj16_grid(int64_t M) {
+    const int64_t want = cdiv(cdiv(M, 16), kGateBW);
+    return (int)(want < 512 ? want : 512);
+}
+template <int KI, int NO>
+static int pj16_launch(const Pj16Args& a, int grid, hipStream_t st) {
+    constexpr size_t lds = Pj16Lds<KI, NO>::total;
+    static_assert(lds <= 160 * 1024, "pj16: LDS budget");
+    if (lds > 64 * 1024 && !allow_lds((const void*)pj16_bwd_kernel<KI, NO>, lds)) { set_error("pj_bwd_bf16: hipFuncSetAttribute failed"); return MNY_EHIP; }
+    hipLaunchKernelGGL((pj16_bwd_kernel<KI, NO>), dim3(grid), dim3(64 * kGateBW), lds, st, a);
+    return check_launch("pj16_bwd_kernel");
+}
+
 static bool gate_shape_ok(int64_t M, int C, int R) {
     return M > 0 && ((C == 40 && R == 10) || (C == 112 && R == 28) || (C == 160 && R == 40));
 }
@@ -612,4 +783,28 @@ extern "C" int mny_gate_bwd3_bf16(const void* y3, const float* s3, const float* 
     a.sc1 = sc1; a.sh1 = sh1; a.sc2 = sc2; a.sh2 = sh2; a.coef2 = coef2; a.coef1 = coef1; a.mean3 = mean3; a.invstd3 = invstd3;
     a.dt = (bf16_t*)dt; a.dwp = dw1_parts; a.red3 = red3;
     return red3 ? gate_bwd_launch<3, true>(a, C, R, (hipStream_t)stream) : gate_bwd_launch<3, false>(a, C, R, (hipStream_t)stream);
+}
+
+extern "C" int mny_pj_bwd_supported_bf16(int64_t M, int Ki, int No, int d_act) {
+    static const bool off = getenv("MNY_NO_PJBWD") != nullptr;
+    return (!off && pj16_shape_ok(M, Ki, No) && d_act != MNY_ACT_HSIGMOID) ? 1 : 0;
+}
+extern "C" int mny_pj_bwd_parts_bf16(int64_t M, int Ki, int No) { return pj16_shape_ok(M, Ki, No) ? pj16_grid(M) : MNY_EINVAL; }
+
+extern "C" int mny_pj_bwd_bf16(const void* g, const void* y, const float* coef, const void* d, const float* d_scale, const float* d_shift,
+                               const float* d_mean, const float* d_invstd, int d_act, const float* w, void* gd, float* dw, float* dw_ws, float* red,
+                               int64_t M, int Ki, int No, void* stream) {
+    MNY_REQUIRE(g && y && coef && d && d_scale && d_shift && d_mean && d_invstd && w && gd && dw_ws && red, "pj_bwd_bf16: null pointer");
+    MNY_REQUIRE(pj16_shape_ok(M, Ki, No) && d_act != MNY_ACT_HSIGMOID, "pj_bwd_bf16: M=%lld Ki=%d No=%d act %d not supported", (long long)M, Ki, No, d_act);
+    Pj16Args a{(const bf16_t*)g, (const bf16_t*)y, coef, (const bf16_t*)d, d_scale, d_shift, d_mean, d_invstd, d_act, w, (bf16_t*)gd, dw_ws, red, M};
+    const int grid = pj16_grid(M);
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if (Ki == 16) rc = pj16_launch<16, 16>(a, grid, st);
+    else if (Ki == 64) rc = pj16_launch<64, 24>(a, grid, st);
+    else if (Ki == 72 && No == 24) rc = pj16_launch<72, 24>(a, grid, st);
+    else if (Ki == 72) rc = pj16_launch<72, 40>(a, grid, st);
+    else rc = pj16_launch<120, 40>(a, grid, st);
+    if (rc || !dw) return rc;                          // dw == NULL: partial rows only (combined later by mny_reduce_batch)
+    return launch_reduce_parts(dw_ws, grid, No * Ki, dw, st);
 }

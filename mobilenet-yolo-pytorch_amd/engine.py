@@ -1095,15 +1095,15 @@ class NetPlan:
                 # linear project unit behind a conv+BN+act unit it alone consumes (the thin bottleneck that closes an inverted-residual block):
                 # ONE pass rebuilds dY in LDS, reads the wide input once and yields the data gradient, the input unit's BN-backward sums and the
                 # weight gradient (csrc/pjbwd.hip) — instead of bn_bwd_apply + pw_dgrad_bnred + pw_wgrad
-                if nd.op == "pw" and not self.bf16 and not self.frozen and o.act == ACT_NONE and not nd.bias and single(nd) and o.id not in self.head_cp:
+                if nd.op == "pw" and not self.frozen and o.act == ACT_NONE and not nd.bias and single(nd) and o.id not in self.head_cp:      # (bf16 storage: mny_pj_bwd_bf16, csrc/gate.hip)
                     # (G is only read here: a gradient buffer shared with the residual path is fine)
                     i = nd.ins[0]
                     prod = i.node
                     if (prod is not None and prod.op in ("dw", "pw") and i.kind == "unit" and gs[i.id].buf is None and n_consumers[i.id] == 1
                             and not takes_own_sums(prod) and view(i)[1] is not None and single(prod)
-                            and _lib.query("mny_pj_bwd_supported", M, i.C, o.C, i.act) == 1):
+                            and _lib.query(K("mny_pj_bwd_supported"), M, i.C, o.C, i.act) == 1):
                         pu = self.units[i.id]
-                        rparts = _lib.query("mny_pj_bwd_parts", M, i.C, o.C)
+                        rparts = _lib.query(K("mny_pj_bwd_parts"), M, i.C, o.C)
                         rbuf = torch.empty(rparts * 2 * i.C, **f32)
                         self.fused_red[i.id] = (rbuf, rparts)
                         dwv = gv(nd.conv + ".weight")
@@ -1112,8 +1112,8 @@ class NetPlan:
                         else:
                             dwv_k, ws_k = dwv, torch.empty(rparts * o.C * i.C, **f32)
                         contribute_kernel(i, lambda out, addend, G=G, u=u, pu=pu, w=P[nd.conv + ".weight"], dwv=dwv_k, wsl=ws_k, rbuf=rbuf, M=M, Ki=i.C, No=o.C, act_=i.act: bwd.add(
-                            "mny_pj_bwd", G, u.Y, self.coef_ws, pu.Y, pu.scale, pu.shift, pu.mean, pu.invstd, act_, w, out, dwv, wsl, rbuf, M, Ki, No, self.stream,
-                            meta=dict(flops=4 * M * Ki * No, bytes=4 * (2 * M * No + 2 * M * Ki), shape="project M%d K%d N%d" % (M, Ki, No))))
+                            self.K("mny_pj_bwd"), G, u.Y, self.coef_ws, pu.Y, pu.scale, pu.shift, pu.mean, pu.invstd, act_, w, out, dwv, wsl, rbuf, M, Ki, No, self.stream,
+                            meta=dict(flops=4 * M * Ki * No, bytes=self.eb * (2 * M * No + 2 * M * Ki), shape="project M%d K%d N%d" % (M, Ki, No))))
                         flush_shared()
                         flush_reduce()
                         bwd.marks[o.name] = len(bwd.calls)

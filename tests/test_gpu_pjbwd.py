@@ -102,3 +102,51 @@ def test_project_unit_backward_equals_the_three_launches(M, Ki, No):
     _lib.call("mny_pw_wgrad", ptr(D), ptr(dsc), ptr(dsh), act, ptr(dY), ptr(dw0), None, ptr(ws), M, Ki, No, st)
     torch.cuda.synchronize()
     assert (dw - dw0).abs().max().item() <= 2e-4 * dw0.abs().max().item() + 1e-3
+
+
+def _q(t):
+    return t.to(torch.bfloat16).to(torch.float64)
+
+
+@pytest.mark.parametrize("M,Ki,No,act", [(16 * 40, 16, 16, 3), (2000, 64, 24, 3), (1234, 72, 24, 3), (4096 + 7, 72, 40, 3), (3000, 120, 40, 3), (128 * 9, 120, 40, 4),
+                                         (50000, 16, 16, 3), (16, 64, 24, 1)])
+def test_project_unit_backward_in_one_pass_bf16_storage(M, Ki, No, act):
+    """mny_pj_bwd_bf16 (csrc/gate.hip): MobileNetV3's thin project convs (models/mobilenetv3.py:57-58,69) on bf16 storage, against fp64 with the
+    unit's rounding points modelled — G, Y, D stored bf16; the matrix operands dY, W and a_d = act(BN(D)) rounded to bf16; gd stored bf16, the
+    BN-backward sums of the depthwise unit taken over the STORED gd."""
+    dev = torch.device("cuda:0")
+    a_id = {1: _lib.ACT_RELU6, 3: _lib.ACT_RELU, 4: _lib.ACT_HSWISH}[act]
+    assert _lib.query("mny_pj_bwd_supported_bf16", M, Ki, No, a_id) == 1
+    G, Y, coef, D, dsc, dsh, dmu, dis, W = make(M, Ki, No, seed=M + Ki, dev=dev)
+    G16, Y16, D16 = G.to(torch.bfloat16), Y.to(torch.bfloat16), D.to(torch.bfloat16)
+    parts = _lib.query("mny_pj_bwd_parts_bf16", M, Ki, No)
+    gd = torch.full((M, Ki), float("nan"), device=dev, dtype=torch.bfloat16)
+    dw = torch.zeros(No, Ki, device=dev)
+    dws = torch.full((parts * No * Ki,), float("nan"), device=dev)
+    red = torch.full((parts, 2, Ki), float("nan"), device=dev)
+    _lib.call("mny_pj_bwd_bf16", ptr(G16), ptr(Y16), ptr(coef), ptr(D16), ptr(dsc), ptr(dsh), ptr(dmu), ptr(dis), a_id, ptr(W), ptr(gd), ptr(dw), ptr(dws), ptr(red),
+              M, Ki, No, stream())
+    torch.cuda.synchronize()
+    Gd, Yd, Dd = G16.double().cpu(), Y16.double().cpu(), D16.double().cpu()
+    c, dscd, dshd, dmud, disd, Wd = (t.double().cpu() for t in (coef, dsc, dsh, dmu, dis, W))
+    dY = (c[0] * Gd.float() + (c[1] * Yd.float() + c[2])).double()           # fp32-ish; the bf16 rounding below dominates
+    gd_ref = _q(dY.float()) @ _q(Wd.float())
+    z = Dd * dscd + dshd
+    if act == 4:
+        a = z * torch.clamp(z + 3, 0, 6) / 6
+        dact = torch.where(z <= -3, torch.zeros_like(z), torch.where(z >= 3, torch.ones_like(z), (2 * z + 3) / 6))
+    else:
+        hi = 6.0 if act == 1 else float("inf")
+        a = torch.clamp(z, 0, hi)
+        dact = ((z > 0) & (z < hi)).double()
+    got = gd.double().cpu()
+    assert torch.isfinite(got).all()
+    assert (got - gd_ref).abs().max().item() <= 1e-2 * gd_ref.abs().max().item()          # bf16 store
+    dz = got * dact                                                                      # sums over the STORED gradient
+    s1, s2 = dz.sum(0), (dz * (Dd - dmud) * disd).sum(0)
+    dw_ref = _q(dY.float()).t() @ _q(a.float())
+    r = red.double().sum(0).cpu()
+    for name, g_, ref, tol in (("dw", dw.double().cpu(), dw_ref, 2e-3), ("dw partial rows", dws.view(parts, No, Ki).double().sum(0).cpu(), dw_ref, 2e-3),
+                               ("s1", r[0], s1, 2e-3), ("s2", r[1], s2, 2e-3)):
+        e = (g_ - ref).abs().max().item()
+        assert e <= tol * ref.abs().max().item() + 1e-3, (name, e, ref.abs().max().item())
