@@ -219,10 +219,18 @@ size_t mny_nms_prefix_offset(int S, int capacity, int num_classes);
  * One pass over (g, y, x) instead of bn_bwd_apply + dw_bwd_weight + dw_bwd_data (7 tensor passes -> 4): rebuilds
  * dY = ca*g*act'(scale*y+shift) + cb*y + cc in registers from the coefficients `coef` = [3][C] written by
  * mny_bn_bwd_finalize, and produces dx (gradient wrt the ACTIVATED input view, + optional addend) and dw [C,1,3,3].
- * `ws`: [mny_dw_bnbwd_parts()][C*9] floats.  Only K == 3, stride == 1 (mny_dw_bnbwd_supported()).
- * replaces the backward of mobilenetv2.py:65-67,79-81 / mbv2_yolo.py:22-24 for those units.                  */
+ * `ws`: [mny_dw_bnbwd_parts_k()][C*K*K] floats.  K == 3 or K == 5, stride == 1 (mny_dw_bnbwd_supported()).
+ * replaces the backward of mobilenetv2.py:65-67,79-81 / mbv2_yolo.py:22-24 for those units.
+ * K == 5 (MobileNetV3's 5x5 units, mobilenetv3.py:54-56,68-69) runs the TILE form (csrc/dwtile.hip): a workgroup owns a tile of
+ * columns x channel groups, dY is rebuilt once per element and shared through a ring of K+1 rows in LDS, every window element
+ * feeds the data gradient (gather) and the weight gradient (over the input pixels a thread owns); dw is [C,1,5,5].  On bf16 storage
+ * the 3x3 units the tile form is faster on take it too (dwt_use() in dwtile.hip states the rule and the measurements).
+ * MNY_NO_DWT5=1 reports K == 5 unsupported (bn_bwd_apply + dw_bwd_weight + dw_bwd_data); MNY_DWT3=1 / 0 forces 3x3 onto / off the tile form.
+ * mny_dw_bnbwd_parts_k(..., flags): bit 0 = bf16 storage, bit 1 = called as mny_dw_bnbwd_red (the row count depends on the form that runs);
+ * mny_dw_bnbwd_parts() == mny_dw_bnbwd_parts_k(..., 3, 0). */
 int mny_dw_bnbwd_supported(int K, int stride);
 int mny_dw_bnbwd_parts(int N, int H, int W, int C);
+int mny_dw_bnbwd_parts_k(int N, int H, int W, int C, int K, int flags);
 int mny_dw_bnbwd(const float* g, const float* y, const float* scale, const float* shift, int act, const float* coef,
                  const float* x, const float* in_scale, const float* in_shift, int in_act, const float* w,
                  const float* addend, float* dx, float* dw, float* ws, int N, int H, int W, int C, int K, int stride,

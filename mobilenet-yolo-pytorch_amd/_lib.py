@@ -39,6 +39,7 @@ _SIGS = {
     "mny_dw_wgrad_parts": (c_int, [c_int] * 6),
     "mny_dw_bnbwd_supported": (c_int, [c_int, c_int]),
     "mny_dw_bnbwd_parts": (c_int, [c_int] * 4),
+    "mny_dw_bnbwd_parts_k": (c_int, [c_int] * 6),
     "mny_dw_bnbwd": (c_int, [P, P, P, P, c_int, P, P, P, P, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "mny_dw_bnbwd_s2_parts": (c_int, [c_int] * 4),
     "mny_dw_bnbwd_s2": (c_int, [P, P, P, P, c_int, P, P, P, P, c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P]),

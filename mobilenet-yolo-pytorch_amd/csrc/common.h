@@ -220,6 +220,13 @@ inline CgLayout make_stencil_layout(int C, int max_cgb = 64) {
 __global__ void reduce_parts_f64_kernel(const float* __restrict__ parts, int nparts, int n, float* __restrict__ out);
 int launch_reduce_parts(const float* parts, int nparts, int n, float* out, hipStream_t st);
 
+// tile form of the fused depthwise-unit backward (dwtile.hip): 5x5 stride 1 (and 3x3 behind MNY_DWT3=1); same arguments as mny_dw_bnbwd[_red]
+bool dwt_use(int K, int bf, int red, int C);      // which form runs the unit
+int dwt_parts(int N, int H, int W, int C, int K);
+int dwt_launch(int bf, const void* g, const void* y, const float* scale, const float* shift, int act, const float* coef, const void* x,
+               const float* in_scale, const float* in_shift, int in_act, const float* w, const void* addend, void* dx, float* dw, float* ws, int N, int H,
+               int W, int C, int K, void* stream, const float* in_mean, const float* in_invstd, float* in_red);
+
 // short-reduction pointwise conv on the vector ALU (pwthin.hip); the entry points of pwgemm.hip route K = 8/16/24/32 problems here
 bool pw_thin_ok(int bf, int red, int64_t M, int K, int N);
 int pw_thin_parts(int64_t M, int K, int N, int red);

@@ -479,8 +479,11 @@ static int dw_bnbwd_impl(const T* g, const T* y, const float* scale, const float
                          const float* in_mean = nullptr, const float* in_invstd = nullptr, float* in_red = nullptr) {
     MNY_REQUIRE(g && y && scale && shift && coef && x && w && dx && ws, "dw_bnbwd: null pointer");
     MNY_REQUIRE(!in_red || (in_mean && in_invstd && in_scale && in_shift), "dw_bnbwd_red: the input must be a BN unit's raw output (scale, shift, mean, invstd)");
-    MNY_REQUIRE(K == 3 && stride == 1, "dw_bnbwd: only 3x3 stride 1 is fused (got K=%d stride=%d); use bn_bwd_apply + dw_bwd_*", K, stride);
+    MNY_REQUIRE(stride == 1 && (K == 3 || (K == 5 && dwt_use(5, 0, 0, C))), "dw_bnbwd: only 3x3 / 5x5 stride 1 are fused (got K=%d stride=%d); use bn_bwd_apply + dw_bwd_*", K, stride);
     MNY_REQUIRE(act != MNY_ACT_HSIGMOID && in_act != MNY_ACT_HSIGMOID, "dw_bnbwd: h-sigmoid views are not supported");
+    if (dwt_use(K, sizeof(T) == 2 ? 1 : 0, in_red != nullptr ? 1 : 0, C))      // tile form (dwtile.hip): every 5x5 unit, the 3x3 units it is faster on
+        return dwt_launch(sizeof(T) == 2 ? 1 : 0, g, y, scale, shift, act, coef, x, in_scale, in_shift, in_act, w, addend, dx, dw, ws, N, H, W, C, K, stream,
+                          in_mean, in_invstd, in_red);
     DwbGeom gm; CgLayout L; int gx;
     int rc = dwb_geom(gm, L, gx, N, H, W, C);
     if (rc) return rc;
@@ -508,7 +511,7 @@ static int dw_bnbwd_impl(const T* g, const T* y, const float* scale, const float
 
 using namespace mny;
 
-extern "C" int mny_dw_bnbwd_supported(int K, int stride) { return (K == 3 && stride == 1) ? 1 : 0; }
+extern "C" int mny_dw_bnbwd_supported(int K, int stride) { return (stride == 1 && (K == 3 || (K == 5 && dwt_use(5, 0, 0, 0)))) ? 1 : 0; }
 
 extern "C" int mny_dw_bnbwd_s2_parts(int N, int H, int W, int C) {
     DwbGeom g; CgLayout L; int gx;
@@ -527,11 +530,15 @@ extern "C" int mny_dw_bnbwd_s2_bf16(const void* g, const void* y, const float* s
                                     (const bf16_t*)addend, (bf16_t*)dx, dw, ws, N, H, W, C, stream);
 }
 
-extern "C" int mny_dw_bnbwd_parts(int N, int H, int W, int C) {
+extern "C" int mny_dw_bnbwd_parts_k(int N, int H, int W, int C, int K, int flags) {
+    if (K != 3 && K != 5) return MNY_EINVAL;
+    if (dwt_use(K, flags & 1, (flags >> 1) & 1, C)) return dwt_parts(N, H, W, C, K);
+    if (K != 3) return MNY_EINVAL;
     DwbGeom g; CgLayout L; int gx;
     if (dwb_geom(g, L, gx, N, H, W, C)) return MNY_EINVAL;
     return gx;
 }
+extern "C" int mny_dw_bnbwd_parts(int N, int H, int W, int C) { return mny_dw_bnbwd_parts_k(N, H, W, C, 3, 0); }     // (fp32 storage, 3x3: the register form)
 
 extern "C" int mny_dw_bnbwd(const float* g, const float* y, const float* scale, const float* shift, int act, const float* coef,
                             const float* x, const float* in_scale, const float* in_shift, int in_act, const float* w,

@@ -992,7 +992,9 @@ class NetPlan:
                 gam = P[nd.bn + ".weight"]
                 if (nd.op == "dw" and os.environ.get("MNY_NO_DWFUSE") != "1" and _lib.query("mny_dw_bnbwd_supported", nd.k, nd.stride) == 1
                         and o.act != _lib.ACT_HSIGMOID and nd.ins[0].act != _lib.ACT_HSIGMOID):
-                    # 3x3 stride-1 depthwise unit: dY is rebuilt in registers, one pass over (G, Y, X) yields dX and dW
+                    # 3x3 (register form) / 5x5 (tile form, csrc/dwtile.hip) stride-1 depthwise unit: dY is rebuilt on chip, one pass over
+                    # (G, Y, X) yields dX and dW
+                    kk = nd.k * nd.k
                     i = nd.ins[0]
                     ish = shape(i)
                     xv = view(i)
@@ -1007,13 +1009,20 @@ class NetPlan:
                     dwv = gv(nd.conv + ".weight")
                     wt = P[nd.conv + ".weight"]
                     dwv_k, ws_k = dwv, self.ws
-                    if self.defer and single(nd):
-                        dparts = _lib.query("mny_dw_bnbwd_parts", N, ish[1], ish[2], o.C)
-                        dwv_k, ws_k = None, defer_job(dparts * o.C * 9, dwv, dparts, o.C * 9)
                     prod = i.node
+                    # the input is the raw output of a conv+BN+act unit consumed ONLY here: this kernel's dX is that unit's complete
+                    # output gradient, so it also leaves the unit's BN-backward sums (mny_dw_bnbwd_red) and the unit's separate
+                    # bn_bwd_reduce pass — a re-read of dX and X — disappears (wide expand units, the stem, the neck's pointwise units)
+                    with_red = (os.environ.get("MNY_NO_DWRED") != "1" and i.kind == "unit" and prod is not None and prod.op in ("pw", "stem")
+                                and gs[i.id].buf is None and n_consumers[i.id] == 1 and not takes_own_sums(prod) and xv[1] is not None
+                                and i.act not in (_lib.ACT_HSIGMOID,))
+                    pflags = (1 if self.bf16 else 0) | (2 if with_red else 0)        # (the row count depends on the form that runs: csrc/dwtile.hip dwt_use)
+                    if self.defer and single(nd):
+                        dparts = _lib.query("mny_dw_bnbwd_parts_k", N, ish[1], ish[2], o.C, nd.k, pflags)
+                        dwv_k, ws_k = None, defer_job(dparts * o.C * kk, dwv, dparts, o.C * kk)
                     # stem -> this depthwise unit (MobileNetV2's first two units): ONE pass yields both units' parameter gradients; the stem's
                     # output gradient (its only consumer is the stem's weight gradient) is never written (csrc/stemdw.hip)
-                    if (not self.bf16 and not self.frozen and i.kind == "unit" and prod is not None and prod.op == "stem" and gs[i.id].buf is None
+                    if (nd.k == 3 and not self.bf16 and not self.frozen and i.kind == "unit" and prod is not None and prod.op == "stem" and gs[i.id].buf is None
                             and n_consumers[i.id] == 1 and not takes_own_sums(prod) and xv[1] is not None and single(nd) and single(prod)
                             and _lib.query("mny_stemdw_supported", N, self.H, self.W, i.C, i.act, o.act) == 1):
                         pu = self.units[i.id]
@@ -1034,25 +1043,20 @@ class NetPlan:
                         flush_reduce()
                         bwd.marks[o.name] = len(bwd.calls)
                         continue
-                    # the input is the raw output of a conv+BN+act unit consumed ONLY here: this kernel's dX is that unit's complete
-                    # output gradient, so it also leaves the unit's BN-backward sums (mny_dw_bnbwd_red) and the unit's separate
-                    # bn_bwd_reduce pass — a re-read of dX and X — disappears (wide expand units, the stem, the neck's pointwise units)
-                    if (os.environ.get("MNY_NO_DWRED") != "1" and i.kind == "unit" and prod is not None and prod.op in ("pw", "stem")
-                            and gs[i.id].buf is None and n_consumers[i.id] == 1 and not takes_own_sums(prod) and xv[1] is not None
-                            and i.act not in (_lib.ACT_HSIGMOID,)):
+                    if with_red:
                         pu = self.units[i.id]
-                        rparts = _lib.query("mny_dw_bnbwd_parts", N, ish[1], ish[2], o.C)
+                        rparts = _lib.query("mny_dw_bnbwd_parts_k", N, ish[1], ish[2], o.C, nd.k, pflags)
                         rbuf = torch.empty(rparts * 2 * i.C, **f32)
                         self.fused_red[i.id] = (rbuf, rparts)
-                        contribute_kernel(i, lambda out, addend, G=G, u=u, xv=xv, wt=wt, dwv=dwv_k, wsl=ws_k, ish=ish, C=o.C, act=o.act, M=M, pu=pu, rbuf=rbuf: bwd.add(
+                        contribute_kernel(i, lambda out, addend, G=G, u=u, xv=xv, wt=wt, dwv=dwv_k, wsl=ws_k, ish=ish, C=o.C, act=o.act, M=M, pu=pu, rbuf=rbuf, k=nd.k: bwd.add(
                             self.K("mny_dw_bnbwd_red"), G, u.Y, u.scale, u.shift, act, self.coef_ws, xv[0], xv[1], xv[2], xv[3], pu.mean, pu.invstd, wt, addend,
-                            out, dwv, wsl, rbuf, N, ish[1], ish[2], C, 3, 1, self.stream,
-                            meta=dict(flops=4 * M * C * 9, bytes=self.eb * 4 * M * C, shape="C%d H%d +red" % (C, ish[1]))))
+                            out, dwv, wsl, rbuf, N, ish[1], ish[2], C, k, 1, self.stream,
+                            meta=dict(flops=4 * M * C * k * k, bytes=self.eb * 4 * M * C, shape="C%d H%d%s +red" % (C, ish[1], " k5" if k == 5 else ""))))
                     else:
-                        contribute_kernel(i, lambda out, addend, G=G, u=u, xv=xv, wt=wt, dwv=dwv_k, wsl=ws_k, ish=ish, C=o.C, act=o.act, M=M: bwd.add(
+                        contribute_kernel(i, lambda out, addend, G=G, u=u, xv=xv, wt=wt, dwv=dwv_k, wsl=ws_k, ish=ish, C=o.C, act=o.act, M=M, k=nd.k: bwd.add(
                             self.K("mny_dw_bnbwd"), G, u.Y, u.scale, u.shift, act, self.coef_ws, xv[0], xv[1], xv[2], xv[3], wt, addend, out, dwv, wsl,
-                            N, ish[1], ish[2], C, 3, 1, self.stream,
-                            meta=dict(flops=4 * M * C * 9, bytes=self.eb * 4 * M * C, shape="C%d H%d" % (C, ish[1]))))
+                            N, ish[1], ish[2], C, k, 1, self.stream,
+                            meta=dict(flops=4 * M * C * k * k, bytes=self.eb * 4 * M * C, shape="C%d H%d%s" % (C, ish[1], " k5" if k == 5 else ""))))
                     flush_shared()
                     flush_reduce()
                     bwd.marks[o.name] = len(bwd.calls)

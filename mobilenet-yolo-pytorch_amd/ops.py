@@ -109,17 +109,18 @@ def dw_bnbwd(g, y, scale, shift, act, coef, xview, w, addend=None, in_stats=None
     in_stats = (mean, invstd) of the unit that produced x: also returns that unit's BN-backward partial sums [parts,2,C]."""
     x, xs, xh, xact = xview
     N, H, W, C = x.shape
-    parts = query("mny_dw_bnbwd_parts", N, H, W, C)
-    ws = _new(parts, C * 9, like=x)
+    k = w.shape[-1]                                     # 3, or 5 (tile form)
+    parts = query("mny_dw_bnbwd_parts_k", N, H, W, C, k, (1 if x.dtype == torch.bfloat16 else 0) | (2 if in_stats is not None else 0))
+    ws = _new(parts, C * k * k, like=x)
     dx = torch.empty_like(x)
-    dw = _new(C, 1, 3, 3, like=x)
+    dw = _new(C, 1, k, k, like=x)
     if in_stats is None:
         call(_k("mny_dw_bnbwd", x), _p(g), _p(y), _p(scale), _p(shift), act, _p(coef), _p(x), _p(xs), _p(xh), xact, _p(w), _p(addend), _p(dx),
-             _p(dw), _p(ws), N, H, W, C, 3, 1, _st())
+             _p(dw), _p(ws), N, H, W, C, k, 1, _st())
         return dx, dw
     red = _new(parts, 2, C, like=x)
     call(_k("mny_dw_bnbwd_red", x), _p(g), _p(y), _p(scale), _p(shift), act, _p(coef), _p(x), _p(xs), _p(xh), xact, _p(in_stats[0]), _p(in_stats[1]),
-         _p(w), _p(addend), _p(dx), _p(dw), _p(ws), _p(red), N, H, W, C, 3, 1, _st())
+         _p(w), _p(addend), _p(dx), _p(dw), _p(ws), _p(red), N, H, W, C, k, 1, _st())
     return dx, dw, red
 
 

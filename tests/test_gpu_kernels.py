@@ -315,11 +315,16 @@ def test_fused_bn_backward_expand_unit_is_run_to_run_deterministic(ops, M, K, Nc
         assert err <= 2 ** -7 * ref.abs().max().item(), err
 
 
-@pytest.mark.parametrize("N,H,W,C,act,xact,dtype", [(2, 11, 11, 32, 1, 1, "f32"), (3, 22, 19, 96, 2, 2, "f32"), (2, 37, 8, 144, 1, 0, "f32"),
-                                                    (1, 5, 5, 960, 0, 1, "f32"), (2, 16, 16, 72, 3, 3, "f32"), (2, 20, 20, 120, 4, 4, "f32"),
-                                                    (2, 33, 17, 64, 1, 1, "bf16"), (2, 9, 9, 240, 4, 4, "bf16")])
-def test_fused_dw_unit_backward(ops, N, H, W, C, act, xact, dtype):
-    """mny_dw_bnbwd: BN-backward-apply + depthwise weight- and data-gradient of a 3x3 stride-1 unit in one pass over
+@pytest.mark.parametrize("N,H,W,C,act,xact,dtype,k", [(2, 11, 11, 32, 1, 1, "f32", 3), (3, 22, 19, 96, 2, 2, "f32", 3), (2, 37, 8, 144, 1, 0, "f32", 3),
+                                                      (1, 5, 5, 960, 0, 1, "f32", 3), (2, 16, 16, 72, 3, 3, "f32", 3), (2, 20, 20, 120, 4, 4, "f32", 3),
+                                                      (2, 33, 17, 64, 1, 1, "bf16", 3), (2, 9, 9, 240, 4, 4, "bf16", 3),
+                                                      (2, 16, 16, 72, 3, 3, "f32", 5), (2, 20, 20, 120, 4, 4, "f32", 5), (3, 22, 19, 96, 2, 2, "f32", 5),
+                                                      (2, 37, 8, 144, 1, 0, "f32", 5), (1, 5, 5, 960, 0, 1, "f32", 5), (2, 3, 35, 40, 4, 3, "f32", 5),
+                                                      (1, 70, 33, 36, 3, 4, "f32", 5), (2, 33, 17, 64, 1, 1, "bf16", 5), (2, 32, 32, 672, 4, 4, "bf16", 5),
+                                                      (2, 9, 9, 240, 4, 4, "bf16", 5), (1, 2, 3, 8, 4, 4, "f32", 5)])
+def test_fused_dw_unit_backward(ops, N, H, W, C, act, xact, dtype, k):
+    """mny_dw_bnbwd: BN-backward-apply + depthwise weight- and data-gradient of a 3x3 (register form, csrc/dwbwd.hip) or 5x5 (tile form,
+    csrc/dwtile.hip: odd sizes, partial column tiles, several strips, one-pixel image) stride-1 unit in one pass over
     (G, Y, X), against torch autograd through conv(groups=C) -> BN(train) -> act.  fp32: 2e-4; bf16 storage: the inputs are
     bf16-representable, dX is rounded once on store (2^-7), dW / dgamma / dbeta are fp32 outputs."""
     acts = dict(ACTS)
@@ -328,18 +333,18 @@ def test_fused_dw_unit_backward(ops, N, H, W, C, act, xact, dtype):
     bf = dtype == "bf16"
     q = (lambda t: t.to(torch.bfloat16).float()) if bf else (lambda t: t)
     x = q(rnd(N, C, H, W, seed=1))
-    w = rnd(C, 1, 3, 3, seed=2, scale=0.4)
+    w = rnd(C, 1, k, k, seed=2, scale=0.4 if k == 3 else 0.25)
     xs, xh = 1 + 0.2 * rnd(C, seed=3), 0.3 * rnd(C, seed=4)
     gamma, beta = 1 + 0.3 * rnd(C, seed=5), 0.2 * rnd(C, seed=6)
     a_in = (acts[xact](x * xs.view(1, -1, 1, 1) + xh.view(1, -1, 1, 1)) if xact or True else x).detach().requires_grad_(True)
     wr, gr, br = w.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
-    y_raw = q(F.conv2d(a_in, wr, None, 1, 1, 1, C).detach())           # the stored (possibly bf16) conv output
+    y_raw = q(F.conv2d(a_in, wr, None, 1, k // 2, 1, C).detach())           # the stored (possibly bf16) conv output
     yr = y_raw.clone().requires_grad_(True)
     out = acts[act](F.batch_norm(yr, None, None, gr, br, True, 0.1, 1e-5))
     g = q(rnd(*out.shape, seed=7))
     out.backward(g)
     dy_ref = yr.grad                                                     # dL/dY through BN(train)+act
-    F.conv2d(a_in, wr, None, 1, 1, 1, C).backward(dy_ref)
+    F.conv2d(a_in, wr, None, 1, k // 2, 1, C).backward(dy_ref)
     dev = (lambda t: nhwc(t).to(torch.bfloat16)) if bf else nhwc
     yd, gd, xd = dev(y_raw), dev(g), dev(x)
     M = N * H * W
@@ -400,10 +405,13 @@ def test_fused_dw_stride2_unit_backward(ops, N, H, W, C, act, xact, dtype):
     check(dw, dw_ref, tw, tw * dw_ref.abs().max().item(), "fused s2 dw: dW")
 
 
-@pytest.mark.parametrize("N,H,W,C,act,xact,dtype", [(2, 11, 11, 32, 1, 1, "f32"), (3, 22, 19, 96, 2, 2, "f32"), (2, 37, 8, 144, 1, 3, "f32"),
-                                                    (1, 5, 5, 960, 0, 1, "f32"), (2, 20, 20, 120, 4, 4, "f32"), (2, 33, 17, 64, 1, 1, "bf16"),
-                                                    (2, 40, 40, 384, 1, 1, "f32")])
-def test_fused_dw_unit_backward_with_producer_bn_sums(ops, N, H, W, C, act, xact, dtype):
+@pytest.mark.parametrize("N,H,W,C,act,xact,dtype,k", [(2, 11, 11, 32, 1, 1, "f32", 3), (3, 22, 19, 96, 2, 2, "f32", 3), (2, 37, 8, 144, 1, 3, "f32", 3),
+                                                      (1, 5, 5, 960, 0, 1, "f32", 3), (2, 20, 20, 120, 4, 4, "f32", 3), (2, 33, 17, 64, 1, 1, "bf16", 3),
+                                                      (2, 40, 40, 384, 1, 1, "f32", 3),
+                                                      (2, 11, 11, 32, 1, 1, "f32", 5), (3, 22, 19, 96, 2, 2, "f32", 5), (2, 37, 8, 144, 1, 3, "f32", 5),
+                                                      (2, 20, 20, 120, 4, 4, "f32", 5), (2, 33, 17, 64, 3, 3, "bf16", 5), (2, 32, 32, 672, 4, 4, "bf16", 5),
+                                                      (4, 16, 16, 960, 4, 4, "bf16", 5)])
+def test_fused_dw_unit_backward_with_producer_bn_sums(ops, N, H, W, C, act, xact, dtype, k):
     """mny_dw_bnbwd_red == mny_dw_bnbwd (same dX, dW) and its extra output == mny_bn_bwd_reduce run on that dX and the raw input:
     the BN-backward sums of the unit that produced the input, without the separate pass."""
     import ctypes
@@ -412,7 +420,7 @@ def test_fused_dw_unit_backward_with_producer_bn_sums(ops, N, H, W, C, act, xact
     q = (lambda t: t.to(torch.bfloat16).float()) if bf else (lambda t: t)
     dev = (lambda t: nhwc(t).to(torch.bfloat16)) if bf else nhwc
     x, y, g, add = (dev(q(rnd(N, C, H, W, seed=s))) for s in (1, 2, 3, 4))
-    w = rnd(C, 1, 3, 3, seed=5, scale=0.4).cuda().contiguous()
+    w = rnd(C, 1, k, k, seed=5, scale=0.4 if k == 3 else 0.25).cuda().contiguous()
     mk = lambda seed, a, b: (a + b * rnd(C, seed=seed)).cuda()          # noqa: E731
     scale, shift, coef = mk(6, 1.0, 0.2), mk(7, 0.0, 0.3), torch.stack((mk(8, 1.0, 0.2), mk(9, 0.0, 0.05), mk(10, 0.0, 0.05))).contiguous()
     xs, xh, xmean, xinv = mk(11, 1.0, 0.2), mk(12, 0.0, 0.3), mk(13, 0.0, 0.2), mk(14, 1.0, 0.1).abs()
@@ -426,9 +434,9 @@ def test_fused_dw_unit_backward_with_producer_bn_sums(ops, N, H, W, C, act, xact
     _lib.call("mny_bn_bwd_reduce" + ("_bf16" if bf else ""), p(dx1), p(x), p(xs), p(xh), xact, p(xmean), p(xinv), p(ref), M, C,
               ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     got, want = red.double().sum(0).cpu(), ref.double().sum(0).cpu()
-    for k in range(2):
-        tol = 2e-5 * want[k].abs().max().item() + 1e-4
-        assert (got[k] - want[k]).abs().max().item() <= tol, (k, (got[k] - want[k]).abs().max().item(), tol)
+    for j in range(2):
+        tol = 2e-5 * want[j].abs().max().item() + 1e-4
+        assert (got[j] - want[j]).abs().max().item() <= tol, (j, (got[j] - want[j]).abs().max().item(), tol)
 
 
 @pytest.mark.parametrize("N,H,W,C,s,act", [(1, 44, 44, 192, 2, 0), (2, 22, 22, 96, 2, 1), (1, 44, 44, 384, 1, 1), (4, 88, 88, 144, 2, 1),
@@ -539,9 +547,9 @@ def test_dgrad_add_with_fused_bn_backward_reduction(ops, M, K, Nc, act):
     _lib.call("mny_bn_bwd_reduce", p(dx), p(y), p(scale), p(shift), act, p(mean), p(invstd), p(ref), M, Nc,
               ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     got, want = red.double().sum(0).cpu(), ref.double().sum(0).cpu()
-    for k in range(2):
-        tol = 2e-5 * want[k].abs().max().item() + 1e-4
-        assert (got[k] - want[k]).abs().max().item() <= tol, (k, (got[k] - want[k]).abs().max().item(), tol)
+    for j in range(2):
+        tol = 2e-5 * want[j].abs().max().item() + 1e-4
+        assert (got[j] - want[j]).abs().max().item() <= tol, (j, (got[j] - want[j]).abs().max().item(), tol)
     # in place: the addend buffer is also the output (how the engine accumulates into an existing gradient buffer)
     buf = add.clone()
     _lib.call("mny_pw_dgrad_bnred_add", p(dy), p(wT), p(buf), p(buf), p(y), p(scale), p(shift), act, p(mean), p(invstd), p(red), M, K, Nc,
