@@ -77,6 +77,10 @@ int mny_dw_fwd(const float* x, const float* in_scale, const float* in_shift, int
                const float* w /*[C,K,K]*/, float* y, float* stats,
                int N, int H, int W, int C, int K, int stride, void* stream);
 int mny_dw_stat_parts(int N, int H, int W, int C, int K, int stride);
+/* the same count for a given storage type: flags bit 0 = bf16 storage.  On bf16 storage the 5x5 stride-1 launches with >= 120 channels (last
+ * 64-channel chunk at least 3/4 full) run the TILE form of csrc/dwtile.hip (every thread loads and activates its own column once, the
+ * window comes back from an LDS ring; MNY_DWTF=0 / 1 forces never / always), which has its own grid. */
+int mny_dw_stat_parts_x(int N, int H, int W, int C, int K, int stride, int flags);
 /* dx[N,H,W,C] = (addend ? addend : 0) + conv_transpose(dy, w); H,W are the INPUT extents */
 int mny_dw_bwd_data(const float* dy, const float* w, const float* addend, float* dx,
                     int N, int H, int W, int C, int K, int stride, void* stream);

@@ -34,6 +34,7 @@ _SIGS = {
     "mny_stem_wgrad_parts": (c_int, [c_int, c_int, c_int, c_int]),
     "mny_dw_fwd": (c_int, [P, P, P, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "mny_dw_stat_parts": (c_int, [c_int] * 6),
+    "mny_dw_stat_parts_x": (c_int, [c_int] * 7),
     "mny_dw_bwd_data": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "mny_dw_bwd_weight": (c_int, [P, P, P, c_int, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "mny_dw_wgrad_parts": (c_int, [c_int] * 6),

@@ -923,6 +923,11 @@ extern "C" int mny_dw_stat_parts(int N, int H, int W, int C, int K, int stride) 
     if (dw_geom(g, L, gx, N, H, W, C, K, stride)) return MNY_EINVAL;
     return gx;
 }
+// flags bit 0: bf16 storage (the tile form of dwtile.hip has its own grid)
+extern "C" int mny_dw_stat_parts_x(int N, int H, int W, int C, int K, int stride, int flags) {
+    if ((K == 3 || K == 5) && C > 0 && C % 4 == 0 && N > 0 && H > 0 && W > 0 && dwt_fwd_use(K, stride, flags & 1, C)) return dwt_fwd_parts(N, H, W, C, K);
+    return mny_dw_stat_parts(N, H, W, C, K, stride);
+}
 extern "C" int mny_dw_wgrad_parts(int N, int H, int W, int C, int K, int stride) {
     DwGeom g; CgLayout L; int gx;
     if (dw_geom(g, L, gx, N, H, W, C, K, stride, 1)) return MNY_EINVAL;
@@ -933,6 +938,8 @@ template <typename T>
 static int dw_fwd_impl(const T* x, const float* in_scale, const float* in_shift, int in_act, const float* w,
                        T* y, float* stats, int N, int H, int W, int C, int K, int stride, void* stream) {
     MNY_REQUIRE(x && w && y, "dw_fwd: null pointer");
+    if (dwt_fwd_use(K, stride, sizeof(T) == 2 ? 1 : 0, C))                                       // tile form (dwtile.hip)
+        return dwt_fwd_launch(sizeof(T) == 2 ? 1 : 0, x, in_scale, in_shift, in_act, w, y, stats, N, H, W, C, K, stream);
     return dw_launch<0, T>(x, in_scale, in_shift, in_act, w, 0, nullptr, y, nullptr, stats, N, H, W, C, K, stride, (hipStream_t)stream);
 }
 extern "C" int mny_dw_fwd(const float* x, const float* in_scale, const float* in_shift, int in_act, const float* w,

@@ -104,10 +104,16 @@ constexpr int kDwtConsts = 9;
 // channel groups per workgroup: 16 (5x5: 32 channels, 3x3: 64): the 2R halo columns of a row are at most one wave's worth of elements,
 // a pixel is 64-256 contiguous bytes, and the window / constant reads use immediate LDS offsets
 constexpr int kDwtCG = 16;
+#ifndef MNY_DWT_PD
+#define MNY_DWT_PD 1
+#endif
+#ifndef MNY_DWT_ALLW2
+#define MNY_DWT_ALLW2 0
+#endif
 
 // KS: 3 / 5.  CPT: channels per thread.  NC: adjacent output columns per thread (they share the taps, the tap accumulators and most of the
 // window reads).  TLDS: the taps are read from LDS next to the window (5x5: 25 x CPT registers the kernel does not have) instead of registers.
-template <typename T, int KS, int CPT, int NC, bool TLDS, bool RED, int AM, int XF, int WPE>
+template <typename T, int KS, int CPT, int NC, bool TLDS, bool RED, int AM, int XF, int WPE, int PD>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void dwb_tile_kernel(
     const T* __restrict__ g, const T* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift, int act,
     const float* __restrict__ coef, const T* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
@@ -229,37 +235,51 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
 
         const int r_begin = h0 - R, r_end = h1 + R;          // dY rows produced for this strip
         int duty = wave < NWD ? ((wave - r_begin) % NWD + NWD) % NWD : -1;       // 0: this wave rebuilds the halo columns of the row
-        Raw pg[NC], py[NC], px[NC], pa[NC], phg, phy;
+        // PD rows of G, Y (+ halo), X, addend are in flight: one register set per row of the queue, the row loop is unrolled PD times so that
+        // every set keeps its registers (shifting the queue would wait for the newest load)
+        struct RowSet { Raw g[NC], y[NC], x[NC], a[NC], hg, hy; };
+        RowSet rs_[PD];
 #pragma unroll
-        for (int q = 0; q < (int)(sizeof(Raw) / 4); ++q) {
-            phg.u[q] = 0u; phy.u[q] = 0u;
+        for (int k = 0; k < PD; ++k)
 #pragma unroll
-            for (int j = 0; j < NC; ++j) pa[j].u[q] = 0u;
-        }
-        auto issue_gy = [&](int r, int k) {
+            for (int q = 0; q < (int)(sizeof(Raw) / 4); ++q) {
+                rs_[k].hg.u[q] = 0u; rs_[k].hy.u[q] = 0u;
+#pragma unroll
+                for (int j = 0; j < NC; ++j) rs_[k].a[j].u[q] = 0u;
+            }
+        const int pdm = PD % NWD;
+        auto duty_at = [&](int d, int ahead_mod) {            // the duty counter `ahead` rows later (it counts down with the row index)
+            if (d < 0) return -1;
+            const int t = d - ahead_mod;
+            return t < 0 ? t + NWD : t;
+        };
+        auto issue_gy = [&](RowSet& q_, int r, int k) {
             const int64_t ro = (int64_t)min(max(r, 0), gm.H - 1) * pitch;
 #pragma unroll
             for (int j = 0; j < NC; ++j) {
-                pg[j] = raw_ld<T, CPT>(at_bytes(gi + ro, own_b[j]));
-                py[j] = raw_ld<T, CPT>(at_bytes(yi + ro, own_b[j]));
+                q_.g[j] = raw_ld<T, CPT>(at_bytes(gi + ro, own_b[j]));
+                q_.y[j] = raw_ld<T, CPT>(at_bytes(yi + ro, own_b[j]));
             }
             if (k == 0) {
-                phg = raw_ld<T, CPT>(at_bytes(gi + ro, h_b));
-                phy = raw_ld<T, CPT>(at_bytes(yi + ro, h_b));
+                q_.hg = raw_ld<T, CPT>(at_bytes(gi + ro, h_b));
+                q_.hy = raw_ld<T, CPT>(at_bytes(yi + ro, h_b));
             }
         };
-        auto issue_xa = [&](int i) {
+        auto issue_xa = [&](RowSet& q_, int i) {
             const int64_t ro = (int64_t)min(max(i, 0), gm.H - 1) * pitch;
 #pragma unroll
             for (int j = 0; j < NC; ++j) {
-                px[j] = raw_ld<T, CPT>(at_bytes(xi + ro, own_b[j]));
-                if (ai) pa[j] = raw_ld<T, CPT>(at_bytes(ai + ro, own_b[j]));
+                q_.x[j] = raw_ld<T, CPT>(at_bytes(xi + ro, own_b[j]));
+                if (ai) q_.a[j] = raw_ld<T, CPT>(at_bytes(ai + ro, own_b[j]));
             }
         };
-        issue_gy(r_begin, duty);
-        issue_xa(r_begin - R);
+#pragma unroll
+        for (int k = 0; k < PD; ++k) {
+            issue_gy(rs_[k], r_begin + k, duty_at(duty, k % NWD));
+            issue_xa(rs_[k], r_begin + k - R);
+        }
         int slot_w = 0;
-        for (int r = r_begin; r < r_end; ++r) {
+        auto step = [&](RowSet& q_, int r) {
             const float rowm = (r >= 0 && r < gm.H) ? 1.f : 0.f;
             float* const wrow = ring + slot_w * rowf;
             {
@@ -267,27 +287,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
                 asm volatile("" : "+v"(q));                  // opaque per iteration: the constant reads stay in the loop
 #pragma unroll
                 for (int j = 0; j < NC; ++j) {
-                    const V d = dyf(raw_widen<T, CPT>(pg[j]), raw_widen<T, CPT>(py[j]), q, rowm * colm[j]);
+                    const V d = dyf(raw_widen<T, CPT>(q_.g[j]), raw_widen<T, CPT>(q_.y[j]), q, rowm * colm[j]);
                     vc_sts<CPT>(wrow + ((pt * NC + j + R) * CG + cgl) * CPT, d);
                 }
             }
             if (duty == 0) {
-                const V d = dyf(raw_widen<T, CPT>(phg), raw_widen<T, CPT>(phy), h_cgl, rowm * hm);
+                const V d = dyf(raw_widen<T, CPT>(q_.hg), raw_widen<T, CPT>(q_.hy), h_cgl, rowm * hm);
                 if (h_v) vc_sts<CPT>(wrow + h_idx, d);
             }
+            issue_gy(q_, r + PD, duty_at(duty, pdm));          // this set's next row (past the strip at the end: clamped, unused)
             duty = duty < 0 ? -1 : (duty == 0 ? NWD - 1 : duty - 1);
-            issue_gy(r + 1, duty);                           // the next row's G, Y (one row past the strip at the end: clamped, unused)
             __syncthreads();
             const int i = r - R;                             // output row whose window [i-R, i+R] is complete now
             if (i >= h0) {
                 V xr[NC], acc[NC], A[NC];
 #pragma unroll
                 for (int j = 0; j < NC; ++j) {
-                    xr[j] = raw_widen<T, CPT>(px[j]);
+                    xr[j] = raw_widen<T, CPT>(q_.x[j]);
                     acc[j] = vc_zero<CPT>();
-                    if (ai) acc[j] = raw_widen<T, CPT>(pa[j]);
+                    if (ai) acc[j] = raw_widen<T, CPT>(q_.a[j]);
                 }
-                issue_xa(i + 1);
+                issue_xa(q_, i + PD);
                 int q = cgl;
                 asm volatile("" : "+v"(q));
                 const float* cb_ = cst + q * CPT;
@@ -405,9 +425,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
                     }
                 }
             } else {
-                issue_xa(i + 1);
+                issue_xa(q_, i + PD);
             }
             slot_w = slot_w + 1 == S ? 0 : slot_w + 1;
+        };
+        for (int r = r_begin; r < r_end; r += PD) {
+#pragma unroll
+            for (int k = 0; k < PD; ++k)
+                if (r + k < r_end) step(rs_[k], r + k);
         }
     }
 
@@ -456,20 +481,205 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
     }
 }
 
+// ---- forward, tile form -------------------------------------------------------------------------------------------------------
+// y = depthwise KxK stride-1 correlation of the ACTIVATED input view + the per-channel (sum, sum of squares) of the stored output (the unit's
+// BatchNorm statistics), bf16 storage.  The register forms (dw3_fwd_kernel / dw5_fwd_kernel) load and transform K input columns per thread and
+// row (1.1-1.4 TB/s for 5x5, 1.3-3.4 TB/s for 3x3 on the MobileNetV3 512x512 shapes); here every thread loads and transforms ITS column(s) once,
+// parks the fp32 result in the LDS ring and reads the window back.  4 channels per thread, taps in registers (no accumulators to compete with),
+// NC = 2 adjacent output columns per thread for 5x5 (30 window reads per 2 outputs instead of 50).
+// replaces nn.Conv2d(groups=C, stride 1) in front of its BatchNorm (models/mobilenetv3.py:54-55, 68-69; models/mobilenetv2.py:65-66, 79-80).
+template <typename T, int KS, int NC, int XF>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void dwf_tile_kernel(
+    const T* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift, int in_act, const float* __restrict__ w,
+    T* __restrict__ y, float* __restrict__ parts, DwtGeom gm) {
+    constexpr int CPT = 4, R = KS / 2, KK = KS * KS, NV = CPT / 2, S = KS + 1, WC = NC + 2 * R;
+    using V = VC<CPT>;
+    using Raw = RawC<T, CPT>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int CG = kDwtCG;
+    const int PT = gm.PC / NC;
+    const int PC = gm.PC, SW = PC + 2 * R;
+    constexpr int colf = CG * CPT;
+    const int rowf = SW * colf;
+    float* const cst = smem;                     // [2][CG][CPT]: the input view's scale / shift
+    float* const ring = smem + 2 * colf;         // [S][SW][CG][CPT]
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int cgl = tid % CG, pt = tid / CG;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NWD = nthr >= 64 ? nthr >> 6 : 1;
+    const bool cvalid = (int)blockIdx.y * CG + cgl < gm.cg_total;
+    const int c = min((int)blockIdx.y * CG + cgl, gm.cg_total - 1) * CPT;
+    if (pt == 0) {
+#pragma unroll
+        for (int e = 0; e < CPT; ++e) {
+            cst[cgl * CPT + e] = (XF != 0 && in_scale) ? in_scale[c + e] : 1.f;
+            cst[colf + cgl * CPT + e] = (XF != 0 && in_scale) ? in_shift[c + e] : 0.f;
+        }
+    }
+    V tap[KK];
+#pragma unroll
+    for (int u = 0; u < KK; ++u)
+#pragma unroll
+        for (int j = 0; j < NV; ++j) tap[u].v[j] = v2f{w[(c + 2 * j) * KK + u], w[(c + 2 * j + 1) * KK + u]};
+    V st1 = vc_zero<CPT>(), st2 = vc_zero<CPT>();
+    constexpr int HE = 2 * R * CG;
+    const bool h_v = lane < HE;
+    const int h_e = min(lane, HE - 1);
+    const int h_s = h_e / CG;
+    const int h_cgl = h_e - h_s * CG;
+    const int h_idx = (h_s < R ? h_e : PC * CG + h_e) * CPT;
+    const int h_col = h_s < R ? h_s - R : PC + h_s - R;
+    const int h_c = min((int)blockIdx.y * CG + h_cgl, gm.cg_total - 1) * CPT;
+    __syncthreads();
+    const float xslope = act_slope(in_act);
+    auto xform = [&](V v, int q, float mask) {
+        const V sc = vc_lds<CPT>(cst + q * CPT), sh = vc_lds<CPT>(cst + colf + q * CPT);
+        V o;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            v2f a = v.v[j];
+            if (XF != 0) {
+                const v2f z = __builtin_elementwise_fma(v.v[j], sc.v[j], sh.v[j]);
+                if (XF == 1) a = v2f{__builtin_amdgcn_fmed3f(z.x, 0.f, 6.f), __builtin_amdgcn_fmed3f(z.y, 0.f, 6.f)};
+                else if (XF == 3) { const v2f t = z * v2f{xslope, xslope}; a = v2f{fmaxf(z.x, t.x), fmaxf(z.y, t.y)}; }
+                else {
+                    const v2f t = z + v2f{3.f, 3.f};
+                    a = z * v2f{__builtin_amdgcn_fmed3f(t.x, 0.f, 6.f), __builtin_amdgcn_fmed3f(t.y, 0.f, 6.f)} * v2f{1.f / 6.f, 1.f / 6.f};
+                }
+            }
+            o.v[j] = a * v2f{mask, mask};                      // zero padding applies to the ACTIVATED input
+        }
+        return o;
+    };
+    const int gxd = gridDim.x;
+    const int lb = (gm.xcd && (gxd & 7) == 0) ? (int)(blockIdx.x & 7) * (gxd >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const int64_t pitch = (int64_t)gm.W * gm.C;
+    for (int64_t tile = lb; tile < gm.ntiles; tile += gxd) {
+        const int wt = (int)(tile % gm.nWT);
+        const int hs = (int)((tile / gm.nWT) % gm.nHS);
+        const int n = (int)(tile / ((int64_t)gm.nWT * gm.nHS));
+        const int w0 = wt * PC, h0 = hs * gm.TH, h1 = min(h0 + gm.TH, gm.H);
+        const int64_t img = (int64_t)n * gm.H * pitch;
+        const T* const xi = x + img;
+        T* const yi = y + img;
+        bool colok[NC];
+        float colm[NC];
+        unsigned own_b[NC];
+#pragma unroll
+        for (int j = 0; j < NC; ++j) {
+            const int wo = w0 + pt * NC + j;
+            colok[j] = wo < gm.W;
+            colm[j] = colok[j] ? 1.f : 0.f;
+            own_b[j] = (unsigned)((min(wo, gm.W - 1) * gm.C + c) * (int)sizeof(T));
+        }
+        const int hwi = w0 + h_col;
+        const float hm = (h_v && hwi >= 0 && hwi < gm.W) ? 1.f : 0.f;
+        const unsigned h_b = (unsigned)((min(max(hwi, 0), gm.W - 1) * gm.C + h_c) * (int)sizeof(T));
+        __syncthreads();
+        const int r_begin = h0 - R, r_end = h1 + R;          // input rows this strip reads
+        int duty = wave < NWD ? ((wave - r_begin) % NWD + NWD) % NWD : -1;
+        Raw px[NC], phx;
+#pragma unroll
+        for (int q = 0; q < (int)(sizeof(Raw) / 4); ++q) phx.u[q] = 0u;
+        auto issue = [&](int r, int k) {
+            const int64_t ro = (int64_t)min(max(r, 0), gm.H - 1) * pitch;
+#pragma unroll
+            for (int j = 0; j < NC; ++j) px[j] = raw_ld<T, CPT>(at_bytes(xi + ro, own_b[j]));
+            if (k == 0) phx = raw_ld<T, CPT>(at_bytes(xi + ro, h_b));
+        };
+        issue(r_begin, duty);
+        int slot_w = 0;
+        for (int r = r_begin; r < r_end; ++r) {
+            const float rowm = (r >= 0 && r < gm.H) ? 1.f : 0.f;
+            float* const wrow = ring + slot_w * rowf;
+            {
+                int q = cgl;
+                asm volatile("" : "+v"(q));
+#pragma unroll
+                for (int j = 0; j < NC; ++j) vc_sts<CPT>(wrow + ((pt * NC + j + R) * CG + cgl) * CPT, xform(raw_widen<T, CPT>(px[j]), q, rowm * colm[j]));
+            }
+            if (duty == 0) {
+                const V a = xform(raw_widen<T, CPT>(phx), h_cgl, rowm * hm);
+                if (h_v) vc_sts<CPT>(wrow + h_idx, a);
+            }
+            duty = duty < 0 ? -1 : (duty == 0 ? NWD - 1 : duty - 1);
+            issue(r + 1, duty);
+            __syncthreads();
+            const int i = r - R;
+            if (i >= h0) {
+                V acc[NC];
+#pragma unroll
+                for (int j = 0; j < NC; ++j) acc[j] = vc_zero<CPT>();
+                const float* wb = ring + (pt * NC * CG + cgl) * CPT;
+#pragma unroll
+                for (int dr = 0; dr < KS; ++dr) {
+                    int sl = slot_w + 2 + dr;
+                    sl = sl >= S ? sl - S : sl;
+                    const float* rb = wb + sl * rowf;
+                    V D[WC];
+#pragma unroll
+                    for (int dq = 0; dq < WC; ++dq) D[dq] = vc_lds<CPT>(rb + dq * colf);
+#pragma unroll
+                    for (int dq = 0; dq < KS; ++dq)
+#pragma unroll
+                        for (int jc = 0; jc < NC; ++jc)
+#pragma unroll
+                            for (int j = 0; j < NV; ++j) acc[jc].v[j] = __builtin_elementwise_fma(tap[dr * KS + dq].v[j], D[jc + dq].v[j], acc[jc].v[j]);
+#pragma unroll
+                    for (int jc = 0; jc < NC; ++jc)
+#pragma unroll
+                        for (int j = 0; j < NV; ++j) asm volatile("" : "+v"(acc[jc].v[j]));
+                    asm volatile("" ::: "memory");
+                }
+#pragma unroll
+                for (int jc = 0; jc < NC; ++jc) {
+                    if (colok[jc] && cvalid) vc_store_stream<T, CPT>(at_bytes(yi + (int64_t)i * pitch, own_b[jc]), acc[jc]);
+#pragma unroll
+                    for (int j = 0; j < NV; ++j) {
+                        const v2f q = v2f{stored<T>(acc[jc].v[j].x), stored<T>(acc[jc].v[j].y)} * v2f{colm[jc], colm[jc]};
+                        st1.v[j] += q;
+                        st2.v[j] = __builtin_elementwise_fma(q, q, st2.v[j]);
+                    }
+                }
+            }
+            slot_w = slot_w + 1 == S ? 0 : slot_w + 1;
+        }
+    }
+    if (parts == nullptr) return;
+    float* const red = ring;
+    const int per = nthr * CPT;
+    __syncthreads();
+    vc_sts<CPT>(red + tid * CPT, st1);
+    vc_sts<CPT>(red + per + tid * CPT, st2);
+    __syncthreads();
+    if (pt < 2 && cvalid) {
+        V a = vc_zero<CPT>();
+        for (int p = 0; p < PT; ++p) {
+            const V t = vc_lds<CPT>(red + pt * per + (p * CG + cgl) * CPT);
+#pragma unroll
+            for (int q = 0; q < NV; ++q) a.v[q] += t.v[q];
+        }
+        float* dst = parts + (int64_t)blockIdx.x * 2 * gm.C + pt * gm.C;
+#pragma unroll
+        for (int q = 0; q < NV; ++q) { dst[c + 2 * q] = a.v[q].x; dst[c + 2 * q + 1] = a.v[q].y; }
+    }
+}
+
 // ---- geometry -------------------------------------------------------------------------------------------------------------
 static inline int dwt_cpt(int K) { return K == 5 ? 2 : 4; }
 static inline int dwt_nc(int K) { return K == 5 ? 2 : 1; }
 
-static int dwt_geom(DwtGeom& g, int& gx, int& chunks, int& threads, size_t& lds, int N, int H, int W, int C, int K) {
+static int dwt_geom(DwtGeom& g, int& gx, int& chunks, int& threads, size_t& lds, int N, int H, int W, int C, int K, bool fwd = false) {
     MNY_REQUIRE(K == 3 || K == 5, "dw_bnbwd (tile form): K=%d is not 3 or 5", K);
-    const int CPT = dwt_cpt(K), R = K / 2;
+    const int CPT = fwd ? 4 : dwt_cpt(K), R = K / 2;
     MNY_REQUIRE(C % 4 == 0 && C > 0, "dw_bnbwd: C=%d must be a positive multiple of 4", C);
     MNY_REQUIRE(N > 0 && H > 0 && W > 0, "dw_bnbwd: empty tensor");
     g.N = N; g.H = H; g.W = W; g.C = C;
     g.cg_total = C / CPT;
     // CG = 16 channel groups per workgroup (compile-time), <= 16 thread columns of NC output columns: the column tiles of a row are made equal;
     // at least 64 / CG thread columns where the halo of a row is a full wave's worth of elements (5x5)
-    const int CG = kDwtCG, NC = dwt_nc(K);
+    const int CG = kDwtCG, NC = dwt_nc(K);      // (the forward uses the same column split: 2 columns per thread for 5x5)
     chunks = (int)cdiv(g.cg_total, CG);
     const int nwt = (int)cdiv(W, (256 / CG) * NC);
     int PT = (int)cdiv(cdiv(W, nwt), NC);
@@ -504,7 +714,7 @@ static int dwt_geom(DwtGeom& g, int& gx, int& chunks, int& threads, size_t& lds,
     if (want > 8) want = (want + 7) & ~(int64_t)7;
     gx = (int)(want < cap ? want : cap);
     if ((int64_t)gx > g.ntiles) gx = (int)g.ntiles;
-    lds = (size_t)((kDwtConsts + (K == 5 ? K * K : 0)) * CG * CPT + (K + 1) * (PC + 2 * R) * CG * CPT) * sizeof(float);
+    lds = (size_t)((fwd ? 2 : kDwtConsts + (K == 5 ? K * K : 0)) * CG * CPT + (K + 1) * (PC + 2 * R) * CG * CPT) * sizeof(float);
     return MNY_OK;
 }
 
@@ -546,7 +756,7 @@ static int dwt_launch_t(const T* g, const T* y, const float* scale, const float*
     dim3 grid(gx, chunks), block(threads);
     // waves per SIMD the register allocation aims at: 3 (168 VGPRs); the 5x5 form with producer sums needs ~205 and runs spill-free at 2
     // (same box, bf16: C672 @32x32 0.323 vs 0.256 ms, C960 @16x16 0.163 vs 0.107)
-#define MNY_DWT_L(RED_, A_, X_) do { auto k = dwb_tile_kernel<T, KS, CPT, NC, TLDS, RED_, A_, X_, (KS == 5 && RED_) ? 2 : 3>; \
+#define MNY_DWT_L(RED_, A_, X_) do { auto k = dwb_tile_kernel<T, KS, CPT, NC, TLDS, RED_, A_, X_, (MNY_DWT_ALLW2 || (KS == 5 && RED_)) ? 2 : 3, MNY_DWT_PD>; \
         hipLaunchKernelGGL(k, grid, block, lds, st, g, y, scale, shift, act, coef, x, in_scale, in_shift, in_act, w, addend, dx, ws, in_mean, in_invstd, in_red, gm); } while (0)
 #define MNY_DWT_S(RED_) switch (am * 4 + xf) { \
         case 0: MNY_DWT_L(RED_, 0, 0); break; case 1: MNY_DWT_L(RED_, 0, 1); break; case 2: MNY_DWT_L(RED_, 0, 2); break; case 3: MNY_DWT_L(RED_, 0, 3); break; \
@@ -570,6 +780,52 @@ int dwt_launch(int bf, const void* g, const void* y, const float* scale, const f
     if (K == 5) return bf ? MNY_DWT(bf16_t, 5) : MNY_DWT(float, 5);
     return bf ? MNY_DWT(bf16_t, 3) : MNY_DWT(float, 3);
 #undef MNY_DWT
+}
+
+
+// ---- forward routing ----------------------------------------------------------------------------------------------------------
+// bf16 storage, stride 1, 5x5 only, the same channel-count rule as the backward (>= 120 channels, last 64-channel chunk at least 3/4 full).
+// Measured round 5 (tools/bench_dwfwd.py, MobileNetV3 512x512 bs 64 shapes, register form -> tile form): 5x5 C672 @32x32 0.127 -> 0.080 ms,
+// C120 @64x64 0.079 -> 0.069, C960 @16x16 0.047 -> 0.044; 3x3 is SLOWER on the tile form (C480 0.042 -> 0.048, C672 0.053 -> 0.062,
+// C320 @32x32 0.026 -> 0.037: three loads per row are no burden for the register form, the barrier per row is one for the tile form).
+// MNY_DWTF=0 / 1: never / every stride-1 launch (A/B).
+bool dwt_fwd_use(int K, int stride, int bf, int C) {
+    static const int env = getenv("MNY_DWTF") ? atoi(getenv("MNY_DWTF")) : -1;
+    if (stride != 1 || (K != 3 && K != 5) || C % 4 != 0) return false;
+    if (env >= 0) return env != 0;
+    if (!bf || C < 120 || K != 5) return false;
+    const int cg = C / 4, chunks = (cg + kDwtCG - 1) / kDwtCG;
+    return 4 * cg >= 3 * chunks * kDwtCG;
+}
+int dwt_fwd_parts(int N, int H, int W, int C, int K) {
+    DwtGeom g; int gx, chunks, threads; size_t lds;
+    if (dwt_geom(g, gx, chunks, threads, lds, N, H, W, C, K, true)) return MNY_EINVAL;
+    return gx;
+}
+template <typename T, int KS>
+static int dwt_fwd_launch_t(const T* x, const float* in_scale, const float* in_shift, int in_act, const float* w, T* y, float* stats, int N, int H, int W,
+                            int C, hipStream_t st) {
+    constexpr int NC = KS == 5 ? 2 : 1;
+    DwtGeom gm; int gx, chunks, threads; size_t lds;
+    int rc = dwt_geom(gm, gx, chunks, threads, lds, N, H, W, C, KS, true);
+    if (rc) return rc;
+    const int xf = (in_scale == nullptr && in_act == MNY_ACT_NONE) ? 0 : (in_act == MNY_ACT_HSWISH ? 2 : (in_act == MNY_ACT_RELU6 ? 1 : 3));
+    MNY_REQUIRE(in_act != MNY_ACT_HSIGMOID, "dw_fwd (tile form): h-sigmoid views are not supported");
+    dim3 grid(gx, chunks), block(threads);
+#define MNY_DWF(X_) do { auto k = dwf_tile_kernel<T, KS, NC, X_>; \
+        if (lds > 64 * 1024 && !allow_lds((const void*)k, lds)) { set_error("dw_fwd: hipFuncSetAttribute failed"); return MNY_EHIP; } \
+        hipLaunchKernelGGL(k, grid, block, lds, st, x, in_scale, in_shift, in_act, w, y, stats, gm); } while (0)
+    switch (xf) { case 0: MNY_DWF(0); break; case 1: MNY_DWF(1); break; case 2: MNY_DWF(2); break; default: MNY_DWF(3); break; }
+#undef MNY_DWF
+    return check_launch("dwf_tile_kernel");
+}
+int dwt_fwd_launch(int bf, const void* x, const float* in_scale, const float* in_shift, int in_act, const float* w, void* y, float* stats, int N, int H,
+                   int W, int C, int K, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (K == 5) return bf ? dwt_fwd_launch_t<bf16_t, 5>((const bf16_t*)x, in_scale, in_shift, in_act, w, (bf16_t*)y, stats, N, H, W, C, st)
+                          : dwt_fwd_launch_t<float, 5>((const float*)x, in_scale, in_shift, in_act, w, (float*)y, stats, N, H, W, C, st);
+    return bf ? dwt_fwd_launch_t<bf16_t, 3>((const bf16_t*)x, in_scale, in_shift, in_act, w, (bf16_t*)y, stats, N, H, W, C, st)
+              : dwt_fwd_launch_t<float, 3>((const float*)x, in_scale, in_shift, in_act, w, (float*)y, stats, N, H, W, C, st);
 }
 
 }  // namespace mny

@@ -392,7 +392,7 @@ class NetPlan:
                     i = nd.ins[0]
                     ish = shape(i)
                     xv = view(i)
-                    parts = _lib.query("mny_dw_stat_parts", N, ish[1], ish[2], o.C, nd.k, nd.stride)
+                    parts = _lib.query("mny_dw_stat_parts_x", N, ish[1], ish[2], o.C, nd.k, nd.stride, 1 if self.bf16 else 0)
                     self.fwd.add(K("mny_dw_fwd"), xv[0], xv[1], xv[2], xv[3], w, u.Y, stats, N, ish[1], ish[2], o.C, nd.k, nd.stride, self.stream,
                                  meta=dict(flops=2 * M * o.C * nd.k * nd.k, bytes=eb * (N * ish[1] * ish[2] * o.C + M * o.C) + 4 * o.C * nd.k * nd.k,
                                            shape="C%d H%d s%d" % (o.C, ish[1], nd.stride)))

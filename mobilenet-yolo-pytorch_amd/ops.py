@@ -81,7 +81,7 @@ def dw_fwd(view, w, stride, want_stats=True):
     K = w.shape[-1]
     Ho, Wo = (H + 2 * (K // 2) - K) // stride + 1, (W + 2 * (K // 2) - K) // stride + 1
     y = _new(N, Ho, Wo, C, like=x, dtype=x.dtype)
-    stats = _new(query("mny_dw_stat_parts", N, H, W, C, K, stride), 2, C, like=x) if want_stats else None
+    stats = _new(query("mny_dw_stat_parts_x", N, H, W, C, K, stride, 1 if x.dtype == torch.bfloat16 else 0), 2, C, like=x) if want_stats else None
     call(_k("mny_dw_fwd", x), _p(x), _p(sc), _p(sh), act, _p(w), _p(y), _p(stats), N, H, W, C, K, stride, _st())
     return y, stats
 

@@ -458,6 +458,27 @@ def test_dw_forward_odd_shapes_and_views(ops, N, H, W, C, s, act, monkeypatch):
     check(s2, r2, 1e-4, 1e-3, "dw stats sumsq")
 
 
+@pytest.mark.parametrize("N,H,W,C,k,act", [(2, 32, 32, 672, 5, 4), (2, 16, 16, 960, 5, 4), (3, 19, 35, 120, 5, 3), (2, 64, 64, 120, 5, 1), (1, 5, 3, 184, 5, 2),
+                                           (3, 7, 50, 200, 5, 0), (2, 2, 3, 320, 5, 3)])
+def test_dw_forward_tile_form_bf16(ops, N, H, W, C, k, act):
+    """The tile form of the stride-1 depthwise forward (csrc/dwtile.hip; bf16 storage, 5x5, >= 120 channels: every thread activates its own column once,
+    the window comes back from an LDS ring; 5x5 with two output columns per thread) against torch on the bf16-representable input: the output
+    within one bf16 rounding (2^-7), the BN partial sums taken over the STORED output (5e-3: fp32 accumulation over <= 8k values per channel)."""
+    from mobilenet_yolo_pytorch_amd import _lib
+    assert _lib.query("mny_dw_stat_parts_x", N, H, W, C, k, 1, 1) > 0
+    x = rnd(N, C, H, W, seed=1).to(torch.bfloat16).float()
+    w = rnd(C, 1, k, k, seed=2, scale=0.4 if k == 3 else 0.25)
+    sc, sh = 1 + 0.2 * rnd(C, seed=3), 0.3 * rnd(C, seed=4)
+    y = F.conv2d(view_ref(x, sc, sh, act), w, None, 1, k // 2, 1, C)
+    got, st = ops.dw_fwd((nhwc(x).to(torch.bfloat16), sc.cuda(), sh.cuda(), act), w.cuda().contiguous(), 1)
+    assert got.dtype == torch.bfloat16
+    check(nchw(got.float()), y, 2.0 ** -7, 2.0 ** -7 * max(1.0, y.abs().max().item()) * 0.25, "tile dw fwd")
+    s1, s2 = stats_got(st)
+    r1, r2 = stats_ref(nchw(got.float()).cpu())
+    check(s1, r1, 5e-3, 5e-3 * max(1.0, r1.abs().max().item()), "tile dw stats sum")
+    check(s2, r2, 5e-3, 5e-3 * max(1.0, r2.abs().max().item()), "tile dw stats sumsq")
+
+
 @pytest.mark.parametrize("M,K,Nc,act", [(4 * 11 * 11, 16, 96, 1), (2 * 22 * 22 + 5, 24, 144, 1), (1000, 64, 384, 1), (777, 160, 960, 2),
                                         (3 * 128 + 1, 96, 512, 0), (130, 32, 192, 1), (64, 320, 960, 1), (900, 40, 120, 4), (500, 112, 672, 3)])
 def test_dgrad_with_fused_bn_backward_reduction(ops, M, K, Nc, act):

@@ -55,7 +55,7 @@ def main():
         sc, sh = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev) * 0.1
         Ho = (H - 1) // s + 1
         y = torch.empty(bs, Ho, Ho, C, device=dev, dtype=dt)
-        parts = _lib.query("mny_dw_stat_parts", bs, H, H, C, k, s)
+        parts = _lib.query("mny_dw_stat_parts_x", bs, H, H, C, k, s, 1 if bf else 0)
         stats = torch.zeros(parts, 2, C, device=dev)
         fn = lambda: _lib.call("mny_dw_fwd" + sfx, ptr(x), ptr(sc), ptr(sh), act, ptr(w), ptr(y), ptr(stats), bs, H, H, C, k, s, st)  # noqa: E731
         ms = timeit(fn, 20)
