@@ -360,7 +360,8 @@ enum {
     MNY_ROUTE_DMA_X6 = 2,       /* LDS-DMA tile kernel, six-product bf16 form */
     MNY_ROUTE_THIN = 3,         /* short-reduction vector-ALU stream kernel (pwthin.hip) */
     MNY_ROUTE_WIDE = 4,         /* barrier-free wide-output kernel (pwwide.hip) */
-    MNY_ROUTE_WGRAD_STREAM = 5  /* barrier-free stream weight-gradient kernel (pwwgs.hip) */
+    MNY_ROUTE_WGRAD_STREAM = 5, /* barrier-free stream weight-gradient kernel (pwwgs.hip) */
+    MNY_ROUTE_WAVE16 = 6        /* bf16 storage, K <= 48 at >= 131072 pixels: a wave per 16 pixels on the bf16 matrix cores (gate.hip pwt_fwd_kernel) */
 };
 int mny_pw_route(int op, int bf16, int64_t M, int K, int Nc);   /* PREDICTION for a plain view (no h-swish input, no bias gradient) */
 /* the family the LAST pointwise-conv call of the calling thread actually took (recorded by the dispatchers where they decide; -1 before

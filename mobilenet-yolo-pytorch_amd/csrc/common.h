@@ -231,6 +231,12 @@ int dwt_launch(int bf, const void* g, const void* y, const float* scale, const f
                const float* in_scale, const float* in_shift, int in_act, const float* w, const void* addend, void* dx, float* dw, float* ws, int N, int H,
                int W, int C, int K, void* stream, const float* in_mean, const float* in_invstd, float* in_red);
 
+// thin pointwise conv forward / plain data gradient, bf16 storage, a wave per 16 pixels on the matrix cores (gate.hip)
+bool pwt_ok(int64_t M, int K, int N, int in_act, bool has_bias);
+int pwt_parts(int64_t M);
+int pwt_launch(const void* x, const float* xs, const float* xb, int xact, const void* w, const void* addend, void* y, float* stats, int64_t M, int K, int N,
+               hipStream_t st);
+
 // short-reduction pointwise conv on the vector ALU (pwthin.hip); the entry points of pwgemm.hip route K = 8/16/24/32 problems here
 bool pw_thin_ok(int bf, int red, int64_t M, int K, int N);
 int pw_thin_parts(int64_t M, int K, int N, int red);

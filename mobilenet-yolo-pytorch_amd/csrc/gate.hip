@@ -658,6 +658,146 @@ static int pj16_launch(const Pj16Args& a, int grid, hipStream_t st) {
     return check_launch("pj16_bwd_kernel");
 }
 
+// ---- thin pointwise conv forward / plain data gradient on the same machinery (bf16 storage) -----------------------------------------
+// y[M][N] = view(x)[M][K] . W^T for K <= 48 at a large pixel count (MobileNetV3's first blocks at 256x256 / 128x128 / 64x64: K = 16, 24, 40):
+// the short-reduction vector-ALU kernel these shapes took runs 1.3-2.5 TB/s (16-40 fma per output element), the LDS-DMA tile kernel has no
+// tile for them.  Here a wave owns 16 pixels: the input row is loaded in the accumulator layout (8 bytes per lane and 16-channel tile),
+// activated, and IS the B operand; the weights (<= 240 x 48) are cut into A-operand chunks by every workgroup in its prologue (a few KB from
+// L2); every 16x16 output tile leaves as one 8-byte store per lane; the BatchNorm statistics (sum, sum of squares of the STORED values) are
+// kept per lane and leave as one partial row per workgroup.  The arithmetic is the bf16 GEMM path's: operands rounded to bf16, fp32 accumulate.
+// replaces nn.Conv2d(K, N, 1) of the thin expand / project / shortcut convs (models/mobilenetv3.py:49,57,63) and its plain data gradient.
+struct PwtArgs {
+    const bf16_t* x; const float* xs; const float* xb; int xact;
+    const bf16_t* w;                                              // [N][K] bf16 (the GEMM weight shadow)
+    const bf16_t* addend; bf16_t* y; float* parts; int64_t M; int K, N;
+};
+
+template <int KT, int NT, int XF, bool STATS>
+__global__ __launch_bounds__(256) void pwt_fwd_kernel(PwtArgs p) {
+    constexpr int KU = (KT + 1) / 2, KP = KU * 32, NP = NT * 16;
+    __shared__ uint4 wa[NT * KU * 64];
+    __shared__ __attribute__((aligned(16))) float cs[KP], cb[KP];
+    __shared__ float red[STATS ? 4 * 2 * NP : 1];
+    const int K = p.K, N = p.N;
+    for (int i = threadIdx.x; i < NT * KU * 64; i += blockDim.x) {
+        const int ln = i & 63, u = (i >> 6) % KU, t = i / (64 * KU);
+        const int row = 16 * t + (ln & 15), kg = ln >> 4;
+        uint32_t v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = 32 * u + (e < 4 ? 4 * kg + e : 16 + 4 * kg + (e - 4));
+            v[e] = (row < N && k < K) ? (uint32_t)p.w[(int64_t)row * K + k].v : 0u;
+        }
+        wa[i] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+    }
+    gate_fill_row(cs, XF != 0 ? p.xs : nullptr, K, KP, 1.f);
+    gate_fill_row(cb, XF != 0 ? p.xb : nullptr, K, KP, 0.f);
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, px = lane & 15, rg = lane >> 4;
+    const int64_t ntiles = (p.M + 15) >> 4;
+    constexpr int NS = STATS ? NT : 1;
+    gate_f4 ssum[NS], qsum[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) { ssum[i] = gate_zero(); qsum[i] = gate_zero(); }
+    const float xslope = act_slope(p.xact);
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+        int lo = lane, cq = 4 * rg;
+        asm volatile("" : "+v"(lo), "+v"(cq));               // opaque per iteration: chunk and constant reads stay in the loop
+        const int64_t m = tile * 16 + px;
+        const bool valid = m < p.M;
+        const bf16_t* xrow = p.x + (valid ? m : 0) * K;
+        uint2 raw[KT];
+#pragma unroll
+        for (int t = 0; t < KT; ++t) raw[t] = (16 * t + 4 * rg < K) ? *reinterpret_cast<const uint2*>(xrow + 16 * t + 4 * rg) : make_uint2(0u, 0u);
+        auto aval = [&](int t) {
+            float4 v = gate_widen(raw[t]);
+            if (XF != 0) {
+                v = gate_fma4(v, gate_ld4(cs + 16 * t + cq), gate_ld4(cb + 16 * t + cq));
+                if (XF == 1) v = make_float4(__builtin_amdgcn_fmed3f(v.x, 0.f, 6.f), __builtin_amdgcn_fmed3f(v.y, 0.f, 6.f), __builtin_amdgcn_fmed3f(v.z, 0.f, 6.f),
+                                             __builtin_amdgcn_fmed3f(v.w, 0.f, 6.f));
+                else if (XF == 2) v = make_float4(v.x * __builtin_amdgcn_fmed3f(v.x + 3.f, 0.f, 6.f) * (1.f / 6.f), v.y * __builtin_amdgcn_fmed3f(v.y + 3.f, 0.f, 6.f) * (1.f / 6.f),
+                                                  v.z * __builtin_amdgcn_fmed3f(v.z + 3.f, 0.f, 6.f) * (1.f / 6.f), v.w * __builtin_amdgcn_fmed3f(v.w + 3.f, 0.f, 6.f) * (1.f / 6.f));
+                else v = make_float4(fmaxf(v.x, xslope * v.x), fmaxf(v.y, xslope * v.y), fmaxf(v.z, xslope * v.z), fmaxf(v.w, xslope * v.w));
+                if (16 * t + 4 * rg >= K) v = f4zero();        // padded channels: the view of 0 is not 0
+            }
+            return v;
+        };
+        gate_f4 acc[NT];
+        gate_product<NT, KU>(acc, wa + lo, [&](int u) { return gate_frag(aval(2 * u), 2 * u + 1 < KT ? aval(2 * u + 1 < KT ? 2 * u + 1 : 0) : f4zero()); });
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int c0 = 16 * t + 4 * rg;
+            float4 o = gate_f(acc[t]);
+            const bool ok = valid && c0 < N;
+            if (p.addend != nullptr && ok) add4(o, ld4(p.addend + m * N + c0));
+            if (ok) st4(p.y + m * N + c0, o);
+            if (STATS) {
+                const float vm = ok ? 1.f : 0.f;
+                const float4 q = stored4<bf16_t>(o);
+                const gate_f4 v = gate_f4{q.x, q.y, q.z, q.w} * vm;
+                ssum[t] += v;
+                qsum[t] += v * v;
+            }
+        }
+    }
+    if (STATS) {                                             // as gate_write_sums, with the row length N known at run time
+#pragma unroll
+        for (int t = 0; t < NS; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float s = ssum[t][i], q = qsum[t][i];
+#pragma unroll
+                for (int k = 1; k < 16; k <<= 1) { s += __shfl_xor(s, k); q += __shfl_xor(q, k); }
+                if (px == 0) { red[(wave * 2 + 0) * NP + 16 * t + 4 * rg + i] = s; red[(wave * 2 + 1) * NP + 16 * t + 4 * rg + i] = q; }
+            }
+        __syncthreads();
+        for (int c = threadIdx.x; c < N; c += blockDim.x) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { s += red[(w * 2 + 0) * NP + c]; q += red[(w * 2 + 1) * NP + c]; }
+            p.parts[(int64_t)blockIdx.x * 2 * N + c] = s;
+            p.parts[(int64_t)blockIdx.x * 2 * N + N + c] = q;
+        }
+    }
+}
+
+// shapes: K a multiple of 8 up to 48, N a multiple of 8 up to 240, and enough pixels that the vector-ALU / tile kernels are the slower choice
+bool pwt_ok(int64_t M, int K, int N, int in_act, bool has_bias) {
+    static const bool off = getenv("MNY_NO_PWT") != nullptr && atoi(getenv("MNY_NO_PWT")) != 0;
+    if (off || has_bias || in_act == MNY_ACT_HSIGMOID) return false;
+    if (K <= 0 || N <= 0 || (K & 7) || (N & 7) || K > 48 || N > 240) return false;
+    return M >= 131072;
+}
+int pwt_parts(int64_t M) {
+    const int64_t want = cdiv(cdiv(M, 16), 4);
+    return (int)(want < 1024 ? want : 1024);
+}
+template <int KT, int XF, bool STATS>
+static int pwt_launch_n(const PwtArgs& a, int grid, hipStream_t st) {
+    const int NT = (a.N + 15) / 16;
+#define MNY_PWT(N_) case N_: hipLaunchKernelGGL((pwt_fwd_kernel<KT, N_, XF, STATS>), dim3(grid), dim3(256), 0, st, a); break
+    switch (NT) {
+        MNY_PWT(1); MNY_PWT(2); MNY_PWT(3); MNY_PWT(4); MNY_PWT(5); MNY_PWT(6); MNY_PWT(7); MNY_PWT(8);
+        MNY_PWT(9); MNY_PWT(10); MNY_PWT(11); MNY_PWT(12); MNY_PWT(13); MNY_PWT(14); default: MNY_PWT(15);
+    }
+#undef MNY_PWT
+    return check_launch("pwt_fwd_kernel");
+}
+int pwt_launch(const void* x, const float* xs, const float* xb, int xact, const void* w, const void* addend, void* y, float* stats, int64_t M, int K, int N,
+               hipStream_t st) {
+    PwtArgs a{(const bf16_t*)x, xs, xb, xact, (const bf16_t*)w, (const bf16_t*)addend, (bf16_t*)y, stats, M, K, N};
+    const int grid = pwt_parts(M);
+    const int xf = (xs == nullptr && xact == MNY_ACT_NONE) ? 0 : (xact == MNY_ACT_RELU6 ? 1 : (xact == MNY_ACT_HSWISH ? 2 : 3));
+    const int KT = (K + 15) / 16;
+#define MNY_PWT_X(KT_, S_) do { switch (xf) { case 0: return pwt_launch_n<KT_, 0, S_>(a, grid, st); case 1: return pwt_launch_n<KT_, 1, S_>(a, grid, st); \
+        case 2: return pwt_launch_n<KT_, 2, S_>(a, grid, st); default: return pwt_launch_n<KT_, 3, S_>(a, grid, st); } } while (0)
+#define MNY_PWT_K(S_) do { if (KT == 1) MNY_PWT_X(1, S_); else if (KT == 2) MNY_PWT_X(2, S_); else MNY_PWT_X(3, S_); } while (0)
+    if (stats) MNY_PWT_K(true); else MNY_PWT_K(false);
+#undef MNY_PWT_K
+#undef MNY_PWT_X
+    return MNY_OK;
+}
+
 static bool gate_shape_ok(int64_t M, int C, int R) {
     return M > 0 && ((C == 40 && R == 10) || (C == 112 && R == 28) || (C == 160 && R == 40));
 }

@@ -2798,6 +2798,7 @@ extern "C" int mny_pw_stat_parts(int64_t M, int K, int Nc) {
 }
 extern "C" int mny_pw_stat_parts_bf16(int64_t M, int K, int Nc) {
     if (M <= 0 || K <= 0 || Nc <= 0) return MNY_EINVAL;
+    if (pwt_ok(M, K, Nc, MNY_ACT_NONE, false)) return pwt_parts(M);
     if (pw_thin_ok(1, 0, M, K, Nc)) return pw_thin_parts(M, K, Nc, 0);
     if ((K & 7) == 0 && getenv("MNY_GEMM_V1") == nullptr) return nt2_plan(M, K, Nc, true, 1).gx;
     return nt_plan(M, K, Nc).gx;
@@ -3051,6 +3052,8 @@ extern "C" int mny_pw_fwd_bf16(const void* x, const float* in_scale, const float
     hipStream_t st = (hipStream_t)stream;
     const bool xf = in_scale != nullptr || in_act != MNY_ACT_NONE;
     static const bool force_v1 = getenv("MNY_GEMM_V1") != nullptr;
+    if (pwt_ok(M, K, Nc, in_act, bias != nullptr))         // K <= 48 at a large pixel count: a wave per 16 pixels on the bf16 matrix cores (gate.hip)
+        return (g_pw_route = MNY_ROUTE_WAVE16, pwt_launch(x, in_scale, in_shift, in_act, w, addend, y, stats, M, K, Nc, st));
     if (pw_thin_ok(1, 0, M, K, Nc))
         return (g_pw_route = MNY_ROUTE_THIN, pw_thin_launch(1, x, in_scale, in_shift, in_act, w, bias, addend, y, stats, M, K, Nc, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, st));
     if ((K & 7) == 0 && !force_v1) {                // LDS-DMA pipeline on the bf16 matrix cores (16-B aligned bf16 rows)
@@ -3084,6 +3087,7 @@ extern "C" int mny_pw_route(int op, int bf16, int64_t M, int K, int Nc) {
         if ((Nc & al) || (K & al) || wgrad_v1) return MNY_ROUTE_TILE_V1;
         return (!bf16 && nt_x6(M, K, Nc)) ? MNY_ROUTE_DMA_X6 : MNY_ROUTE_DMA_F32;
     }
+    if (bf16 && op == 0 && pwt_ok(M, K, Nc, MNY_ACT_NONE, false)) return MNY_ROUTE_WAVE16;
     if (pw_thin_ok(bf16 ? 1 : 0, op, M, K, Nc)) return MNY_ROUTE_THIN;
     if (!bf16 && pw_wide_ok(M, K, Nc, op == 1)) return MNY_ROUTE_WIDE;
     if ((K & al) || gemm_v1) return MNY_ROUTE_TILE_V1;
