@@ -222,7 +222,7 @@ int launch_reduce_parts(const float* parts, int nparts, int n, float* out, hipSt
 
 // tile form of the fused depthwise-unit backward (dwtile.hip): 5x5 stride 1 (and 3x3 behind MNY_DWT3=1); same arguments as mny_dw_bnbwd[_red]
 bool dwt_use(int K, int bf, int red, int C);      // which form runs the unit
-int dwt_parts(int N, int H, int W, int C, int K);
+int dwt_parts(int N, int H, int W, int C, int K, int bf);
 bool dwt_fwd_use(int K, int stride, int bf, int C);    // tile form of the depthwise forward (bf16 storage, stride 1)
 int dwt_fwd_parts(int N, int H, int W, int C, int K);
 int dwt_fwd_launch(int bf, const void* x, const float* in_scale, const float* in_shift, int in_act, const float* w, void* y, float* stats, int N, int H,

@@ -532,7 +532,7 @@ extern "C" int mny_dw_bnbwd_s2_bf16(const void* g, const void* y, const float* s
 
 extern "C" int mny_dw_bnbwd_parts_k(int N, int H, int W, int C, int K, int flags) {
     if (K != 3 && K != 5) return MNY_EINVAL;
-    if (dwt_use(K, flags & 1, (flags >> 1) & 1, C)) return dwt_parts(N, H, W, C, K);
+    if (dwt_use(K, flags & 1, (flags >> 1) & 1, C)) return dwt_parts(N, H, W, C, K, flags & 1);
     if (K != 3) return MNY_EINVAL;
     DwbGeom g; CgLayout L; int gx;
     if (dwb_geom(g, L, gx, N, H, W, C)) return MNY_EINVAL;

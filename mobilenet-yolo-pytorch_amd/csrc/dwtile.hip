@@ -113,7 +113,7 @@ constexpr int kDwtCG = 16;
 
 // KS: 3 / 5.  CPT: channels per thread.  NC: adjacent output columns per thread (they share the taps, the tap accumulators and most of the
 // window reads).  TLDS: the taps are read from LDS next to the window (5x5: 25 x CPT registers the kernel does not have) instead of registers.
-template <typename T, int KS, int CPT, int NC, bool TLDS, bool RED, int AM, int XF, int WPE, int PD>
+template <typename T, int KS, int CPT, int NC, bool TLDS, bool RED, int AM, int XF, int WPE, int PD, int CG_>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) void dwb_tile_kernel(
     const T* __restrict__ g, const T* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift, int act,
     const float* __restrict__ coef, const T* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, 8))) v
     using V = VC<CPT>;
     using Raw = RawC<T, CPT>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int CG = kDwtCG;
+    constexpr int CG = CG_;                      // channel groups per workgroup: 16; 4 / 18 for the 16- / 72-channel layers (3x3, bf16 storage)
     const int PT = gm.PC / NC;                   // thread columns of a tile; PC = PT * NC output columns
     const int PC = gm.PC, SW = PC + 2 * R;
     constexpr int colf = CG * CPT;               // floats per column of a ring row
@@ -669,8 +669,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
 // ---- geometry -------------------------------------------------------------------------------------------------------------
 static inline int dwt_cpt(int K) { return K == 5 ? 2 : 4; }
 static inline int dwt_nc(int K) { return K == 5 ? 2 : 1; }
+// channel groups per workgroup of the backward tile kernel: 16, except the 3x3 layers whose channel count fills 16-group chunks badly:
+// C = 16 (4 groups: a pixel is 32 contiguous bytes, a wave covers 16 columns) and C = 72 (18 groups in one chunk)
+static inline int dwt_pick_cg(int K, int C, int bf) {
+    if (bf && K == 3 && C == 16) return 4;
+    if (bf && K == 3 && C == 72) return 18;
+    return kDwtCG;
+}
 
-static int dwt_geom(DwtGeom& g, int& gx, int& chunks, int& threads, size_t& lds, int N, int H, int W, int C, int K, bool fwd = false) {
+static int dwt_geom(DwtGeom& g, int& gx, int& chunks, int& threads, size_t& lds, int N, int H, int W, int C, int K, int bf, bool fwd = false) {
     MNY_REQUIRE(K == 3 || K == 5, "dw_bnbwd (tile form): K=%d is not 3 or 5", K);
     const int CPT = fwd ? 4 : dwt_cpt(K), R = K / 2;
     MNY_REQUIRE(C % 4 == 0 && C > 0, "dw_bnbwd: C=%d must be a positive multiple of 4", C);
@@ -679,11 +686,11 @@ static int dwt_geom(DwtGeom& g, int& gx, int& chunks, int& threads, size_t& lds,
     g.cg_total = C / CPT;
     // CG = 16 channel groups per workgroup (compile-time), <= 16 thread columns of NC output columns: the column tiles of a row are made equal;
     // at least 64 / CG thread columns where the halo of a row is a full wave's worth of elements (5x5)
-    const int CG = kDwtCG, NC = dwt_nc(K);      // (the forward uses the same column split: 2 columns per thread for 5x5)
+    const int CG = fwd ? kDwtCG : dwt_pick_cg(K, C, bf), NC = dwt_nc(K);      // (the forward uses the same column split: 2 columns per thread for 5x5)
     chunks = (int)cdiv(g.cg_total, CG);
     const int nwt = (int)cdiv(W, (256 / CG) * NC);
     int PT = (int)cdiv(cdiv(W, nwt), NC);
-    const int pt_min = (int)cdiv(2 * R * CG, 64) * (64 / CG);
+    const int pt_min = (int)cdiv(64, CG);                    // at least one whole wave: the halo duty needs 2R*CG <= 64 lanes of it
     if (PT < pt_min) PT = pt_min;
     if (PT * NC < 2 * R) PT = (int)cdiv(2 * R, NC);
     const int PC = PT * NC;
@@ -730,15 +737,17 @@ bool dwt_use(int K, int bf, int red, int C) {
     if (K == 5) return !no5;
     if (K != 3) return false;
     if (env3 >= 0) return env3 != 0;
-    if (!bf || C < 120) return false;
+    if (!bf) return false;
+    if (C == 16 || C == 72) return !red;                    // own chunk widths (dwt_pick_cg): C16 @256x256 0.280 -> 0.192 ms, C72 @128x128 0.313 -> 0.237; with producer sums 0.292 vs 0.294 / 0.319 vs 0.350
+    if (C < 120) return false;
     const int cg = C / 4, chunks = (cg + kDwtCG - 1) / kDwtCG;
     if (4 * cg < 3 * chunks * kDwtCG) return false;
     return !red || C <= 192;
 }
 
-int dwt_parts(int N, int H, int W, int C, int K) {
+int dwt_parts(int N, int H, int W, int C, int K, int bf) {
     DwtGeom g; int gx, chunks, threads; size_t lds;
-    if (dwt_geom(g, gx, chunks, threads, lds, N, H, W, C, K)) return MNY_EINVAL;
+    if (dwt_geom(g, gx, chunks, threads, lds, N, H, W, C, K, bf)) return MNY_EINVAL;
     return gx;
 }
 
@@ -749,14 +758,17 @@ static int dwt_launch_t(const T* g, const T* y, const float* scale, const float*
     constexpr int CPT = KS == 5 ? 2 : 4, NC = KS == 5 ? 2 : 1;
     constexpr bool TLDS = KS == 5;
     DwtGeom gm; int gx, chunks, threads; size_t lds;
-    int rc = dwt_geom(gm, gx, chunks, threads, lds, N, H, W, C, KS);
+    int rc = dwt_geom(gm, gx, chunks, threads, lds, N, H, W, C, KS, sizeof(T) == 2 ? 1 : 0);
     if (rc) return rc;
     const int am = act == MNY_ACT_NONE ? 0 : (act == MNY_ACT_HSWISH ? 2 : 1);
     const int xf = (in_scale == nullptr && in_act == MNY_ACT_NONE) ? 0 : (in_act == MNY_ACT_HSWISH ? 2 : (in_act == MNY_ACT_RELU6 ? 1 : 3));
     dim3 grid(gx, chunks), block(threads);
     // waves per SIMD the register allocation aims at: 3 (168 VGPRs); the 5x5 form with producer sums needs ~205 and runs spill-free at 2
     // (same box, bf16: C672 @32x32 0.323 vs 0.256 ms, C960 @16x16 0.163 vs 0.107)
-#define MNY_DWT_L(RED_, A_, X_) do { auto k = dwb_tile_kernel<T, KS, CPT, NC, TLDS, RED_, A_, X_, (MNY_DWT_ALLW2 || (KS == 5 && RED_)) ? 2 : 3, MNY_DWT_PD>; \
+#define MNY_DWT_LC(RED_, A_, X_, CG_) do { auto k = dwb_tile_kernel<T, KS, CPT, NC, TLDS, RED_, A_, X_, (MNY_DWT_ALLW2 || (KS == 5 && RED_)) ? 2 : 3, MNY_DWT_PD, CG_>; \
+        hipLaunchKernelGGL(k, grid, block, lds, st, g, y, scale, shift, act, coef, x, in_scale, in_shift, in_act, w, addend, dx, ws, in_mean, in_invstd, in_red, gm); } while (0)
+#define MNY_DWT_L(RED_, A_, X_) do { if constexpr (KS == 3 && sizeof(T) == 2) { if (gm.CG == 4) { MNY_DWT_LC(RED_, A_, X_, 4); break; } if (gm.CG == 18) { MNY_DWT_LC(RED_, A_, X_, 18); break; } } \
+        auto k = dwb_tile_kernel<T, KS, CPT, NC, TLDS, RED_, A_, X_, (MNY_DWT_ALLW2 || (KS == 5 && RED_)) ? 2 : 3, MNY_DWT_PD, kDwtCG>; \
         hipLaunchKernelGGL(k, grid, block, lds, st, g, y, scale, shift, act, coef, x, in_scale, in_shift, in_act, w, addend, dx, ws, in_mean, in_invstd, in_red, gm); } while (0)
 #define MNY_DWT_S(RED_) switch (am * 4 + xf) { \
         case 0: MNY_DWT_L(RED_, 0, 0); break; case 1: MNY_DWT_L(RED_, 0, 1); break; case 2: MNY_DWT_L(RED_, 0, 2); break; case 3: MNY_DWT_L(RED_, 0, 3); break; \
@@ -765,6 +777,7 @@ static int dwt_launch_t(const T* g, const T* y, const float* scale, const float*
     if (in_red) { MNY_DWT_S(true) } else { MNY_DWT_S(false) }
 #undef MNY_DWT_S
 #undef MNY_DWT_L
+#undef MNY_DWT_LC
     rc = check_launch("dwb_tile_kernel");
     if (rc || !dw) return rc;                       // dw == NULL: partials only (combined later by mny_reduce_batch)
     return launch_reduce_parts(ws, gx, C * KS * KS, dw, st);
@@ -799,7 +812,7 @@ bool dwt_fwd_use(int K, int stride, int bf, int C) {
 }
 int dwt_fwd_parts(int N, int H, int W, int C, int K) {
     DwtGeom g; int gx, chunks, threads; size_t lds;
-    if (dwt_geom(g, gx, chunks, threads, lds, N, H, W, C, K, true)) return MNY_EINVAL;
+    if (dwt_geom(g, gx, chunks, threads, lds, N, H, W, C, K, 1, true)) return MNY_EINVAL;
     return gx;
 }
 template <typename T, int KS>
@@ -807,7 +820,7 @@ static int dwt_fwd_launch_t(const T* x, const float* in_scale, const float* in_s
                             int C, hipStream_t st) {
     constexpr int NC = KS == 5 ? 2 : 1;
     DwtGeom gm; int gx, chunks, threads; size_t lds;
-    int rc = dwt_geom(gm, gx, chunks, threads, lds, N, H, W, C, KS, true);
+    int rc = dwt_geom(gm, gx, chunks, threads, lds, N, H, W, C, KS, sizeof(T) == 2 ? 1 : 0, true);
     if (rc) return rc;
     const int xf = (in_scale == nullptr && in_act == MNY_ACT_NONE) ? 0 : (in_act == MNY_ACT_HSWISH ? 2 : (in_act == MNY_ACT_RELU6 ? 1 : 3));
     MNY_REQUIRE(in_act != MNY_ACT_HSIGMOID, "dw_fwd (tile form): h-sigmoid views are not supported");

@@ -321,7 +321,8 @@ def test_fused_bn_backward_expand_unit_is_run_to_run_deterministic(ops, M, K, Nc
                                                       (2, 16, 16, 72, 3, 3, "f32", 5), (2, 20, 20, 120, 4, 4, "f32", 5), (3, 22, 19, 96, 2, 2, "f32", 5),
                                                       (2, 37, 8, 144, 1, 0, "f32", 5), (1, 5, 5, 960, 0, 1, "f32", 5), (2, 3, 35, 40, 4, 3, "f32", 5),
                                                       (1, 70, 33, 36, 3, 4, "f32", 5), (2, 33, 17, 64, 1, 1, "bf16", 5), (2, 32, 32, 672, 4, 4, "bf16", 5),
-                                                      (2, 9, 9, 240, 4, 4, "bf16", 5), (1, 2, 3, 8, 4, 4, "f32", 5)])
+                                                      (2, 9, 9, 240, 4, 4, "bf16", 5), (1, 2, 3, 8, 4, 4, "f32", 5),
+                                                      (2, 33, 70, 16, 3, 3, "bf16", 3), (2, 20, 21, 72, 3, 3, "bf16", 3), (1, 40, 40, 480, 4, 4, "bf16", 3)])
 def test_fused_dw_unit_backward(ops, N, H, W, C, act, xact, dtype, k):
     """mny_dw_bnbwd: BN-backward-apply + depthwise weight- and data-gradient of a 3x3 (register form, csrc/dwbwd.hip) or 5x5 (tile form,
     csrc/dwtile.hip: odd sizes, partial column tiles, several strips, one-pixel image) stride-1 unit in one pass over
@@ -410,7 +411,8 @@ def test_fused_dw_stride2_unit_backward(ops, N, H, W, C, act, xact, dtype):
                                                       (2, 40, 40, 384, 1, 1, "f32", 3),
                                                       (2, 11, 11, 32, 1, 1, "f32", 5), (3, 22, 19, 96, 2, 2, "f32", 5), (2, 37, 8, 144, 1, 3, "f32", 5),
                                                       (2, 20, 20, 120, 4, 4, "f32", 5), (2, 33, 17, 64, 3, 3, "bf16", 5), (2, 32, 32, 672, 4, 4, "bf16", 5),
-                                                      (4, 16, 16, 960, 4, 4, "bf16", 5)])
+                                                      (4, 16, 16, 960, 4, 4, "bf16", 5), (2, 33, 70, 16, 3, 3, "bf16", 3), (2, 20, 21, 72, 3, 3, "bf16", 3),
+                                                      (2, 24, 24, 160, 4, 4, "bf16", 3)])
 def test_fused_dw_unit_backward_with_producer_bn_sums(ops, N, H, W, C, act, xact, dtype, k):
     """mny_dw_bnbwd_red == mny_dw_bnbwd (same dX, dW) and its extra output == mny_bn_bwd_reduce run on that dX and the raw input:
     the BN-backward sums of the unit that produced the input, without the separate pass."""
