@@ -235,7 +235,8 @@ int dwt_launch(int bf, const void* g, const void* y, const float* scale, const f
 bool pwt_ok(int64_t M, int K, int N, int in_act, bool has_bias);
 int pwt_parts(int64_t M);
 int pwt_launch(const void* x, const float* xs, const float* xb, int xact, const void* w, const void* addend, void* y, float* stats, int64_t M, int K, int N,
-               hipStream_t st);
+               hipStream_t st, const void* rY = nullptr, const float* r_scale = nullptr, const float* r_shift = nullptr, const float* r_mean = nullptr,
+               const float* r_invstd = nullptr, int r_act = 0);      // rY != NULL: the data-gradient + BN-backward-sums form (stats = the partial rows)
 
 // short-reduction pointwise conv on the vector ALU (pwthin.hip); the entry points of pwgemm.hip route K = 8/16/24/32 problems here
 bool pw_thin_ok(int bf, int red, int64_t M, int K, int N);

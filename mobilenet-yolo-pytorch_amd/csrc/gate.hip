@@ -670,14 +670,19 @@ struct PwtArgs {
     const bf16_t* x; const float* xs; const float* xb; int xact;
     const bf16_t* w;                                              // [N][K] bf16 (the GEMM weight shadow)
     const bf16_t* addend; bf16_t* y; float* parts; int64_t M; int K, N;
+    // RED (data gradient of a 1x1 conv whose INPUT was the raw output rY of a conv+BN+act unit): that unit's BN-backward sums leave with dx
+    const bf16_t* rY; const float* r_scale; const float* r_shift; const float* r_mean; const float* r_invstd; int r_act;
 };
 
-template <int KT, int NT, int XF, bool STATS>
+// SUMS: 0 none, 1 BatchNorm statistics of the stored output, 2 RED (sum dz, sum dz * yhat with dz = stored(dx) * act'(r_scale * rY + r_shift))
+template <int KT, int NT, int XF, int SUMS>
 __global__ __launch_bounds__(256) void pwt_fwd_kernel(PwtArgs p) {
+    constexpr bool STATS = SUMS != 0;
     constexpr int KU = (KT + 1) / 2, KP = KU * 32, NP = NT * 16;
     __shared__ uint4 wa[NT * KU * 64];
     __shared__ __attribute__((aligned(16))) float cs[KP], cb[KP];
     __shared__ float red[STATS ? 4 * 2 * NP : 1];
+    __shared__ __attribute__((aligned(16))) float rc[SUMS == 2 ? 4 * NP : 4];          // RED: scale | shift | mean | invstd of the producer unit, zero-padded rows
     const int K = p.K, N = p.N;
     for (int i = threadIdx.x; i < NT * KU * 64; i += blockDim.x) {
         const int ln = i & 63, u = (i >> 6) % KU, t = i / (64 * KU);
@@ -692,6 +697,10 @@ __global__ __launch_bounds__(256) void pwt_fwd_kernel(PwtArgs p) {
     }
     gate_fill_row(cs, XF != 0 ? p.xs : nullptr, K, KP, 1.f);
     gate_fill_row(cb, XF != 0 ? p.xb : nullptr, K, KP, 0.f);
+    if (SUMS == 2) {
+        gate_fill_row(rc, p.r_scale, N, NP); gate_fill_row(rc + NP, p.r_shift, N, NP);
+        gate_fill_row(rc + 2 * NP, p.r_mean, N, NP); gate_fill_row(rc + 3 * NP, p.r_invstd, N, NP);
+    }
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, px = lane & 15, rg = lane >> 4;
     const int64_t ntiles = (p.M + 15) >> 4;
@@ -731,12 +740,23 @@ __global__ __launch_bounds__(256) void pwt_fwd_kernel(PwtArgs p) {
             const bool ok = valid && c0 < N;
             if (p.addend != nullptr && ok) add4(o, ld4(p.addend + m * N + c0));
             if (ok) st4(p.y + m * N + c0, o);
-            if (STATS) {
+            if (SUMS == 1) {
                 const float vm = ok ? 1.f : 0.f;
                 const float4 q = stored4<bf16_t>(o);
                 const gate_f4 v = gate_f4{q.x, q.y, q.z, q.w} * vm;
                 ssum[t] += v;
                 qsum[t] += v * v;
+            }
+            if (SUMS == 2) {
+                const float vm = ok ? 1.f : 0.f;
+                const float4 q = stored4<bf16_t>(o);
+                const float4 yc = ok ? ld4(p.rY + m * N + c0) : f4zero();
+                const float4 rs = gate_ld4(rc + 16 * t + cq), rh = gate_ld4(rc + NP + 16 * t + cq), rm = gate_ld4(rc + 2 * NP + 16 * t + cq),
+                             ri = gate_ld4(rc + 3 * NP + 16 * t + cq);
+                const gate_f4 dz = gate_f4{q.x * act_bwd(fmaf(yc.x, rs.x, rh.x), p.r_act), q.y * act_bwd(fmaf(yc.y, rs.y, rh.y), p.r_act),
+                                           q.z * act_bwd(fmaf(yc.z, rs.z, rh.z), p.r_act), q.w * act_bwd(fmaf(yc.w, rs.w, rh.w), p.r_act)} * vm;
+                ssum[t] += dz;
+                qsum[t] += dz * gate_f4{(yc.x - rm.x) * ri.x, (yc.y - rm.y) * ri.y, (yc.z - rm.z) * ri.z, (yc.w - rm.w) * ri.w};
             }
         }
     }
@@ -772,10 +792,10 @@ int pwt_parts(int64_t M) {
     const int64_t want = cdiv(cdiv(M, 16), 4);
     return (int)(want < 1024 ? want : 1024);
 }
-template <int KT, int XF, bool STATS>
+template <int KT, int XF, int SUMS>
 static int pwt_launch_n(const PwtArgs& a, int grid, hipStream_t st) {
     const int NT = (a.N + 15) / 16;
-#define MNY_PWT(N_) case N_: hipLaunchKernelGGL((pwt_fwd_kernel<KT, N_, XF, STATS>), dim3(grid), dim3(256), 0, st, a); break
+#define MNY_PWT(N_) case N_: hipLaunchKernelGGL((pwt_fwd_kernel<KT, N_, XF, SUMS>), dim3(grid), dim3(256), 0, st, a); break
     switch (NT) {
         MNY_PWT(1); MNY_PWT(2); MNY_PWT(3); MNY_PWT(4); MNY_PWT(5); MNY_PWT(6); MNY_PWT(7); MNY_PWT(8);
         MNY_PWT(9); MNY_PWT(10); MNY_PWT(11); MNY_PWT(12); MNY_PWT(13); MNY_PWT(14); default: MNY_PWT(15);
@@ -784,15 +804,22 @@ static int pwt_launch_n(const PwtArgs& a, int grid, hipStream_t st) {
     return check_launch("pwt_fwd_kernel");
 }
 int pwt_launch(const void* x, const float* xs, const float* xb, int xact, const void* w, const void* addend, void* y, float* stats, int64_t M, int K, int N,
-               hipStream_t st) {
-    PwtArgs a{(const bf16_t*)x, xs, xb, xact, (const bf16_t*)w, (const bf16_t*)addend, (bf16_t*)y, stats, M, K, N};
+               hipStream_t st, const void* rY, const float* r_scale, const float* r_shift, const float* r_mean, const float* r_invstd, int r_act) {
+    PwtArgs a{(const bf16_t*)x, xs, xb, xact, (const bf16_t*)w, (const bf16_t*)addend, (bf16_t*)y, stats, M, K, N,
+              (const bf16_t*)rY, r_scale, r_shift, r_mean, r_invstd, r_act};
     const int grid = pwt_parts(M);
     const int xf = (xs == nullptr && xact == MNY_ACT_NONE) ? 0 : (xact == MNY_ACT_RELU6 ? 1 : (xact == MNY_ACT_HSWISH ? 2 : 3));
     const int KT = (K + 15) / 16;
+    if (rY != nullptr) {                                     // data gradient + BN-backward sums: no input view
+        MNY_REQUIRE(xf == 0 && stats && r_scale && r_shift && r_mean && r_invstd, "pw_dgrad_bnred (wave form): bad arguments");
+        if (KT == 1) return pwt_launch_n<1, 0, 2>(a, grid, st);
+        if (KT == 2) return pwt_launch_n<2, 0, 2>(a, grid, st);
+        return pwt_launch_n<3, 0, 2>(a, grid, st);
+    }
 #define MNY_PWT_X(KT_, S_) do { switch (xf) { case 0: return pwt_launch_n<KT_, 0, S_>(a, grid, st); case 1: return pwt_launch_n<KT_, 1, S_>(a, grid, st); \
         case 2: return pwt_launch_n<KT_, 2, S_>(a, grid, st); default: return pwt_launch_n<KT_, 3, S_>(a, grid, st); } } while (0)
 #define MNY_PWT_K(S_) do { if (KT == 1) MNY_PWT_X(1, S_); else if (KT == 2) MNY_PWT_X(2, S_); else MNY_PWT_X(3, S_); } while (0)
-    if (stats) MNY_PWT_K(true); else MNY_PWT_K(false);
+    if (stats) MNY_PWT_K(1); else MNY_PWT_K(0);
 #undef MNY_PWT_K
 #undef MNY_PWT_X
     return MNY_OK;

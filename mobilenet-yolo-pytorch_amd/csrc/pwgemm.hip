@@ -2898,6 +2898,10 @@ static int pw_dgrad_bnred_impl(const void* dy, const void* wT, void* dx, const v
     MNY_REQUIRE(dy && wT && dx && y && scale && shift && mean && invstd && red, "pw_dgrad_bnred: null pointer");
     MNY_REQUIRE(dgrad_bnred_ok(M, K, Nc, act) && (!BF || (K & 7) == 0), "pw_dgrad_bnred: unsupported problem M=%lld K=%d N=%d act=%d (see mny_pw_dgrad_bnred_supported)",
                 (long long)M, K, Nc, act);
+    if (BF && pwt_ok(M, K, Nc, MNY_ACT_NONE, false)) {       // K <= 48 at a large pixel count: a wave per 16 pixels (gate.hip)
+        g_pw_route = MNY_ROUTE_WAVE16;
+        return pwt_launch(dy, nullptr, nullptr, MNY_ACT_NONE, wT, addend, dx, red, M, K, Nc, (hipStream_t)stream, y, scale, shift, mean, invstd, act);
+    }
     if (pw_thin_ok(BF, 1, M, K, Nc)) g_pw_route = MNY_ROUTE_THIN;
     if (pw_thin_ok(BF, 1, M, K, Nc))
         return pw_thin_launch(BF, dy, nullptr, nullptr, MNY_ACT_NONE, wT, nullptr, addend, dx, red, M, K, Nc, addend ? 2 : 1, y, scale, shift, mean, invstd, act,
@@ -2947,7 +2951,7 @@ extern "C" int mny_pw_dgrad_bnred_add_supported(int64_t M, int K, int Nc, int ac
     return dgrad_bnred_ok(M, K, Nc, act) && (pw_thin_ok(0, 1, M, K, Nc) || pw_wide_ok(M, K, Nc, true) || nt2_plan(M, K, Nc, false, 0, kRedMaxTn).TN <= 3) ? 1 : 0;
 }
 extern "C" int mny_pw_dgrad_bnred_add_supported_bf16(int64_t M, int K, int Nc, int act) {
-    return dgrad_bnred_ok(M, K, Nc, act) && (K & 7) == 0 && (pw_thin_ok(1, 1, M, K, Nc) || nt2_plan(M, K, Nc, false, 1, kRedMaxTn).TN <= 3) ? 1 : 0;
+    return dgrad_bnred_ok(M, K, Nc, act) && (K & 7) == 0 && (pwt_ok(M, K, Nc, MNY_ACT_NONE, false) || pw_thin_ok(1, 1, M, K, Nc) || nt2_plan(M, K, Nc, false, 1, kRedMaxTn).TN <= 3) ? 1 : 0;
 }
 extern "C" int mny_pw_dgrad_bnred_add(const float* dy, const float* wT, const float* addend, float* dx, const float* y, const float* scale, const float* shift,
                                       int act, const float* mean, const float* invstd, float* red, int64_t M, int K, int Nc, void* stream) {
@@ -2963,6 +2967,7 @@ extern "C" int mny_pw_dgrad_bnred_add_bf16(const void* dy, const void* wT, const
 extern "C" int mny_pw_dgrad_bnred_supported_bf16(int64_t M, int K, int Nc, int act) { return dgrad_bnred_ok(M, K, Nc, act) && (K & 7) == 0 ? 1 : 0; }
 extern "C" int mny_pw_dgrad_bnred_parts_bf16(int64_t M, int K, int Nc) {
     if (M <= 0 || K <= 0 || Nc <= 0 || (K & 7)) return MNY_EINVAL;
+    if (pwt_ok(M, K, Nc, MNY_ACT_NONE, false)) return pwt_parts(M);
     if (pw_thin_ok(1, 1, M, K, Nc)) return pw_thin_parts(M, K, Nc, 1);
     return nt2_plan(M, K, Nc, false, 1, kRedMaxTn).gx;
 }

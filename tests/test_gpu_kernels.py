@@ -580,11 +580,13 @@ def test_dgrad_add_with_fused_bn_backward_reduction(ops, M, K, Nc, act):
     assert torch.equal(buf, dx)
 
 
-def test_dgrad_with_fused_bn_backward_reduction_bf16(ops):
-    """bf16 twin: sums are taken over the ROUNDED dx (what a separate reduce pass would read back), y is bf16."""
+@pytest.mark.parametrize("M,K,Nc,act,with_add", [(777, 96, 384, 1, False), (131077, 24, 72, 4, False), (140001, 16, 16, 1, True), (131072, 40, 120, 3, False),
+                                                 (131075, 48, 240, 4, True), (131080, 24, 64, 2, False)])
+def test_dgrad_with_fused_bn_backward_reduction_bf16(ops, M, K, Nc, act, with_add):
+    """bf16 twin: sums are taken over the ROUNDED dx (what a separate reduce pass would read back), y is bf16.  The >= 131072-pixel cases with
+    K <= 48 take the wave-per-16-pixels kernel (gate.hip pwt_fwd_kernel, SUMS = 2), with and without the addend form."""
     import ctypes
     from mobilenet_yolo_pytorch_amd import _lib
-    M, K, Nc, act = 777, 96, 384, 1
     bf = torch.bfloat16
     dy = rnd(M, K, seed=1).cuda().to(bf)
     w = (rnd(K, Nc, seed=2) / K ** 0.5)
@@ -596,13 +598,23 @@ def test_dgrad_with_fused_bn_backward_reduction_bf16(ops):
     dx = torch.empty(M, Nc, device="cuda", dtype=bf)
     red = torch.empty(parts, 2, Nc, device="cuda")
     p = lambda t: ctypes.c_void_p(t.data_ptr())
-    _lib.call("mny_pw_dgrad_bnred_bf16", p(dy), p(wT), p(dx), p(y), p(scale), p(shift), act, p(mean), p(invstd), p(red), M, K, Nc,
-              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    add = rnd(M, Nc, seed=8).cuda().to(bf) if with_add else None
+    if with_add:
+        assert _lib.query("mny_pw_dgrad_bnred_add_supported_bf16", M, K, Nc, act) == 1
+        _lib.call("mny_pw_dgrad_bnred_add_bf16", p(dy), p(wT), p(add), p(dx), p(y), p(scale), p(shift), act, p(mean), p(invstd), p(red), M, K, Nc,
+                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    else:
+        _lib.call("mny_pw_dgrad_bnred_bf16", p(dy), p(wT), p(dx), p(y), p(scale), p(shift), act, p(mean), p(invstd), p(red), M, K, Nc,
+                  ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     ref_dx = dy.float().cpu().double() @ w.to(bf).float().double()
+    if with_add:
+        ref_dx = ref_dx + add.float().cpu().double()
     assert (dx.float().cpu().double() - ref_dx).abs().max().item() <= 2 ** -7 * ref_dx.abs().max().item()
     z = y.float().cpu().double() * scale.cpu().double() + shift.cpu().double()
-    dz = dx.float().cpu().double() * ((z > 0) & (z < 6)).double()
+    dact = {1: lambda z: ((z > 0) & (z < 6)).double(), 2: lambda z: torch.where(z > 0, 1.0, 0.1).double(), 3: lambda z: (z > 0).double(),
+            4: lambda z: torch.where(z <= -3, 0.0, torch.where(z >= 3, 1.0, (2 * z + 3) / 6)).double()}[act]
+    dz = dx.float().cpu().double() * dact(z)
     xhat = (y.float().cpu().double() - mean.cpu().double()) * invstd.cpu().double()
     s1, s2 = red[:, 0].double().sum(0).cpu(), red[:, 1].double().sum(0).cpu()
     assert (s1 - dz.sum(0)).abs().max().item() <= 2e-5 * dz.abs().sum(0).max().item() + 1e-5
