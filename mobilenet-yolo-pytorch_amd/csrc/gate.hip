@@ -709,15 +709,31 @@ __global__ __launch_bounds__(256) void pwt_fwd_kernel(PwtArgs p) {
 #pragma unroll
     for (int i = 0; i < NS; ++i) { ssum[i] = gate_zero(); qsum[i] = gate_zero(); }
     const float xslope = act_slope(p.xact);
-    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+    // the NEXT tile's input row is requested before this one is multiplied (a wave has one 512-byte load per tile in flight otherwise:
+    // 16 -> 16 @256x256 ran 2.5 TB/s); RED: the producer's raw output of THIS tile is requested before the products, used after them
+    auto load_row = [&](int64_t tile, uint2 (&r)[KT]) {
+        const int64_t mm = tile * 16 + px;
+        const bf16_t* xrow = p.x + (mm < p.M ? mm : 0) * K;
+#pragma unroll
+        for (int t = 0; t < KT; ++t) r[t] = (16 * t + 4 * rg < K) ? *reinterpret_cast<const uint2*>(xrow + 16 * t + 4 * rg) : make_uint2(0u, 0u);
+    };
+    const int64_t tstep = (int64_t)gridDim.x * 4;
+    uint2 nraw[KT];
+    load_row((int64_t)blockIdx.x * 4 + wave, nraw);
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += tstep) {
         int lo = lane, cq = 4 * rg;
         asm volatile("" : "+v"(lo), "+v"(cq));               // opaque per iteration: chunk and constant reads stay in the loop
         const int64_t m = tile * 16 + px;
         const bool valid = m < p.M;
-        const bf16_t* xrow = p.x + (valid ? m : 0) * K;
         uint2 raw[KT];
 #pragma unroll
-        for (int t = 0; t < KT; ++t) raw[t] = (16 * t + 4 * rg < K) ? *reinterpret_cast<const uint2*>(xrow + 16 * t + 4 * rg) : make_uint2(0u, 0u);
+        for (int t = 0; t < KT; ++t) raw[t] = nraw[t];
+        load_row(tile + tstep < ntiles ? tile + tstep : tile, nraw);
+        uint2 yraw[SUMS == 2 ? NT : 1];
+        if (SUMS == 2) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) yraw[t] = (valid && 16 * t + 4 * rg < N) ? *reinterpret_cast<const uint2*>(p.rY + m * N + 16 * t + 4 * rg) : make_uint2(0u, 0u);
+        }
         auto aval = [&](int t) {
             float4 v = gate_widen(raw[t]);
             if (XF != 0) {
@@ -750,7 +766,7 @@ __global__ __launch_bounds__(256) void pwt_fwd_kernel(PwtArgs p) {
             if (SUMS == 2) {
                 const float vm = ok ? 1.f : 0.f;
                 const float4 q = stored4<bf16_t>(o);
-                const float4 yc = ok ? ld4(p.rY + m * N + c0) : f4zero();
+                const float4 yc = gate_widen(yraw[SUMS == 2 ? t : 0]);
                 const float4 rs = gate_ld4(rc + 16 * t + cq), rh = gate_ld4(rc + NP + 16 * t + cq), rm = gate_ld4(rc + 2 * NP + 16 * t + cq),
                              ri = gate_ld4(rc + 3 * NP + 16 * t + cq);
                 const gate_f4 dz = gate_f4{q.x * act_bwd(fmaf(yc.x, rs.x, rh.x), p.r_act), q.y * act_bwd(fmaf(yc.y, rs.y, rh.y), p.r_act),
