@@ -428,7 +428,12 @@ def test_fused_dw_unit_backward_with_producer_bn_sums(ops, N, H, W, C, act, xact
     xs, xh, xmean, xinv = mk(11, 1.0, 0.2), mk(12, 0.0, 0.3), mk(13, 0.0, 0.2), mk(14, 1.0, 0.1).abs()
     dx0, dw0 = ops.dw_bnbwd(g, y, scale, shift, act, coef, (x, xs, xh, xact), w, addend=add)
     dx1, dw1, red = ops.dw_bnbwd(g, y, scale, shift, act, coef, (x, xs, xh, xact), w, addend=add, in_stats=(xmean, xinv))
-    assert torch.equal(dx0, dx1) and torch.equal(dw0, dw1)
+    if not (torch.equal(dx0, dx1) and torch.equal(dw0, dw1)):
+        # the same form (register / tile) gives the same bits; the routing rule of csrc/dwtile.hip may send the two calls to different forms
+        # (bf16, 16 / 72 channels: tile without producer sums, register form with them): then the same values up to the storage rounding
+        assert bf and C in (16, 72), "plain and with-sums results differ although both calls take the same kernel form"
+        check(dx1.float(), dx0.float(), 2.0 ** -7, 2.0 ** -7 * dx0.float().abs().max().item(), "dX across forms")
+        check(dw1, dw0, 1e-3, 1e-3 * dw0.abs().max().item(), "dW across forms")
     p = lambda t: ctypes.c_void_p(t.data_ptr())                          # noqa: E731
     M = N * H * W
     parts = _lib.query("mny_bn_bwd_parts", M, C)
