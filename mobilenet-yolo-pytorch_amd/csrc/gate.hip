@@ -810,12 +810,11 @@ int pwt_parts(int64_t M) {
 }
 template <int KT, int XF, int SUMS>
 static int pwt_launch_n(const PwtArgs& a, int grid, hipStream_t st) {
-    const int NT = (a.N + 15) / 16;
-#define MNY_PWT(N_) case N_: hipLaunchKernelGGL((pwt_fwd_kernel<KT, N_, XF, SUMS>), dim3(grid), dim3(256), 0, st, a); break
-    switch (NT) {
-        MNY_PWT(1); MNY_PWT(2); MNY_PWT(3); MNY_PWT(4); MNY_PWT(5); MNY_PWT(6); MNY_PWT(7); MNY_PWT(8);
-        MNY_PWT(9); MNY_PWT(10); MNY_PWT(11); MNY_PWT(12); MNY_PWT(13); MNY_PWT(14); default: MNY_PWT(15);
-    }
+    const int NT = (a.N + 15) / 16;           // 16-column output tiles; instantiated for 1-5, 8, 15 (N = 16 ... 80, 120, 240): the counts in between run the next
+                                               // larger one (its extra tiles are all-zero weight chunks and masked stores)
+#define MNY_PWT(N_) hipLaunchKernelGGL((pwt_fwd_kernel<KT, N_, XF, SUMS>), dim3(grid), dim3(256), 0, st, a)
+    if (NT <= 1) MNY_PWT(1); else if (NT == 2) MNY_PWT(2); else if (NT == 3) MNY_PWT(3); else if (NT == 4) MNY_PWT(4); else if (NT == 5) MNY_PWT(5);
+    else if (NT <= 8) MNY_PWT(8); else MNY_PWT(15);
 #undef MNY_PWT
     return check_launch("pwt_fwd_kernel");
 }

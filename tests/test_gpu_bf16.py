@@ -90,7 +90,8 @@ def test_dw_bf16(ops, N, H, W, C, K, s, act):
                                              # >= 131072 pixels with K <= 48: the wave-per-16-pixels kernel (gate.hip pwt_fwd_kernel), ragged last tile,
                                              # N not a multiple of 16, every view, K = 40 (2.5 channel tiles), the plain data gradient at K = N = 16
                                              (131072 + 37, 16, 64, 3, False), (140000, 16, 16, 1, False), (131075, 24, 72, 4, False),
-                                             (131072, 40, 120, 3, False), (131080, 40, 240, 4, False), (131073, 48, 8, 2, False)])
+                                             (131072, 40, 120, 3, False), (131080, 40, 240, 4, False), (131073, 48, 8, 2, False),
+                                             (131072, 16, 96, 1, False), (131074, 40, 200, 4, False)])     # tile counts that run the next larger instantiation
 def test_pw_bf16(ops, M, K, Nc, act, bias):
     gen = lambda s: torch.Generator().manual_seed(s)   # noqa: E731
     x = rnd(M, K, seed=1)

@@ -586,7 +586,7 @@ def test_dgrad_add_with_fused_bn_backward_reduction(ops, M, K, Nc, act):
 
 
 @pytest.mark.parametrize("M,K,Nc,act,with_add", [(777, 96, 384, 1, False), (131077, 24, 72, 4, False), (140001, 16, 16, 1, True), (131072, 40, 120, 3, False),
-                                                 (131075, 48, 240, 4, True), (131080, 24, 64, 2, False)])
+                                                 (131075, 48, 240, 4, True), (131080, 24, 64, 2, False), (131072, 32, 104, 1, False)])
 def test_dgrad_with_fused_bn_backward_reduction_bf16(ops, M, K, Nc, act, with_add):
     """bf16 twin: sums are taken over the ROUNDED dx (what a separate reduce pass would read back), y is bf16.  The >= 131072-pixel cases with
     K <= 48 take the wave-per-16-pixels kernel (gate.hip pwt_fwd_kernel, SUMS = 2), with and without the addend form."""
