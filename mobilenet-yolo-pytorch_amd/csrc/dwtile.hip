@@ -6,17 +6,21 @@
 // bn_bwd_apply + dw5_wgrad (1.0-1.4 TB/s: five transformed input columns per row) + dw_bwd_data + the producer's bn_bwd_reduce.
 //
 // Here a workgroup owns a tile of PC output columns x CG channel groups and walks down a strip of rows:
-//   * every thread loads G, Y of ITS column once per row, rebuilds dY = ca*G*act'(sc*Y+sh) + cb*Y + cc once and parks it (fp32) in
+//   * every thread loads G, Y of ITS column(s) once per row, rebuilds dY = ca*G*act'(sc*Y+sh) + cb*Y + cc once and parks it (fp32) in
 //     a ring of K+1 rows in LDS; the 2*(K/2) halo columns of the tile are rebuilt by one extra pass of one wave (the duty rotates
-//     over the waves with the row index);
-//   * after one barrier per row each thread reads the KxK window of dY around its output pixel from LDS and uses every element
+//     over the whole waves with the row index);
+//   * after one barrier per row each thread reads the KxK window of dY around its output pixel(s) from LDS and uses every element
 //     twice: dX += w_flipped * D (data gradient as a gather) and dW[tap] += a * D with a = the activated input at the thread's
 //     own pixel (weight gradient summed over the INPUT pixels the thread owns: no window of the input is needed);
-//   * 5x5: a thread owns 2 channels, so the 25 taps and the 25 accumulators stay in registers (100 VGPRs) and a window element is
-//     an 8-byte LDS read; 3x3: 4 channels per thread;
+//   * 3x3: a thread owns 4 channels x 1 column, the 9 taps and 9 accumulators in registers;
+//     5x5: 2 channels x 2 ADJACENT columns (the two share the accumulators and 4 of 6 window columns: 30 window reads per 2 outputs instead of
+//     50), the 25 accumulator pairs in registers and the 25 taps read from LDS next to the window — taps AND accumulators in registers is
+//     100 VGPRs of the 168 three waves per SIMD leave;
 //   * the next row's G, Y, X (and addend) are requested before the current row is consumed (raw registers, widened when used);
 //   * RED (the input is the raw output of a conv+BN+act unit consumed only here): the unit's BN-backward sums leave with dX.
 // Partial rows [gridDim.x][C*K*K] (taps) and [gridDim.x][2][C] (RED) are combined by the usual fixed-order launches.
+// Measurements, the routing rule (which units take this form) and what did not work: dwt_use() below, LAB_NOTES.md R5.5,
+// profiles/r05_pmc_dwtile.txt.
 //
 // replaces, for these units, the autograd backward of nn.Conv2d(groups=C, kernel 5, stride 1) + nn.BatchNorm2d + ReLU / h-swish
 // (models/mobilenetv3.py:54-56,68-69).
@@ -79,7 +83,6 @@ template <typename T, int CPT> __device__ __forceinline__ VC<CPT> raw_widen(RawC
     }
     return o;
 }
-typedef unsigned dwt_u4v __attribute__((ext_vector_type(4)));
 template <typename T, int CPT> __device__ __forceinline__ void vc_store_stream(T* p, VC<CPT> v) {
     if constexpr (sizeof(T) == 4) {
         if constexpr (CPT == 4) {
