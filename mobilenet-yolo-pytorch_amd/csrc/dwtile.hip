@@ -1,4 +1,5 @@
-// Fused backward of a depthwise KxK stride-1 conv+BN+activation unit, TILE form (K = 5; K = 3 behind MNY_DWT3=1).
+// Fused backward (and the 5x5 forward) of a depthwise KxK stride-1 conv+BN+activation unit, TILE form: every 5x5 unit, and on bf16 storage the 3x3 units
+// it is faster on (dwt_use() holds the rule; MNY_DWT3=0 / 1 forces it off / on for 3x3).
 //
 // The register form of dwbwd.hip (thread = 4 channels x one column, every thread rebuilds dY at all K columns it meets) does not
 // carry over to 5x5: 25 tap accumulators x 4 channels + a 5-column dY history is > 250 VGPRs, and each element of G, Y would be
