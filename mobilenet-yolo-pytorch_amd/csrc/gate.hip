@@ -683,6 +683,14 @@ __global__ __launch_bounds__(256) void pwt_fwd_kernel(PwtArgs p) {
     __shared__ __attribute__((aligned(16))) float cs[KP], cb[KP];
     __shared__ float red[STATS ? 4 * 2 * NP : 1];
     __shared__ __attribute__((aligned(16))) float rc[SUMS == 2 ? 4 * NP : 4];          // RED: scale | shift | mean | invstd of the producer unit, zero-padded rows
+    // The 16 x N outputs of a wave's pixel tile are ONE contiguous run of y (row-major, consecutive pixels).  Stored straight from the accumulator
+    // layout every store instruction writes 16 separate 32-byte pieces (lane (px, rg) holds 4 channels of its pixel): 16 -> 64 @256x256 (537 MB,
+    // past the last-level cache) ran 2.5 TB/s against 3.3 of the vector-ALU kernel, 4.6 TB/s with the detour.  For 2-5 output tiles (N = 24 ... 80) the tile is parked in LDS
+    // ([pixel][N + 8] bf16: the row pitch keeps the 16 pixel lanes of a write on different banks) and leaves as whole 16-byte lanes of that run.
+    constexpr bool FLAT = NT >= 2 && NT <= 5;      // (N = 16 is already one contiguous 512-byte store per wave: 0.053 vs 0.060 ms; N = 120 stays in the
+                                                     // last-level cache at these sizes: 0.040 vs 0.045 ms)
+    constexpr int SPITCH = NP + 8;                                   // bf16 elements per staged pixel row
+    __shared__ __attribute__((aligned(16))) uint16_t stage[FLAT ? 4 * 16 * SPITCH : 8];
     const int K = p.K, N = p.N;
     for (int i = threadIdx.x; i < NT * KU * 64; i += blockDim.x) {
         const int ln = i & 63, u = (i >> 6) % KU, t = i / (64 * KU);
@@ -749,13 +757,15 @@ __global__ __launch_bounds__(256) void pwt_fwd_kernel(PwtArgs p) {
         };
         gate_f4 acc[NT];
         gate_product<NT, KU>(acc, wa + lo, [&](int u) { return gate_frag(aval(2 * u), 2 * u + 1 < KT ? aval(2 * u + 1 < KT ? 2 * u + 1 : 0) : f4zero()); });
+        uint16_t* const stw = stage + (FLAT ? wave * 16 * SPITCH : 0);
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int c0 = 16 * t + 4 * rg;
             float4 o = gate_f(acc[t]);
             const bool ok = valid && c0 < N;
             if (p.addend != nullptr && ok) add4(o, ld4(p.addend + m * N + c0));
-            if (ok) st4(p.y + m * N + c0, o);
+            if (FLAT) *reinterpret_cast<uint2*>(stw + px * SPITCH + c0) = make_uint2(pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w));
+            else if (ok) st4(p.y + m * N + c0, o);               // (plain stores: non-temporal 8-byte pieces measured 2x slower here)
             if (SUMS == 1) {
                 const float vm = ok ? 1.f : 0.f;
                 const float4 q = stored4<bf16_t>(o);
@@ -773,6 +783,23 @@ __global__ __launch_bounds__(256) void pwt_fwd_kernel(PwtArgs p) {
                                            q.z * act_bwd(fmaf(yc.z, rs.z, rh.z), p.r_act), q.w * act_bwd(fmaf(yc.w, rs.w, rh.w), p.r_act)} * vm;
                 ssum[t] += dz;
                 qsum[t] += dz * gate_f4{(yc.x - rm.x) * ri.x, (yc.y - rm.y) * ri.y, (yc.z - rm.z) * ri.z, (yc.w - rm.w) * ri.w};
+            }
+        }
+        if (FLAT) {
+            // the wave's own staging rows: LDS is in order per wave, the wait below is all the synchronisation the hand-over needs
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int64_t m0 = tile * 16;
+            const int rows = (int)(p.M - m0 < 16 ? p.M - m0 : 16);
+            const int chunks = rows * N / 8;                        // 16-byte pieces of the contiguous run (N % 8 == 0)
+            uint4* const dst = reinterpret_cast<uint4*>(p.y + m0 * N);
+            const int cpr = N / 8;                                   // pieces per pixel row
+#pragma unroll
+            for (int j = 0; j < (16 * NP / 8 + 63) / 64; ++j) {
+                const int q = lane + 64 * j;
+                if (q < chunks) {
+                    const int r = q / cpr, cc = q - r * cpr;
+                    dst[q] = *reinterpret_cast<const uint4*>(stw + r * SPITCH + cc * 8);
+                }
             }
         }
     }
