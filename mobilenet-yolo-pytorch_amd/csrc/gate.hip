@@ -510,7 +510,12 @@ struct Pj16Lds {
     static constexpr size_t consts = (size_t)(4 * CP + 3 * NP) * 4;
     static constexpr size_t xch = (size_t)(16 * CT + 16 * NT) * kGatePitch * 2;
     static constexpr size_t red = (size_t)kGateBW * 2 * CP * 4;
-    static constexpr size_t total = chunks + consts + xch + red;
+    // the 16 x KI outputs of a wave's pixel tile are one contiguous run of gd: parked here ([pixel][CP + 8] bf16) and stored as whole 16-byte lanes
+    // (straight from the accumulator layout every store instruction writes 16 separate 32-byte pieces, non-temporal at that)
+    static constexpr bool flat = CT >= 2;
+    static constexpr int spitch = CP + 8;
+    static constexpr size_t stage = flat ? (size_t)kGateBW * 16 * spitch * 2 : 0;
+    static constexpr size_t total = chunks + consts + xch + red + stage;
 };
 
 template <int KI, int NO>
@@ -524,6 +529,7 @@ __global__ __launch_bounds__(64 * kGateBW) void pj16_bwd_kernel(Pj16Args p) {
     unsigned short* xa = reinterpret_cast<unsigned short*>(pj_lds + L::chunks + L::consts);       // a_d^T [16 CT][pitch]
     unsigned short* xb = xa + 16 * CT * kGatePitch;                                               // dY^T  [16 NT][pitch]
     float* red = reinterpret_cast<float*>(pj_lds + L::chunks + L::consts + L::xch);
+    unsigned short* stage = reinterpret_cast<unsigned short*>(pj_lds + L::chunks + L::consts + L::xch + L::red);
 
     for (int idx = threadIdx.x; idx < CT * NU * 64; idx += blockDim.x)
         wa[idx] = gate_chunk(p.w, KI, NO, 1, KI, idx / (64 * NU), (idx >> 6) % NU, idx & 63);     // (ki, no) = w[no * KI + ki]
@@ -589,7 +595,8 @@ __global__ __launch_bounds__(64 * kGateBW) void pj16_bwd_kernel(Pj16Args p) {
             const float4 z = gate_fma4(dv, gate_ld4(cd + 0 * CP + cl), gate_ld4(cd + 1 * CP + cl));
             const float4 mu = gate_ld4(cd + 2 * CP + cl), is = gate_ld4(cd + 3 * CP + cl);
             const float4 o = gate_f(acc[t]);
-            if (c0 < KI && valid) st4_stream(p.gd + m * KI + c0, o);
+            if (L::flat) *reinterpret_cast<uint2*>(stage + (wave * 16 + px) * L::spitch + c0) = make_uint2(gate_pack2(o.x, o.y), gate_pack2(o.z, o.w));
+            else if (c0 < KI && valid) st4(p.gd + m * KI + c0, o);
             const float4 os = stored4<bf16_t>(o);
             const float zz[4] = {z.x, z.y, z.z, z.w}, ov[4] = {os.x, os.y, os.z, os.w}, dd[4] = {dv.x, dv.y, dv.z, dv.w};
             const float mv[4] = {mu.x, mu.y, mu.z, mu.w}, iv[4] = {is.x, is.y, is.z, is.w};
@@ -599,6 +606,23 @@ __global__ __launch_bounds__(64 * kGateBW) void pj16_bwd_kernel(Pj16Args p) {
                 ssum[t][i] += dz;
                 qsum[t][i] = fmaf(dz, (dd[i] - mv[i]) * iv[i], qsum[t][i]);
                 xa[(16 * t + 4 * rg + i) * kGatePitch + col] = (unsigned short)(gate_pack2(act_fwd(zz[i], p.d_act) * vm, 0.f) & 0xffffu);
+            }
+        }
+        if (L::flat) {                                              // the wave's own rows: LDS is in order per wave
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int64_t m0 = (it * kGateBW + wave) * 16;
+            const int64_t left = p.M - m0;
+            const int rows = left >= 16 ? 16 : (left > 0 ? (int)left : 0);
+            constexpr int cpr = KI / 8;                              // 16-byte pieces per pixel row (KI % 8 == 0)
+            const int chunks = rows * cpr;
+            uint4* const dst = reinterpret_cast<uint4*>(p.gd + (left > 0 ? m0 : 0) * KI);
+#pragma unroll
+            for (int j = 0; j < (16 * cpr + 63) / 64; ++j) {
+                const int q = lane + 64 * j;
+                if (q < chunks) {
+                    const int r = q / cpr, cc = q - r * cpr;
+                    dst[q] = *reinterpret_cast<const uint4*>(stage + (wave * 16 + r) * L::spitch + cc * 8);
+                }
             }
         }
 #pragma unroll
