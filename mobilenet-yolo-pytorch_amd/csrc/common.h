@@ -238,6 +238,13 @@ int pwt_launch(const void* x, const float* xs, const float* xb, int xact, const 
                hipStream_t st, const void* rY = nullptr, const float* r_scale = nullptr, const float* r_shift = nullptr, const float* r_mean = nullptr,
                const float* r_invstd = nullptr, int r_act = 0);      // rY != NULL: the data-gradient + BN-backward-sums form (stats = the partial rows)
 
+// thin expand unit backward on bf16 storage, wave form (gate.hip pwe_sums_kernel / pwe_dgrad_kernel); pw_bnbwd_finalize_launch: pwgemm.hip
+bool pwe_ok(int64_t M, int K, int N);
+size_t pwe_ws_floats(int64_t M, int K, int N);
+int pwe_launch(const void* g, const void* y, const float* scale, const float* shift, int act, const float* mean, const float* invstd, const float* gamma,
+               const void* x, const float* in_scale, const float* in_shift, int in_act, const float* w, const void* addend, void* dx, float* dw,
+               float* dgamma, float* dbeta, float* ws, int64_t M, int K, int Nc, hipStream_t st);
+
 // short-reduction pointwise conv on the vector ALU (pwthin.hip); the entry points of pwgemm.hip route K = 8/16/24/32 problems here
 bool pw_thin_ok(int bf, int red, int64_t M, int K, int N);
 int pw_thin_parts(int64_t M, int K, int N, int red);

@@ -891,6 +891,320 @@ int pwt_launch(const void* x, const float* xs, const float* xb, int xact, const 
     return MNY_OK;
 }
 
+// ---- thin expand unit backward (conv K -> N + BN + ReLU-family activation), bf16 storage, on the same machinery ------------------------
+// mny_pw_bnbwd's algebra (pwgemm.hip): dW = ca o (dz^T B) + cb o (W B^T B) + cc x colsum(B), dX = dz (ca o W) + B Q + bias with dz = G * act'(BN(Y)),
+// B = the activated input view.  Its bf16 instantiation keeps the fp32 32x32x2 matrix instructions and reads LDS one element per lane and
+// instruction: element-rate-bound at 2.9 TB/s on 16 -> 64 @256x256 (0.41 + 0.24 ms).  Here
+//   stage A (pwe_sums_kernel): a wave per 16 pixels loads G, Y (N wide) and X (K thin) in the accumulator layout, forms dz and B per lane, keeps the
+//     per-channel sums (s1 = sum dz, s2 = sum dz * yhat, s3 = sum B) per lane, leaves the act' bits of its 4 N channels per tile as one word per lane,
+//     and parks dz^T, B^T (bf16) for the workgroup's 128 pixels in LDS like the gate's weight-gradient passes: every wave owns tiles of
+//     P1 = dz^T B [N x K] and of the Gram matrix B^T B [K x K] over those pixels (v_mfma_f32_16x16x32_bf16).  One partial row per workgroup in the
+//     layout pw_bnbwd_finalize_kernel reads (P1 | Gram | s1 | s2 | s3);
+//   stage B (pwe_dgrad_kernel): dX tile = B1 . dz + Q . B + bias, B1 = ca o W^T [K][N] and Q [K][K] cut to bf16 A-operand chunks per workgroup,
+//     dz rebuilt from G and the mask word (Y is not read again).
+// Operands of the matrix products are rounded to bf16 (what the bf16 GEMM path does with every operand); sums, coefficients, outputs fp32 / as stored.
+// autograd of nn.Conv2d(K, N, 1) + BatchNorm2d + ReLU of the first MobileNetV3 blocks (models/mobilenetv3.py:49-51,67).
+struct PweArgs {
+    const bf16_t* g; const bf16_t* y; const float* sc; const float* sh; int act; const float* mean; const float* invstd;
+    const bf16_t* x; const float* xs; const float* xb; int xact;
+    float* partial; uint32_t* mask; int64_t M; int K, N;
+    const float* B1; const float* Q; const float* bias; const bf16_t* addend; bf16_t* dx;
+};
+// Stage A: BW waves per workgroup park 16 BW pixels and share the tiles.  Measured (whole unit, same box): 16 -> 64 @256x256 8 waves 0.701 ms, 4 waves
+// 0.592 (two workgroups per CU: one's barriers overlap the other's loads), a barrier-free variant (every wave transposes its own 16 pixels, 32-deep
+// matrix instruction half empty) 0.628, the fp32-MFMA kernel of pwgemm.hip 0.779; 24 -> 72 @128x128: 8 waves 0.220, 4 waves 0.272, pwgemm.hip 0.256.
+template <int KT, int NT, int BW>
+struct PweLds {
+    static constexpr int kPweBW = BW, kPwePitch = 16 * BW + 8;
+    static constexpr int KP = KT * 16, NP = NT * 16;
+    static constexpr size_t consts = (size_t)(4 * NP + 2 * KP) * 4;
+    static constexpr size_t xch = (size_t)(16 * KT + 16 * NT) * kPwePitch * 2;
+    static constexpr size_t red = (size_t)kPweBW * (2 * NP + KP) * 4;
+    static constexpr size_t total = consts + xch + red;
+};
+
+template <int KT, int NT, int BW>
+__global__ __launch_bounds__(64 * BW) void pwe_sums_kernel(PweArgs p) {
+    typedef PweLds<KT, NT, BW> L;
+    constexpr int kPweBW = BW, kPwePitch = L::kPwePitch;
+    constexpr int KP = L::KP, NP = L::NP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char pe_lds[];
+    float* cw = reinterpret_cast<float*>(pe_lds);                  // wide side: 0 scale, 1 shift, 2 mean, 3 invstd
+    float* ck = cw + 4 * NP;                                       // thin side: 0 in_scale, 1 in_shift
+    unsigned short* xa = reinterpret_cast<unsigned short*>(pe_lds + L::consts);          // B^T  [16 KT][pitch]
+    unsigned short* xb = xa + 16 * KT * kPwePitch;                                      // dz^T [16 NT][pitch]
+    float* red = reinterpret_cast<float*>(pe_lds + L::consts + L::xch);
+    const int K = p.K, N = p.N;
+    gate_fill_row(cw, p.sc, N, NP); gate_fill_row(cw + NP, p.sh, N, NP); gate_fill_row(cw + 2 * NP, p.mean, N, NP); gate_fill_row(cw + 3 * NP, p.invstd, N, NP);
+    gate_fill_row(ck, p.xs, K, KP, 1.f); gate_fill_row(ck + KP, p.xb, K, KP, 0.f);
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, px = lane & 15, rg = lane >> 4;
+    const int64_t ntiles = (p.M + 15) >> 4;
+    const int64_t niter = (ntiles + kPweBW - 1) / kPweBW;
+    const float aslope = act_slope(p.act), ahi = act_hi(p.act), xslope = act_slope(p.xact), xhi = act_hi(p.xact);
+    const bool has_xf = p.xs != nullptr || p.xact != MNY_ACT_NONE;
+    gate_f4 s1[NT], s2[NT], s3[KT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) { s1[i] = gate_zero(); s2[i] = gate_zero(); }
+#pragma unroll
+    for (int i = 0; i < KT; ++i) s3[i] = gate_zero();
+    constexpr int NTILE = NT * KT + KT * KT, JT = (NTILE + kPweBW - 1) / kPweBW;       // P1 tiles, then Gram tiles
+    gate_f4 wacc[JT];
+#pragma unroll
+    for (int j = 0; j < JT; ++j) wacc[j] = gate_zero();
+    uint2 ng[NT], ny[NT], nx[KT];
+    auto request = [&](int64_t it) {
+        const int64_t m = (it * kPweBW + wave) * 16 + px;
+        const int64_t mr = (it < niter && m < p.M) ? m : 0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const bool ok = 16 * t + 4 * rg < N;
+            ng[t] = ok ? *reinterpret_cast<const uint2*>(p.g + mr * N + 16 * t + 4 * rg) : make_uint2(0u, 0u);
+            ny[t] = ok ? *reinterpret_cast<const uint2*>(p.y + mr * N + 16 * t + 4 * rg) : make_uint2(0u, 0u);
+        }
+#pragma unroll
+        for (int t = 0; t < KT; ++t) nx[t] = (16 * t + 4 * rg < K) ? *reinterpret_cast<const uint2*>(p.x + mr * K + 16 * t + 4 * rg) : make_uint2(0u, 0u);
+    };
+    request(blockIdx.x);
+    for (int64_t it = blockIdx.x; it < niter; it += gridDim.x) {
+        int cq = 4 * rg;
+        asm volatile("" : "+v"(cq));                               // opaque per iteration: the constant reads stay in the loop
+        const int64_t tile = it * kPweBW + wave;
+        const int64_t m = tile * 16 + px;
+        const bool valid = m < p.M;
+        const float vm = valid ? 1.f : 0.f;
+        uint2 rgv[NT], ryv[NT], rxv[KT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { rgv[t] = ng[t]; ryv[t] = ny[t]; }
+#pragma unroll
+        for (int t = 0; t < KT; ++t) rxv[t] = nx[t];
+        request(it + gridDim.x);
+        const int col = 16 * wave + px;
+        uint32_t bits = 0u;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int cl = 16 * t + cq;
+            const float4 G = gate_widen(rgv[t]), Y = gate_widen(ryv[t]);
+            const float4 sc = gate_ld4(cw + cl), sh = gate_ld4(cw + NP + cl), mu = gate_ld4(cw + 2 * NP + cl), is = gate_ld4(cw + 3 * NP + cl);
+            const float gv[4] = {G.x, G.y, G.z, G.w}, yv[4] = {Y.x, Y.y, Y.z, Y.w}, scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+            const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, isv[4] = {is.x, is.y, is.z, is.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float z = fmaf(yv[i], scv[i], shv[i]);
+                const bool on = z > 0.f && z < ahi;                  // act' = on ? 1 : slope
+                bits |= on ? (1u << (4 * t + i)) : 0u;
+                const float dz = (on ? gv[i] : gv[i] * aslope) * vm;
+                s1[t][i] += dz;
+                s2[t][i] = fmaf(dz, (yv[i] - muv[i]) * isv[i], s2[t][i]);
+                xb[(16 * t + 4 * rg + i) * kPwePitch + col] = (unsigned short)(gate_pack2(dz, 0.f) & 0xffffu);
+            }
+        }
+        if (valid) p.mask[tile * 64 + lane] = bits;
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            const int cl = 16 * t + cq;
+            const float4 X = gate_widen(rxv[t]);
+            const float4 xs = gate_ld4(ck + cl), xh = gate_ld4(ck + KP + cl);
+            const float xv[4] = {X.x, X.y, X.z, X.w}, xsv[4] = {xs.x, xs.y, xs.z, xs.w}, xhv[4] = {xh.x, xh.y, xh.z, xh.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float b = xv[i];
+                if (has_xf) { const float xz = fmaf(xv[i], xsv[i], xhv[i]); b = fminf(fmaxf(xz, xslope * xz), xhi); }
+                b = (16 * t + 4 * rg + i < K) ? b * vm : 0.f;        // padded channels: the view of 0 is not 0
+                s3[t][i] += b;
+                xa[(16 * t + 4 * rg + i) * kPwePitch + col] = (unsigned short)(gate_pack2(b, 0.f) & 0xffffu);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < JT; ++j) {                             // P1 tiles: rows n (xb), columns k (xa); Gram tiles: rows k (xa), columns k' (xa)
+            const int q = wave + kPweBW * j;
+            if (q < NTILE) {
+                const bool gram = q >= NT * KT;
+                const int qq = gram ? q - NT * KT : q;
+                const int tr = qq / KT, tc = qq % KT;
+                const unsigned short* pa = (gram ? xa : xb) + (16 * tr + px) * kPwePitch + 8 * rg;
+                const unsigned short* pb = xa + (16 * tc + px) * kPwePitch + 8 * rg;
+#pragma unroll
+                for (int ks = 0; ks < kPweBW / 2; ++ks) {
+                    const uint4 a = *reinterpret_cast<const uint4*>(pa + 32 * ks), b = *reinterpret_cast<const uint4*>(pb + 32 * ks);
+                    wacc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), wacc[j], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // one partial row of the workgroup: P1[N*K] | Gram[K*K] | s1[N] | s2[N] | s3[K]
+    float* dst = p.partial + (int64_t)blockIdx.x * bnw_stride(N, K);
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+        const int q = wave + kPweBW * j;
+        if (q < NTILE) {
+            const bool gram = q >= NT * KT;
+            const int qq = gram ? q - NT * KT : q;
+            const int tr = qq / KT, tc = qq % KT;
+            const int c = 16 * tc + px;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 16 * tr + 4 * rg + i;
+                if (c < K && r < (gram ? K : N)) dst[(gram ? (int64_t)N * K : 0) + (int64_t)r * K + c] = wacc[j][i];
+            }
+        }
+    }
+    // sums: over the 16 pixel lanes, then the waves in order
+    float* vdst = dst + (int64_t)N * K + (int64_t)K * K;
+    auto fold = [&](float v) {
+#pragma unroll
+        for (int k = 1; k < 16; k <<= 1) v += __shfl_xor(v, k);
+        return v;
+    };
+    constexpr int RW = 2 * NP + KP;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float a = fold(s1[t][i]), b = fold(s2[t][i]);
+            if (px == 0) { red[wave * RW + 16 * t + 4 * rg + i] = a; red[wave * RW + NP + 16 * t + 4 * rg + i] = b; }
+        }
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float a = fold(s3[t][i]);
+            if (px == 0) red[wave * RW + 2 * NP + 16 * t + 4 * rg + i] = a;
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * N + K; c += blockDim.x) {
+        const int src = c < N ? c : (c < 2 * N ? NP + (c - N) : 2 * NP + (c - 2 * N));
+        float a = 0.f;
+#pragma unroll
+        for (int w = 0; w < kPweBW; ++w) a += red[w * RW + src];
+        vdst[c] = a;
+    }
+}
+
+template <int KT, int NT>
+__global__ __launch_bounds__(256) void pwe_dgrad_kernel(PweArgs p) {
+    constexpr int NU = (NT + 1) / 2, KU = (KT + 1) / 2, KP = KT * 16;
+    __shared__ uint4 wb1[KT * NU * 64];                            // B1 chunks: rows k, contraction over n
+    __shared__ uint4 wq[KT * KU * 64];                             // Q chunks: rows k, contraction over k' (Q is symmetric)
+    __shared__ __attribute__((aligned(16))) float ck[3 * KP];      // in_scale | in_shift | bias
+    const int K = p.K, N = p.N;
+    for (int i = threadIdx.x; i < KT * NU * 64; i += blockDim.x) wb1[i] = gate_chunk(p.B1, K, N, N, 1, i / (64 * NU), (i >> 6) % NU, i & 63);
+    for (int i = threadIdx.x; i < KT * KU * 64; i += blockDim.x) wq[i] = gate_chunk(p.Q, K, K, K, 1, i / (64 * KU), (i >> 6) % KU, i & 63);
+    gate_fill_row(ck, p.xs, K, KP, 1.f); gate_fill_row(ck + KP, p.xb, K, KP, 0.f); gate_fill_row(ck + 2 * KP, p.bias, K, KP, 0.f);
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, px = lane & 15, rg = lane >> 4;
+    const int64_t ntiles = (p.M + 15) >> 4;
+    const float aslope = act_slope(p.act), xslope = act_slope(p.xact), xhi = act_hi(p.xact);
+    const bool has_xf = p.xs != nullptr || p.xact != MNY_ACT_NONE;
+    const int64_t tstep = (int64_t)gridDim.x * 4;
+    uint2 ng[NT], nx[KT];
+    uint32_t nbits;
+    auto request = [&](int64_t tile) {
+        const int64_t mm = tile * 16 + px;
+        const int64_t mr = mm < p.M ? mm : 0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) ng[t] = (16 * t + 4 * rg < N) ? *reinterpret_cast<const uint2*>(p.g + mr * N + 16 * t + 4 * rg) : make_uint2(0u, 0u);
+#pragma unroll
+        for (int t = 0; t < KT; ++t) nx[t] = (16 * t + 4 * rg < K) ? *reinterpret_cast<const uint2*>(p.x + mr * K + 16 * t + 4 * rg) : make_uint2(0u, 0u);
+        nbits = p.mask[(tile < ntiles ? tile : 0) * 64 + lane];
+    };
+    request((int64_t)blockIdx.x * 4 + wave);
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += tstep) {
+        int lo = lane, cq = 4 * rg;
+        asm volatile("" : "+v"(lo), "+v"(cq));
+        const int64_t m = tile * 16 + px;
+        const bool valid = m < p.M;
+        uint2 rgv[NT], rxv[KT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) rgv[t] = ng[t];
+#pragma unroll
+        for (int t = 0; t < KT; ++t) rxv[t] = nx[t];
+        const uint32_t bits = nbits;
+        request(tile + tstep < ntiles ? tile + tstep : tile);
+        auto dzval = [&](int t) {
+            const float4 G = gate_widen(rgv[t]);
+            return make_float4(((bits >> (4 * t + 0)) & 1u) ? G.x : G.x * aslope, ((bits >> (4 * t + 1)) & 1u) ? G.y : G.y * aslope,
+                               ((bits >> (4 * t + 2)) & 1u) ? G.z : G.z * aslope, ((bits >> (4 * t + 3)) & 1u) ? G.w : G.w * aslope);
+        };
+        auto bval = [&](int t) {
+            float4 v = gate_widen(rxv[t]);
+            if (has_xf) {
+                v = gate_fma4(v, gate_ld4(ck + 16 * t + cq), gate_ld4(ck + KP + 16 * t + cq));
+                v = make_float4(fminf(fmaxf(v.x, xslope * v.x), xhi), fminf(fmaxf(v.y, xslope * v.y), xhi), fminf(fmaxf(v.z, xslope * v.z), xhi),
+                                fminf(fmaxf(v.w, xslope * v.w), xhi));
+                if (16 * t + 4 * rg >= K) v = f4zero();
+            }
+            return v;
+        };
+        gate_f4 acc[KT], acq[KT];
+        gate_product<KT, NU>(acc, wb1 + lo, [&](int u) { return gate_frag(dzval(2 * u), 2 * u + 1 < NT ? dzval(2 * u + 1 < NT ? 2 * u + 1 : 0) : f4zero()); });
+        gate_product<KT, KU>(acq, wq + lo, [&](int u) { return gate_frag(bval(2 * u), 2 * u + 1 < KT ? bval(2 * u + 1 < KT ? 2 * u + 1 : 0) : f4zero()); });
+#pragma unroll
+        for (int t = 0; t < KT; ++t) {
+            const int c0 = 16 * t + 4 * rg;
+            const float4 bi = gate_ld4(ck + 2 * KP + 16 * t + cq);
+            float4 o = gate_f(acc[t] + acq[t]);
+            o.x += bi.x; o.y += bi.y; o.z += bi.z; o.w += bi.w;
+            const bool ok = valid && c0 < K;
+            if (p.addend != nullptr && ok) add4(o, ld4(p.addend + m * K + c0));
+            if (ok) st4(p.dx + m * K + c0, o);
+        }
+    }
+}
+
+// shapes of the wave form: K = 16 / 24 / 32, N <= 80 (five 16-channel tiles: the per-lane sums of stage A fit 2 waves per SIMD; 8 tiles spilled), enough pixels
+bool pwe_ok(int64_t M, int K, int N) {
+    static const bool off = getenv("MNY_NO_PWE") != nullptr && atoi(getenv("MNY_NO_PWE")) != 0;
+    return !off && M >= 131072 && (K == 16 || K == 24 || K == 32) && N > K && N <= 80 && (N & 7) == 0;
+}
+static inline int pwe_bw(int K) { return K <= 16 ? 4 : 8; }
+int pwe_grid(int64_t M, int K) {
+    const int64_t want = cdiv(cdiv(M, 16), pwe_bw(K));
+    return (int)(want < 512 ? want : 512);
+}
+size_t pwe_ws_floats(int64_t M, int K, int N) {       // partial rows + reduced row + B1 + Q + bias + one mask word per lane and 16-pixel tile
+    return (size_t)(pwe_grid(M, K) + 1) * bnw_stride(N, K) + (size_t)N * K + (size_t)K * K + 64 + 64 + (size_t)cdiv(M, 16) * 64 + 64;
+}
+template <int KT, int BW>
+static int pwe_launch_a(const PweArgs& a, int NT, int grid, hipStream_t st) {
+#define MNY_PWE_A(N_) do { constexpr size_t lds = PweLds<KT, N_, BW>::total; \
+        if (lds > 64 * 1024 && !allow_lds((const void*)pwe_sums_kernel<KT, N_, BW>, lds)) { set_error("pw_bnbwd (wave form): hipFuncSetAttribute failed"); return MNY_EHIP; } \
+        hipLaunchKernelGGL((pwe_sums_kernel<KT, N_, BW>), dim3(grid), dim3(64 * BW), lds, st, a); } while (0)
+    if (NT <= 4) MNY_PWE_A(4); else MNY_PWE_A(5);
+#undef MNY_PWE_A
+    return check_launch("pwe_sums_kernel");
+}
+template <int KT>
+static int pwe_launch_b(const PweArgs& a, int NT, int grid, hipStream_t st) {
+    if (NT <= 4) hipLaunchKernelGGL((pwe_dgrad_kernel<KT, 4>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((pwe_dgrad_kernel<KT, 5>), dim3(grid), dim3(256), 0, st, a);
+    return check_launch("pwe_dgrad_kernel");
+}
+// the whole unit: stage A -> combine + fp64 finalize (pw_bnbwd_finalize_launch, pwgemm.hip) -> stage B.  Same arguments as mny_pw_bnbwd_bf16.
+int pwe_launch(const void* g, const void* y, const float* scale, const float* shift, int act, const float* mean, const float* invstd, const float* gamma,
+               const void* x, const float* in_scale, const float* in_shift, int in_act, const float* w, const void* addend, void* dx, float* dw,
+               float* dgamma, float* dbeta, float* ws, int64_t M, int K, int Nc, hipStream_t st) {
+    const int grid = pwe_grid(M, K);
+    const int64_t stride = bnw_stride(Nc, K);
+    float* red = ws + (size_t)grid * stride;
+    float* B1 = red + stride;
+    float* Q = B1 + (size_t)Nc * K;
+    float* bias = Q + (size_t)K * K;
+    uint32_t* mask = reinterpret_cast<uint32_t*>(bias + 64 + ((64 - ((bias + 64 - ws) & 15)) & 15));      // 64-byte aligned
+    PweArgs a{(const bf16_t*)g, (const bf16_t*)y, scale, shift, act, mean, invstd, (const bf16_t*)x, in_scale, in_shift, in_act, ws, mask, M, K, Nc,
+              B1, Q, bias, (const bf16_t*)addend, (bf16_t*)dx};
+    const int NT = (Nc + 15) / 16;
+    int rc = K <= 16 ? pwe_launch_a<1, 4>(a, NT, grid, st) : pwe_launch_a<2, 8>(a, NT, grid, st);
+    if (rc) return rc;
+    rc = pw_bnbwd_finalize_launch(ws, grid, red, w, gamma, mean, invstd, M, Nc, K, dw, dgamma, dbeta, B1, Q, bias, st);
+    if (rc || !dx) return rc;
+    const int64_t want = cdiv(cdiv(M, 16), 4);
+    const int grid2 = (int)(want < 1024 ? want : 1024);
+    return K <= 16 ? pwe_launch_b<1>(a, NT, grid2, st) : pwe_launch_b<2>(a, NT, grid2, st);
+}
+
 static bool gate_shape_ok(int64_t M, int C, int R) {
     return M > 0 && ((C == 40 && R == 10) || (C == 112 && R == 28) || (C == 160 && R == 40));
 }

@@ -3251,8 +3251,11 @@ extern "C" int mny_pw_bnbwd_supported(int64_t M, int K, int Nc) { return bnw_sup
 extern "C" size_t mny_pw_bnbwd_ws_floats(int64_t M, int K, int Nc) {
     if (!bnw_supported(M, K, Nc)) return 0;
     BnwPlan pl = bnw_plan(M, K, Nc);
-    // partials + reduced row + B1 + Q + bias + 1-bit activation mask (M/2 * TI 64-bit words)
-    return (size_t)(pl.splits + 1) * bnw_stride(Nc, K) + (size_t)Nc * K + (size_t)K * K + 64 + 64 + (size_t)((M / 2 + 66) / 2 * 2) * pl.TI * 2;
+    // partials + reduced row + B1 + Q + bias + 1-bit activation mask (M/2 * TI 64-bit words); the wave form of bf16 storage (gate.hip) lays its own
+    // buffers out in the same workspace: the larger of the two
+    const size_t base = (size_t)(pl.splits + 1) * bnw_stride(Nc, K) + (size_t)Nc * K + (size_t)K * K + 64 + 64 + (size_t)((M / 2 + 66) / 2 * 2) * pl.TI * 2;
+    const size_t wave = pwe_ok(M, K, Nc) ? pwe_ws_floats(M, K, Nc) : 0;
+    return base > wave ? base : wave;
 }
 
 extern "C" int mny_pw_bnbwd(const float* g, const float* y, const float* scale, const float* shift, int act,
@@ -3344,8 +3347,10 @@ extern "C" int mny_pw_bnbwd_bf16(const void* g, const void* y, const float* scal
     MNY_REQUIRE(bnw_supported_bf16(M, K, Nc), "pw_bnbwd_bf16: shape M=%lld K=%d N=%d not supported (mny_pw_bnbwd_supported_bf16)", (long long)M, K, Nc);
     MNY_REQUIRE(in_act != MNY_ACT_HSWISH && in_act != MNY_ACT_HSIGMOID && act != MNY_ACT_HSWISH && act != MNY_ACT_HSIGMOID,
                 "pw_bnbwd_bf16: h-swish / h-sigmoid activations are not supported");
-    BnwPlan pl = bnw_plan(M, K, Nc);
     hipStream_t st = (hipStream_t)stream;
+    if (pwe_ok(M, K, Nc))                                    // wave form on the bf16 matrix cores (gate.hip)
+        return pwe_launch(g, y, scale, shift, act, mean, invstd, gamma, x, in_scale, in_shift, in_act, w, addend, dx, dw, dgamma, dbeta, ws, M, K, Nc, st);
+    BnwPlan pl = bnw_plan(M, K, Nc);
     const int64_t stride = bnw_stride(Nc, K);
     float* red = ws + (size_t)pl.splits * stride;
     float* B1 = red + stride;

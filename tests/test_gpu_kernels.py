@@ -242,7 +242,8 @@ def test_fused_bn_backward_expand_unit(ops, M, K, Nc, act, xact):
 
 
 @pytest.mark.parametrize("M,K,Nc,act,xact", [(8192, 16, 64, 3, 0), (5000, 24, 72, 3, 3), (4100, 32, 192, 2, 1), (6007, 16, 96, 1, 1),
-                                             (70001, 24, 144, 1, 0), (131077, 8, 96, 1, 3), (262147, 24, 72, 3, 1), (4223, 8, 64, 0, 0)])
+                                             (70001, 24, 144, 1, 0), (131077, 8, 96, 1, 3), (262147, 24, 72, 3, 1), (4223, 8, 64, 0, 0),
+                                             (131075, 16, 64, 3, 3), (200003, 32, 72, 2, 1), (262144, 16, 72, 1, 0)])
 def test_fused_bn_backward_expand_unit_bf16_storage(ops, M, K, Nc, act, xact):
     """mny_pw_bnbwd_bf16 (round 3: the thin ReLU expand units of MobileNetV3 — 16->64, 24->72 — and MobileNetV2's under bf16 storage):
     G, Y, X, addend, dX in bf16, everything else fp32.  Reference = the fp32 fused kernel (itself checked against torch autograd above)
@@ -270,14 +271,19 @@ def test_fused_bn_backward_expand_unit_bf16_storage(ops, M, K, Nc, act, xact):
         a, b = a.detach().cpu().double().reshape(-1), b.detach().cpu().double().reshape(-1)
         err = (a - b).abs().max().item()
         assert err <= tol * (b.abs().max().item() + 1e-12), "%s rel err %.2e" % (what, err / (b.abs().max().item() + 1e-12))
-    rel(dw, dw32, 1e-5, "dW")
+    # >= 131072 pixels, K in {16, 24, 32}, N <= 80: the wave form (csrc/gate.hip pwe_*): the operands of its matrix products (dz, the activated input,
+    # ca o W, Q) are rounded to bf16 like every operand of the bf16 GEMM path, the sums stay exact.  The test's G is zero-mean noise, so an entry of
+    # dz^T B is a random-walk sum and inherits the PER-TERM rounding (2^-9 / sqrt 3 rms) as its relative error: measured 2.4e-3 ... 3.2e-3 of max |dW|
+    # over the N*K entries -> 8e-3; a wrong tile or lane mapping is an O(1) error.  dX: one more rounding.
+    wave = M >= 131072 and K in (16, 24, 32) and Nc <= 80 and os.environ.get("MNY_NO_PWE") is None
+    rel(dw, dw32, 8e-3 if wave else 1e-5, "dW")
     rel(dgamma, dg32, 1e-5, "dgamma")
     rel(dbeta, db32, 1e-5, "dbeta")
-    rel(dx, dx32, 2 ** -8, "dX")
+    rel(dx, dx32, 2 ** -7 if wave else 2 ** -8, "dX")
     # without a data gradient / without an addend
     dxn, dwn, _, _ = ops.pw_bnbwd(gd, yd, scale, shift, act, mean, invstd, gamma.cuda(), (xd, xs.cuda(), xh.cuda(), xact), w.cuda())
     dxr, _, _, _ = ops.pw_bnbwd(gd.float(), yd.float(), scale, shift, act, mean, invstd, gamma.cuda(), (xd.float(), xs.cuda(), xh.cuda(), xact), w.cuda())
-    rel(dxn, dxr, 2 ** -8, "dX (no addend)")
+    rel(dxn, dxr, 2 ** -7 if wave else 2 ** -8, "dX (no addend)")
     assert torch.equal(dwn, dw)
 
 
