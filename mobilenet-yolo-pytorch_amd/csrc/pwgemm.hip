@@ -643,7 +643,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((X6 == 3 &&
                     if (p.bias) { v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }        // wave-uniform: only the two head convs carry a bias
                     if (nvec) {
                         if (pAdd) add4(v, ld4(pAdd + row * p.N + colq));
-                        st4_stream(pC + row * p.N + colq, v);
+                        // a row of this 32-column tile is 128 contiguous bytes in fp32 (whole lines: streaming stores) but 64 in bf16 storage: non-temporal
+                        // PARTIAL lines cost DRAM efficiency (round 5: MobileNetV3 512x512 bs 64 bf16 14.05 -> 13.91 ms with plain stores, same box)
+                        if (sizeof(T) == 2) st4(pC + row * p.N + colq, v); else st4_stream(pC + row * p.N + colq, v);
                     } else {
                         // ragged width (75-channel heads, 10-channel gate): rows are not 16-B aligned -> up to four element stores
                         // off ONE address (the transposed layout keeps this cheap: one row, consecutive columns)
