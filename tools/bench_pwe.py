@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Timing of the fused backward of the thin expand units of the MobileNetV3-YOLO 512x512 bs-64 plan on bf16 storage (mny_pw_bnbwd_bf16: 16 -> 64 @256x256,
+24 -> 72 @128x128): the wave form of csrc/gate.hip (pwe_sums_kernel + finalize + pwe_dgrad_kernel); MNY_NO_PWE=1: the fp32-MFMA kernels of pwgemm.hip.
+    python tools/bench_pwe.py      -> ms per whole unit (all its launches)"""
 import sys, os
 sys.path.insert(0, '/root/repo')
 import torch
