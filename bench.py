@@ -143,6 +143,8 @@ def parse():
     ap.add_argument("--launch-check", action="store_true",
                     help="CPU-only self-test of the N-rank launch path: the ranks meet over gloo, rank 0 prints one JSON line (tests/test_host_logic_cpu.py)")
     ap.add_argument("--dp-overhead-child", action="store_true", help="internal: the 1-rank RCCL leg of the default run, in its own process")
+    ap.add_argument("--full-json", action="store_true", help="print the verbose line (explanatory strings, plan fingerprints, algorithmic bytes per "
+                    "entry point: what tools/prof_*summary.py read) instead of the compact one sized for an 8 kB stdout tail")
     ap.add_argument("--detail", default="", help="comma list of entry points (or `all`): print their per-call table to stderr")
     return ap.parse_args()
 
@@ -220,6 +222,76 @@ def cpu_baseline(budget_s=30.0):
             "sample": "median of 5 fwd+bwd steps (2 warm-up) at bs=%d, 352x352, oracle/net_ref.py (torch CPU fp32, %d threads; "
                       "host: %s, os.cpu_count()=%d, usable=%d)%s" % (bs, threads, cpu_model_name(), os.cpu_count() or 0, cores, note),
             "min_ms": round(min(times) * 1e3, 1), "median_ms": round(med * 1e3, 1)}
+
+
+def cpu_baseline_c3(budget_s=30.0):
+    """configs[3] beside its GPU number: oracle/net_ref_v3.py (the stock torch ops of models/mobilenetv3.py / mbv3_yolo.py + the restated
+    loss) fwd+bwd at bs=4, 512x512, torch CPU fp32 (the CPU port has no bf16 storage mode), 1 warm-up + up to 3 timed steps inside the budget."""
+    import statistics
+    from oracle import net_ref_v3, procedural
+    torch.manual_seed(0)
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    m = net_ref_v3.RefYoloV3(procedural.VOC_CONFIG).train()
+    bs = 4
+    x = procedural.images(bs, 512, 512, seed=0)
+    tg = procedural.targets(bs, seed=1, empty_every=16)
+
+    def step():
+        for p in m.parameters():
+            p.grad = None
+        t0 = time.perf_counter()
+        r = m(x, tg)
+        (r[0][0] + r[1][0]).backward()
+        return time.perf_counter() - t0
+    w = step()
+    times = [step()]
+    while len(times) < 3 and (len(times) + 1) * max(w, times[0]) < budget_s:
+        times.append(step())
+    med = statistics.median(times)
+    return {"value": round(bs / med, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "median of %d fwd+bwd steps (1 warm-up) at bs=%d, 512x512, oracle/net_ref_v3.py, torch CPU fp32, %d threads" % (len(times), bs, cores),
+            "median_ms": round(med * 1e3, 1)}
+
+
+def c1_leg(device):
+    """BASELINE configs[0]: MobileNetV2-YOLO 352x352 bs=2 inference (eval forward + anchor decode + per-class NMS, inference.py) — the
+    reference's CPU-runnable case: the product on the GPU and the oracle (torch CPU + oracle/yolo_ref.py + oracle/nms_ref.c) on the host."""
+    import statistics
+    from mobilenet_yolo_pytorch_amd import yolo
+    from oracle import net_ref, procedural
+    torch.manual_seed(0)
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    ref = procedural.fill_state_dict_(net_ref.RefYolo(procedural.VOC_CONFIG)).eval()
+    m = yolo(procedural.VOC_CONFIG)
+    m.load_state_dict(ref.state_dict())
+    m = m.to(device).eval()
+    x = procedural.images(2, SIZE, SIZE, seed=3)
+    xd = x.to(device)
+    with torch.no_grad():
+        det_ref = ref(x)
+        det = m(xd)
+        cpu = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            ref(x)
+            cpu.append(time.perf_counter() - t0)
+        for _ in range(5):
+            m(xd)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            m(xd)
+        torch.cuda.synchronize()
+        gpu = (time.perf_counter() - t0) / 20
+    same = all(len(a) == len(b) for a, b in zip(det, det_ref))
+    cm = statistics.median(cpu)
+    return {"workload": "MobileNetV2-YOLO 352x352 bs=2 eval forward + decode + per-class NMS (BASELINE configs[0])",
+            "value": round(2 / gpu, 1), "unit": "images/s", "ms": round(gpu * 1e3, 3), "detections": int(sum(len(d) for d in det)),
+            "counts_match_cpu": bool(same),
+            "cpu_baseline": {"value": round(2 / cm, 2), "unit": "images/s", "cores": cores, "kind": "port", "median_ms": round(cm * 1e3, 1),
+                             "sample": "median of 5 runs, oracle/net_ref.py eval + yolo_ref decode + nms_ref.c, torch CPU fp32"}}
 
 
 def h2d_bench(step, x, steps=10):
@@ -584,6 +656,47 @@ def config3_leg(device, steps=12, warmup=4):
     del model, plan
     torch.cuda.empty_cache()
     return res
+
+
+_ROOF_KEEP = ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_bf16x6", "traffic", "launches_per_step", "ms_per_step", "algorithmic_bytes_per_launch")
+
+
+def compact_line(res):
+    """The ONE stdout line, sized for a tail of 8 kB.  A tail keeps the END of a line, so the evidence that must survive comes last: side
+    legs first, then configs[0] / configs[3], then the roofline objects (worst fraction first), then the contract's scalar keys with
+    `roofline` and `cpu_baseline`.  Explanatory strings (how a figure was measured, where its traffic came from: DESIGN.md §4,
+    profiles/README.md), plan fingerprints and per-entry-point algorithmic bytes are in the --full-json line only."""
+    def roof(o):
+        return {k: o[k] for k in _ROOF_KEEP if k in o} if isinstance(o, dict) else o
+
+    def slim(o, drop=("note", "sample", "measured", "traffic_source", "matches_cpu_note", "host")):
+        if isinstance(o, dict):
+            return {k: slim(v, drop) for k, v in o.items() if k not in drop}
+        if isinstance(o, list):
+            return [slim(v, drop) for v in o]
+        return o
+    out = {}
+    for k in ("pcie_inclusive", "prep", "map", "optimizer", "nms", "dp_overhead", "data_parallel"):
+        if k in res:
+            out[k] = slim(res[k])
+    if "config0" in res:
+        out["config0"] = slim(res["config0"], drop=("note",))
+    if "config3" in res:
+        c3 = dict(res["config3"])
+        if isinstance(c3.get("roofline"), dict):
+            c3["roofline"] = {k: v for k, v in c3["roofline"].items() if k not in ("note", "traffic_source")}
+        out["config3"] = c3
+    more = sorted(res.get("roofline_more", []), key=lambda o: o.get("frac", 1.0))
+    if more:
+        out["roofline_more"] = [roof(o) for o in more]
+    if "roofline_hbm" in res:
+        out["roofline_hbm"] = roof(res["roofline_hbm"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        out[k] = res[k]
+    if "cpu_baseline" in res:
+        out["cpu_baseline"] = res["cpu_baseline"]
+    out["roofline"] = roof(res["roofline"])
+    return out
 
 
 def allreduce_model(payload_bytes, n_buckets):
@@ -972,12 +1085,15 @@ def main():
             t_leg = time.perf_counter()
             try:
                 res[name] = fn(*fargs)
-            except BaseException as e:                                          # noqa: BLE001 — incl. KeyboardInterrupt from the budget alarm
+            except Exception as e:                                              # noqa: BLE001 — incl. the budget alarm's TimeoutError; Ctrl-C / SystemExit propagate (the line still prints in `finally`)
                 res[name] = {"error": repr(e)[:300]}
                 try:
                     torch.cuda.synchronize()
                 except Exception:                                               # noqa: BLE001
                     pass
+                import gc
+                gc.collect()                                                    # a leg cut mid-way leaves a half-built plan behind: free it before the next leg
+                torch.cuda.empty_cache()
             print("bench: side leg %s %.1f s" % (name, time.perf_counter() - t_leg), file=sys.stderr)
 
         def with_budget(seconds, fn, *fargs):
@@ -998,6 +1114,12 @@ def main():
             if world == 1 and not a.no_nms and headline:
                 del out
                 side("config3", with_budget, 240, config3_leg, device)
+                if not a.no_cpu_baseline and isinstance(res.get("config3"), dict) and "error" not in res["config3"]:
+                    try:
+                        res["config3"]["cpu_baseline"] = with_budget(120, cpu_baseline_c3)
+                    except Exception as e:                                      # noqa: BLE001
+                        res["config3"]["cpu_baseline"] = {"error": repr(e)[:200]}
+                side("config0", with_budget, 120, c1_leg, device)
             if world == 1 and not a.no_nms:
                 side("nms", nms_bench, device)
                 side("map", map_bench, device)
@@ -1005,7 +1127,11 @@ def main():
                 side("optimizer", optimizer_bench, model)
                 side("pcie_inclusive", h2d_bench, step, x)
         finally:
-            print(json.dumps(res), flush=True)
+            if a.full_json:
+                print(json.dumps(res), flush=True)
+            else:
+                print(json.dumps(res), file=sys.stderr, flush=True)            # the verbose object, for the log
+                print(json.dumps(compact_line(res), separators=(",", ":")), flush=True)
     if use_dp:
         dist.destroy_process_group()
 

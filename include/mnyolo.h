@@ -256,6 +256,36 @@ int mny_dw_bnbwd_red(const float* g, const float* y, const float* scale, const f
                      const float* in_invstd, const float* w, const float* addend, float* dx, float* dw, float* ws, float* in_red,
                      int N, int H, int W, int C, int K, int stride, void* stream);
 
+/* ---- low-rank BatchNorm backward of a WIDE expand unit (csrc/lrbwd.hip) --------------------------------------------------------
+ * autograd of nn.Conv2d(K, C, 1) + nn.BatchNorm2d + ReLU6 / ReLU / h-swish with C >= 2K (models/mobilenetv2.py:73-78,
+ * models/mobilenetv3.py:49-51,67) WITHOUT the bn_bwd_apply pass over the C-wide tensors.  The depthwise unit behind it stores
+ * dzc = ca o dL/da o act'(z) (ca = gamma * invstd = the unit's forward scale) instead of dL/da (mny_dw_bnbwd_red_dz: same arguments and
+ * partial rows as mny_dw_bnbwd_red); then with X the unit's viewed K-wide input and Y = X W^T:
+ *     dX = dzc W + X Q + r,    Q = W^T diag(cb) W,  r = cc^T W          (mny_pw_fwd data gradient on dzc, then mny_pw_lr_fix)
+ *     dW = dzc^T X + cb o (W G) + cc (x) s,   G = X^T X,  s = colsum(X)   (mny_pw_wgrad on dzc, then mny_lr_wfix)
+ * with (ca, cb, cc) = the coefficient rows of mny_bn_bwd_finalize.
+ * mny_lr_gram : partial rows [mny_lr_gram_parts(M, K)][K*K + K] = (G | s) of the VIEWED input (combine with mny_reduce_batch).
+ * mny_lr_prep : q[K][K] = Q (symmetric, so it is its own NT operand) and r[K], on the fp32 matrix cores.
+ * mny_pw_lr_fix : dx = view(x) Q + r + addend (addend may be dx; in_scale / in_shift = the LINEAR view of the unit's input, or NULL, NULL);
+ *               red != NULL: the BN-backward sums of the unit whose complete output gradient dx now is (ry = its raw output [M][K], r_* = its
+ *               view / statistics), rows [mny_pw_lr_fix_parts(M, K, r_act)][2][K].
+ * mny_lr_wfix : dw[C][K] += cb o (W G) + cc (x) s in place; gram_sums = the combined [K*K + K] row of mny_lr_gram.               */
+int mny_lr_supported(int64_t M, int K, int C);
+int mny_lr_gram_parts(int64_t M, int K);
+int mny_lr_gram(const float* x, const float* in_scale, const float* in_shift, int in_act, float* parts, int64_t M, int K, void* stream);
+int mny_lr_gram_bf16(const void* x, const float* in_scale, const float* in_shift, int in_act, float* parts, int64_t M, int K, void* stream);
+int mny_lr_prep(const float* coef, const float* w, float* q, float* r, int C, int K, void* stream);
+int mny_pw_lr_fix_parts(int64_t M, int K, int r_act);
+int mny_pw_lr_fix(const float* x, const float* in_scale, const float* in_shift, const float* q, const float* r, const float* addend, float* dx,
+                  const float* ry, const float* r_scale, const float* r_shift, int r_act, const float* r_mean, const float* r_invstd, float* red,
+                  int64_t M, int K, void* stream);
+int mny_lr_wfix(float* dw, const float* gram_sums, const float* coef, const float* w, int C, int K, void* stream);
+int mny_dw_bnbwd_red_dz_supported(int K, int C, int bf16);
+int mny_dw_bnbwd_red_dz(const float* g, const float* y, const float* scale, const float* shift, int act, const float* coef,
+                        const float* x, const float* in_scale, const float* in_shift, int in_act, const float* in_mean,
+                        const float* in_invstd, const float* w, const float* addend, float* dx, float* dw, float* ws, float* in_red,
+                        int N, int H, int W, int C, int K, int stride, void* stream);
+
 /* ---- row padding for the detection heads' backward ---------------------------------------------------------
  * The head gradient dL/dhead is [M][75] (yolo_loss.py:84 channel layout): rows are neither 16-B aligned nor a multiple
  * of 4 wide, which would put its weight- and data-gradient GEMMs on the register-staged kernels.  mny_pad_rows copies it

@@ -139,6 +139,17 @@ _SIGS["mny_gate_fwd_bf16"] = (c_int, [P, P, P, P, P, P, P, P, P, P, P, c_int, P,
 _SIGS["mny_gate_bwd1_bf16"] = (c_int, [P] * 12 + [c_int64, c_int, c_int, P])
 _SIGS["mny_gate_bwd2_bf16"] = (c_int, [P] * 14 + [c_int64, c_int, c_int, P])
 _SIGS["mny_gate_bwd3_bf16"] = (c_int, [P] * 16 + [c_int64, c_int, c_int, P])
+# low-rank BatchNorm backward of the wide expand units (csrc/lrbwd.hip)
+_SIGS["mny_lr_supported"] = (c_int, [c_int64, c_int, c_int])
+_SIGS["mny_lr_gram_parts"] = (c_int, [c_int64, c_int])
+_SIGS["mny_lr_gram"] = (c_int, [P, P, P, c_int, P, c_int64, c_int, P])
+_SIGS["mny_lr_gram_bf16"] = _SIGS["mny_lr_gram"]
+_SIGS["mny_lr_prep"] = (c_int, [P, P, P, P, c_int, c_int, P])
+_SIGS["mny_pw_lr_fix_parts"] = (c_int, [c_int64, c_int, c_int])
+_SIGS["mny_pw_lr_fix"] = (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, P, P, P, c_int64, c_int, P])
+_SIGS["mny_lr_wfix"] = (c_int, [P, P, P, P, c_int, c_int, P])
+_SIGS["mny_dw_bnbwd_red_dz_supported"] = (c_int, [c_int, c_int, c_int])
+_SIGS["mny_dw_bnbwd_red_dz"] = _SIGS["mny_dw_bnbwd_red"]
 _SIGS["mny_transpose_bf16"] = _SIGS["mny_transpose"]
 _SIGS["mny_cvt_f32_bf16"] = (c_int, [P, P, c_int64, P])
 _SIGS["mny_cvt_batch_f32_bf16"] = (c_int, [P, P, c_int, P])

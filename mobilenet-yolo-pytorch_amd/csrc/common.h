@@ -259,6 +259,13 @@ int pw_wide_launch(const float* A, const float* in_scale, const float* in_shift,
                    int64_t M, int K, int N, const float* rY, const float* r_scale, const float* r_shift, const float* r_mean,
                    const float* r_invstd, int r_act, const float* addend, hipStream_t st);
 
+// mny_pw_lr_fix on the barrier-free kernel (K = 64 / 96, whole 32-row tiles): dx = (in_scale o x + in_shift) Q + bias + addend, + the sums
+bool pw_wide_fix_ok(int64_t M, int K);
+int pw_wide_fix_parts(int64_t M, int K);
+int pw_wide_fix_launch(const float* A, const float* in_scale, const float* in_shift, const float* Q, const float* bias, const float* addend, float* C,
+                       float* stats, int64_t M, int K, const float* rY, const float* r_scale, const float* r_shift, const float* r_mean,
+                       const float* r_invstd, int r_act, hipStream_t st);
+
 // weight gradient with one narrow side (64 / 96 channels): barrier-free stream kernel (pwwgs.hip); fp32 storage, no bias gradient
 bool pw_wgs_ok(int64_t M, int K, int N);
 int pw_wgs_splits(int64_t M, int K, int N);

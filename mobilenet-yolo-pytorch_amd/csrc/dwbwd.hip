@@ -27,6 +27,7 @@ struct DwbGeom {
     int64_t nstrips;
     int cg_total, cgb;
     int xcd;            // XCD-contiguous strip order (workgroup b runs on XCD b % 8): column / row halos shared with the neighbours hit the same L2
+    int dz;             // RED only: store  in_scale o dX o act_P'(z)  instead of dX (mny_dw_bnbwd_red_dz: the producer's low-rank BN backward, csrc/lrbwd.hip)
 };
 
 // AM: activation of THIS unit: 0 = none (act' = 1), 1 = min(max(z, slope z), hi) family, 2 = hswish
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                     const int64_t o = img + ((int64_t)(r - 1) * gm.W + wo) * gm.C;
                     float4 out = f4u(P0);
                     if (addend) add4(out, ld4(addend + o));
-                    st4_stream(dx + o, out);
+                    if (!RED || !gm.dz) st4_stream(dx + o, out);
                     if (RED) {                                      // BN-backward sums of the unit that produced X (raw x of row r-1 was parked below)
                         const float4 xc = xcs[tid], mu = my[16 * gm.cgb], is = my[17 * gm.cgb];
                         const float4 gq = stored4<T>(out);
@@ -181,6 +182,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                         float4 dz;
                         dz.x = gq.x * pact(xc.x, xsc.lo.x, xsh.lo.x); dz.y = gq.y * pact(xc.y, xsc.lo.y, xsh.lo.y);
                         dz.z = gq.z * pact(xc.z, xsc.hi.x, xsh.hi.x); dz.w = gq.w * pact(xc.w, xsc.hi.y, xsh.hi.y);
+                        if (gm.dz)                                  // the unit in front takes its gradient pre-multiplied: ca = gamma * invstd = in_scale
+                            st4_stream(dx + o, make_float4(dz.x * xsc.lo.x, dz.y * xsc.lo.y, dz.z * xsc.hi.x, dz.w * xsc.hi.y));
                         float4 a1 = xcs[256 + tid], a2 = xcs[512 + tid];
                         add4(a1, dz);
                         fma4(a2, dz, make_float4((xc.x - mu.x) * is.x, (xc.y - mu.y) * is.y, (xc.z - mu.z) * is.z, (xc.w - mu.w) * is.w));
@@ -404,7 +407,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
 static int dwb2_geom(DwbGeom& g, CgLayout& L, int& gx, int N, int H, int W, int C) {
     MNY_REQUIRE(C % 4 == 0 && C > 0, "dw_bnbwd_s2: C=%d must be a positive multiple of 4", C);
     MNY_REQUIRE(N > 0 && H > 0 && W > 0, "dw_bnbwd_s2: empty tensor");
-    g.N = N; g.H = H; g.W = W; g.C = C;
+    g.N = N; g.H = H; g.W = W; g.C = C; g.dz = 0;
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     static const int th2 = getenv("MNY_DWB2_TH") ? atoi(getenv("MNY_DWB2_TH")) : 16;     // quad rows per strip (the 4 launches of a step: 8: 2.33, 16: 2.30, 32: 2.42, 64: 2.50 ms)
     const int ns = (int)cdiv(Ho, th2);
@@ -453,7 +456,7 @@ static int dw_bnbwd_s2_impl(const T* g, const T* y, const float* scale, const fl
 static int dwb_geom(DwbGeom& g, CgLayout& L, int& gx, int N, int H, int W, int C) {
     MNY_REQUIRE(C % 4 == 0 && C > 0, "dw_bnbwd: C=%d must be a positive multiple of 4", C);
     MNY_REQUIRE(N > 0 && H > 0 && W > 0, "dw_bnbwd: empty tensor");
-    g.N = N; g.H = H; g.W = W; g.C = C;
+    g.N = N; g.H = H; g.W = W; g.C = C; g.dz = 0;
     static const int th = getenv("MNY_DWB_TH") ? atoi(getenv("MNY_DWB_TH")) : 32;   // strip height (3 halo rows per strip): 16 -> 32: 5.32 -> 5.22 ms
     const int ns = (int)cdiv(H, th);
     g.TH = (int)cdiv(H, ns);
@@ -476,8 +479,9 @@ template <typename T>
 static int dw_bnbwd_impl(const T* g, const T* y, const float* scale, const float* shift, int act, const float* coef,
                          const T* x, const float* in_scale, const float* in_shift, int in_act, const float* w,
                          const T* addend, T* dx, float* dw, float* ws, int N, int H, int W, int C, int K, int stride, void* stream,
-                         const float* in_mean = nullptr, const float* in_invstd = nullptr, float* in_red = nullptr) {
+                         const float* in_mean = nullptr, const float* in_invstd = nullptr, float* in_red = nullptr, bool store_dz = false) {
     MNY_REQUIRE(g && y && scale && shift && coef && x && w && dx && ws, "dw_bnbwd: null pointer");
+    MNY_REQUIRE(!store_dz || (in_red && !dwt_use(K, sizeof(T) == 2 ? 1 : 0, 1, C)), "dw_bnbwd_red_dz: register form with producer sums only (mny_dw_bnbwd_red_dz_supported)");
     MNY_REQUIRE(!in_red || (in_mean && in_invstd && in_scale && in_shift), "dw_bnbwd_red: the input must be a BN unit's raw output (scale, shift, mean, invstd)");
     MNY_REQUIRE(stride == 1 && (K == 3 || (K == 5 && dwt_use(5, 0, 0, C))), "dw_bnbwd: only 3x3 / 5x5 stride 1 are fused (got K=%d stride=%d); use bn_bwd_apply + dw_bwd_*", K, stride);
     MNY_REQUIRE(act != MNY_ACT_HSIGMOID && in_act != MNY_ACT_HSIGMOID, "dw_bnbwd: h-sigmoid views are not supported");
@@ -487,6 +491,7 @@ static int dw_bnbwd_impl(const T* g, const T* y, const float* scale, const float
     DwbGeom gm; CgLayout L; int gx;
     int rc = dwb_geom(gm, L, gx, N, H, W, C);
     if (rc) return rc;
+    gm.dz = store_dz ? 1 : 0;
     dim3 grid(gx, L.chunks), block(L.threads);
     hipStream_t st = (hipStream_t)stream;
     const int am = act == MNY_ACT_NONE ? 0 : (act == MNY_ACT_HSWISH ? 2 : 1);
@@ -554,6 +559,17 @@ extern "C" int mny_dw_bnbwd_red(const float* g, const float* y, const float* sca
     MNY_REQUIRE(in_red && in_mean && in_invstd, "dw_bnbwd_red: null pointer");
     return dw_bnbwd_impl<float>(g, y, scale, shift, act, coef, x, in_scale, in_shift, in_act, w, addend, dx, dw, ws, N, H, W, C, K, stride, stream,
                                 in_mean, in_invstd, in_red);
+}
+
+// the same, storing  in_scale o dX o act_P'(in_scale x + in_shift)  instead of dX: the producer unit P runs the low-rank BN backward (csrc/lrbwd.hip)
+extern "C" int mny_dw_bnbwd_red_dz_supported(int K, int C, int bf16) { return (K == 3 && !dwt_use(3, bf16 ? 1 : 0, 1, C)) ? 1 : 0; }
+extern "C" int mny_dw_bnbwd_red_dz(const float* g, const float* y, const float* scale, const float* shift, int act, const float* coef,
+                                   const float* x, const float* in_scale, const float* in_shift, int in_act, const float* in_mean, const float* in_invstd,
+                                   const float* w, const float* addend, float* dx, float* dw, float* ws, float* in_red, int N, int H, int W, int C,
+                                   int K, int stride, void* stream) {
+    MNY_REQUIRE(in_red && in_mean && in_invstd, "dw_bnbwd_red_dz: null pointer");
+    return dw_bnbwd_impl<float>(g, y, scale, shift, act, coef, x, in_scale, in_shift, in_act, w, addend, dx, dw, ws, N, H, W, C, K, stride, stream,
+                                in_mean, in_invstd, in_red, true);
 }
 
 extern "C" int mny_dw_bnbwd_red_bf16(const void* g, const void* y, const float* scale, const float* shift, int act, const float* coef,

@@ -577,6 +577,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((X6 == 3 &&
                 const bool ccol = col < p.N;
                 const int cc = ccol ? col : 0;
                 const float rsc = p.r_scale[cc], rsh = p.r_shift[cc], rmu = p.r_mean[cc], ris = p.r_invstd[cc];
+                const float rbias = p.bias ? p.bias[cc] : 0.f;   // (mny_pw_lr_fix: the gradient carries a per-column constant; data gradients have none)
                 const float rslope = act_slope(p.r_act), rhi = act_hi(p.r_act);
                 const int64_t rbase = m0 + wv * 32 + 4 * khalf;
                 const int rows_left = (int)max((int64_t)0, min((int64_t)64, p.M - rbase));   // rows rbase + 8*gq + j, 8*gq + j < rows_left, exist
@@ -595,7 +596,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((X6 == 3 &&
                     for (int j = 0; j < 4; ++j) {
                         const float z = fmaf(yv[j], rsc, rsh);
                         const float dact = p.r_act >= MNY_ACT_HSWISH ? act_bwd(z, p.r_act) : (z > 0.f ? 1.f : rslope) * (z < rhi ? 1.f : 0.f);
-                        const float dz = stored<T>(acc[u][gq * 4 + j] + av[j]) * dact;
+                        const float dz = stored<T>(acc[u][gq * 4 + j] + rbias + av[j]) * dact;
                         if (ccol && 8 * gq + j < rows_left) { s1[u] += dz; s2[u] = fmaf(dz, (yv[j] - rmu) * ris, s2[u]); }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -2978,6 +2979,50 @@ extern "C" int mny_pw_dgrad_bnred_bf16(const void* dy, const void* wT, void* dx,
     return pw_dgrad_bnred_impl<1>(dy, wT, dx, y, scale, shift, act, mean, invstd, red, M, K, Nc, stream);
 }
 
+// ---- low-rank BatchNorm-backward correction of a wide expand unit's data gradient (csrc/lrbwd.hip) ----------------------------------
+// dx = view(x) Q + r + addend  (x the K-wide input of the unit behind its LINEAR view in_scale / in_shift — applied where the A fragment is read,
+// as in every forward GEMM —, Q [K][K] symmetric and r [K] from mny_lr_prep, addend = the main term dzc W, usually dx itself); with `red` the
+// BN-backward sums of the unit whose complete output gradient dx now is (its raw output ry, as mny_pw_dgrad_bnred_add).  Always the LDS-DMA
+// kernel, column tiles of <= 96 (the addend form's limit).
+static bool lr_fix_wide(int64_t M, int K, int r_act) {       // which kernel a call WITH a reduction target takes — the one rule for the launch and the row count
+    static const bool no_wide_fix = getenv("MNY_LR_FIX_DMA") != nullptr;          // (A/B: always the LDS-DMA kernel)
+    return !no_wide_fix && pw_wide_fix_ok(M, K) && r_act < MNY_ACT_HSWISH;
+}
+static int pw_lr_fix_impl(const float* x, const float* in_scale, const float* in_shift, const float* q, const float* r, const float* addend, float* dx,
+                          const float* ry, const float* r_scale, const float* r_shift, int r_act, const float* r_mean, const float* r_invstd, float* red,
+                          int64_t M, int K, void* stream) {
+    MNY_REQUIRE(x && q && r && addend && dx && M > 0 && K > 0 && (K & 3) == 0 && (!in_scale) == (!in_shift), "pw_lr_fix: bad arguments (K=%d)", K);
+    MNY_REQUIRE(!red || (ry && r_scale && r_shift && r_mean && r_invstd && r_act >= MNY_ACT_NONE && r_act <= MNY_ACT_HSIGMOID), "pw_lr_fix: incomplete reduction target");
+    const bool xf = in_scale != nullptr;
+    if (red && lr_fix_wide(M, K, r_act)) {            // K = 64 / 96 at whole 32-row tiles: the barrier-free kernel of pwwide.hip
+        g_pw_route = MNY_ROUTE_WIDE;
+        return pw_wide_fix_launch(x, in_scale, in_shift, q, r, addend, dx, red, M, K, ry, r_scale, r_shift, r_mean, r_invstd, r_act, (hipStream_t)stream);
+    }
+    Nt2Plan p2 = nt2_plan(M, K, K, xf, 0, 3);
+    MNY_REQUIRE(p2.lds <= 64 * 1024, "pw_lr_fix: K=%d too large", K);
+    Gemm2Args g{x, in_scale, in_shift, MNY_ACT_NONE, q, r, addend, dx, red, M, K, K, p2.m_tiles, p2.tiles_per_block, p2.gx, p2.n_tiles,
+                ry, r_scale, r_shift, r_mean, r_invstd, r_act};
+    const bool x6 = nt_x6(M, K, K);
+    Nt2Kernel k;
+#define MNY_FX(T) (xf ? (x6 ? (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 1, 0, 2, 1> : (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 1, 0, 2>) \
+                      : (x6 ? (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 0, 0, 2, 1> : (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 0, 0, 2>))
+    if (red) switch (p2.TN) { case 1: k = MNY_FX(1); break; case 2: k = MNY_FX(2); break; default: k = MNY_FX(3); break; }
+    else k = nt2_kernel(p2.TN, xf ? 1 : 0, 0, x6 ? 1 : 0);
+#undef MNY_FX
+    g_pw_route = x6 ? MNY_ROUTE_DMA_X6 : MNY_ROUTE_DMA_F32;
+    hipLaunchKernelGGL(k, dim3(p2.grid), dim3(256), p2.lds, (hipStream_t)stream, g);
+    return check_launch("pw_gemm_nt_dma_kernel<lr_fix>");
+}
+extern "C" int mny_pw_lr_fix_parts(int64_t M, int K, int r_act) {
+    if (M <= 0 || K <= 0 || (K & 3)) return MNY_EINVAL;
+    return lr_fix_wide(M, K, r_act) ? pw_wide_fix_parts(M, K) : nt2_plan(M, K, K, true, 0, 3).gx;
+}
+extern "C" int mny_pw_lr_fix(const float* x, const float* in_scale, const float* in_shift, const float* q, const float* r, const float* addend, float* dx,
+                             const float* ry, const float* r_scale, const float* r_shift, int r_act, const float* r_mean, const float* r_invstd, float* red,
+                             int64_t M, int K, void* stream) {
+    return pw_lr_fix_impl(x, in_scale, in_shift, q, r, addend, dx, ry, r_scale, r_shift, r_act, r_mean, r_invstd, red, M, K, stream);
+}
+
 // ---- forward / data-gradient GEMMs on pre-cut weight planes (fp32 plans, six-product form) ---------------------------------------
 // Planes pay where the matrix pipe is the bound.  Round 2: a stage of B grew from 64 to 96 bytes per row, which cost the mid-size shapes
 // their third resident workgroup (7-18 % faster from ~60 FLOP per byte up, 10-30 % slower below ~40).  Round 3: the plane ring is two
@@ -3059,6 +3104,10 @@ extern "C" int mny_pw_fwd_bf16(const void* x, const float* in_scale, const float
     hipStream_t st = (hipStream_t)stream;
     const bool xf = in_scale != nullptr || in_act != MNY_ACT_NONE;
     static const bool force_v1 = getenv("MNY_GEMM_V1") != nullptr;
+    // mny_pw_stat_parts_bf16 sizes the caller's partial rows from (M, K, Nc) alone: a view / bias that moves the call to another kernel family
+    // than the query assumed would write a different number of rows than mny_bn_finalize sums — refuse it instead
+    MNY_REQUIRE(!stats || pwt_ok(M, K, Nc, in_act, bias != nullptr) == pwt_ok(M, K, Nc, MNY_ACT_NONE, false),
+                "pw_fwd_bf16: statistics with in_act=%d at M=%lld K=%d N=%d take another kernel family than mny_pw_stat_parts_bf16 counted rows for", in_act, (long long)M, K, Nc);
     if (pwt_ok(M, K, Nc, in_act, bias != nullptr))         // K <= 48 at a large pixel count: a wave per 16 pixels on the bf16 matrix cores (gate.hip)
         return (g_pw_route = MNY_ROUTE_WAVE16, pwt_launch(x, in_scale, in_shift, in_act, w, addend, y, stats, M, K, Nc, st));
     if (pw_thin_ok(1, 0, M, K, Nc))

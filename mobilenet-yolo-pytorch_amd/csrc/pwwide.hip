@@ -32,11 +32,14 @@ struct WideArgs {
     int gx, n_blocks; int64_t ntiles;     // m-runs (= partial rows), column blocks, 32-row tiles
     const float* rY; const float* r_scale; const float* r_shift; const float* r_mean; const float* r_invstd; int r_act;
     const float* addend;
+    const float* bias;                    // MODE 4: a per-column constant of the product (mny_pw_lr_fix)
 };
 
 // XF: 0 = A as is, 1 = scale/shift + clamp family, 2 = scale/shift + h-swish
 // MODE: 0 = plain, 1 = column sums / sums of squares of C, 2 = BN-backward sums of the unit C is the gradient of, 3 = the same over C + addend
-//       (MODE >= 2 takes A as is; XF then names the activation family of THAT unit: 0 = clamp family, 2 = h-swish / h-sigmoid)
+//       (MODE 2 / 3 take A as is; XF then names the activation family of THAT unit: 0 = clamp family, 2 = h-swish / h-sigmoid)
+//       4 = MODE 3 behind a LINEAR view of A (in_scale / in_shift, no activation) and with a per-column constant `bias` in the product:
+//           the low-rank BatchNorm-backward correction dx = view(x) Q + r + addend with the sums over it (mny_pw_lr_fix, csrc/lrbwd.hip)
 template <int KS, int TNB, int XF, int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void pw_wide_kernel(WideArgs p) {
     constexpr int BN = 32 * TNB;
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         *reinterpret_cast<v4f_t*>(dst + 256) = __builtin_bit_cast(v4f_t, mm);
         *reinterpret_cast<v4f_t*>(dst + 512) = __builtin_bit_cast(v4f_t, ll);
     }
-    if (XF != 0 && MODE < 2) {
+    if ((XF != 0 && MODE < 2) || MODE == 4) {
         const bool has = p.in_scale != nullptr;
         for (int k = tid; k < KS * 16; k += 256) {
             sScale[k] = k < K ? (has ? p.in_scale[k] : 1.f) : 0.f;
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int64_t nslots = (int64_t)p.gx * 4;
     const unsigned rowb = (unsigned)N * 4u;                      // bytes per output row
     float4 g[2 * KS];
-    float ry[MODE >= 2 ? 16 : 1], ra[MODE == 3 ? 16 : 1];
+    float ry[MODE >= 2 ? 16 : 1], ra[MODE >= 3 ? 16 : 1];
     auto load_g = [&](int64_t tile, int s) {
         const int64_t r = tile * 32 + lrow;
         const float* row = p.A + (r < p.M ? r : p.M - 1) * K;
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const float* ub = p.rY + tile * 32 * N;
 #pragma unroll
         for (int r = 0; r < 16; ++r) ry[r] = ld1(at_bytes(ub + (int64_t)(8 * (r >> 2) + (r & 3)) * N, voff));
-        if constexpr (MODE == 3) {
+        if constexpr (MODE >= 3) {
             const float* ua = p.addend + tile * 32 * N;
 #pragma unroll
             for (int r = 0; r < 16; ++r) ra[r] = ld1(at_bytes(ua + (int64_t)(8 * (r >> 2) + (r & 3)) * N, voff));
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int s = 0; s < KS; ++s) {
             const float4 a0 = g[2 * s], a1 = g[2 * s + 1];
             float z[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-            if (XF != 0 && MODE < 2) {
+            if ((XF != 0 && MODE < 2) || MODE == 4) {
                 // RULE (DESIGN 4 "Determinism"): in a kernel that keeps MFMAs in flight the vector ALU consumes an LDS result only
                 // behind an EXPLICIT `s_waitcnt lgkmcnt(0)` that carries the destination registers — never behind the compiler's counted
                 // lgkmcnt(N > 0) alone (the reduction form's table read, consumed behind a counted wait, returned run-to-run different
@@ -142,7 +145,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float t = fmaf(z[e], sv[e], hv[e]);
-                    z[e] = XF == 1 ? fminf(fmaxf(t, slope * t), hi) : t * fminf(fmaxf(t + 3.f, 0.f), 6.f) * (1.f / 6.f);
+                    z[e] = MODE == 4 ? t : (XF == 1 ? fminf(fmaxf(t, slope * t), hi) : t * fminf(fmaxf(t + 3.f, 0.f), 6.f) * (1.f / 6.f));
                 }
             }
             x6_split(v4f_t{z[0], z[1], z[2], z[3]}, v4f_t{z[4], z[5], z[6], z[7]}, ah[s], am[s], al[s]);
@@ -162,9 +165,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // gfx950 the LDS counter can run ahead of the register write while an MFMA still in the pipe reads those registers: do not let the
             // vector ALU consume an LDS result that lands in operand registers of a just-issued MFMA.
             float4 rc = f4zero();
+            float cbias = 0.f;
             if (MODE >= 2) {
                 const int colx = n0 + u * 32 + lrow;
                 rc = make_float4(p.r_scale[colx], p.r_shift[colx], p.r_mean[colx], p.r_invstd[colx]);
+                if (MODE == 4) cbias = p.bias[colx];
             }
             f32x16 acc, acc1;
 #pragma unroll
@@ -198,7 +203,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         const float dsg = (zz > -3.f && zz < 3.f) ? (1.f / 6.f) : 0.f;
                         dact = rhsig ? dsg : dsw;
                     }
-                    if (MODE == 3) acc[r] += ra[r];              // the sums are over the COMPLETE gradient = product + addend (stored as such)
+                    if (MODE >= 3) acc[r] += ra[r];              // the sums are over the COMPLETE gradient = product + addend (stored as such)
+                    if (MODE == 4) acc[r] += cbias;
                     const float dz = acc[r] * dact;
                     s1[u] += dz; s2[u] = fmaf(dz, (ry[r] - rc.z) * rc.w, s2[u]);
                 }
@@ -337,6 +343,10 @@ static WideKernel wide_pick_fwd(int xf, int mode) {
 }
 template <int KS, int TNB>
 static WideKernel wide_pick_red(int xf, int mode) {      // clamp-family units only: the h-swish / h-sigmoid builds of this form spill (see wide_tnb)
+    if (mode == 4) {
+        if constexpr (KS == TNB * 2) return pw_wide_kernel<KS, TNB, 0, 4>;       // (square products only: K = N = 64, 96)
+        else return nullptr;
+    }
     return mode == 2 ? pw_wide_kernel<KS, TNB, 0, 2> : pw_wide_kernel<KS, TNB, 0, 3>;
 }
 static WideKernel wide_pick(int KS, int TNB, int xf, int mode) {
@@ -350,6 +360,24 @@ static WideKernel wide_pick(int KS, int TNB, int xf, int mode) {
         case 52: return wide_pick_fwd<5, 2>(xf, mode); case 53: return wide_pick_fwd<5, 3>(xf, mode); case 54: return wide_pick_fwd<5, 4>(xf, mode);
         case 62: return wide_pick_fwd<6, 2>(xf, mode); case 63: return wide_pick_fwd<6, 3>(xf, mode); default: return wide_pick_fwd<6, 4>(xf, mode);
     }
+}
+
+// the low-rank BN-backward correction (mny_pw_lr_fix): dx = (in_scale o x + in_shift) Q + bias + addend and the sums of the unit dx is the gradient of
+bool pw_wide_fix_ok(int64_t M, int K) { return pw_wide_ok(M, K, K, true) && (M & 31) == 0 && (K == 64 || K == 96); }
+int pw_wide_fix_parts(int64_t M, int K) { return wide_plan(M, K, K, true).gx; }
+int pw_wide_fix_launch(const float* A, const float* in_scale, const float* in_shift, const float* Q, const float* bias, const float* addend, float* C,
+                       float* stats, int64_t M, int K, const float* rY, const float* r_scale, const float* r_shift, const float* r_mean,
+                       const float* r_invstd, int r_act, hipStream_t st) {
+    MNY_REQUIRE(pw_wide_fix_ok(M, K) && rY && addend && bias && stats && r_act < MNY_ACT_HSWISH, "pw_wide_fix: unsupported problem M=%lld K=%d", (long long)M, K);
+    const WidePlan pl = wide_plan(M, K, K, true);
+    WideArgs a{A, in_scale, in_shift, MNY_ACT_NONE, Q, C, stats, M, K, K, pl.gx, pl.n_blocks, pl.ntiles, rY, r_scale, r_shift, r_mean, r_invstd, r_act, addend, bias};
+    const WideKernel k = wide_pick(pl.KS, pl.TNB, 0, 4);
+    MNY_REQUIRE(k != nullptr, "pw_wide_fix: no kernel for K=%d", K);
+    if (!allow_lds((const void*)k, 80 * 1024)) {
+        set_error("pw_wide: hipFuncSetAttribute failed"); return MNY_EHIP;
+    }
+    hipLaunchKernelGGL(k, dim3(pl.grid), dim3(256), pl.lds, st, a);
+    return check_launch("pw_wide_kernel<fix>");
 }
 
 // mode 0/1: forward (stats != null -> 1); mode 2/3: data gradient + BN-backward sums (addend != null -> 3)
@@ -366,7 +394,7 @@ int pw_wide_launch(const float* A, const float* in_scale, const float* in_shift,
     MNY_REQUIRE(!rY || r_act < MNY_ACT_HSWISH, "pw_wide: the reduction form knows the clamp family only (mny_pw_dgrad_bnred_supported)");
     MNY_REQUIRE(rY || !addend, "pw_wide: a plain addend is not supported (callers route it to the LDS-DMA kernel)");
     MNY_REQUIRE(in_act != MNY_ACT_HSIGMOID, "pw_wide: h-sigmoid input transform is not supported");
-    WideArgs a{A, in_scale, in_shift, in_act, W, C, stats, M, K, N, pl.gx, pl.n_blocks, pl.ntiles, rY, r_scale, r_shift, r_mean, r_invstd, r_act, addend};
+    WideArgs a{A, in_scale, in_shift, in_act, W, C, stats, M, K, N, pl.gx, pl.n_blocks, pl.ntiles, rY, r_scale, r_shift, r_mean, r_invstd, r_act, addend, nullptr};
     const WideKernel k = wide_pick(pl.KS, pl.TNB, XF, mode);
     if (!allow_lds((const void*)k, 80 * 1024)) {      // > 64 KB of dynamic LDS needs an explicit opt-in per kernel (and device)
         set_error("pw_wide: hipFuncSetAttribute failed"); return MNY_EHIP;

@@ -55,16 +55,9 @@ class CallList:
         """A host-side step of the list (stream fork / join): any callable returning None."""
         self.calls.append((fn, (), name, None))
 
-    _HACK_SKIP = tuple(v for v in os.environ.get("MNY_HACK_SKIP", "").split(",") if v)     # timing experiments only: entry points left out after 8 runs (stale results!)
-    _hack_runs = 0
-
     def run(self, begin=0, end=None):
         lib = _lib.load()
-        if self._HACK_SKIP:
-            CallList._hack_runs += 1
         for fn, args, name, _ in self.calls[begin:end]:
-            if self._HACK_SKIP and CallList._hack_runs > 8 and name in self._HACK_SKIP:
-                continue
             rc = fn(*args)
             if rc:
                 raise MnyError("%s failed (%d): %s" % (name, rc, lib.mny_last_error().decode()))
@@ -259,6 +252,12 @@ class NetPlan:
         self._side_stream = torch.cuda.Stream(dev) if self.side_on else None
         self._ev_fork = torch.cuda.Event() if self.side_on else None
         self._ev_join = torch.cuda.Event() if self.side_on else None
+        # a second side stream for the SHORT dependent kernels of the low-rank BN backward (mny_lr_prep): they must not queue behind the weight
+        # gradients of the first one, and the main stream waits for exactly them (its own event pair)
+        self.stream_side2 = _vp(0)
+        self._side2_stream = torch.cuda.Stream(dev) if self.side_on else None
+        self._ev_fork2 = torch.cuda.Event() if self.side_on else None
+        self._ev_join2 = torch.cuda.Event() if self.side_on else None
         self._side_used = False
         self.graphs = {}
         self.eager_steps = 0
@@ -652,7 +651,7 @@ class NetPlan:
         # the data-parallel buckets still complete early).  MNY_NO_DEFER=1: the per-layer combines.
         self.defer = os.environ.get("MNY_NO_DEFER") != "1"
         defer_every = int(os.environ.get("MNY_DEFER_EVERY", "16"))
-        self._red_jobs, self._red_keep = [], []
+        self._red_jobs, self._red_keep, self._post_reduce = [], [], []
         uses = {}
         for nd in order:                                          # a module applied twice (mbv3_yolo.py:133-134) adds a second contribution right
             if nd.conv:                                            # after its producing call: its combines stay inline
@@ -684,12 +683,15 @@ class NetPlan:
             # of 4-5 launches on the critical path of both benchmark configurations.)  MNY_REDUCE_MAIN=1: the round-4 placement.
             if self.side_on and os.environ.get("MNY_REDUCE_MAIN") != "1":
                 bwd.add_py(self._fork_side, "fork")
-                bwd.add("mny_reduce_batch", jdev, bdev, len(block_job), self.stream_side, meta=dict(writes=[job[1].data_ptr() for job in self._red_jobs]))
+                red_stream = self.stream_side
             else:
                 if self.side_on:
                     bwd.add_py(self._join_side, "join")           # the partials of side-stream weight gradients must have landed
-                bwd.add("mny_reduce_batch", jdev, bdev, len(block_job), self.stream, meta=dict(writes=[job[1].data_ptr() for job in self._red_jobs]))
-            self._red_jobs = []
+                red_stream = self.stream
+            bwd.add("mny_reduce_batch", jdev, bdev, len(block_job), red_stream, meta=dict(writes=[job[1].data_ptr() for job in self._red_jobs]))
+            for hook in self._post_reduce:                        # corrections of combined weight gradients (low-rank BN backward): same stream, right behind the combine
+                hook(red_stream)
+            self._red_jobs, self._post_reduce = [], []
 
         # workspaces shared by all layers (single stream => sequential use)
         ws_floats = 1
@@ -790,6 +792,37 @@ class NetPlan:
                 return False
             psh = shape(po)
             return _lib.query(K("mny_pw_bnbwd_supported"), psh[0] * psh[1] * psh[2], pi.C, po.C) == 1
+        def red_target(i, nd):
+            """The conv+BN+act unit whose COMPLETE output gradient the data gradient of `nd` w.r.t. its input `i` is — its BN-backward sums can
+            leave with that gradient (no mny_bn_bwd_reduce pass) — or None.  `i` itself when it is a unit and `nd` its last consumer; or, looking
+            through a residual add (round 6): the add's unit operand that only the add consumes takes the sum's gradient unchanged (an alias)."""
+            if i.id in loss_ids or last_consumer.get(i.id) is not nd:
+                return None
+            t = None
+            if i.kind == "unit":
+                t = i
+            elif i.node is not None and i.node.op == "add" and os.environ.get("MNY_NO_ADDRED") != "1":
+                cands = [v for v in i.node.ins[:1 + (i.node.k & 1)] if v.kind == "unit" and n_consumers[v.id] == 1 and v.id not in loss_ids]
+                if len(cands) == 1:
+                    t = cands[0]
+            if (t is None or t.node is None or t.node.op not in ("dw", "pw") or takes_own_sums(t.node) or t.id not in self.units
+                    or self.units[t.id].Y is None or gs[t.id].buf is not None and t is not i):
+                return None
+            return t
+
+        # wide expand units on the low-rank BN backward (csrc/lrbwd.hip): the depthwise unit behind stores ca o G o act'(z), both GEMMs run on
+        # that tensor and the BatchNorm terms are K-wide corrections — no bn_bwd_apply pass over the C-wide tensors.  lr_units: value ids
+        self.lr_units = set()
+
+        def lr_ok(pn):
+            if (self.bf16 or self.frozen or not self.defer or pn.op != "pw" or pn.bias or not single(pn) or pn.out.id in self.head_cp
+                    or takes_own_sums(pn) or os.environ.get("MNY_NO_LR") == "1"):
+                return False
+            pi = pn.ins[0]
+            if pi.act != ACT_NONE or pi.kind not in ("unit", "real"):
+                return False                     # the thin input's view must be linear: it is folded into the correction's operands
+            psh = shape(pn.out)
+            return _lib.query("mny_lr_supported", psh[0] * psh[1] * psh[2], pi.C, pn.out.C) == 1
         # W^T of every generic pointwise unit, all in one launch at the head of the backward list (one per layer was 39 launches)
         self.t_batch = os.environ.get("MNY_NO_TBATCH") != "1"
         if self.t_batch:
@@ -984,6 +1017,60 @@ class NetPlan:
                 flush_shared()
                 bwd.marks[o.name] = len(bwd.calls)
                 continue
+            if nd.op == "pw" and o.id in self.lr_units:
+                # wide expand unit, low-rank BN backward: G holds dzc = ca o dL/da o act'(z) (written by the depthwise unit behind, whose epilogue also
+                # left this unit's BN-backward sums).  dW = dzc^T X + cb o (W X^T X) + cc (x) colsum(X);  dX = dzc W + X Q + r.
+                u = self.units[o.id]
+                i = nd.ins[0]
+                xv = view(i)
+                Kc, C = i.C, o.C
+                w = P[nd.conv + ".weight"]
+                red_buf, red_parts = self.fused_red[o.id]
+                coef_u = torch.empty(3 * C, **f32)                 # private: the side-stream weight-gradient correction reads it long after coef_ws is reused
+                bwd.add(fin_name, red_buf, red_parts, M, P[nd.bn + ".weight"], u.mean, u.invstd, gv(nd.bn + ".weight"), gv(nd.bn + ".bias"), coef_u, C, self.stream)
+                bq, rb = torch.empty(Kc * Kc, **f32), torch.empty(Kc, **f32)
+                prep_side = self.side_on and os.environ.get("MNY_LR_PREP_MAIN") != "1"       # Q, r under the main-term GEMM below; joined in front of the correction
+                if prep_side:
+                    bwd.add_py(self._fork_side2, "fork")
+                bwd.add("mny_lr_prep", coef_u, w, bq, rb, C, Kc, self.stream_side2 if prep_side else self.stream)
+                dwv = gv(nd.conv + ".weight")
+                if self.side_on:
+                    bwd.add_py(self._fork_side, "fork")
+                st_w = self.stream_side if self.side_on else self.stream
+                psplits = _lib.query("mny_pw_wgrad_splits", M, Kc, C)
+                pws = defer_job(max(_lib.query("mny_pw_wgrad_ws_floats", M, Kc, C), psplits * C * Kc), dwv, psplits, C * Kc)
+                bwd.add("mny_pw_wgrad", xv[0], xv[1], xv[2], xv[3], G, None, None, pws, M, Kc, C, st_w,
+                        meta=dict(flops=2 * M * Kc * C, bytes=eb * (M * Kc + M * C) + 4 * Kc * C, shape="M%d K%d N%d" % (M, Kc, C)))
+                gparts = _lib.query("mny_lr_gram_parts", M, Kc)
+                gsum = torch.empty(Kc * Kc + Kc, **f32)
+                gws = defer_job(gparts * (Kc * Kc + Kc), gsum, gparts, Kc * Kc + Kc)
+                bwd.add("mny_lr_gram", xv[0], xv[1], xv[2], xv[3], gws, M, Kc, st_w,
+                        meta=dict(flops=2 * M * Kc * Kc, bytes=eb * M * Kc, shape="gram M%d K%d" % (M, Kc)))
+                self._post_reduce.append(lambda st, dwv=dwv, gsum=gsum, coef_u=coef_u, w=w, C=C, Kc=Kc: bwd.add("mny_lr_wfix", dwv, gsum, coef_u, w, C, Kc, st))
+                wT = self.wT[nd.conv]
+                wT6 = getattr(self, "wT6", {}).get(nd.conv)
+                contribute_kernel(i, lambda out, addend, G=G, wT=wT, wT6=wT6, M=M, K=C, Nc=Kc: bwd.add(
+                    "mny_pw_fwd_w6" if wT6 is not None else "mny_pw_fwd", G, None, None, ACT_NONE, wT6 if wT6 is not None else wT, None, addend, out, None,
+                    M, K, Nc, self.stream, label="mny_pw_fwd",
+                    meta=dict(flops=2 * M * K * Nc, bytes=self.eb * (M * K + M * Nc) + 4 * K * Nc, shape="dgrad M%d K%d N%d" % (M, K, Nc))))
+                buf = gs[i.id].buf
+                if prep_side:
+                    bwd.add_py(self._join_side2, "join")
+                tgt = red_target(i, nd) if os.environ.get("MNY_NO_REDFUSE") != "1" else None
+                if tgt is not None:
+                    pu = self.units[tgt.id]
+                    rparts = _lib.query("mny_pw_lr_fix_parts", M, Kc, tgt.act)
+                    rbuf = torch.empty(rparts * 2 * Kc, **f32)
+                    self.fused_red[tgt.id] = (rbuf, rparts)
+                    bwd.add("mny_pw_lr_fix", xv[0], xv[1], xv[2], bq, rb, buf, buf, pu.Y, pu.scale, pu.shift, tgt.act, pu.mean, pu.invstd, rbuf, M, Kc, self.stream,
+                            meta=dict(flops=2 * M * Kc * Kc, bytes=eb * 4 * M * Kc, shape="lr fix+red M%d K%d" % (M, Kc)))
+                else:
+                    bwd.add("mny_pw_lr_fix", xv[0], xv[1], xv[2], bq, rb, buf, buf, None, None, None, 0, None, None, None, M, Kc, self.stream,
+                            meta=dict(flops=2 * M * Kc * Kc, bytes=eb * 3 * M * Kc, shape="lr fix M%d K%d" % (M, Kc)))
+                flush_shared()
+                flush_reduce()
+                bwd.marks[o.name] = len(bwd.calls)
+                continue
             if nd.op == "pwb":
                 dY = G
             else:
@@ -1048,10 +1135,15 @@ class NetPlan:
                         rparts = _lib.query("mny_dw_bnbwd_parts_k", N, ish[1], ish[2], o.C, nd.k, pflags)
                         rbuf = torch.empty(rparts * 2 * i.C, **f32)
                         self.fused_red[i.id] = (rbuf, rparts)
-                        contribute_kernel(i, lambda out, addend, G=G, u=u, xv=xv, wt=wt, dwv=dwv_k, wsl=ws_k, ish=ish, C=o.C, act=o.act, M=M, pu=pu, rbuf=rbuf, k=nd.k: bwd.add(
-                            self.K("mny_dw_bnbwd_red"), G, u.Y, u.scale, u.shift, act, self.coef_ws, xv[0], xv[1], xv[2], xv[3], pu.mean, pu.invstd, wt, addend,
-                            out, dwv, wsl, rbuf, N, ish[1], ish[2], C, k, 1, self.stream,
-                            meta=dict(flops=4 * M * C * k * k, bytes=self.eb * 4 * M * C, shape="C%d H%d%s +red" % (C, ish[1], " k5" if k == 5 else ""))))
+                        # the producer is a wide expand unit on the low-rank BN backward: it takes its gradient as ca o dX o act'(z) (mny_dw_bnbwd_red_dz)
+                        lr = prod.op == "pw" and lr_ok(prod) and _lib.query("mny_dw_bnbwd_red_dz_supported", nd.k, o.C, int(self.bf16)) == 1
+                        if lr:
+                            self.lr_units.add(i.id)
+                        red_name = "mny_dw_bnbwd_red_dz" if lr else self.K("mny_dw_bnbwd_red")
+                        contribute_kernel(i, lambda out, addend, G=G, u=u, xv=xv, wt=wt, dwv=dwv_k, wsl=ws_k, ish=ish, C=o.C, act=o.act, M=M, pu=pu, rbuf=rbuf, k=nd.k, red_name=red_name, lr=lr: bwd.add(
+                            red_name, G, u.Y, u.scale, u.shift, act, self.coef_ws, xv[0], xv[1], xv[2], xv[3], pu.mean, pu.invstd, wt, addend,
+                            out, dwv, wsl, rbuf, N, ish[1], ish[2], C, k, 1, self.stream, label=self.K("mny_dw_bnbwd_red"),
+                            meta=dict(flops=4 * M * C * k * k, bytes=self.eb * 4 * M * C, shape="C%d H%d%s +red%s" % (C, ish[1], " k5" if k == 5 else "", " dz" if lr else ""))))
                     else:
                         contribute_kernel(i, lambda out, addend, G=G, u=u, xv=xv, wt=wt, dwv=dwv_k, wsl=ws_k, ish=ish, C=o.C, act=o.act, M=M, k=nd.k: bwd.add(
                             self.K("mny_dw_bnbwd"), G, u.Y, u.scale, u.shift, act, self.coef_ws, xv[0], xv[1], xv[2], xv[3], wt, addend, out, dwv, wsl,
@@ -1189,43 +1281,41 @@ class NetPlan:
                 # (bf16 storage: round 2 measured the epilogue's 2-byte loads of the unit's output at what the saved pass cost, 3 281 vs
                 # 3 293 img/s on MobileNetV3 512; with round 3's kernels it wins — same-box A/B 17.65-17.70 vs 17.93-17.99 ms/step — and is on;
                 # MNY_REDFUSE_BF16=0 turns it off for A/B)
-                if (os.environ.get("MNY_NO_REDFUSE") != "1" and (not self.bf16 or os.environ.get("MNY_REDFUSE_BF16") != "0")
-                        and prod is not None and prod.op in ("dw", "pw") and gs[i.id].buf is None
-                        and n_consumers[i.id] == 1 and not takes_own_sums(prod)
-                        and _lib.query(K("mny_pw_dgrad_bnred_supported"), M, oc, i.C, i.act) == 1):
+                # the unit whose complete output gradient this data gradient is (i itself, or — through a residual add — the add's unit operand)
+                tgt = red_target(i, nd) if (os.environ.get("MNY_NO_REDFUSE") != "1" and (not self.bf16 or os.environ.get("MNY_REDFUSE_BF16") != "0")) else None
+                if (tgt is not None and gs[i.id].buf is None
+                        and _lib.query(K("mny_pw_dgrad_bnred_supported"), M, oc, i.C, tgt.act) == 1):
                     # this data gradient IS the complete dL/d(output) of a conv+BN+act unit whose backward starts with a BN reduction:
                     # the sums are taken from the GEMM's own output tile (+ the unit's raw output), the separate reduce pass is dropped
-                    pu = self.units[i.id]
+                    pu = self.units[tgt.id]
                     rparts = _lib.query(K("mny_pw_dgrad_bnred_parts"), M, oc, i.C)
                     rbuf = torch.empty(rparts * 2 * i.C, **f32)
-                    self.fused_red[i.id] = (rbuf, rparts)
+                    self.fused_red[tgt.id] = (rbuf, rparts)
                     if wT6 is not None:
-                        contribute_kernel(i, lambda out, addend, dY=dY, wT6=wT6, M=M, K=oc, Nc=i.C, pu=pu, rbuf=rbuf, act_=i.act: bwd.add(
+                        contribute_kernel(i, lambda out, addend, dY=dY, wT6=wT6, M=M, K=oc, Nc=i.C, pu=pu, rbuf=rbuf, act_=tgt.act: bwd.add(
                             "mny_pw_dgrad_bnred_w6", dY, wT6, None, out, pu.Y, pu.scale, pu.shift, act_, pu.mean, pu.invstd, rbuf, M, K, Nc, self.stream,
                             label="mny_pw_dgrad_bnred",
                             meta=dict(flops=2 * M * K * Nc, bytes=self.eb * (M * K + 2 * M * Nc) + 4 * K * Nc, shape="dgrad+red M%d K%d N%d" % (M, K, Nc))))
                     else:
-                        contribute_kernel(i, lambda out, addend, dY=dY, wT=wT, M=M, K=oc, Nc=i.C, pu=pu, rbuf=rbuf, act_=i.act: bwd.add(
+                        contribute_kernel(i, lambda out, addend, dY=dY, wT=wT, M=M, K=oc, Nc=i.C, pu=pu, rbuf=rbuf, act_=tgt.act: bwd.add(
                             self.K("mny_pw_dgrad_bnred"), dY, wT, out, pu.Y, pu.scale, pu.shift, act_, pu.mean, pu.invstd, rbuf, M, K, Nc, self.stream,
                             meta=dict(flops=2 * M * K * Nc, bytes=self.eb * (M * K + 2 * M * Nc) + 4 * K * Nc, shape="dgrad+red M%d K%d N%d" % (M, K, Nc))))
-                elif (os.environ.get("MNY_NO_REDFUSE") != "1" and os.environ.get("MNY_NO_REDADD") != "1"
-                        and (not self.bf16 or os.environ.get("MNY_REDFUSE_BF16") != "0")
-                        and prod is not None and prod.op in ("dw", "pw") and gs[i.id].buf is not None and last_consumer.get(i.id) is nd
-                        and i.id not in loss_ids and not takes_own_sums(prod)
-                        and _lib.query(K("mny_pw_dgrad_bnred_add_supported"), M, oc, i.C, i.act) == 1):
+                elif (tgt is not None and os.environ.get("MNY_NO_REDADD") != "1" and gs[i.id].buf is not None
+                        and _lib.query(K("mny_pw_dgrad_bnred_add_supported"), M, oc, i.C, tgt.act) == 1):
                     # the LAST contribution to the output gradient of a conv+BN+act unit (a project conv feeding a residual add and the
-                    # next block): the earlier contributions arrive as the addend, the epilogue sees the complete gradient -> BN sums here
-                    pu = self.units[i.id]
+                    # next block — or the block input that IS that residual sum): the earlier contributions arrive as the addend, the epilogue
+                    # sees the complete gradient -> BN sums here
+                    pu = self.units[tgt.id]
                     rparts = _lib.query(K("mny_pw_dgrad_bnred_parts"), M, oc, i.C)
                     rbuf = torch.empty(rparts * 2 * i.C, **f32)
-                    self.fused_red[i.id] = (rbuf, rparts)
+                    self.fused_red[tgt.id] = (rbuf, rparts)
                     if wT6 is not None:
-                        contribute_kernel(i, lambda out, addend, dY=dY, wT6=wT6, M=M, K=oc, Nc=i.C, pu=pu, rbuf=rbuf, act_=i.act: bwd.add(
+                        contribute_kernel(i, lambda out, addend, dY=dY, wT6=wT6, M=M, K=oc, Nc=i.C, pu=pu, rbuf=rbuf, act_=tgt.act: bwd.add(
                             "mny_pw_dgrad_bnred_w6", dY, wT6, addend, out, pu.Y, pu.scale, pu.shift, act_, pu.mean, pu.invstd, rbuf, M, K, Nc, self.stream,
                             label="mny_pw_dgrad_bnred_add",
                             meta=dict(flops=2 * M * K * Nc, bytes=self.eb * (M * K + 3 * M * Nc) + 4 * K * Nc, shape="dgrad+add+red M%d K%d N%d" % (M, K, Nc))))
                     else:
-                        contribute_kernel(i, lambda out, addend, dY=dY, wT=wT, M=M, K=oc, Nc=i.C, pu=pu, rbuf=rbuf, act_=i.act: bwd.add(
+                        contribute_kernel(i, lambda out, addend, dY=dY, wT=wT, M=M, K=oc, Nc=i.C, pu=pu, rbuf=rbuf, act_=tgt.act: bwd.add(
                             self.K("mny_pw_dgrad_bnred_add"), dY, wT, addend, out, pu.Y, pu.scale, pu.shift, act_, pu.mean, pu.invstd, rbuf, M, K, Nc, self.stream,
                             meta=dict(flops=2 * M * K * Nc, bytes=self.eb * (M * K + 3 * M * Nc) + 4 * K * Nc, shape="dgrad+add+red M%d K%d N%d" % (M, K, Nc))))
                 else:
@@ -1405,6 +1495,7 @@ class NetPlan:
         self.stream.value = torch.cuda.current_stream(self.dev).cuda_stream
         # event-bracketed runs (bench breakdown) keep everything on one stream so the brackets mean something
         self.stream_side.value = self._side_stream.cuda_stream if (self.side_on and self.timing is None) else self.stream.value
+        self.stream_side2.value = self._side2_stream.cuda_stream if (self.side_on and self.timing is None) else self.stream.value
         self.x_ptr.value = self.saved_x.data_ptr()
         self.g_scale.copy_(g_losses.reshape(self.g_scale.numel()).to(self.g_scale.dtype))
         if self.reducer is not None:
@@ -1420,6 +1511,16 @@ class NetPlan:
             self._ev_fork.record(torch.cuda.current_stream(self.dev))
             self._side_stream.wait_event(self._ev_fork)
             self._side_used = True
+
+    def _fork_side2(self):
+        if self.side_on and self.timing is None:
+            self._ev_fork2.record(torch.cuda.current_stream(self.dev))
+            self._side2_stream.wait_event(self._ev_fork2)
+
+    def _join_side2(self):
+        if self.side_on and self.timing is None:
+            self._ev_join2.record(self._side2_stream)
+            torch.cuda.current_stream(self.dev).wait_event(self._ev_join2)
 
     def _join_side(self):
         if self._side_used:

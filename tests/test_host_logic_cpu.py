@@ -109,3 +109,29 @@ def test_allreduce_model_is_monotone_and_small_against_the_step():
     spec.loader.exec_module(b)
     m = b.allreduce_model(4935990 * 4, 4)
     assert m["n2_ms"] < m["n4_ms"] < m["n8_ms"] < 1.0            # 19.7 MB of fp32 gradients: well under a millisecond on xGMI
+
+
+def test_compact_bench_line_fits_an_8k_tail_and_keeps_every_roofline_object():
+    """the driver keeps an 8 kB tail of stdout.  The compact line (what `python bench.py` prints) must stay well under
+    that and end with the evidence: every roofline object (worst fraction first), configs[3], cpu_baseline and the contract's keys."""
+    import importlib.util
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod3", os.path.join(repo, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    res = json.load(open(os.path.join(repo, "profiles", "r05_bench_n1.json")))       # a real verbose line (round 5)
+    res["config0"] = {"workload": "x" * 100, "value": 1.0, "unit": "images/s", "ms": 1.0, "cpu_baseline": {"value": 1.0, "unit": "images/s", "cores": 16, "kind": "port", "sample": "y" * 100}}
+    res["config3"]["cpu_baseline"] = {"value": 1.0, "unit": "images/s", "cores": 16, "kind": "port", "sample": "z" * 120}
+    c = b.compact_line(res)
+    line = json.dumps(c, separators=(",", ":"))
+    assert len(line) < 7500, len(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline", "roofline_hbm", "roofline_more", "config3", "config0"):
+        assert k in c, k
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in c["roofline"], k
+    assert {o["kernel"] for o in c["roofline_more"]} == {o["kernel"] for o in res["roofline_more"]}
+    fr = [o["frac"] for o in c["roofline_more"]]
+    assert fr == sorted(fr)                                                             # worst first
+    tail = line[-5000:]                                                                 # even a 5 kB tail holds the roofline block and configs[3]
+    assert '"roofline_more"' in tail and '"config3"' in tail and '"roofline_hbm"' in tail

@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 # one stream in EVERY step of the profiled runs (warm-up and second-pass steps too): with the weight gradients on the side stream a small
 # kernel that shares the CUs with one of them is recorded with a stretched duration (bn_bwd_finalize: 5.6 -> 10.3 us average)
 export MNY_SIDE_STREAM=0
-rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_stats -o run -- python3 $REPO/bench.py --steps 10 --warmup 3 --bracket-every 1 --no-cpu-baseline --no-nms > $REPO/gpurun_out/prof_stats.json 2> $REPO/gpurun_out/prof_stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $REPO/gpurun_out/prof_stats -o run -- python3 $REPO/bench.py --steps 10 --warmup 3 --bracket-every 1 --no-cpu-baseline --no-nms --full-json > $REPO/gpurun_out/prof_stats.json 2> $REPO/gpurun_out/prof_stats.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $REPO/gpurun_out/prof_fetch -o run -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-nms > /dev/null 2> $REPO/gpurun_out/prof_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $REPO/gpurun_out/prof_write -o run -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-nms > /dev/null 2> $REPO/gpurun_out/prof_write.err
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $REPO/gpurun_out/prof_mfma -o run -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-nms > /dev/null 2> $REPO/gpurun_out/prof_mfma.err
