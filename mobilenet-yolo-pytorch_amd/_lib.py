@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MNY_LIB") or os.path.join(HERE, "libmnyolo.so")     # MNY_LIB: A/B another build on the same GPU box
 
 ACT_NONE, ACT_RELU6, ACT_LEAKY, ACT_RELU, ACT_HSWISH, ACT_HSIGMOID = 0, 1, 2, 3, 4, 5
-ROUTE_TILE_V1, ROUTE_DMA_F32, ROUTE_DMA_X6, ROUTE_THIN, ROUTE_WIDE, ROUTE_WGRAD_STREAM = 0, 1, 2, 3, 4, 5      # mny_pw_route
+ROUTE_TILE_V1, ROUTE_DMA_F32, ROUTE_DMA_X6, ROUTE_THIN, ROUTE_WIDE, ROUTE_WGRAD_STREAM, ROUTE_WAVE16 = 0, 1, 2, 3, 4, 5, 6      # mny_pw_route
 
 
 class MnyError(RuntimeError):

@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256) void lr_gram_kernel(const T* __restrict__ x, c
             const T* xr = x + row * K;
             a[u] = ld1(xr + (oki ? ci : 0));
 #pragma unroll
-            for (int t = 0; t < TJ; ++t) b[u][t] = ld1(xr + cj[t]);
+            for (int t = 0; t < TJ; ++t)
+                if (t >= ti) b[u][t] = ld1(xr + cj[t]);   // (G is symmetric: the band's tiles left of the diagonal come from the transposed write below)
         }
     };
     int64_t g = wv;
@@ -81,6 +82,7 @@ __global__ __launch_bounds__(256) void lr_gram_kernel(const T* __restrict__ x, c
             const float a = rok ? act_fwd(fmaf(ra[u], si, hi_), act) : 0.f;
 #pragma unroll
             for (int t = 0; t < TJ; ++t) {
+                if (t < ti) continue;                                        // wave-uniform
                 const float b = rok ? act_fwd(fmaf(rb[u][t], sj[t], hj[t]), act) : 0.f;
                 cs[t] += b;
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
@@ -91,7 +93,8 @@ __global__ __launch_bounds__(256) void lr_gram_kernel(const T* __restrict__ x, c
             for (int u = 0; u < U; ++u) {
                 ra[u] = na[u];
 #pragma unroll
-                for (int t = 0; t < TJ; ++t) rb[u][t] = nb[u][t];
+                for (int t = 0; t < TJ; ++t)
+                    if (t >= ti) rb[u][t] = nb[u][t];
             }
         }
     }
@@ -111,11 +114,13 @@ __global__ __launch_bounds__(256) void lr_gram_kernel(const T* __restrict__ x, c
         __syncthreads();
     }
     float* prow = parts + (int64_t)blockIdx.x * ((int64_t)K * K + K);
-    for (int e = tid; e < 32 * BW; e += 256) {
+    for (int e = tid; e < 32 * BW; e += 256) {           // the band from the diagonal tile on, and its mirror image below the diagonal
         const int i = e / BW, j = e - i * BW;
-        if (ti * 32 + i < K && j < K) prow[(int64_t)(ti * 32 + i) * K + j] = red[e];
+        if (j < ti * 32 || ti * 32 + i >= K || j >= K) continue;
+        prow[(int64_t)(ti * 32 + i) * K + j] = red[e];
+        if (j >= (ti + 1) * 32) prow[(int64_t)j * K + ti * 32 + i] = red[e];
     }
-    if (ti == 0) {                                       // column sums: the two pixels of a pair, then the four waves
+    if (ti == 0) {                                       // column sums (every tile column is live in band 0): the two pixels of a pair, then the four waves
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < TJ; ++t) {

@@ -266,7 +266,9 @@ struct Gemm2Args {   // A / B / addend / C: float* (BF = 0) or bf16_t* (BF = 1)
 #ifndef MNY_W6_SWP
 #define MNY_W6_SWP 1              // planes mode without a reduction epilogue: the A fragment of stage t is read, transformed and cut BETWEEN the MFMAs of stage t-1 (0: one stage at a time)
 #endif
-template <int TN, int XF, int BF, int RED = 0, int X6 = 0>
+// RB (RED kernels only): the product carries the per-column constant p.bias INSIDE the sums of the reduction epilogue (mny_pw_lr_fix); a template
+// flag, not a run-time test: one more live register in the data-gradient instantiations broke the bf16 TN = 3 addend form (NaN outputs, round 6)
+template <int TN, int XF, int BF, int RED = 0, int X6 = 0, int RB = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((X6 == 3 && RED == 0 && MNY_W6_SWP) ? 2 : 3, 8))) void pw_gemm_nt_dma_kernel(Gemm2Args p) {
     using T = typename std::conditional<BF != 0, bf16_t, float>::type;
     constexpr int EPC = BF ? 8 : 4;                                           // elements per 16-B chunk
@@ -577,7 +579,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((X6 == 3 &&
                 const bool ccol = col < p.N;
                 const int cc = ccol ? col : 0;
                 const float rsc = p.r_scale[cc], rsh = p.r_shift[cc], rmu = p.r_mean[cc], ris = p.r_invstd[cc];
-                const float rbias = p.bias ? p.bias[cc] : 0.f;   // (mny_pw_lr_fix: the gradient carries a per-column constant; data gradients have none)
+                float rbias = 0.f;                                // (mny_pw_lr_fix: the gradient carries a per-column constant; data gradients have none)
+                if constexpr (RB != 0) rbias = p.bias[cc];
                 const float rslope = act_slope(p.r_act), rhi = act_hi(p.r_act);
                 const int64_t rbase = m0 + wv * 32 + 4 * khalf;
                 const int rows_left = (int)max((int64_t)0, min((int64_t)64, p.M - rbase));   // rows rbase + 8*gq + j, 8*gq + j < rows_left, exist
@@ -596,7 +599,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((X6 == 3 &&
                     for (int j = 0; j < 4; ++j) {
                         const float z = fmaf(yv[j], rsc, rsh);
                         const float dact = p.r_act >= MNY_ACT_HSWISH ? act_bwd(z, p.r_act) : (z > 0.f ? 1.f : rslope) * (z < rhi ? 1.f : 0.f);
-                        const float dz = stored<T>(acc[u][gq * 4 + j] + rbias + av[j]) * dact;
+                        const float dz = stored<T>(RB != 0 ? acc[u][gq * 4 + j] + rbias + av[j] : acc[u][gq * 4 + j] + av[j]) * dact;
                         if (ccol && 8 * gq + j < rows_left) { s1[u] += dz; s2[u] = fmaf(dz, (yv[j] - rmu) * ris, s2[u]); }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -3004,8 +3007,8 @@ static int pw_lr_fix_impl(const float* x, const float* in_scale, const float* in
                 ry, r_scale, r_shift, r_mean, r_invstd, r_act};
     const bool x6 = nt_x6(M, K, K);
     Nt2Kernel k;
-#define MNY_FX(T) (xf ? (x6 ? (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 1, 0, 2, 1> : (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 1, 0, 2>) \
-                      : (x6 ? (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 0, 0, 2, 1> : (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 0, 0, 2>))
+#define MNY_FX(T) (xf ? (x6 ? (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 1, 0, 2, 1, 1> : (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 1, 0, 2, 0, 1>) \
+                      : (x6 ? (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 0, 0, 2, 1, 1> : (Nt2Kernel)pw_gemm_nt_dma_kernel<T, 0, 0, 2, 0, 1>))
     if (red) switch (p2.TN) { case 1: k = MNY_FX(1); break; case 2: k = MNY_FX(2); break; default: k = MNY_FX(3); break; }
     else k = nt2_kernel(p2.TN, xf ? 1 : 0, 0, x6 ? 1 : 0);
 #undef MNY_FX

@@ -45,17 +45,23 @@ def _gate_conv_forward(self, x):
 
 
 @contextlib.contextmanager
-def bf16_storage(model):
-    """Inside the context, `model` (a RefYolo / RefYoloV3) computes what the product's bf16-storage plan computes."""
+def bf16_storage(model, gate_fused=True, absorbed=None):
+    """Inside the context, `model` (a RefYolo / RefYoloV3) computes what the product's bf16-storage plan computes.
+
+    The two facts about the plan that move rounding points are ARGUMENTS, taken by the tests from the product's plan itself so that the
+    model cannot drift from what ran: `gate_fused` — the per-pixel gates run as one unit (plan.gates non-empty; with
+    MNY_NO_GATE=1 their two convs are ordinary convs with stored outputs and the multiply is a stored tensor); `absorbed` — names of the
+    blocks (e.g. "backbone.bneck.3") whose residual add absorbs the gate's multiply (plan.gates[...]["add"] is not None); None = every
+    stride-1 block with a gate (what the default plan does)."""
     from . import net_ref_v3
     gates = [m for m in model.modules() if isinstance(m, net_ref_v3.PixelGate)]
-    gate_convs = {id(c) for gt in gates for c in gt.modules() if isinstance(c, nn.Conv2d)}
+    gate_convs = {id(c) for gt in gates for c in gt.modules() if isinstance(c, nn.Conv2d)} if gate_fused else set()
     convs = [m for m in model.modules() if isinstance(m, nn.Conv2d)]
     for m in convs:
         m.forward = types.MethodType(_gate_conv_forward if id(m) in gate_convs else _conv_forward, m)
-    for blk in model.modules():
+    for name, blk in model.named_modules():
         if isinstance(blk, net_ref_v3.V3Block) and blk.se is not None:
-            blk.se._absorbed_by_add = blk.stride == 1
+            blk.se._absorbed_by_add = gate_fused and (blk.stride == 1 if absorbed is None else name in absorbed)
     old = net_ref.STORE
     net_ref.STORE = q
     try:

@@ -111,7 +111,7 @@ def run_forward(case, C, R):
 
 
 @pytest.mark.parametrize("C,R", SHAPES)
-@pytest.mark.parametrize("M,residual", [(16 * 37 + 5, None), (4096, "real"), (64 * 64 * 3, "view")])
+@pytest.mark.parametrize("M,residual", [(16 * 37 + 5, None), (4096, "real"), (64 * 64 * 3, "view"), (32768 * 2 + 21, "view")])      # the last: above the capped grid (32 768 pixels), ragged — every workgroup accumulates several 16-pixel tiles into its partial row
 def test_gate_forward_matches_torch(C, R, M, residual):
     case = make_case(M, C, R, seed=C + M, residual=residual)
     ref = ref_forward(*case)
@@ -163,7 +163,7 @@ def ref_backward(case, dout):
 
 
 @pytest.mark.parametrize("C,R", SHAPES)
-@pytest.mark.parametrize("M", [16 * 37 + 5, 128 * 40])
+@pytest.mark.parametrize("M", [16 * 37 + 5, 128 * 40, 32768 * 2 + 21])          # the last: above the capped grid, ragged (multi-tile accumulation of the partial rows and dW partials, tail masking)
 def test_gate_backward_matches_autograd(C, R, M):
     dev = torch.device("cuda:0")
     case = make_case(M, C, R, seed=3 * C + M, residual=None)

@@ -109,6 +109,7 @@ def _q(t):
 
 
 @pytest.mark.parametrize("M,Ki,No,act", [(16 * 40, 16, 16, 3), (2000, 64, 24, 3), (1234, 72, 24, 3), (4096 + 7, 72, 40, 3), (3000, 120, 40, 3), (128 * 9, 120, 40, 4),
+                                         (65536 * 2 + 21, 72, 24, 3), (65536 + 4103, 120, 40, 3),       # above the 65 536-pixel cap of the grid, ragged
                                          (50000, 16, 16, 3), (16, 64, 24, 1)])
 def test_project_unit_backward_in_one_pass_bf16_storage(M, Ki, No, act):
     """mny_pj_bwd_bf16 (csrc/gate.hip): MobileNetV3's thin project convs (models/mobilenetv3.py:57-58,69) on bf16 storage, against fp64 with the
