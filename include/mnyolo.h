@@ -280,6 +280,12 @@ int mny_pw_lr_fix(const float* x, const float* in_scale, const float* in_shift, 
                   const float* ry, const float* r_scale, const float* r_shift, int r_act, const float* r_mean, const float* r_invstd, float* red,
                   int64_t M, int K, void* stream);
 int mny_lr_wfix(float* dw, const float* gram_sums, const float* coef, const float* w, int C, int K, void* stream);
+/* ... and for a 3x3 STRIDE-2 unit (fp32 storage, ReLU6 view of the producer): mny_dw_bnbwd_s2 with dx = in_scale o dX o relu6'(z) and the producer's
+ * BN-backward sums as partial rows in_red[mny_dw_bnbwd_s2_parts()][2][C] (models/mobilenetv2.py:73-81 at stride 2: block 96 -> 576 -> 160). */
+int mny_dw_bnbwd_s2_red_dz(const float* g, const float* y, const float* scale, const float* shift, int act, const float* coef,
+                           const float* x, const float* in_scale, const float* in_shift, int in_act, const float* in_mean,
+                           const float* in_invstd, const float* w, const float* addend, float* dx, float* dw, float* ws, float* in_red,
+                           int N, int H, int W, int C, void* stream);
 int mny_dw_bnbwd_red_dz_supported(int K, int C, int bf16);
 int mny_dw_bnbwd_red_dz(const float* g, const float* y, const float* scale, const float* shift, int act, const float* coef,
                         const float* x, const float* in_scale, const float* in_shift, int in_act, const float* in_mean,

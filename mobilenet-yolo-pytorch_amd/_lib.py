@@ -150,6 +150,7 @@ _SIGS["mny_pw_lr_fix"] = (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, P, P, P, 
 _SIGS["mny_lr_wfix"] = (c_int, [P, P, P, P, c_int, c_int, P])
 _SIGS["mny_dw_bnbwd_red_dz_supported"] = (c_int, [c_int, c_int, c_int])
 _SIGS["mny_dw_bnbwd_red_dz"] = _SIGS["mny_dw_bnbwd_red"]
+_SIGS["mny_dw_bnbwd_s2_red_dz"] = (c_int, [P, P, P, P, c_int, P, P, P, P, c_int, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P])
 _SIGS["mny_transpose_bf16"] = _SIGS["mny_transpose"]
 _SIGS["mny_cvt_f32_bf16"] = (c_int, [P, P, c_int64, P])
 _SIGS["mny_cvt_batch_f32_bf16"] = (c_int, [P, P, c_int, P])

@@ -245,11 +245,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
 //   dX of the 2x2 input quad from dY[i..i+1][j..j+1] with statically known taps (see dw_bwd_data_s2k3_kernel);
 //   dW += dY[i][j] * a[2i-1..2i+1][2j-1..2j+1]: input rows 2i, 2i+1 are loaded (three columns), row 2i-1 is carried over.
 // Same LDS-resident per-channel constants, masks instead of selects and XCD-contiguous strips as the stride-1 kernel.
-template <typename T, int AM, int XF>
+// RDZ (round 6, fp32 storage, ReLU6 input view): the input is the raw output of a wide expand unit P consumed only here and P runs the low-rank BN
+// backward (csrc/lrbwd.hip): the kernel stores  in_scale o dX o act_P'(z)  instead of dX and leaves P's BN-backward sums (sum dz, sum dz * xhat) as
+// partial rows in_red[gridDim.x][2][C] — mny_dw_bnbwd_red_dz for the stride-2 unit.
+template <typename T, int AM, int XF, bool RDZ = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void dw_bnbwd_s2k3_kernel(
     const T* __restrict__ g, const T* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift, int act,
     const float* __restrict__ coef, const T* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
-    int in_act, const float* __restrict__ w, const T* __restrict__ addend, T* __restrict__ dx, float* __restrict__ parts, DwbGeom gm) {
+    int in_act, const float* __restrict__ w, const T* __restrict__ addend, T* __restrict__ dx, float* __restrict__ parts, DwbGeom gm,
+    const float* __restrict__ in_mean = nullptr, const float* __restrict__ in_invstd = nullptr, float* __restrict__ in_red = nullptr) {
     __shared__ float4 red[256];
     extern __shared__ __attribute__((aligned(16))) float4 cst[];
     const int tid = threadIdx.x;
@@ -272,7 +276,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
         cst[13 * gm.cgb + cgl] = ld4(coef + 2 * gm.C + c);
         cst[14 * gm.cgb + cgl] = (XF != 0 && in_scale) ? ld4(in_scale + c) : f4one();
         cst[15 * gm.cgb + cgl] = (XF != 0 && in_scale) ? ld4(in_shift + c) : f4zero();
+        if (RDZ) { cst[16 * gm.cgb + cgl] = ld4(in_mean + c); cst[17 * gm.cgb + cgl] = ld4(in_invstd + c); }
     }
+    F4P rs1 = f4p0(), rs2 = f4p0();                      // RDZ: the producer's BN-backward sums of this thread's channels
     __syncthreads();
     if (cvalid) {
 #define WG(t) f4p(my[(t) * gm.cgb])
@@ -327,10 +333,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
             // summed over the input pixels a thread owns (each meets the one to four dY values whose window covers it, with the taps the
             // data gradient uses), so no halo column 2j-1 and no halo row 2i-1 of the 4x-sized input tensor is read any more: 4 input
             // loads per quad row instead of 6 (+ a carried row).
-            auto x_row = [&](int hi, const float4* my, F4P (&a)[2]) {
+            auto x_row = [&](int hi, const float4* my, F4P (&a)[2], float4 (&raw)[2]) {
                 const float rm = (hi >= 0 && hi < gm.H) ? 1.f : 0.f;
                 const T* p = xn + (int64_t)min(max(hi, 0), gm.H - 1) * pitch;
-                float4 raw[2];
 #pragma unroll
                 for (int q = 0; q < 2; ++q) raw[q] = ld4(p + xoff[q + 1]);
                 const F4P xsc = f4p(my[14 * gm.cgb]), xsh = f4p(my[15 * gm.cgb]);
@@ -354,9 +359,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                 asm volatile("" : "+v"(lo));                       // keeps the LDS constant reads inside the loop (see the stride-1 kernel)
                 const float4* my = cst + lo;
                 F4P d10, d11, a0[2], a1[2];
+                float4 raw0[2], raw1[2];
                 dy_row(i + 1, my, d10, d11);
-                x_row(2 * i, my, a0);
-                x_row(2 * i + 1, my, a1);
+                x_row(2 * i, my, a0, raw0);
+                x_row(2 * i + 1, my, a1, raw1);
                 // weight gradient: input (2i, 2j) <-> tap 4 of dY[i][j]; (2i, 2j+1) <-> taps 5 / 3 of dY[i][j] / dY[i][j+1]; (2i+1, 2j) <-> 7 / 1 of
                 // dY[i][j] / dY[i+1][j]; (2i+1, 2j+1) <-> 8 / 6 / 2 / 0 of dY[i][j] / dY[i][j+1] / dY[i+1][j] / dY[i+1][j+1]
                 pfma(wp[4], a0[0], d00);
@@ -379,6 +385,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                     if (hv) add4(f10, ld4(addend + base + pitch));
                     if (hv && wv2) add4(f11, ld4(addend + base + pitch + gm.C));
                 }
+                if constexpr (RDZ) {
+                    // dz = dX * relu6'(z) of the producer, its sums, and the stored value in_scale o dz (pixels outside the image: dz = 0 by the masks below)
+                    const F4P xsc = f4p(my[14 * gm.cgb]), xsh = f4p(my[15 * gm.cgb]), mu = f4p(my[16 * gm.cgb]), is = f4p(my[17 * gm.cgb]);
+                    auto one = [&](float4& f, const float4 rawv, float ok) {
+                        const F4P R = f4p(rawv), F = f4p(f);
+                        const v2f z0 = __builtin_elementwise_fma(R.lo, xsc.lo, xsh.lo), z1 = __builtin_elementwise_fma(R.hi, xsc.hi, xsh.hi);
+                        const v2f m0 = v2f{(z0.x > 0.f && z0.x < 6.f) ? ok : 0.f, (z0.y > 0.f && z0.y < 6.f) ? ok : 0.f};
+                        const v2f m1 = v2f{(z1.x > 0.f && z1.x < 6.f) ? ok : 0.f, (z1.y > 0.f && z1.y < 6.f) ? ok : 0.f};
+                        const v2f d0 = F.lo * m0, d1 = F.hi * m1;
+                        rs1.lo += d0; rs1.hi += d1;
+                        rs2.lo = __builtin_elementwise_fma(d0, (R.lo - mu.lo) * is.lo, rs2.lo);
+                        rs2.hi = __builtin_elementwise_fma(d1, (R.hi - mu.hi) * is.hi, rs2.hi);
+                        const v2f o0 = d0 * xsc.lo, o1 = d1 * xsc.hi;
+                        f = make_float4(o0.x, o0.y, o1.x, o1.y);
+                    };
+                    one(f00, raw0[0], 1.f);
+                    one(f01, raw0[1], wv2 ? 1.f : 0.f);
+                    one(f10, raw1[0], hv ? 1.f : 0.f);
+                    one(f11, raw1[1], (hv && wv2) ? 1.f : 0.f);
+                }
                 st4_stream(dx + base, f00);
                 if (wv2) st4_stream(dx + base + gm.C, f01);
                 if (hv) st4_stream(dx + base + pitch, f10);
@@ -399,6 +425,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
             float* dst = parts + (int64_t)blockIdx.x * gm.C * 9;
             dst[(c + 0) * 9 + t] = a.x; dst[(c + 1) * 9 + t] = a.y;
             dst[(c + 2) * 9 + t] = a.z; dst[(c + 3) * 9 + t] = a.w;
+        }
+    }
+    if constexpr (RDZ) {                                 // per-block partial row of the producer's sums, fixed order over the pixel slots
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            __syncthreads();
+            red[tid] = f4u(k == 0 ? rs1 : rs2);
+            __syncthreads();
+            if (pix == 0 && cvalid) {
+                float4 a = f4zero();
+                for (int p = 0; p < ppb; ++p) add4(a, red[p * gm.cgb + cgl]);
+                st4(in_red + (int64_t)blockIdx.x * 2 * gm.C + k * gm.C + c, a);
+            }
         }
     }
 }
@@ -449,6 +488,28 @@ static int dw_bnbwd_s2_impl(const T* g, const T* y, const float* scale, const fl
     }
 #undef MNY_L2
     rc = check_launch("dw_bnbwd_s2k3_kernel");
+    if (rc || !dw) return rc;
+    return launch_reduce_parts(ws, gx, C * 9, dw, st);
+}
+
+// stride-2 unit behind a wide expand unit on the low-rank BN backward: dx = in_scale o dX o relu6'(z), + the producer's sums (fp32 storage, ReLU6 view)
+static int dw_bnbwd_s2_red_dz_impl(const float* g, const float* y, const float* scale, const float* shift, int act, const float* coef,
+                                   const float* x, const float* in_scale, const float* in_shift, int in_act, const float* in_mean, const float* in_invstd,
+                                   const float* w, const float* addend, float* dx, float* dw, float* ws, float* in_red, int N, int H, int W, int C, void* stream) {
+    MNY_REQUIRE(g && y && scale && shift && coef && x && w && dx && ws && in_scale && in_shift && in_mean && in_invstd && in_red, "dw_bnbwd_s2_red_dz: null pointer");
+    MNY_REQUIRE(in_act == MNY_ACT_RELU6 && act != MNY_ACT_HSIGMOID, "dw_bnbwd_s2_red_dz: the producer's activation must be ReLU6 (got %d)", in_act);
+    DwbGeom gm; CgLayout L; int gx;
+    int rc = dwb2_geom(gm, L, gx, N, H, W, C);
+    if (rc) return rc;
+    dim3 grid(gx, L.chunks), block(L.threads);
+    hipStream_t st = (hipStream_t)stream;
+    const int am = act == MNY_ACT_NONE ? 0 : (act == MNY_ACT_HSWISH ? 2 : 1);
+    const size_t lds = (size_t)18 * L.cgb * sizeof(float4);
+#define MNY_L2R(A_) hipLaunchKernelGGL((dw_bnbwd_s2k3_kernel<float, A_, 1, true>), grid, block, lds, st, g, y, scale, shift, act, coef, x, in_scale, in_shift, \
+                                       in_act, w, addend, dx, ws, gm, in_mean, in_invstd, in_red)
+    switch (am) { case 0: MNY_L2R(0); break; case 1: MNY_L2R(1); break; default: MNY_L2R(2); break; }
+#undef MNY_L2R
+    rc = check_launch("dw_bnbwd_s2k3_kernel<red_dz>");
     if (rc || !dw) return rc;
     return launch_reduce_parts(ws, gx, C * 9, dw, st);
 }
@@ -561,6 +622,12 @@ extern "C" int mny_dw_bnbwd_red(const float* g, const float* y, const float* sca
                                 in_mean, in_invstd, in_red);
 }
 
+extern "C" int mny_dw_bnbwd_s2_red_dz(const float* g, const float* y, const float* scale, const float* shift, int act, const float* coef,
+                                      const float* x, const float* in_scale, const float* in_shift, int in_act, const float* in_mean, const float* in_invstd,
+                                      const float* w, const float* addend, float* dx, float* dw, float* ws, float* in_red, int N, int H, int W, int C,
+                                      void* stream) {
+    return dw_bnbwd_s2_red_dz_impl(g, y, scale, shift, act, coef, x, in_scale, in_shift, in_act, in_mean, in_invstd, w, addend, dx, dw, ws, in_red, N, H, W, C, stream);
+}
 // the same, storing  in_scale o dX o act_P'(in_scale x + in_shift)  instead of dX: the producer unit P runs the low-rank BN backward (csrc/lrbwd.hip)
 extern "C" int mny_dw_bnbwd_red_dz_supported(int K, int C, int bf16) { return (K == 3 && !dwt_use(3, bf16 ? 1 : 0, 1, C)) ? 1 : 0; }
 extern "C" int mny_dw_bnbwd_red_dz(const float* g, const float* y, const float* scale, const float* shift, int act, const float* coef,

@@ -1172,6 +1172,23 @@ class NetPlan:
                     if self.defer and single(nd):
                         dparts = _lib.query("mny_dw_bnbwd_s2_parts", N, ish[1], ish[2], o.C)
                         dwv_k, ws_k = None, defer_job(dparts * o.C * 9, dwv, dparts, o.C * 9)
+                    prod = i.node
+                    # behind a wide expand unit on the low-rank BN backward (round 6): the producer's sums and  ca o dX o relu6'(z)  leave with this pass
+                    if (not self.bf16 and i.kind == "unit" and prod is not None and prod.op == "pw" and gs[i.id].buf is None and n_consumers[i.id] == 1
+                            and xv[1] is not None and i.act == _lib.ACT_RELU6 and lr_ok(prod) and os.environ.get("MNY_NO_LR_S2") != "1"):
+                        pu = self.units[i.id]
+                        rparts = _lib.query("mny_dw_bnbwd_s2_parts", N, ish[1], ish[2], o.C)
+                        rbuf = torch.empty(rparts * 2 * i.C, **f32)
+                        self.fused_red[i.id] = (rbuf, rparts)
+                        self.lr_units.add(i.id)
+                        contribute_kernel(i, lambda out, addend, G=G, u=u, xv=xv, wt=wt, dwv=dwv_k, wsl=ws_k, ish=ish, C=o.C, act=o.act, M=M, pu=pu, rbuf=rbuf: bwd.add(
+                            "mny_dw_bnbwd_s2_red_dz", G, u.Y, u.scale, u.shift, act, self.coef_ws, xv[0], xv[1], xv[2], xv[3], pu.mean, pu.invstd, wt, addend, out, dwv, wsl, rbuf,
+                            N, ish[1], ish[2], C, self.stream, label=self.K("mny_dw_bnbwd_s2"),
+                            meta=dict(flops=4 * M * C * 9, bytes=self.eb * (2 * M * C + 2 * N * ish[1] * ish[2] * C), shape="C%d H%d s2 +red dz" % (C, ish[1]))))
+                        flush_shared()
+                        flush_reduce()
+                        bwd.marks[o.name] = len(bwd.calls)
+                        continue
                     contribute_kernel(i, lambda out, addend, G=G, u=u, xv=xv, wt=wt, dwv=dwv_k, wsl=ws_k, ish=ish, C=o.C, act=o.act, M=M: bwd.add(
                         self.K("mny_dw_bnbwd_s2"), G, u.Y, u.scale, u.shift, act, self.coef_ws, xv[0], xv[1], xv[2], xv[3], wt, addend, out, dwv, wsl,
                         N, ish[1], ish[2], C, self.stream,

@@ -174,3 +174,41 @@ def test_depthwise_backward_stores_the_masked_scaled_gradient(C, H, W, in_act):
     want = dx0 * ((z > 0) & (z < 6)).float() * xsc
     assert torch.isfinite(dx1).all()
     assert (dx1 - want).abs().max().item() <= 1e-6 * want.abs().max().item()
+
+
+@pytest.mark.parametrize("C,H,W,act", [(576, 22, 22, 1), (96, 31, 17, 1), (192, 12, 12, 1)])
+def test_stride2_depthwise_backward_stores_the_masked_scaled_gradient_and_the_producer_sums(C, H, W, act):
+    """mny_dw_bnbwd_s2_red_dz == mny_dw_bnbwd_s2 with dx replaced by in_scale o dx o relu6'(in_scale x + in_shift), same dw, and its partial rows
+    sum to what mny_bn_bwd_reduce computes over (that dx, x) — odd sizes included (the masked last row / column)."""
+    dev = torch.device("cuda:0")
+    N = 3
+    g = torch.Generator().manual_seed(C + H)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev).contiguous()      # noqa: E731
+    G, Y, X = rnd(N, Ho, Wo, C), rnd(N, Ho, Wo, C), rnd(N, H, W, C) * 2
+    sc, sh = (torch.rand(C, generator=g) + 0.5).to(dev), (torch.randn(C, generator=g) * 0.3).to(dev)
+    coef = torch.stack((torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1)).to(dev).contiguous()
+    xsc, xsh = (torch.rand(C, generator=g) + 0.5).to(dev), (torch.randn(C, generator=g) * 0.5 + 1.0).to(dev)
+    xmu, xis = (torch.randn(C, generator=g) * 0.2).to(dev), (torch.rand(C, generator=g) + 0.5).to(dev)
+    wt = (torch.randn(C, 1, 3, 3, generator=g) / 3).to(dev).contiguous()
+    parts = _lib.query("mny_dw_bnbwd_s2_parts", N, H, W, C)
+    dx0, dw0 = torch.full((N, H, W, C), float("nan"), device=dev), torch.zeros(C, 1, 3, 3, device=dev)
+    ws = torch.zeros(parts * C * 9, device=dev)
+    _lib.call("mny_dw_bnbwd_s2", ptr(G), ptr(Y), ptr(sc), ptr(sh), _lib.ACT_RELU6, ptr(coef), ptr(X), ptr(xsc), ptr(xsh), _lib.ACT_RELU6, ptr(wt), None,
+              ptr(dx0), ptr(dw0), ptr(ws), N, H, W, C, stream())
+    dx1, dw1 = torch.full((N, H, W, C), float("nan"), device=dev), torch.zeros(C, 1, 3, 3, device=dev)
+    red = torch.full((parts, 2, C), float("nan"), device=dev)
+    _lib.call("mny_dw_bnbwd_s2_red_dz", ptr(G), ptr(Y), ptr(sc), ptr(sh), _lib.ACT_RELU6, ptr(coef), ptr(X), ptr(xsc), ptr(xsh), _lib.ACT_RELU6, ptr(xmu), ptr(xis),
+              ptr(wt), None, ptr(dx1), ptr(dw1), ptr(ws), ptr(red), N, H, W, C, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(dw0, dw1)
+    z = X * xsc + xsh
+    mask = ((z > 0) & (z < 6)).float()
+    want = dx0 * mask * xsc
+    assert torch.isfinite(dx1).all()
+    assert (dx1 - want).abs().max().item() <= 1e-6 * want.abs().max().item()
+    dz = (dx0 * mask).double()
+    s = red.double().sum(0)
+    s1, s2 = dz.sum((0, 1, 2)), (dz * ((X.double() - xmu.double()) * xis.double())).sum((0, 1, 2))
+    assert (s[0] - s1).abs().max().item() <= 2e-5 * dz.abs().sum((0, 1, 2)).max().item() + 1e-4
+    assert (s[1] - s2).abs().max().item() <= 2e-5 * (dz * ((X.double() - xmu.double()) * xis.double())).abs().sum((0, 1, 2)).max().item() + 1e-4
