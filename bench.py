@@ -101,7 +101,7 @@ import torch  # noqa: E402
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 MFMA peak
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
-PROFILE_TAG = "r05"               # profiles/<tag>_traffic_*.json: PMC passes of this round (tools/prof_round.sh + tools/prof_summary.py)
+PROFILE_TAG = "r06"               # profiles/<tag>_traffic_*.json: PMC passes of this round (tools/prof_round.sh + tools/prof_summary.py)
 BATCH = 256
 SIZE = 352
 

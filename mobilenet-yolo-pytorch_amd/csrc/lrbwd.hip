@@ -53,50 +53,58 @@ __global__ __launch_bounds__(256) void lr_gram_kernel(const T* __restrict__ x, c
     float cs[TJ];
 #pragma unroll
     for (int t = 0; t < TJ; ++t) cs[t] = 0.f;
-    // a wave takes groups of U consecutive pixel pairs, every fourth group; the NEXT group's loads are requested before this group's products
+    // a wave takes groups of U consecutive pixel pairs, every fourth group; the NEXT group's loads are requested before this group's products.
+    // G is symmetric: band ti forms only the tiles on and right of the diagonal (the mirror image is written below).  The band index is a
+    // COMPILE-TIME constant of the loop body (one copy per band, selected once): run-time `t >= ti` tests around the loads and MFMAs of the
+    // unrolled tile loop cost more than the skipped tiles saved (K = 64: 31 -> 44 us).
     constexpr int U = TJ <= 3 ? 4 : 2;
     const int64_t npairs = (r1 - r0 + 1) / 2;
     const int64_t ngroups = (npairs + U - 1) / U;
-    float ra[U], rb[U][TJ];
-    auto load = [&](int64_t gidx, float (&a)[U], float (&b)[U][TJ]) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            int64_t row = r0 + 2 * (gidx * U + u) + half;
-            if (row >= r1) row = r1 - 1;                 // clamped (a valid address); masked where it is used
-            const T* xr = x + row * K;
-            a[u] = ld1(xr + (oki ? ci : 0));
-#pragma unroll
-            for (int t = 0; t < TJ; ++t)
-                if (t >= ti) b[u][t] = ld1(xr + cj[t]);   // (G is symmetric: the band's tiles left of the diagonal come from the transposed write below)
-        }
-    };
-    int64_t g = wv;
-    if (g < ngroups) load(g, ra, rb);
-    for (; g < ngroups; g += 4) {
-        float na[U], nb[U][TJ];
-        const bool more = g + 4 < ngroups;
-        if (more) load(g + 4, na, nb);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const bool rok = r0 + 2 * (g * U + u) + half < r1;
-            const float a = rok ? act_fwd(fmaf(ra[u], si, hi_), act) : 0.f;
-#pragma unroll
-            for (int t = 0; t < TJ; ++t) {
-                if (t < ti) continue;                                        // wave-uniform
-                const float b = rok ? act_fwd(fmaf(rb[u][t], sj[t], hj[t]), act) : 0.f;
-                cs[t] += b;
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
-            }
-        }
-        if (more) {
+    auto band = [&](auto tic) {
+        constexpr int TI = decltype(tic)::value;
+        float ra[U], rb[U][TJ];
+        auto load = [&](int64_t gidx, float (&a)[U], float (&b)[U][TJ]) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                ra[u] = na[u];
+                int64_t row = r0 + 2 * (gidx * U + u) + half;
+                if (row >= r1) row = r1 - 1;             // clamped (a valid address); masked where it is used
+                const T* xr = x + row * K;
+                a[u] = ld1(xr + (oki ? ci : 0));
 #pragma unroll
-                for (int t = 0; t < TJ; ++t)
-                    if (t >= ti) rb[u][t] = nb[u][t];
+                for (int t = TI; t < TJ; ++t) b[u][t] = ld1(xr + cj[t]);
+            }
+        };
+        int64_t g = wv;
+        if (g < ngroups) load(g, ra, rb);
+        for (; g < ngroups; g += 4) {
+            float na[U], nb[U][TJ];
+            const bool more = g + 4 < ngroups;
+            if (more) load(g + 4, na, nb);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool rok = r0 + 2 * (g * U + u) + half < r1;
+                const float a = rok ? act_fwd(fmaf(ra[u], si, hi_), act) : 0.f;
+#pragma unroll
+                for (int t = TI; t < TJ; ++t) {
+                    const float b = rok ? act_fwd(fmaf(rb[u][t], sj[t], hj[t]), act) : 0.f;
+                    cs[t] += b;
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+                }
+            }
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    ra[u] = na[u];
+#pragma unroll
+                    for (int t = TI; t < TJ; ++t) rb[u][t] = nb[u][t];
+                }
             }
         }
+    };
+    if constexpr (TJ <= 5) {
+        static_for<0, TJ>([&](auto tic) { if (ti == decltype(tic)::value) band(tic); });
+    } else {
+        band(std::integral_constant<int, 0>{});          // (K > 160: every tile of every band, no mirror writes)
     }
     // fixed-order sum of the four waves' bands through LDS
     constexpr int BW = 32 * TJ;
@@ -116,9 +124,9 @@ __global__ __launch_bounds__(256) void lr_gram_kernel(const T* __restrict__ x, c
     float* prow = parts + (int64_t)blockIdx.x * ((int64_t)K * K + K);
     for (int e = tid; e < 32 * BW; e += 256) {           // the band from the diagonal tile on, and its mirror image below the diagonal
         const int i = e / BW, j = e - i * BW;
-        if (j < ti * 32 || ti * 32 + i >= K || j >= K) continue;
+        if ((TJ <= 5 && j < ti * 32) || ti * 32 + i >= K || j >= K) continue;
         prow[(int64_t)(ti * 32 + i) * K + j] = red[e];
-        if (j >= (ti + 1) * 32) prow[(int64_t)j * K + ti * 32 + i] = red[e];
+        if (TJ <= 5 && j >= (ti + 1) * 32) prow[(int64_t)j * K + ti * 32 + i] = red[e];
     }
     if (ti == 0) {                                       // column sums (every tile column is live in band 0): the two pixels of a pair, then the four waves
         __syncthreads();

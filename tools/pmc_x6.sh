@@ -14,7 +14,7 @@ pass c SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_ACTIVE_INST_SCA
 cd $R
 python3 - > gpurun_out/pmc_x6.txt <<'PY'
 import csv, glob, collections, re
-def short(n): return re.sub(r'\(.*', '', n).replace('void mny::', '').replace('mny::', '')[:80]
+def short(n): return re.sub(r', 0>$', '>', re.sub(r'\(.*', '', n).replace('void mny::', '').replace('mny::', ''))[:80] if 'pw_gemm_nt_dma' in n else re.sub(r'\(.*', '', n).replace('void mny::', '').replace('mny::', '')[:80]
 want = ('pw_gemm_nt_dma_kernel<4, 1, 0, 0, 3>', 'pw_gemm_nt_dma_kernel<4, 0, 0, 0, 3>', 'pw_wgrad_dma_kernel<0, 2, 2, 1>', 'pw_gemm_nt_dma_kernel<3, 0, 0, 1, 3>',
         'pw_gemm_nt_dma_kernel<5, 1, 0, 0, 3>', 'pw_wgrad_stream_kernel<2, 3>', 'pw_wide_kernel<6, 3, 0, 2>')
 tot = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.defaultdict(collections.Counter)
