@@ -1433,32 +1433,12 @@ __global__ __launch_bounds__(256) void pw_wgrad_dma_kernel(WgradArgs p) {
             bf16x8_t ah[TI], am[TI], al[TI];
 #pragma unroll
             for (int i = 0; i < TI; ++i) {
-#ifdef MNY_EXP_HALFCUT      // timing experiment (WRONG results): what the kernel costs with half the operand cuts — the bound of a cut shared between waves
-                if (i > 0) { ah[i] = ah[0]; am[i] = am[0]; al[i] = al[0]; continue; }
-#endif
                 const v4f_t x0 = {a_base[0 * BI + i * 32], a_base[2 * BI + i * 32], a_base[4 * BI + i * 32], a_base[6 * BI + i * 32]};
                 const v4f_t x1 = {a_base[8 * BI + i * 32], a_base[10 * BI + i * 32], a_base[12 * BI + i * 32], a_base[14 * BI + i * 32]};
                 x6_split(x0, x1, ah[i], am[i], al[i]);
             }
-#ifdef MNY_EXP_HALFCUT
-            bf16x8_t bh0, bm0, bl0;
-#endif
 #pragma unroll
             for (int j = 0; j < TJ; ++j) {
-#ifdef MNY_EXP_HALFCUT
-                if (j > 0) {
-#pragma unroll
-                    for (int i = 0; i < TI; ++i) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh0, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl0, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm0, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh0, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm0, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh0, acc[i][j], 0, 0, 0);
-                    }
-                    continue;
-                }
-#endif
                 float z[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -1467,9 +1447,6 @@ __global__ __launch_bounds__(256) void pw_wgrad_dma_kernel(WgradArgs p) {
                 }
                 bf16x8_t bh, bm, bl;
                 x6_split(v4f_t{z[0], z[1], z[2], z[3]}, v4f_t{z[4], z[5], z[6], z[7]}, bh, bm, bl);
-#ifdef MNY_EXP_HALFCUT
-                bh0 = bh; bm0 = bm; bl0 = bl;
-#endif
 #pragma unroll
                 for (int i = 0; i < TI; ++i) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh, acc[i][j], 0, 0, 0);
