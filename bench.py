@@ -1129,8 +1129,7 @@ def main():
         finally:
             if a.full_json:
                 print(json.dumps(res), flush=True)
-            else:
-                print(json.dumps(res), file=sys.stderr, flush=True)            # the verbose object, for the log
+            else:                                # (nothing large on stderr either: the driver's 8 kB tail is stdout FOLLOWED by stderr)
                 print(json.dumps(compact_line(res), separators=(",", ":")), flush=True)
     if use_dp:
         dist.destroy_process_group()
