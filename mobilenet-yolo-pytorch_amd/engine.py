@@ -347,10 +347,31 @@ class NetPlan:
                 self.gates[emit_at.out.id] = gate
                 self.gate_units[se0.out.id] = gate
                 self.gate_units[se3.out.id] = gate
+        # Nodes no loss (or detection output) depends on — MobileNetV2-YOLO's always-on seg branch under a config without a `seg` section
+        # (mbv2_yolo.py:155-156: computed, BatchNorm running statistics updated, result dropped) — feed nothing on the main stream: in a
+        # training plan they run on the SIDE stream next to the rest of the forward pass (their own statistics workspace), joined behind the heads.
+        live = set()
+        stack = list(g.outputs) + ([g.seg_out] if g.seg_out is not None else [])
+        while stack:
+            v = stack.pop()
+            if v.node is None or v.id in live:
+                continue
+            live.add(v.id)
+            stack.extend(v.node.ins)
+        self.dead_side = bool(self.side_on and bn_batch and os.environ.get("MNY_NO_DEAD_SIDE") != "1"
+                              and any(nd.out.id not in live and nd.op in ("dw", "pw", "add") for nd in g.nodes))
+        self.stats_ws_side = torch.empty(max_parts * 2 * maxC, **f32) if self.dead_side else self.stats_ws
+        dead_forked = False
         for nd in g.nodes:
             o = nd.out
             shp = shape(o)
             M = shp[0] * shp[1] * shp[2]
+            dead = self.dead_side and o.id not in live and nd.op in ("dw", "pw", "add") and o.id not in self.exdw_pw and o.id not in self.exdw_dw
+            st_n = self.stream_side if dead else self.stream          # the stream and statistics workspace of this node's calls
+            sws_n = self.stats_ws_side if dead else self.stats_ws
+            if dead and not dead_forked:
+                self.fwd.add_py(self._fork_side, "fork")                # the side stream waits for what the main stream has enqueued (the branch's input)
+                dead_forked = True
             if nd.op == "pw" and o.id in self.gate_units:
                 u = _Unit()                                   # a hidden unit of a gate: its BN coefficients live here, the calls come with the gate
                 u.Y = None                                    # never materialised
@@ -372,7 +393,7 @@ class NetPlan:
                 u.act, u.C, u.M, u.shape = o.act, o.C, M, shp
                 self.units[o.id] = u
                 w = P[nd.conv + ".weight"]
-                stats = self.stats_ws if bn_batch else None
+                stats = sws_n if bn_batch else None
                 if nd.op == "stem":
                     parts = _lib.query("mny_stem_stat_parts", N, H, W, o.C)
                     self.fwd.add(K("mny_stem_fwd"), self.x_ptr, w, u.Y, stats, N, H, W, o.C, self.stream,
@@ -392,7 +413,7 @@ class NetPlan:
                     ish = shape(i)
                     xv = view(i)
                     parts = _lib.query("mny_dw_stat_parts_x", N, ish[1], ish[2], o.C, nd.k, nd.stride, 1 if self.bf16 else 0)
-                    self.fwd.add(K("mny_dw_fwd"), xv[0], xv[1], xv[2], xv[3], w, u.Y, stats, N, ish[1], ish[2], o.C, nd.k, nd.stride, self.stream,
+                    self.fwd.add(K("mny_dw_fwd"), xv[0], xv[1], xv[2], xv[3], w, u.Y, stats, N, ish[1], ish[2], o.C, nd.k, nd.stride, st_n,
                                  meta=dict(flops=2 * M * o.C * nd.k * nd.k, bytes=eb * (N * ish[1] * ish[2] * o.C + M * o.C) + 4 * o.C * nd.k * nd.k,
                                            shape="C%d H%d s%d" % (o.C, ish[1], nd.stride)))
                 elif o.id in self.exdw_pw:
@@ -409,13 +430,13 @@ class NetPlan:
                     parts = _lib.query(K("mny_pw_stat_parts"), M, i.C, o.C)
                     w6 = self._w6_planes(w, M, i.C, o.C)
                     self.fwd.add("mny_pw_fwd_w6" if w6 is not None else K("mny_pw_fwd"), xv[0], xv[1], xv[2], xv[3],
-                                 w6 if w6 is not None else self._gemm_weight(w), None, None, u.Y, stats, M, i.C, o.C, self.stream, label=K("mny_pw_fwd"),
+                                 w6 if w6 is not None else self._gemm_weight(w), None, None, u.Y, stats, M, i.C, o.C, st_n, label=K("mny_pw_fwd"),
                                  meta=dict(flops=2 * M * i.C * o.C, bytes=eb * (M * i.C + M * o.C) + 4 * i.C * o.C, shape="M%d K%d N%d" % (M, i.C, o.C)))
                 gam, bet = P[nd.bn + ".weight"], P[nd.bn + ".bias"]
                 rm, rv = P[nd.bn + ".running_mean"], P[nd.bn + ".running_var"]
                 if bn_batch:
-                    self.fwd.add("mny_bn_finalize", self.stats_ws, parts, M, gam, bet, BN_EPS, BN_MOMENTUM, rm, rv,
-                                 u.scale, u.shift, u.mean, u.invstd, o.C, self.stream)
+                    self.fwd.add("mny_bn_finalize", sws_n, parts, M, gam, bet, BN_EPS, BN_MOMENTUM, rm, rv,
+                                 u.scale, u.shift, u.mean, u.invstd, o.C, st_n)
                 else:
                     self.fwd.add("mny_bn_eval_coeffs", gam, bet, rm, rv, BN_EPS, u.scale, u.shift, o.C, self.stream)
                     if self.frozen:                          # the backward kernels' yhat = (y - running_mean) * invstd
@@ -434,6 +455,8 @@ class NetPlan:
                     t32 = torch.empty(shp, **f32)
                     self.fwd.add("mny_cvt_bf16_f32", t, t32, t.numel(), self.stream)
                     self.head32[o.id] = t32
+                if g.outputs and o is g.outputs[0]:
+                    self._head0_call = self.fwd.calls[-1]        # the first head exists behind THIS call (found again by identity: batched launches are inserted at the head of the list later)
             elif nd.op == "add":
                 a = view(nd.ins[0])
                 has_b, has_up = nd.k & 1, nd.k & 2
@@ -443,7 +466,7 @@ class NetPlan:
                     assert nd.ins[-1].kind == "real"
                 t = torch.empty(shp, **act)
                 self.reals[o.id] = t
-                self.fwd.add(K("mny_add_views"), a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], up, t, shp[0], shp[1], shp[2], shp[3], self.stream)
+                self.fwd.add(K("mny_add_views"), a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], up, t, shp[0], shp[1], shp[2], shp[3], st_n)
             elif nd.op == "mul":
                 a, b = view(nd.ins[0]), view(nd.ins[1])
                 t = torch.empty(shp, **act)
@@ -472,6 +495,8 @@ class NetPlan:
         self.seg_head = self.head32.get(g.seg_out.id, self.reals[g.seg_out.id]) if g.seg_out is not None else None
         self.loss_outputs = list(g.outputs) + ([g.seg_out] if g.seg_out is not None else [])     # values a loss reads
         self._build_detection()
+        if dead_forked or getattr(self, "_loss_side", False):
+            self.fwd.add_py(self._join_side, "join")                    # the dead branch's tensors (and the workspace it used) are free again before anything reuses them
         if training and (bn_batch or self.frozen):
             self._build_backward()
 
@@ -532,8 +557,19 @@ class NetPlan:
                 nbytes = _lib.query("mny_yolo_loss_ws_bytes", ctypes.byref(self.hp[hi]), 0)
                 ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
                 self.loss_ws.append(ws)
+                # the first head's loss (five short, latency-bound launches) runs on the side stream from the moment that head exists, next to the
+                # second head's branch (round 6; joined at the end of the list); MNY_NO_LOSS_SIDE=1: both losses at the end, on the main stream
+                pos = next((k + 1 for k, c in enumerate(self.fwd.calls) if c is getattr(self, "_head0_call", None)), None)
+                early = (hi == 0 and self.side_on and self.bn_batch and pos is not None and pos < len(self.fwd.calls)
+                         and os.environ.get("MNY_NO_LOSS_SIDE") != "1")
                 self.fwd.add("mny_yolo_loss", self.heads[hi], self.t_ptr, self.off_ptr, self.anchors[hi], self.masks[hi],
-                             ctypes.byref(self.hp[hi]), self.out14[hi], self.dheads[hi], ws, self.stream)
+                             ctypes.byref(self.hp[hi]), self.out14[hi], self.dheads[hi], ws, self.stream_side if early else self.stream)
+                if early:
+                    loss_call = self.fwd.calls.pop()
+                    self.fwd.add_py(self._fork_side, "fork")
+                    fork_call = self.fwd.calls.pop()
+                    self.fwd.calls[pos:pos] = [fork_call, loss_call]
+                    self._loss_side = True
             self.t_dev = torch.zeros(max(4 * N, 64), 5, **f32)
             self.off_dev = torch.zeros(N + 1, device=dev, dtype=torch.int32)
             if self.seg_head is not None:             # mbv2_yolo.py:167-170: SegLoss on the raw seg head
@@ -1496,6 +1532,8 @@ class NetPlan:
 
     def forward_train(self, x, targets, seg_maps=None):
         x = self._bind(x)
+        self.stream_side.value = self._side_stream.cuda_stream if (self.side_on and self.timing is None) else self.stream.value
+        self.stream_side2.value = self._side2_stream.cuda_stream if (self.side_on and self.timing is None) else self.stream.value
         self.set_targets(targets)
         if self.seg_head is not None:
             if seg_maps is None:
