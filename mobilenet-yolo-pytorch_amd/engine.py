@@ -362,16 +362,47 @@ class NetPlan:
                               and any(nd.out.id not in live and nd.op in ("dw", "pw", "add") for nd in g.nodes))
         self.stats_ws_side = torch.empty(max_parts * 2 * maxC, **f32) if self.dead_side else self.stats_ws
         dead_forked = False
+        # A second forward LANE (round 6): the stride-16 neck / head chain (conv_for_S16, connect_for_S16, yolo_headS16: mbv2_yolo.py:146-153,
+        # mbv3_yolo.py:133-138) is independent of the stride-32 chain (features2 / bneck2, conv_for_S32, connect_for_S32, yolo_headS32) except for
+        # ONE edge (the upsampled stride-32 feature).  Every conv of a chain is followed by its BatchNorm finalize — a dependent ~6 us launch + the
+        # dispatch gap behind it — so two chains on two streams fill each other's bubbles.  Lane-2 nodes run on the second side stream with their own
+        # statistics workspace; a lane-2 node whose input was produced on the main stream since the last fork waits for it (fork2), the main stream
+        # waits for lane 2 before the losses (join2).  MEASURED SLOWER (same-box A/B, parity-green): headline 34.73 / 34.78 -> 34.78 / 34.89 ms,
+        # MobileNetV3 512x512 bf16 13.86 / 13.85 -> 13.99 / 14.02 ms — the two chains' kernels share the CUs and the cross-stream waits cost more than the
+        # finalize bubbles they fill.  OFF by default; MNY_LANE2=1 turns it on for A/B.
+        lane2_on = bool(self.side_on and bn_batch and os.environ.get("MNY_LANE2") == "1")
+        lane2_prefix = ("conv_for_S16", "connect_for_S16", "yolo_headS16")
+        self.stats_ws_lane2 = torch.empty(max_parts * 2 * maxC, **f32) if lane2_on else self.stats_ws
+        made = {}                     # value id -> (lane, index in the call list behind which it exists)
+        prev_node = None
+        last_fork2 = -1
+        lane2_used = False
         for nd in g.nodes:
             o = nd.out
             shp = shape(o)
             M = shp[0] * shp[1] * shp[2]
             dead = self.dead_side and o.id not in live and nd.op in ("dw", "pw", "add") and o.id not in self.exdw_pw and o.id not in self.exdw_dw
-            st_n = self.stream_side if dead else self.stream          # the stream and statistics workspace of this node's calls
-            sws_n = self.stats_ws_side if dead else self.stats_ws
+            if prev_node is not None:
+                made[prev_node[0]] = (prev_node[1], len(self.fwd.calls))   # the previous node's value exists behind the calls appended so far
+            path = nd.conv or (nd.out.name if nd.op in ("add", "partadd") else "")
+            lane2 = (lane2_on and not dead and nd.op in ("dw", "pw", "pwb", "add", "partadd") and path.startswith(lane2_prefix)
+                     and o.id not in self.exdw_pw and o.id not in self.exdw_dw and o.id not in self.gates and o.id not in self.gate_units
+                     and o.id not in self.gate_absorbed)
+            st_n = self.stream_side if dead else (self.stream_side2 if lane2 else self.stream)          # the stream and statistics workspace of this node's calls
+            sws_n = self.stats_ws_side if dead else (self.stats_ws_lane2 if lane2 else self.stats_ws)
             if dead and not dead_forked:
                 self.fwd.add_py(self._fork_side, "fork")                # the side stream waits for what the main stream has enqueued (the branch's input)
                 dead_forked = True
+            if lane2:
+                if any(made.get(v.id, (0, -1))[0] == 0 and made.get(v.id, (0, -1))[1] > last_fork2 for v in nd.ins) or not lane2_used:
+                    self.fwd.add_py(self._fork_side2, "fork")           # an input made on the main stream since the last fork: lane 2 waits for it
+                    last_fork2 = len(self.fwd.calls)
+                lane2_used = True
+            elif not dead and any(made.get(v.id, (0, -1))[0] == 2 for v in nd.ins):
+                self.fwd.add_py(self._join_side2, "join")               # (no graph of this package has such an edge; kept correct for any)
+                for k_ in [k_ for k_, mv in made.items() if mv[0] == 2]:
+                    made[k_] = (0, made[k_][1])
+            prev_node = (o.id, 2 if lane2 else (1 if dead else 0))
             if nd.op == "pw" and o.id in self.gate_units:
                 u = _Unit()                                   # a hidden unit of a gate: its BN coefficients live here, the calls come with the gate
                 u.Y = None                                    # never materialised
@@ -449,11 +480,11 @@ class NetPlan:
                 w6 = self._w6_planes(P[nd.conv + ".weight"], M, i.C, o.C)
                 self.fwd.add("mny_pw_fwd_w6" if w6 is not None else K("mny_pw_fwd"), xv[0], xv[1], xv[2], xv[3],
                              w6 if w6 is not None else self._gemm_weight(P[nd.conv + ".weight"]), P[nd.conv + ".bias"], None, t, None,
-                             M, i.C, o.C, self.stream, label=K("mny_pw_fwd"),
+                             M, i.C, o.C, st_n, label=K("mny_pw_fwd"),
                              meta=dict(flops=2 * M * i.C * o.C, bytes=eb * (M * i.C + M * o.C) + 4 * i.C * o.C, shape="M%d K%d N%d" % (M, i.C, o.C)))
                 if self.bf16:                    # loss / decode read the head in fp32
                     t32 = torch.empty(shp, **f32)
-                    self.fwd.add("mny_cvt_bf16_f32", t, t32, t.numel(), self.stream)
+                    self.fwd.add("mny_cvt_bf16_f32", t, t32, t.numel(), st_n)
                     self.head32[o.id] = t32
                 if g.outputs and o is g.outputs[0]:
                     self._head0_call = self.fwd.calls[-1]        # the first head exists behind THIS call (found again by identity: batched launches are inserted at the head of the list later)
@@ -477,10 +508,12 @@ class NetPlan:
                 up = self.reals[nd.ins[1].id]
                 t = torch.empty(shp, **act)
                 self.reals[o.id] = t
-                self.fwd.add(K("mny_partadd_up"), a[0], a[1], a[2], a[3], up, t, shp[0], shp[1], shp[2], nd.ins[0].C, o.C, self.stream)
+                self.fwd.add(K("mny_partadd_up"), a[0], a[1], a[2], a[3], up, t, shp[0], shp[1], shp[2], nd.ins[0].C, o.C, st_n)
             else:
                 raise AssertionError(nd.op)
 
+        if lane2_used:
+            self.fwd.add_py(self._join_side2, "join")                   # both lanes meet before the losses / the decode
         self._flush_cvt_jobs()
         self._flush_cut_jobs(self.fwd, at_head=True)
         if self.gates:                                        # the gates' weights as matrix-core operand chunks, one launch per pass for all of them
