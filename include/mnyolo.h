@@ -118,6 +118,16 @@ int mny_pw_bnbwd(const float* g, const float* y, const float* scale, const float
                  const float* x, const float* in_scale, const float* in_shift, int in_act,
                  const float* w, const float* addend, float* dx, float* dw, float* dgamma, float* dbeta,
                  float* ws, int64_t M, int K, int Nc, void* stream);
+/* mny_pw_bnbwd whose data gradient completes the output gradient of the conv+BN+act unit in front of the expand unit (the project conv of the previous
+ * block, directly or through the residual add that hands it the gradient unchanged): that unit's BN-backward sums (sum dz, sum dz*xhat over the STORED dx;
+ * ry = its raw output [M][K], r_scale / r_shift / r_act = its view, clamp family) leave with the second stage, red[mny_pw_bnbwd_red_parts()][2][K] —
+ * no mny_bn_bwd_reduce pass over (dx, ry).  fp32 storage, N in {96, 144, 192} (mny_pw_bnbwd_red_supported). */
+int mny_pw_bnbwd_red_supported(int64_t M, int K, int Nc);
+int mny_pw_bnbwd_red_parts(int64_t M, int K, int Nc);
+int mny_pw_bnbwd_red(const float* g, const float* y, const float* scale, const float* shift, int act, const float* mean, const float* invstd,
+                     const float* gamma, const float* x, const float* in_scale, const float* in_shift, int in_act, const float* w,
+                     const float* addend, float* dx, float* dw, float* dgamma, float* dbeta, float* ws, const float* ry, const float* r_scale,
+                     const float* r_shift, int r_act, const float* r_mean, const float* r_invstd, float* red, int64_t M, int K, int Nc, void* stream);
 int mny_transpose(const float* src /*[R,Cc]*/, float* dst /*[Cc,R]*/, int R, int Cc, void* stream);
 
 /* ---- BatchNorm (training / eval), eps 1e-5, momentum 0.1 ---------------------------------

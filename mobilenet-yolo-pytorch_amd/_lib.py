@@ -148,6 +148,9 @@ _SIGS["mny_lr_prep"] = (c_int, [P, P, P, P, c_int, c_int, P])
 _SIGS["mny_pw_lr_fix_parts"] = (c_int, [c_int64, c_int, c_int])
 _SIGS["mny_pw_lr_fix"] = (c_int, [P, P, P, P, P, P, P, P, P, P, c_int, P, P, P, c_int64, c_int, P])
 _SIGS["mny_lr_wfix"] = (c_int, [P, P, P, P, c_int, c_int, P])
+_SIGS["mny_pw_bnbwd_red_supported"] = (c_int, [c_int64, c_int, c_int])
+_SIGS["mny_pw_bnbwd_red_parts"] = (c_int, [c_int64, c_int, c_int])
+_SIGS["mny_pw_bnbwd_red"] = (c_int, [P, P, P, P, c_int, P, P, P, P, P, P, c_int, P, P, P, P, P, P, P, P, P, P, c_int, P, P, P, c_int64, c_int, c_int, P])
 _SIGS["mny_dw_bnbwd_red_dz_supported"] = (c_int, [c_int, c_int, c_int])
 _SIGS["mny_dw_bnbwd_red_dz"] = _SIGS["mny_dw_bnbwd_red"]
 _SIGS["mny_dw_bnbwd_s2_red_dz"] = (c_int, [P, P, P, P, c_int, P, P, P, P, c_int, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P])

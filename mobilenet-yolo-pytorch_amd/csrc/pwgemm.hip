@@ -2313,6 +2313,9 @@ struct BndArgs {
     const float* X; const float* xsc; const float* xsh; int xact;
     const float* B1; const float* Q; const float* bias; const float* addend; float* C;
     int64_t npairs; int64_t M; int N; int Kc; int TI; int m_tiles, tiles_per_block;
+    // RED (pw_bnbwd_dgrad2_kernel<.., true>, round 6): C is the complete output gradient of the conv+BN+act unit whose raw output is rY: its
+    // BN-backward sums leave as one partial row per workgroup, red[gridDim.x][2][Kc]
+    const float* rY; const float* r_scale; const float* r_shift; const float* r_mean; const float* r_invstd; int r_act; float* red;
 };
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void pw_bnbwd_dgrad_kernel(BndArgs p) {
@@ -2568,7 +2571,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
 // T: storage type of G, X, the addend and dX (bf16_t for bf16-storage plans: 8-byte loads widened to fp32, the same cuts and products —
 // the bf16-exact G has empty mid / lo pieces, which costs matrix-pipe cycles this HBM-bound kernel has to spare — one RNE on store).
 // HALF: N = 16 NS - 8 (the last stage's upper eight columns do not exist: N = 72 of MobileNetV3).
-template <int NS, typename T = float, bool HALF = false>
+template <int NS, typename T = float, bool HALF = false, bool RED = false>
 __global__ __launch_bounds__(256) void pw_bnbwd_dgrad2_kernel(BndArgs p) {
     constexpr int N = NS * 16 - (HALF ? 8 : 0), NW = (N + 31) / 32;               // mask words (32 columns each) per row
     const T* const pG = reinterpret_cast<const T*>(p.G);
@@ -2613,6 +2616,9 @@ __global__ __launch_bounds__(256) void pw_bnbwd_dgrad2_kernel(BndArgs p) {
     const bool cok = colq < Kc;
     const int colc = cok ? colq : 0;
     const float4 bv = ld4(p.bias + colc);
+    float4 rsc = f4one(), rsh = f4zero(), rmu = f4zero(), ris = f4zero(), rs1 = f4zero(), rs2 = f4zero();
+    if constexpr (RED) { rsc = ld4(p.r_scale + colc); rsh = ld4(p.r_shift + colc); rmu = ld4(p.r_mean + colc); ris = ld4(p.r_invstd + colc); }
+    const float rslope = act_slope(p.r_act), rhi = act_hi(p.r_act);
     const unsigned* mask32 = reinterpret_cast<const unsigned*>(p.mask);
     const int64_t mstride = 2 * p.npairs;                        // 32-bit mask words per 32-column tile
 
@@ -2741,9 +2747,44 @@ __global__ __launch_bounds__(256) void pw_bnbwd_dgrad2_kernel(BndArgs p) {
             }
             const int64_t row = m0 + 8 * gq + 4 * khalf + jq;
             if (cok && row < p.M) st4_stream(pC + row * Kc + colq, o);
+            if constexpr (RED) {                                     // sums over the STORED gradient of the unit in front (its raw output row: a thin 16-B load)
+                if (cok && row < p.M) {
+                    const float4 yv = ld4(reinterpret_cast<const float*>(p.rY) + row * Kc + colq);
+                    const float ov[4] = {o.x, o.y, o.z, o.w}, yy[4] = {yv.x, yv.y, yv.z, yv.w};
+                    const float sc4[4] = {rsc.x, rsc.y, rsc.z, rsc.w}, sh4[4] = {rsh.x, rsh.y, rsh.z, rsh.w};
+                    const float mu4[4] = {rmu.x, rmu.y, rmu.z, rmu.w}, is4[4] = {ris.x, ris.y, ris.z, ris.w};
+                    float a1[4] = {rs1.x, rs1.y, rs1.z, rs1.w}, a2[4] = {rs2.x, rs2.y, rs2.z, rs2.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float z = fmaf(yy[e], sc4[e], sh4[e]);
+                        const float dz = ov[e] * ((z > 0.f ? 1.f : rslope) * (z < rhi ? 1.f : 0.f));
+                        a1[e] += dz;
+                        a2[e] = fmaf(dz, (yy[e] - mu4[e]) * is4[e], a2[e]);
+                    }
+                    rs1 = make_float4(a1[0], a1[1], a1[2], a1[3]); rs2 = make_float4(a2[0], a2[1], a2[2], a2[3]);
+                }
+            }
         }
         asm volatile("" ::: "memory");
         load_ad(next);
+    }
+    if constexpr (RED) {                                             // one partial row per workgroup: the eight lanes of a column quad, then the four waves, fixed order
+        __syncthreads();
+        float4* sr = reinterpret_cast<float4*>(sB);                  // [2][256]
+        sr[tid] = rs1; sr[256 + tid] = rs2;
+        __syncthreads();
+        if (tid < 16 && tid * 4 < Kc) {                              // thread = column quad
+            float4 a = f4zero(), b = f4zero();
+            for (int w = 0; w < 4; ++w)
+                for (int h = 0; h < 2; ++h)
+                    for (int j = 0; j < 4; ++j) {
+                        const int l = w * 64 + h * 32 + tid * 4 + j;
+                        add4(a, sr[l]); add4(b, sr[256 + l]);
+                    }
+            float* dst = p.red + (int64_t)blockIdx.x * 2 * Kc;
+            st4(dst + tid * 4, a);
+            st4(dst + Kc + tid * 4, b);
+        }
     }
 }
 
@@ -3312,12 +3353,25 @@ extern "C" size_t mny_pw_bnbwd_ws_floats(int64_t M, int K, int Nc) {
     return base > wave ? base : wave;
 }
 
-extern "C" int mny_pw_bnbwd(const float* g, const float* y, const float* scale, const float* shift, int act,
-                            const float* mean, const float* invstd, const float* gamma,
-                            const float* x, const float* in_scale, const float* in_shift, int in_act,
-                            const float* w, const float* addend, float* dx /* may be NULL: no data gradient */,
-                            float* dw, float* dgamma, float* dbeta, float* ws, int64_t M, int K, int Nc, void* stream) {
+static bool bnw_red_ok(int64_t M, int K, int Nc) {      // the data-gradient stage that can carry the sums of the unit in front: the barrier-free second generation
+    static const int v2 = getenv("MNY_BND_V2") ? atoi(getenv("MNY_BND_V2")) : 1;
+    return bnw_supported(M, K, Nc) && v2 && (Nc == 96 || Nc == 144 || Nc == 192);
+}
+static int bnw_red_grid(int64_t M) {
+    static const int v2_grid = getenv("MNY_BND_V2_GRID") ? atoi(getenv("MNY_BND_V2_GRID")) : 512;
+    const int64_t tiles = cdiv(M, 32);
+    return (int)(cdiv(tiles, 4) < v2_grid ? cdiv(tiles, 4) : v2_grid);
+}
+static int pw_bnbwd_impl(const float* g, const float* y, const float* scale, const float* shift, int act,
+                         const float* mean, const float* invstd, const float* gamma,
+                         const float* x, const float* in_scale, const float* in_shift, int in_act,
+                         const float* w, const float* addend, float* dx /* may be NULL: no data gradient */,
+                         float* dw, float* dgamma, float* dbeta, float* ws, int64_t M, int K, int Nc, void* stream,
+                         const float* ry = nullptr, const float* r_scale = nullptr, const float* r_shift = nullptr, int r_act = 0,
+                         const float* r_mean = nullptr, const float* r_invstd = nullptr, float* red_out = nullptr) {
     MNY_REQUIRE(g && y && scale && shift && mean && invstd && gamma && x && w && dw && dgamma && dbeta && ws, "pw_bnbwd: null pointer");
+    MNY_REQUIRE(!red_out || (dx && ry && r_scale && r_shift && r_mean && r_invstd && r_act >= MNY_ACT_NONE && r_act < MNY_ACT_HSWISH && bnw_red_ok(M, K, Nc)),
+                "pw_bnbwd_red: incomplete reduction target or unsupported shape (mny_pw_bnbwd_red_supported)");
     MNY_REQUIRE(bnw_supported(M, K, Nc), "pw_bnbwd: shape M=%lld K=%d N=%d not supported (need K<=32, N<=192, N>K)", (long long)M, K, Nc);
     MNY_REQUIRE(in_act != MNY_ACT_HSWISH && in_act != MNY_ACT_HSIGMOID && act != MNY_ACT_HSWISH && act != MNY_ACT_HSIGMOID,
                 "pw_bnbwd: h-swish / h-sigmoid activations are not supported");
@@ -3368,12 +3422,16 @@ extern "C" int mny_pw_bnbwd(const float* g, const float* y, const float* scale, 
     if (!allow_lds((const void*)pw_bnbwd_dgrad_kernel, 96 * 1024)) {
         set_error("pw_bnbwd: hipFuncSetAttribute failed"); return MNY_EHIP;
     }
-    BndArgs d{g, mask, act, x, in_scale, in_shift, in_act, B1, Q, bias, addend, dx, npairs, M, Nc, K, pl.TI, pl.m_tiles, pl.tiles_per_block};
-    static const int v2 = getenv("MNY_BND_V2") ? atoi(getenv("MNY_BND_V2")) : 1;
-    static const int v2_grid = getenv("MNY_BND_V2_GRID") ? atoi(getenv("MNY_BND_V2_GRID")) : 512;
-    if (v2 && (Nc == 96 || Nc == 144 || Nc == 192)) {             // second generation: barrier-free direct fragment loads (N % 16 == 0 instantiations)
-        const int64_t tiles = cdiv(M, 32);
-        const int grid = (int)(cdiv(tiles, 4) < v2_grid ? cdiv(tiles, 4) : v2_grid);
+    BndArgs d{g, mask, act, x, in_scale, in_shift, in_act, B1, Q, bias, addend, dx, npairs, M, Nc, K, pl.TI, pl.m_tiles, pl.tiles_per_block,
+              ry, r_scale, r_shift, r_mean, r_invstd, r_act, red_out};
+    if (bnw_red_ok(M, K, Nc)) {                                    // second generation: barrier-free direct fragment loads (N % 16 == 0 instantiations)
+        const int grid = bnw_red_grid(M);
+        if (red_out) {
+            if (Nc == 96) hipLaunchKernelGGL((pw_bnbwd_dgrad2_kernel<6, float, false, true>), dim3(grid), dim3(256), 0, st, d);
+            else if (Nc == 144) hipLaunchKernelGGL((pw_bnbwd_dgrad2_kernel<9, float, false, true>), dim3(grid), dim3(256), 0, st, d);
+            else hipLaunchKernelGGL((pw_bnbwd_dgrad2_kernel<12, float, false, true>), dim3(grid), dim3(256), 0, st, d);
+            return check_launch("pw_bnbwd_dgrad2_kernel<red>");
+        }
         if (Nc == 96) hipLaunchKernelGGL(pw_bnbwd_dgrad2_kernel<6>, dim3(grid), dim3(256), 0, st, d);
         else if (Nc == 144) hipLaunchKernelGGL(pw_bnbwd_dgrad2_kernel<9>, dim3(grid), dim3(256), 0, st, d);
         else hipLaunchKernelGGL(pw_bnbwd_dgrad2_kernel<12>, dim3(grid), dim3(256), 0, st, d);
@@ -3381,6 +3439,27 @@ extern "C" int mny_pw_bnbwd(const float* g, const float* y, const float* scale, 
     }
     hipLaunchKernelGGL(pw_bnbwd_dgrad_kernel, dim3(pl.gx2), dim3(256), pl.lds2, st, d);
     return check_launch("pw_bnbwd_dgrad_kernel");
+}
+extern "C" int mny_pw_bnbwd(const float* g, const float* y, const float* scale, const float* shift, int act,
+                            const float* mean, const float* invstd, const float* gamma,
+                            const float* x, const float* in_scale, const float* in_shift, int in_act,
+                            const float* w, const float* addend, float* dx /* may be NULL: no data gradient */,
+                            float* dw, float* dgamma, float* dbeta, float* ws, int64_t M, int K, int Nc, void* stream) {
+    return pw_bnbwd_impl(g, y, scale, shift, act, mean, invstd, gamma, x, in_scale, in_shift, in_act, w, addend, dx, dw, dgamma, dbeta, ws, M, K, Nc, stream);
+}
+// ... whose data gradient completes the output gradient of the conv+BN+act unit in front (raw output ry [M][K], view r_scale / r_shift / r_act of the clamp
+// family, statistics r_mean / r_invstd): that unit's BN-backward sums leave with it, red[mny_pw_bnbwd_red_parts(M, K, Nc)][2][K] (fp32 storage, N in {96, 144, 192})
+extern "C" int mny_pw_bnbwd_red_supported(int64_t M, int K, int Nc) { return bnw_red_ok(M, K, Nc) ? 1 : 0; }
+extern "C" int mny_pw_bnbwd_red_parts(int64_t M, int K, int Nc) { return bnw_red_ok(M, K, Nc) ? bnw_red_grid(M) : MNY_EINVAL; }
+extern "C" int mny_pw_bnbwd_red(const float* g, const float* y, const float* scale, const float* shift, int act,
+                                const float* mean, const float* invstd, const float* gamma,
+                                const float* x, const float* in_scale, const float* in_shift, int in_act,
+                                const float* w, const float* addend, float* dx, float* dw, float* dgamma, float* dbeta, float* ws,
+                                const float* ry, const float* r_scale, const float* r_shift, int r_act, const float* r_mean, const float* r_invstd, float* red,
+                                int64_t M, int K, int Nc, void* stream) {
+    MNY_REQUIRE(red && dx, "pw_bnbwd_red: null pointer");
+    return pw_bnbwd_impl(g, y, scale, shift, act, mean, invstd, gamma, x, in_scale, in_shift, in_act, w, addend, dx, dw, dgamma, dbeta, ws, M, K, Nc, stream,
+                         ry, r_scale, r_shift, r_act, r_mean, r_invstd, red);
 }
 
 // ---- bf16-storage twin (round 3): G, Y, X, addend, dX are bf16; W, statistics, dW / dgamma / dbeta, the workspace stay fp32 --------------

@@ -1079,6 +1079,24 @@ class NetPlan:
                 dwv, dgv, dbv = gv(nd.conv + ".weight"), gv(nd.bn + ".weight"), gv(nd.bn + ".bias")
                 gam = P[nd.bn + ".weight"]
                 w = P[nd.conv + ".weight"]
+                # the data gradient of this unit completes the output gradient of the unit in front (the previous block's project conv, directly or
+                # through the residual add): that unit's BN-backward sums leave with stage 2 (round 6: mny_pw_bnbwd_red, fp32 storage)
+                tgt = red_target(i, nd) if (not self.bf16 and os.environ.get("MNY_NO_REDFUSE") != "1" and os.environ.get("MNY_NO_BNW_RED") != "1") else None
+                if tgt is not None and (tgt.act in (_lib.ACT_HSWISH, _lib.ACT_HSIGMOID) or _lib.query("mny_pw_bnbwd_red_supported", M, i.C, o.C) != 1):
+                    tgt = None
+                if tgt is not None:
+                    pu = self.units[tgt.id]
+                    rparts = _lib.query("mny_pw_bnbwd_red_parts", M, i.C, o.C)
+                    rbuf = torch.empty(rparts * 2 * i.C, **f32)
+                    self.fused_red[tgt.id] = (rbuf, rparts)
+                    contribute_kernel(i, lambda out, addend, G=G, u=u, xv=xv, w=w, gam=gam, dwv=dwv, dgv=dgv, dbv=dbv, M=M, K=i.C, Nc=o.C, act=o.act, pu=pu, rbuf=rbuf, ract=tgt.act:
+                                      bwd.add("mny_pw_bnbwd_red", G, u.Y, u.scale, u.shift, act, u.mean, u.invstd, gam, xv[0], xv[1], xv[2], xv[3],
+                                              w, addend, out, dwv, dgv, dbv, self.ws, pu.Y, pu.scale, pu.shift, ract, pu.mean, pu.invstd, rbuf, M, K, Nc, self.stream,
+                                              label="mny_pw_bnbwd",
+                                              meta=dict(flops=6 * M * K * Nc, bytes=self.eb * (3 * M * Nc + 3 * M * K), shape="M%d K%d N%d +red" % (M, K, Nc))))
+                    flush_shared()
+                    bwd.marks[o.name] = len(bwd.calls)
+                    continue
                 contribute_kernel(i, lambda out, addend, G=G, u=u, xv=xv, w=w, gam=gam, dwv=dwv, dgv=dgv, dbv=dbv, M=M, K=i.C, Nc=o.C, act=o.act:
                                   bwd.add(self.K("mny_pw_bnbwd"), G, u.Y, u.scale, u.shift, act, u.mean, u.invstd, gam, xv[0], xv[1], xv[2], xv[3],
                                           w, addend, out, dwv, dgv, dbv, self.ws, M, K, Nc, self.stream,

@@ -212,3 +212,44 @@ def test_stride2_depthwise_backward_stores_the_masked_scaled_gradient_and_the_pr
     s1, s2 = dz.sum((0, 1, 2)), (dz * ((X.double() - xmu.double()) * xis.double())).sum((0, 1, 2))
     assert (s[0] - s1).abs().max().item() <= 2e-5 * dz.abs().sum((0, 1, 2)).max().item() + 1e-4
     assert (s[1] - s2).abs().max().item() <= 2e-5 * (dz * ((X.double() - xmu.double()) * xis.double())).abs().sum((0, 1, 2)).max().item() + 1e-4
+
+
+@pytest.mark.parametrize("M,K,Nc,ract", [(70001, 24, 144, 0), (50000, 32, 192, 0), (40003, 16, 96, 1), (8192, 32, 192, 0)])
+def test_thin_expand_unit_backward_leaves_the_sums_of_the_unit_in_front(M, K, Nc, ract):
+    """mny_pw_bnbwd_red == mny_pw_bnbwd (same dx, dW, dgamma, dbeta, bit for bit) + partial rows that sum to what mny_bn_bwd_reduce computes over
+    (that dx, the raw output of the unit in front) — the expand conv of a residual block handing the project conv of the previous block its BN sums."""
+    dev = torch.device("cuda:0")
+    from mobilenet_yolo_pytorch_amd import ops
+    act = _lib.ACT_RELU6
+    r_act = {0: _lib.ACT_NONE, 1: _lib.ACT_RELU6}[ract]
+    assert _lib.query("mny_pw_bnbwd_red_supported", M, K, Nc) == 1
+    g = torch.Generator().manual_seed(M + K)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev).contiguous()      # noqa: E731
+    x = rnd(1, 1, M, K)
+    w = (rnd(Nc, K) * K ** -0.5).contiguous()
+    xs, xh = (torch.rand(K, generator=g) + 0.5).to(dev), (torch.randn(K, generator=g) * 0.3).to(dev)
+    gamma, beta = (torch.rand(Nc, generator=g) + 0.5).to(dev), (torch.randn(Nc, generator=g) * 0.2).to(dev)
+    yd, st_ = ops.pw_fwd((x, xs, xh, _lib.ACT_NONE), w)
+    scale, shift, mean, invstd = ops.bn_finalize(st_, M, gamma, beta)
+    G, add = rnd(1, 1, M, Nc), rnd(1, 1, M, K)
+    dx0, dw0, dg0, db0 = ops.pw_bnbwd(G, yd, scale, shift, act, mean, invstd, gamma, (x, xs, xh, _lib.ACT_NONE), w, addend=add)
+    ry = rnd(M, K) * 2
+    rsc, rsh = (torch.rand(K, generator=g) + 0.5).to(dev), (torch.randn(K, generator=g) * 0.5 + 1.0).to(dev)
+    rmu, ris = (torch.randn(K, generator=g) * 0.2).to(dev), (torch.rand(K, generator=g) + 0.5).to(dev)
+    ws = torch.empty(int(_lib.query("mny_pw_bnbwd_ws_floats", M, K, Nc)), device=dev)
+    dx1 = torch.full((M, K), float("nan"), device=dev)
+    dw1, dg1, db1 = torch.empty(Nc, K, device=dev), torch.empty(Nc, device=dev), torch.empty(Nc, device=dev)
+    parts = _lib.query("mny_pw_bnbwd_red_parts", M, K, Nc)
+    red = torch.full((parts, 2, K), float("nan"), device=dev)
+    _lib.call("mny_pw_bnbwd_red", ptr(G), ptr(yd), ptr(scale), ptr(shift), act, ptr(mean), ptr(invstd), ptr(gamma), ptr(x), ptr(xs), ptr(xh), _lib.ACT_NONE,
+              ptr(w), ptr(add), ptr(dx1), ptr(dw1), ptr(dg1), ptr(db1), ptr(ws), ptr(ry), ptr(rsc), ptr(rsh), r_act, ptr(rmu), ptr(ris), ptr(red), M, K, Nc, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(dx1, dx0.view(M, K)) and torch.equal(dw1, dw0) and torch.equal(dg1, dg0) and torch.equal(db1, db0)
+    z = ry.double() * rsc.double() + rsh.double()
+    dact = torch.ones_like(z) if ract == 0 else ((z > 0) & (z < 6)).double()
+    dz = dx1.double() * dact
+    xhat = (ry.double() - rmu.double()) * ris.double()
+    s = red.double().sum(0)
+    assert torch.isfinite(s).all()
+    assert (s[0] - dz.sum(0)).abs().max().item() <= 2e-5 * dz.abs().sum(0).max().item() + 1e-4
+    assert (s[1] - (dz * xhat).sum(0)).abs().max().item() <= 2e-5 * (dz * xhat).abs().sum(0).max().item() + 1e-4
