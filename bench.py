@@ -564,8 +564,10 @@ def step_signature(plan):
     import hashlib
     # (device launches only: the host-side fork / join steps of the side stream are absent from the single-stream runs the profile
     # scripts make — counting them made every committed whole-step profile look stale against the default plan, rounds 4 and 5)
-    items = ["%s:%s" % (name, (meta or {}).get("shape", "")) for calls in (plan.fwd.calls, plan.bwd.calls) for _fn, _args, name, meta in calls
-             if name not in ("fork", "join", "py")]
+    # ... and, round 6, as a MULTISET: the single-stream profile runs place the first head's loss at the end of the forward list, the default
+    # two-stream plan right behind that head — the same launches in another order)
+    items = sorted("%s:%s" % (name, (meta or {}).get("shape", "")) for calls in (plan.fwd.calls, plan.bwd.calls) for _fn, _args, name, meta in calls
+                   if name not in ("fork", "join", "py"))
     return len(items), hashlib.sha256("|".join(items).encode()).hexdigest()[:16]
 
 
