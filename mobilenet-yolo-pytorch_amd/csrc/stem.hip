@@ -253,6 +253,194 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
     }
 }
 
+// ---- weight gradient on the matrix cores (Cout = 16 / 32) ---------------------------------------------------------------
+// dW[Cout][27] = sum over output pixels of dY[pixel][Cout] (x) patch[pixel][27] is a GEMM whose reduction runs over the PIXELS:
+// v_mfma_f32_16x16x4_f32 (exact fp32) takes four pixels per instruction, A = dY^T (16 channels x 4 pixels), B = the pixels' taps
+// (4 pixels x 16 of the 27 taps, two instructions per four pixels).  A workgroup owns the same 8 x 32 tile of output pixels as the
+// vector-ALU form above and stages the same input patch; dY of the tile (rebuilt from (G, Y, coef) when REB — the arithmetic of
+// stem_tile_kernel's MODE 2, value for value) goes through LDS once as [pixel][channel] fp32, written with 16-B global loads of 8
+// channels per lane and read back as the A operand (64 consecutive dwords per wave: conflict-free).  Lane (l16, lg) reads tap
+// l16 (+16) of pixel lg of the group for B — a lane-constant patch offset.  The vector-ALU form spent 108 FMAs + 27 LDS broadcasts per
+// lane and pixel pass on a kernel whose bytes would take a third of its time (stem_tile_kernel<bf16, 2>, 512^2 bs 64: 0.256 ms at
+// 2.5 TB/s counted); here a lane's work per tile is two 16-B loads per tensor, the rebuild of 16 values and 48 LDS reads.
+typedef float stem_f32x4 __attribute__((ext_vector_type(4)));
+template <typename T> struct StemRaw8;
+template <> struct StemRaw8<float> { float4 a, b; };
+template <> struct StemRaw8<bf16_t> { uint4 u; };
+__device__ __forceinline__ void stem_ld8(StemRaw8<float>& r, const float* p) { r.a = ld4(p); r.b = ld4(p + 4); }
+__device__ __forceinline__ void stem_ld8(StemRaw8<bf16_t>& r, const bf16_t* p) { r.u = *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ void stem_widen8(const StemRaw8<float>& r, float (&v)[8]) {
+    v[0] = r.a.x; v[1] = r.a.y; v[2] = r.a.z; v[3] = r.a.w; v[4] = r.b.x; v[5] = r.b.y; v[6] = r.b.z; v[7] = r.b.w;
+}
+__device__ __forceinline__ void stem_widen8(const StemRaw8<bf16_t>& r, float (&v)[8]) {
+    const unsigned u[4] = {r.u.x, r.u.y, r.u.z, r.u.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(u[i] << 16); v[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u); }
+}
+
+template <typename T, int NCT, int REB>
+__global__ __launch_bounds__(256) void stem_wgrad_mfma_kernel(const float* __restrict__ x, const T* __restrict__ dy, const T* __restrict__ yraw,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                                              const float* __restrict__ coef, int act, float* __restrict__ parts, StemGeom g,
+                                                              int tiles_h, int tiles_w) {
+    constexpr int CO = 16 * NCT, NH = CO / 8, NPIX = ST_TH * ST_TW;
+    static_assert(NPIX == 256, "one (pixel, 8-channel part) item per thread and pass");
+    __shared__ __attribute__((aligned(16))) float tile[3 * ST_IH * ST_IWP];
+    __shared__ __attribute__((aligned(16))) float dyT[NPIX * CO];          // [pixel][channel]; the end-of-kernel fold reuses it
+    __shared__ float cst[REB ? 5 * CO : 1];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l16 = lane & 15, lg = lane >> 4;
+    if (REB) {
+        for (int i = tid; i < CO; i += 256) {
+            cst[i] = scale[i]; cst[CO + i] = shift[i]; cst[2 * CO + i] = coef[i]; cst[3 * CO + i] = coef[g.Cout + i]; cst[4 * CO + i] = coef[2 * g.Cout + i];
+        }
+    }
+    int toff[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int t = min(16 * h + l16, 26);                   // taps 27..31 of the second half: a valid address, the column is discarded
+        const int ci = t / 9, kh = (t % 9) / 3, kw = t % 3;
+        toff[h] = (ci * ST_IH + kh) * ST_IWP + kw + ST_C0;
+    }
+    stem_f32x4 acc[NCT][2];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) { acc[ct][0] = stem_f32x4{0.f, 0.f, 0.f, 0.f}; acc[ct][1] = stem_f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const int64_t plane = (int64_t)g.H * g.W;
+    const int64_t ntiles = (int64_t)g.N * tiles_h * tiles_w;
+    constexpr int NX4 = (3 * ST_IH * (ST_IWP / 4) + 255) / 256;           // 16-B patch loads per thread and tile
+    const bool w4 = (g.W & 3) == 0;                                        // a float4 of the patch is wholly inside or wholly outside the row
+    // Everything a tile reads from HBM is REQUESTED one tile ahead, into registers, right before the previous tile's matrix phase
+    // (NX4 + 2 NH 16-B loads per lane in flight under 32 MFMAs per wave), and lands in LDS behind the barrier that retires that phase.
+    StemRaw8<T> rg[NH], ry[NH];
+    float4 xr[NX4];
+    auto origin = [&](int64_t tl, int64_t& n, int& ho0, int& wo0) {       // 32-bit tile arithmetic (the launcher refuses >= 2^31 tiles)
+        const unsigned t = (unsigned)tl, r = t / (unsigned)tiles_w;
+        n = r / (unsigned)tiles_h;
+        ho0 = (int)(r % (unsigned)tiles_h) * ST_TH; wo0 = (int)(t % (unsigned)tiles_w) * ST_TW;
+    };
+    auto request = [&](int64_t tl) {
+        int64_t n; int ho0, wo0;
+        origin(tl, n, ho0, wo0);
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+            const int item = tid + 256 * i, px = item / NH, part = item % NH;
+            const int ho = min(ho0 + px / ST_TW, g.Ho - 1), wo = min(wo0 + px % ST_TW, g.Wo - 1);
+            const int64_t o = ((n * g.Ho + ho) * g.Wo + wo) * g.Cout + 8 * part;
+            stem_ld8(rg[i], dy + o);
+            if (REB) stem_ld8(ry[i], yraw + o);
+        }
+        if (w4) {
+            const int hi0 = 2 * ho0 - 1, wi0 = 2 * wo0 - 1;
+#pragma unroll
+            for (int k = 0; k < NX4; ++k) {
+                const int i = tid + 256 * k;
+                const int q4 = i % (ST_IWP / 4), row = (i / (ST_IWP / 4)) % ST_IH, ci = i / ((ST_IWP / 4) * ST_IH);
+                const int hi = hi0 + row, wi = wi0 - ST_C0 + 4 * q4;
+                xr[k] = f4zero();
+                if (i < 3 * ST_IH * (ST_IWP / 4) && hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) xr[k] = ld4(x + (n * 3 + ci) * plane + (int64_t)hi * g.W + wi);
+            }
+        }
+    };
+    request(blockIdx.x);
+    for (int64_t tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+        int64_t n; int ho0, wo0;
+        origin(tl, n, ho0, wo0);
+        __syncthreads();                        // previous tile fully consumed
+        if (w4) {
+#pragma unroll
+            for (int k = 0; k < NX4; ++k) {
+                const int i = tid + 256 * k;
+                const int q4 = i % (ST_IWP / 4), row = (i / (ST_IWP / 4)) % ST_IH, ci = i / ((ST_IWP / 4) * ST_IH);
+                if (i < 3 * ST_IH * (ST_IWP / 4)) *reinterpret_cast<float4*>(tile + (ci * ST_IH + row) * ST_IWP + 4 * q4) = xr[k];
+            }
+        } else {
+            const int hi0 = 2 * ho0 - 1, wi0 = 2 * wo0 - 1;
+            for (int i = tid; i < 3 * ST_IH * ST_IW; i += 256) {
+                const int col = i % ST_IW, row = (i / ST_IW) % ST_IH, ci = i / (ST_IW * ST_IH);
+                const int hi = hi0 + row, wi = wi0 + col;
+                tile[(ci * ST_IH + row) * ST_IWP + ST_C0 + col] =
+                    (hi >= 0 && hi < g.H && wi >= 0 && wi < g.W) ? x[(n * 3 + ci) * plane + (int64_t)hi * g.W + wi] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+            const int item = tid + 256 * i, px = item / NH, part = item % NH;
+            const bool ok = ho0 + px / ST_TW < g.Ho && wo0 + px % ST_TW < g.Wo;
+            float d[8];
+            stem_widen8(rg[i], d);
+            if (REB) {
+                float yv[8];
+                stem_widen8(ry[i], yv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int c = 8 * part + e;
+                    d[e] = fmaf(cst[2 * CO + c], d[e] * act_bwd(fmaf(yv[e], cst[c], cst[CO + c]), act), fmaf(cst[3 * CO + c], yv[e], cst[4 * CO + c]));
+                }
+            }
+            if (!ok) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) d[e] = 0.f;
+            }
+            float* q = dyT + px * CO + 8 * part;
+            *reinterpret_cast<float4*>(q) = make_float4(d[0], d[1], d[2], d[3]);
+            *reinterpret_cast<float4*>(q + 4) = make_float4(d[4], d[5], d[6], d[7]);
+        }
+        __syncthreads();
+        if (tl + gridDim.x < ntiles) request(tl + gridDim.x);
+#pragma unroll 4
+        for (int gi = 0; gi < 16; ++gi) {
+            const int px = 64 * wave + 4 * gi + lg;
+            const float* tp = tile + (2 * (px >> 5)) * ST_IWP + 2 * (px & 31);
+            const float b0 = tp[toff[0]], b1 = tp[toff[1]];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const float a = dyT[px * CO + 16 * ct + l16];
+                acc[ct][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc[ct][0], 0, 0, 0);
+                acc[ct][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc[ct][1], 0, 0, 0);
+            }
+        }
+    }
+    // fold the four waves' accumulators in wave order; lane (l16, lg) holds dW[channel 16 ct + 4 lg + v][tap 16 h + l16]
+    __syncthreads();
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) dyT[((wave * NCT + ct) * 2 + h) * 256 + lane * 4 + v] = acc[ct][h][v];
+    __syncthreads();
+    float* dst = parts + (int64_t)blockIdx.x * g.Cout * 27;
+    for (int e = tid; e < NCT * 2 * 256; e += 256) {
+        const int v = e & 3, ln = (e >> 2) & 63, h = (e >> 8) & 1, ct = e >> 9;
+        const int ch = 16 * ct + 4 * (ln >> 4) + v, tap = 16 * h + (ln & 15);
+        if (tap < 27) {
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) a += dyT[((w * NCT + ct) * 2 + h) * 256 + ln * 4 + v];
+            dst[ch * 27 + tap] = a;
+        }
+    }
+}
+
+static bool stem_mfma_ok(int Cout) {
+    static const bool off = getenv("MNY_STEM_WGRAD_VALU") && getenv("MNY_STEM_WGRAD_VALU")[0] == '1';
+    return !off && (Cout == 16 || Cout == 32);
+}
+static int stem_mfma_grid(const StemGeom& g) {
+    static const int env = getenv("MNY_STEM_WG_GRID") ? atoi(getenv("MNY_STEM_WG_GRID")) : 0;
+    const int64_t want = (int64_t)g.N * cdiv(g.Ho, ST_TH) * cdiv(g.Wo, ST_TW);
+    const int cap = env > 0 ? env : (g.Cout == 16 ? 768 : 512);      // 148-160 VGPRs at 16 channels (three resident workgroups per CU), 176-200 at 32 (two)
+    return (int)(want < cap ? want : cap);
+}
+template <typename T, int REB>
+static int stem_mfma_launch(const float* x, const T* dy, const T* yraw, const float* scale, const float* shift, const float* coef, int act, float* ws,
+                            const StemGeom& g, hipStream_t st) {
+    const int gx = stem_mfma_grid(g), th = (int)cdiv(g.Ho, ST_TH), tw = (int)cdiv(g.Wo, ST_TW);
+    MNY_REQUIRE((int64_t)g.N * th * tw < ((int64_t)1 << 31), "stem_wgrad: too many tiles");
+    if (g.Cout == 16) hipLaunchKernelGGL((stem_wgrad_mfma_kernel<T, 1, REB>), dim3(gx), dim3(256), 0, st, x, dy, yraw, scale, shift, coef, act, ws, g, th, tw);
+    else hipLaunchKernelGGL((stem_wgrad_mfma_kernel<T, 2, REB>), dim3(gx), dim3(256), 0, st, x, dy, yraw, scale, shift, coef, act, ws, g, th, tw);
+    return check_launch("stem_wgrad_mfma_kernel");
+}
+
 static bool stem_tiled_ok(int Cout) { const int cgn = Cout / 4; return cgn > 0 && 256 % cgn == 0; }
 
 static int stem_geom(StemGeom& g, int& gx, int N, int H, int W, int Cout) {
@@ -277,7 +465,11 @@ extern "C" int mny_stem_stat_parts(int N, int H, int W, int Cout) {
     if (stem_geom(g, gx, N, H, W, Cout)) return MNY_EINVAL;
     return gx;
 }
-extern "C" int mny_stem_wgrad_parts(int N, int H, int W, int Cout) { return mny_stem_stat_parts(N, H, W, Cout); }
+extern "C" int mny_stem_wgrad_parts(int N, int H, int W, int Cout) {
+    StemGeom g; int gx;
+    if (stem_geom(g, gx, N, H, W, Cout)) return MNY_EINVAL;
+    return stem_mfma_ok(Cout) ? stem_mfma_grid(g) : gx;
+}
 
 template <typename T>
 static int stem_fwd_impl(const float* x_nchw, const float* w, T* y, float* stats, int N, int H, int W, int Cout, void* stream) {
@@ -306,6 +498,12 @@ static int stem_wgrad_impl(const float* x_nchw, const T* dy, float* dw, float* w
     StemGeom g; int gx;
     int rc = stem_geom(g, gx, N, H, W, Cout);
     if (rc) return rc;
+    if (stem_mfma_ok(Cout)) {
+        gx = stem_mfma_grid(g);
+        rc = stem_mfma_launch<T, 0>(x_nchw, dy, (const T*)nullptr, nullptr, nullptr, nullptr, 0, ws, g, (hipStream_t)stream);
+        if (rc || !dw) return rc;
+        return launch_reduce_parts(ws, gx, Cout * 27, dw, (hipStream_t)stream);
+    }
     if (stem_tiled_ok(Cout))
         hipLaunchKernelGGL((stem_tile_kernel<T, 1>), dim3(gx), dim3(256), 0, (hipStream_t)stream, x_nchw, (const float*)nullptr, (T*)nullptr, dy, ws, g,
                            (int)cdiv(g.Ho, ST_TH), (int)cdiv(g.Wo, ST_TW));
@@ -326,6 +524,12 @@ static int stem_bnwgrad_impl(const float* x_nchw, const T* gout, const T* y, con
     StemGeom g; int gx;
     int rc = stem_geom(g, gx, N, H, W, Cout);
     if (rc) return rc;
+    if (stem_mfma_ok(Cout)) {
+        gx = stem_mfma_grid(g);
+        rc = stem_mfma_launch<T, 1>(x_nchw, gout, y, scale, shift, coef, act, ws, g, (hipStream_t)stream);
+        if (rc || !dw) return rc;
+        return launch_reduce_parts(ws, gx, Cout * 27, dw, (hipStream_t)stream);
+    }
     hipLaunchKernelGGL((stem_tile_kernel<T, 2>), dim3(gx), dim3(256), 0, (hipStream_t)stream, x_nchw, (const float*)nullptr, (T*)nullptr, gout, ws, g,
                        (int)cdiv(g.Ho, ST_TH), (int)cdiv(g.Wo, ST_TW), y, scale, shift, coef, act);
     rc = check_launch("stem_tile_kernel<bn-wgrad>");

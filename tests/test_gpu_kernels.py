@@ -158,7 +158,8 @@ def test_bn_train_forward_backward(ops, N, H, W, C, act):
     check(nchw(yd * sc2 + sh2), ze, 1e-4, 1e-5, "bn eval coeffs")
 
 
-@pytest.mark.parametrize("N,H,W,Co", [(2, 32, 32, 32), (3, 22, 18, 16), (1, 352, 352, 32), (2, 20, 26, 12), (2, 130, 70, 32)])
+@pytest.mark.parametrize("N,H,W,Co", [(2, 32, 32, 32), (3, 22, 18, 16), (1, 352, 352, 32), (2, 20, 26, 12), (2, 130, 70, 32),
+                                      (4, 512, 512, 16), (3, 100, 132, 32)])      # 1024 tiles > the 768 workgroups of the matrix-core weight gradient; ragged tiles
 def test_stem(ops, N, H, W, Co):
     x = rnd(N, 3, H, W, seed=1)
     w = rnd(Co, 3, 3, 3, seed=2, scale=0.3)
@@ -517,7 +518,8 @@ def test_dgrad_with_fused_bn_backward_reduction(ops, M, K, Nc, act):
 
 
 @pytest.mark.parametrize("N,H,W,Co,act,dtype", [(2, 32, 32, 32, 1, torch.float32), (3, 22, 18, 16, 2, torch.float32), (1, 130, 70, 32, 1, torch.float32),
-                                                 (2, 64, 64, 16, 1, torch.bfloat16)])
+                                                 (2, 64, 64, 16, 1, torch.bfloat16), (4, 512, 512, 16, 4, torch.bfloat16), (2, 100, 132, 16, 4, torch.bfloat16),
+                                                 (3, 70, 50, 32, 4, torch.bfloat16)])
 def test_stem_weight_gradient_with_fused_bn_backward(ops, N, H, W, Co, act, dtype):
     """mny_stem_bnwgrad(x, G, Y) == mny_bn_bwd_apply -> mny_stem_wgrad on the same inputs (and the same dgamma / dbeta)."""
     x = rnd(N, 3, H, W, seed=1).cuda()
@@ -533,6 +535,41 @@ def test_stem_weight_gradient_with_fused_bn_backward(ops, N, H, W, Co, act, dtyp
     assert torch.equal(dg2, dgamma) and torch.equal(db2, dbeta)
     tol = 2e-5 if dtype == torch.float32 else 1e-2              # bf16: the unfused path rounds dY to bf16, the fused one keeps it in fp32
     assert (got - ref).abs().max().item() <= tol * ref.abs().max().item() + 1e-6
+
+
+@pytest.mark.parametrize("N,H,W,Co,act,dtype", [(5, 256, 320, 16, 4, torch.bfloat16), (2, 100, 132, 16, 4, torch.float32), (3, 70, 50, 32, 1, torch.bfloat16),
+                                                 (2, 96, 96, 32, 1, torch.float32)])
+def test_stem_weight_gradient_on_the_matrix_cores_against_fp64(N, H, W, Co, act, dtype):
+    """mny_stem_bnwgrad (stem_wgrad_mfma_kernel for Cout 16 / 32: dY rebuilt from (G, Y, coef), reduction over the pixels on
+    v_mfma_f32_16x16x4_f32) against an fp64 weight gradient of the fp64-rebuilt dY: ragged tiles, W % 4 != 0, several tiles per workgroup."""
+    import ctypes
+    from mobilenet_yolo_pytorch_amd import _lib
+    ptr = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    dev = torch.device("cuda:0")
+    sfx = "_bf16" if dtype == torch.bfloat16 else ""
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    x = rnd(N, 3, H, W, seed=1).to(dev)
+    y = rnd(N, Ho, Wo, Co, seed=2).to(dev).to(dtype)
+    g = rnd(N, Ho, Wo, Co, seed=3).to(dev).to(dtype)
+    scale, shift = (0.5 + torch.rand(Co, generator=torch.Generator().manual_seed(4))).to(dev), (0.2 * rnd(Co, seed=5)).to(dev)
+    coef = torch.stack([0.5 + torch.rand(Co, generator=torch.Generator().manual_seed(6)), 0.05 * rnd(Co, seed=7), 0.05 * rnd(Co, seed=8)]).contiguous().to(dev)
+    parts = _lib.query("mny_stem_wgrad_parts", N, H, W, Co)
+    ws = torch.full((parts, Co * 27), 7.0, device=dev)
+    dw = torch.zeros(Co, 3, 3, 3, device=dev)
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.call("mny_stem_bnwgrad" + sfx, ptr(x), ptr(g), ptr(y), ptr(scale), ptr(shift), act, ptr(coef), ptr(dw), ptr(ws), N, H, W, Co, st)
+    torch.cuda.synchronize()
+    yd, gd = y.double().cpu(), g.double().cpu()
+    z = yd * scale.double().cpu() + shift.double().cpu()
+    if act == 4:
+        d = torch.where(z <= -3, torch.zeros_like(z), torch.where(z >= 3, torch.ones_like(z), (2 * z + 3) / 6))
+    else:
+        d = ((z > 0) & (z < 6)).double()
+    cf = coef.double().cpu()
+    dY = cf[0] * gd * d + cf[1] * yd + cf[2]
+    ref = torch.nn.grad.conv2d_weight(x.double().cpu(), (Co, 3, 3, 3), dY.permute(0, 3, 1, 2).contiguous(), stride=2, padding=1)
+    err = (dw.double().cpu() - ref).abs().max().item()
+    assert err <= 2e-6 * ref.abs().max().item() + 1e-6 * (dY.abs().mean().item() * x.abs().mean().item() * N * Ho * Wo) ** 0.5, err
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
