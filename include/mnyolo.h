@@ -296,6 +296,20 @@ int mny_dw_bnbwd_s2_red_dz(const float* g, const float* y, const float* scale, c
                            const float* x, const float* in_scale, const float* in_shift, int in_act, const float* in_mean,
                            const float* in_invstd, const float* w, const float* addend, float* dx, float* dw, float* ws, float* in_red,
                            int N, int H, int W, int C, void* stream);
+/* Fused backward of a depthwise 5x5 STRIDE-2 conv+BN+act unit (models/mobilenetv3.py:88,100: Block(5, 24->72->40, s2), Block(5, 160->672->160, s2);
+ * replaces the autograd backward of nn.Conv2d(groups=C, 5, stride 2, pad 2) + nn.BatchNorm2d + ReLU / h-swish): dY rebuilt from (g, y, coef) on
+ * chip, one pass over (g, y, x) yields dx (+ addend) and the weight-gradient partials ws[mny_dw_bnbwd_s2k5_parts()][C*25] (dw == NULL leaves them to
+ * mny_reduce_batch).  in_red != NULL (with in_mean / in_invstd / in_scale / in_shift of the unit that produced x, consumed only here): that unit's
+ * BN-backward sums as partial rows in_red[parts][2][C].  C even. */
+int mny_dw_bnbwd_s2k5_parts(int N, int H, int W, int C);
+int mny_dw_bnbwd_s2k5(const float* g, const float* y, const float* scale, const float* shift, int act, const float* coef,
+                      const float* x, const float* in_scale, const float* in_shift, int in_act, const float* in_mean,
+                      const float* in_invstd, const float* w, const float* addend, float* dx, float* dw, float* ws, float* in_red,
+                      int N, int H, int W, int C, void* stream);
+int mny_dw_bnbwd_s2k5_bf16(const void* g, const void* y, const float* scale, const float* shift, int act, const float* coef,
+                           const void* x, const float* in_scale, const float* in_shift, int in_act, const float* in_mean,
+                           const float* in_invstd, const float* w, const void* addend, void* dx, float* dw, float* ws, float* in_red,
+                           int N, int H, int W, int C, void* stream);
 int mny_dw_bnbwd_red_dz_supported(int K, int C, int bf16);
 int mny_dw_bnbwd_red_dz(const float* g, const float* y, const float* scale, const float* shift, int act, const float* coef,
                         const float* x, const float* in_scale, const float* in_shift, int in_act, const float* in_mean,

@@ -154,6 +154,9 @@ _SIGS["mny_pw_bnbwd_red"] = (c_int, [P, P, P, P, c_int, P, P, P, P, P, P, c_int,
 _SIGS["mny_dw_bnbwd_red_dz_supported"] = (c_int, [c_int, c_int, c_int])
 _SIGS["mny_dw_bnbwd_red_dz"] = _SIGS["mny_dw_bnbwd_red"]
 _SIGS["mny_dw_bnbwd_s2_red_dz"] = (c_int, [P, P, P, P, c_int, P, P, P, P, c_int, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P])
+_SIGS["mny_dw_bnbwd_s2k5_parts"] = (c_int, [c_int] * 4)
+_SIGS["mny_dw_bnbwd_s2k5"] = _SIGS["mny_dw_bnbwd_s2_red_dz"]
+_SIGS["mny_dw_bnbwd_s2k5_bf16"] = _SIGS["mny_dw_bnbwd_s2_red_dz"]
 _SIGS["mny_transpose_bf16"] = _SIGS["mny_transpose"]
 _SIGS["mny_cvt_f32_bf16"] = (c_int, [P, P, c_int64, P])
 _SIGS["mny_cvt_batch_f32_bf16"] = (c_int, [P, P, c_int, P])

@@ -514,6 +514,276 @@ static int dw_bnbwd_s2_red_dz_impl(const float* g, const float* y, const float* 
     return launch_reduce_parts(ws, gx, C * 9, dw, st);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused backward of a depthwise 5x5 STRIDE-2 conv+BN+activation unit (MobileNetV3: Block(5, 24 -> 72 -> 40, s2) and
+// Block(5, 160 -> 672 -> 160, s2), models/mobilenetv3.py:88,100).  Unfused these ran bn_bwd_apply + dw5_wgrad + dw_bwd_data_s2k5
+// (+ the producer's bn_bwd_reduce); here (G, Y, X) are read once and dX written once, in one launch.
+// The register form of the 3x3 stride-2 kernel above carries over because a stride-2 unit's input quad (rows 2i, 2i+1 x columns 2j, 2j+1)
+// meets only a 3 x 3 window of dY — rows i-1..i+1, columns j-1..j+1 — whatever the filter size; what grows is the tap count: the even
+// input row 2i meets dY rows i-1 / i / i+1 through filter rows 4 / 2 / 0, the odd row 2i+1 meets rows i / i+1 through 3 / 1 (the same
+// for columns), so the quad uses each of the 25 taps exactly once: 25 packed FMAs for dX and 25 for dW per step.  Thread = TWO channels
+// x one quad column (25 accumulator pairs = 50 VGPRs; four channels would be 100 + a 36-register window: two waves per SIMD), walking
+// down quad rows: dY row i+1 is rebuilt from (G, Y) at three columns per step, rows i-1 and i are carried.  Taps and per-channel
+// constants in LDS as pairs.  RED: the input is the raw output of a conv+BN+act unit consumed only here — its BN-backward sums
+// (sum dz, sum dz * xhat) leave with dX as partial rows in_red[gridDim.x][2][C].
+template <typename T> __device__ __forceinline__ v2f ld2(const T* p);
+template <> __device__ __forceinline__ v2f ld2<float>(const float* p) { return *reinterpret_cast<const v2f*>(p); }
+template <> __device__ __forceinline__ v2f ld2<bf16_t>(const bf16_t* p) {
+    const uint32_t u = *reinterpret_cast<const uint32_t*>(p);
+    return v2f{__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)};
+}
+__device__ __forceinline__ void st2_stream(float* p, v2f v) { __builtin_nontemporal_store(v, reinterpret_cast<v2f*>(p)); }
+__device__ __forceinline__ void st2_stream(bf16_t* p, v2f v) { __builtin_nontemporal_store(pack_bf16x2(v.x, v.y), reinterpret_cast<uint32_t*>(p)); }
+
+constexpr int kDw5Consts = 25 + 9;      // 25 taps, scale, shift, ca, cb, cc, input scale / shift, producer mean / invstd
+
+template <typename T, int AM, int XF, bool RED>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) void dw_bnbwd_s2k5_kernel(
+    const T* __restrict__ g, const T* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift, int act,
+    const float* __restrict__ coef, const T* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+    int in_act, const float* __restrict__ w, const T* __restrict__ addend, T* __restrict__ dx, float* __restrict__ parts, DwbGeom gm,
+    const float* __restrict__ in_mean, const float* __restrict__ in_invstd, float* __restrict__ in_red) {
+    __shared__ v2f red[256];
+    extern __shared__ __attribute__((aligned(16))) v2f cst2[];          // [kDw5Consts][cgb]
+    const int tid = threadIdx.x;
+    const int cgl = tid % gm.cgb, pix = tid / gm.cgb, ppb = blockDim.x / gm.cgb;
+    const int cg = blockIdx.y * gm.cgb + cgl;                            // channel PAIR
+    const bool cvalid = cg < gm.cg_total;
+    const int c = cg * 2;
+    const int Ho = (gm.H - 1) / 2 + 1, Wo = (gm.W - 1) / 2 + 1;          // = quad rows / columns (pad 2: (H + 4 - 5) / 2 + 1)
+
+    v2f wacc[25];
+#pragma unroll
+    for (int t = 0; t < 25; ++t) wacc[t] = v2f{0.f, 0.f};
+    if (pix == 0 && cvalid) {
+        auto put = [&](int k, const float* src, float fill) { cst2[k * gm.cgb + cgl] = src ? v2f{src[c], src[c + 1]} : v2f{fill, fill}; };
+#pragma unroll
+        for (int t = 0; t < 25; ++t) cst2[t * gm.cgb + cgl] = v2f{w[c * 25 + t], w[(c + 1) * 25 + t]};
+        put(25, scale, 1.f); put(26, shift, 0.f);
+        put(27, coef, 0.f); put(28, coef + gm.C, 0.f); put(29, coef + 2 * gm.C, 0.f);
+        put(30, XF != 0 ? in_scale : nullptr, 1.f); put(31, XF != 0 ? in_shift : nullptr, 0.f);
+        put(32, RED ? in_mean : nullptr, 0.f); put(33, RED ? in_invstd : nullptr, 1.f);
+    }
+    v2f rs1 = v2f{0.f, 0.f}, rs2 = v2f{0.f, 0.f};
+    __syncthreads();
+    if (cvalid) {
+        const float slope = act_slope(act), hi = act_hi(act);
+        const float xslope = act_slope(in_act);
+        auto dact = [&](float z) {
+            if (AM == 2) return z <= -3.f ? 0.f : (z >= 3.f ? 1.f : (2.f * z + 3.f) * (1.f / 6.f));
+            return (z > 0.f ? 1.f : slope) * (z < hi ? 1.f : 0.f);
+        };
+        auto xf2 = [&](v2f v, v2f s, v2f h) {
+            if (XF == 0) return v;
+            const v2f z = __builtin_elementwise_fma(v, s, h);
+            if (XF == 1) return v2f{__builtin_amdgcn_fmed3f(z.x, 0.f, 6.f), __builtin_amdgcn_fmed3f(z.y, 0.f, 6.f)};
+            if (XF == 3) { const v2f t = z * v2f{xslope, xslope}; return v2f{fmaxf(z.x, t.x), fmaxf(z.y, t.y)}; }
+            const v2f t = z + v2f{3.f, 3.f};
+            return z * v2f{__builtin_amdgcn_fmed3f(t.x, 0.f, 6.f), __builtin_amdgcn_fmed3f(t.y, 0.f, 6.f)} * v2f{1.f / 6.f, 1.f / 6.f};
+        };
+        auto pact = [&](float z) {                             // derivative of the producer's activation (RED)
+            if (XF == 1) return (z > 0.f ? 1.f : 0.f) * (z < 6.f ? 1.f : 0.f);
+            if (XF == 2) return z <= -3.f ? 0.f : (z >= 3.f ? 1.f : (2.f * z + 3.f) * (1.f / 6.f));
+            return z > 0.f ? 1.f : xslope;
+        };
+        const int gxd = gridDim.x;
+        const int lb = (gm.xcd && (gxd & 7) == 0) ? (int)(blockIdx.x & 7) * (gxd >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+        const int64_t pitch = (int64_t)gm.W * gm.C, opitch = (int64_t)Wo * gm.C;
+        for (int64_t strip = (int64_t)lb * ppb + pix; strip < gm.nstrips; strip += (int64_t)gxd * ppb) {
+            const int j = (int)(strip % Wo);
+            const int hs = (int)((strip / Wo) % gm.nHS);
+            const int n = (int)(strip / ((int64_t)Wo * gm.nHS));
+            const int i0 = hs * gm.TH, i1 = min(i0 + gm.TH, Ho);
+            const T* xn = x + (int64_t)n * gm.H * pitch + c;
+            const int64_t on = (int64_t)n * Ho * opitch + c;
+            int goff[3];
+            float cm[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { const int wo = j - 1 + q; cm[q] = (wo >= 0 && wo < Wo) ? 1.f : 0.f; goff[q] = min(max(wo, 0), Wo - 1) * gm.C; }
+            const bool wv2 = 2 * j + 1 < gm.W;
+            const int xoff0 = 2 * j * gm.C, xoff1 = min(2 * j + 1, gm.W - 1) * gm.C;
+
+            // dY of output row `ho` at columns j-1, j, j+1 (zero outside the output)
+            auto dy_row = [&](int ho, const v2f* my, v2f (&d)[3]) {
+                const float rm = (ho >= 0 && ho < Ho) ? 1.f : 0.f;
+                const int64_t ro = on + (int64_t)min(max(ho, 0), Ho - 1) * opitch;
+                v2f gv[3], yv[3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { gv[q] = ld2<T>(g + ro + goff[q]); yv[q] = ld2<T>(y + ro + goff[q]); }
+                const v2f sc = my[25 * gm.cgb], sh = my[26 * gm.cgb], ca = my[27 * gm.cgb], cb = my[28 * gm.cgb], cc = my[29 * gm.cgb];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    v2f dd = gv[q];
+                    if (AM != 0) { const v2f z = __builtin_elementwise_fma(yv[q], sc, sh); dd = gv[q] * v2f{dact(z.x), dact(z.y)}; }
+                    const float m = rm * cm[q];
+                    d[q] = __builtin_elementwise_fma(ca, dd, __builtin_elementwise_fma(cb, yv[q], cc)) * v2f{m, m};
+                }
+            };
+            v2f D[3][3];                                         // D[dr][dq] = dY[i - 1 + dr][j - 1 + dq]
+            {
+                int lo = cgl;
+                asm volatile("" : "+v"(lo));
+                const v2f* my = cst2 + lo;
+                dy_row(i0 - 1, my, D[0]);
+                dy_row(i0, my, D[1]);
+            }
+            for (int i = i0; i < i1; ++i) {
+                int lo = cgl;
+                asm volatile("" : "+v"(lo));                       // keeps the LDS constant reads inside the loop
+                const v2f* my = cst2 + lo;
+                dy_row(i + 1, my, D[2]);
+                // the thread's own input quad, raw and activated (zero outside the image)
+                v2f raw[2][2], A[2][2];
+                const bool hv = 2 * i + 1 < gm.H;
+                {
+                    const T* p0 = xn + (int64_t)(2 * i) * pitch;
+                    const T* p1 = xn + (int64_t)min(2 * i + 1, gm.H - 1) * pitch;
+                    raw[0][0] = ld2<T>(p0 + xoff0); raw[0][1] = ld2<T>(p0 + xoff1);
+                    raw[1][0] = ld2<T>(p1 + xoff0); raw[1][1] = ld2<T>(p1 + xoff1);
+                    const v2f xsc = my[30 * gm.cgb], xsh = my[31 * gm.cgb];
+                    const float m01 = wv2 ? 1.f : 0.f, m10 = hv ? 1.f : 0.f, m11 = (hv && wv2) ? 1.f : 0.f;
+                    A[0][0] = xf2(raw[0][0], xsc, xsh);
+                    A[0][1] = xf2(raw[0][1], xsc, xsh) * v2f{m01, m01};
+                    A[1][0] = xf2(raw[1][0], xsc, xsh) * v2f{m10, m10};
+                    A[1][1] = xf2(raw[1][1], xsc, xsh) * v2f{m11, m11};
+                }
+                v2f o[2][2];
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) o[a][b] = v2f{0.f, 0.f};
+                // input (2i + a, 2j + b) meets dY[i - 1 + dr][j - 1 + dq] through tap (kh, kw) = (4 + a - 2 dr, 4 + b - 2 dq): even rows / columns
+                // dr, dq = 0..2, odd ones 1..2
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int dr = a; dr < 3; ++dr)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b)
+#pragma unroll
+                            for (int dq = b; dq < 3; ++dq) {
+                                const int u = (4 + a - 2 * dr) * 5 + (4 + b - 2 * dq);
+                                const v2f d = D[dr][dq];
+                                o[a][b] = __builtin_elementwise_fma(d, my[u * gm.cgb], o[a][b]);
+                                wacc[u] = __builtin_elementwise_fma(A[a][b], d, wacc[u]);
+                            }
+                const int64_t base = (int64_t)n * gm.H * pitch + (int64_t)(2 * i) * pitch + (int64_t)(2 * j) * gm.C + c;
+                if (addend) {
+                    o[0][0] += ld2<T>(addend + base);
+                    if (wv2) o[0][1] += ld2<T>(addend + base + gm.C);
+                    if (hv) o[1][0] += ld2<T>(addend + base + pitch);
+                    if (hv && wv2) o[1][1] += ld2<T>(addend + base + pitch + gm.C);
+                }
+                st2_stream(dx + base, o[0][0]);
+                if (wv2) st2_stream(dx + base + gm.C, o[0][1]);
+                if (hv) st2_stream(dx + base + pitch, o[1][0]);
+                if (hv && wv2) st2_stream(dx + base + pitch + gm.C, o[1][1]);
+                if constexpr (RED) {
+                    const v2f xsc = my[30 * gm.cgb], xsh = my[31 * gm.cgb], mu = my[32 * gm.cgb], is = my[33 * gm.cgb];
+                    auto one = [&](v2f ov, v2f rv, float ok) {
+                        const v2f gq = v2f{stored<T>(ov.x), stored<T>(ov.y)};            // the gradient as the consumer of dX reads it back
+                        const v2f z = __builtin_elementwise_fma(rv, xsc, xsh);
+                        const v2f dz = gq * v2f{pact(z.x) * ok, pact(z.y) * ok};
+                        rs1 += dz;
+                        rs2 = __builtin_elementwise_fma(dz, (rv - mu) * is, rs2);
+                    };
+                    one(o[0][0], raw[0][0], 1.f);
+                    one(o[0][1], raw[0][1], wv2 ? 1.f : 0.f);
+                    one(o[1][0], raw[1][0], hv ? 1.f : 0.f);
+                    one(o[1][1], raw[1][1], (hv && wv2) ? 1.f : 0.f);
+                }
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { D[0][q] = D[1][q]; D[1][q] = D[2][q]; }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 25; ++t) {
+        __syncthreads();
+        red[tid] = wacc[t];
+        __syncthreads();
+        if (pix == 0 && cvalid) {
+            v2f a = v2f{0.f, 0.f};
+            for (int p = 0; p < ppb; ++p) a += red[p * gm.cgb + cgl];
+            float* dst = parts + (int64_t)blockIdx.x * gm.C * 25;
+            dst[c * 25 + t] = a.x; dst[(c + 1) * 25 + t] = a.y;
+        }
+    }
+    if constexpr (RED) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            __syncthreads();
+            red[tid] = k == 0 ? rs1 : rs2;
+            __syncthreads();
+            if (pix == 0 && cvalid) {
+                v2f a = v2f{0.f, 0.f};
+                for (int p = 0; p < ppb; ++p) a += red[p * gm.cgb + cgl];
+                *reinterpret_cast<v2f*>(in_red + (int64_t)blockIdx.x * 2 * gm.C + k * gm.C + c) = a;
+            }
+        }
+    }
+}
+
+// geometry of the 5x5 stride-2 kernel: channel PAIRS, <= 64 pairs per workgroup (grid.y chunks), strips of TH quad rows
+static int dwb5_geom(DwbGeom& g, int& chunks, int& threads, int& gx, int N, int H, int W, int C) {
+    MNY_REQUIRE(C % 2 == 0 && C > 0, "dw_bnbwd_s2k5: C=%d must be a positive even number", C);
+    MNY_REQUIRE(N > 0 && H > 0 && W > 0, "dw_bnbwd_s2k5: empty tensor");
+    g.N = N; g.H = H; g.W = W; g.C = C; g.dz = 0;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    static const int th5 = getenv("MNY_DWB5_TH") ? atoi(getenv("MNY_DWB5_TH")) : 16;
+    const int ns = (int)cdiv(Ho, th5);
+    g.TH = (int)cdiv(Ho, ns);
+    g.nHS = (int)cdiv(Ho, g.TH);
+    g.nstrips = (int64_t)N * Wo * g.nHS;
+    g.cg_total = C / 2;
+    static const int cgb5 = getenv("MNY_DWB5_CGB") ? atoi(getenv("MNY_DWB5_CGB")) : 64;
+    chunks = (int)cdiv(g.cg_total, cgb5);
+    g.cgb = (int)cdiv(g.cg_total, chunks);
+    const int ppb = 256 / g.cgb > 0 ? 256 / g.cgb : 1;
+    threads = g.cgb * ppb;
+    int64_t want = cdiv(g.nstrips, ppb);
+    static const int res5 = getenv("MNY_DWB5_RES") ? atoi(getenv("MNY_DWB5_RES")) : 768;
+    int cap = res5 / chunks > 0 ? res5 / chunks : 1;
+    g.xcd = 1;
+    if (cap > 8) cap &= ~7;
+    if (want > 8) want = (want + 7) & ~(int64_t)7;
+    gx = (int)(want < cap ? want : cap);
+    return MNY_OK;
+}
+
+template <typename T>
+static int dw_bnbwd_s2k5_impl(const T* g, const T* y, const float* scale, const float* shift, int act, const float* coef,
+                              const T* x, const float* in_scale, const float* in_shift, int in_act, const float* in_mean, const float* in_invstd,
+                              const float* w, const T* addend, T* dx, float* dw, float* ws, float* in_red, int N, int H, int W, int C, void* stream) {
+    MNY_REQUIRE(g && y && scale && shift && coef && x && w && dx && ws, "dw_bnbwd_s2k5: null pointer");
+    MNY_REQUIRE(act != MNY_ACT_HSIGMOID && in_act != MNY_ACT_HSIGMOID, "dw_bnbwd_s2k5: h-sigmoid views are not supported");
+    MNY_REQUIRE(!in_red || (in_mean && in_invstd && in_scale && in_shift), "dw_bnbwd_s2k5: the producer's sums need its mean / invstd and view");
+    DwbGeom gm; int chunks, threads, gx;
+    int rc = dwb5_geom(gm, chunks, threads, gx, N, H, W, C);
+    if (rc) return rc;
+    dim3 grid(gx, chunks), block(threads);
+    hipStream_t st = (hipStream_t)stream;
+    const int am = act == MNY_ACT_NONE ? 0 : (act == MNY_ACT_HSWISH ? 2 : 1);
+    const int xf = (in_scale == nullptr && in_act == MNY_ACT_NONE) ? 0 : (in_act == MNY_ACT_HSWISH ? 2 : (in_act == MNY_ACT_RELU6 ? 1 : 3));
+    const size_t lds = (size_t)kDw5Consts * gm.cgb * sizeof(v2f);
+#define MNY_L5(A_, X_)                                                                                                                              \
+    do {                                                                                                                                            \
+        if (in_red) hipLaunchKernelGGL((dw_bnbwd_s2k5_kernel<T, A_, X_, true>), grid, block, lds, st, g, y, scale, shift, act, coef, x, in_scale,  \
+                                       in_shift, in_act, w, addend, dx, ws, gm, in_mean, in_invstd, in_red);                                        \
+        else hipLaunchKernelGGL((dw_bnbwd_s2k5_kernel<T, A_, X_, false>), grid, block, lds, st, g, y, scale, shift, act, coef, x, in_scale,        \
+                                in_shift, in_act, w, addend, dx, ws, gm, in_mean, in_invstd, in_red);                                               \
+    } while (0)
+    switch (am * 4 + xf) {
+        case 0: MNY_L5(0, 0); break; case 1: MNY_L5(0, 1); break; case 2: MNY_L5(0, 2); break; case 3: MNY_L5(0, 3); break;
+        case 4: MNY_L5(1, 0); break; case 5: MNY_L5(1, 1); break; case 6: MNY_L5(1, 2); break; case 7: MNY_L5(1, 3); break;
+        case 8: MNY_L5(2, 0); break; case 9: MNY_L5(2, 1); break; case 10: MNY_L5(2, 2); break; default: MNY_L5(2, 3); break;
+    }
+#undef MNY_L5
+    rc = check_launch("dw_bnbwd_s2k5_kernel");
+    if (rc || !dw) return rc;
+    return launch_reduce_parts(ws, gx, C * 25, dw, st);
+}
+
 static int dwb_geom(DwbGeom& g, CgLayout& L, int& gx, int N, int H, int W, int C) {
     MNY_REQUIRE(C % 4 == 0 && C > 0, "dw_bnbwd: C=%d must be a positive multiple of 4", C);
     MNY_REQUIRE(N > 0 && H > 0 && W > 0, "dw_bnbwd: empty tensor");
@@ -594,6 +864,27 @@ extern "C" int mny_dw_bnbwd_s2_bf16(const void* g, const void* y, const float* s
                                     const void* addend, void* dx, float* dw, float* ws, int N, int H, int W, int C, void* stream) {
     return dw_bnbwd_s2_impl<bf16_t>((const bf16_t*)g, (const bf16_t*)y, scale, shift, act, coef, (const bf16_t*)x, in_scale, in_shift, in_act, w,
                                     (const bf16_t*)addend, (bf16_t*)dx, dw, ws, N, H, W, C, stream);
+}
+
+// 5x5 stride-2 unit (fp32 / bf16 storage): ws [mny_dw_bnbwd_s2k5_parts()][C*25]; in_red != NULL: + the producer's BN-backward sums [parts][2][C]
+extern "C" int mny_dw_bnbwd_s2k5_parts(int N, int H, int W, int C) {
+    DwbGeom g; int chunks, threads, gx;
+    if (dwb5_geom(g, chunks, threads, gx, N, H, W, C)) return MNY_EINVAL;
+    return gx;
+}
+extern "C" int mny_dw_bnbwd_s2k5(const float* g, const float* y, const float* scale, const float* shift, int act, const float* coef,
+                                 const float* x, const float* in_scale, const float* in_shift, int in_act, const float* in_mean, const float* in_invstd,
+                                 const float* w, const float* addend, float* dx, float* dw, float* ws, float* in_red, int N, int H, int W, int C,
+                                 void* stream) {
+    return dw_bnbwd_s2k5_impl<float>(g, y, scale, shift, act, coef, x, in_scale, in_shift, in_act, in_mean, in_invstd, w, addend, dx, dw, ws, in_red,
+                                     N, H, W, C, stream);
+}
+extern "C" int mny_dw_bnbwd_s2k5_bf16(const void* g, const void* y, const float* scale, const float* shift, int act, const float* coef,
+                                      const void* x, const float* in_scale, const float* in_shift, int in_act, const float* in_mean, const float* in_invstd,
+                                      const float* w, const void* addend, void* dx, float* dw, float* ws, float* in_red, int N, int H, int W, int C,
+                                      void* stream) {
+    return dw_bnbwd_s2k5_impl<bf16_t>((const bf16_t*)g, (const bf16_t*)y, scale, shift, act, coef, (const bf16_t*)x, in_scale, in_shift, in_act, in_mean,
+                                      in_invstd, w, (const bf16_t*)addend, (bf16_t*)dx, dw, ws, in_red, N, H, W, C, stream);
 }
 
 extern "C" int mny_dw_bnbwd_parts_k(int N, int H, int W, int C, int K, int flags) {

@@ -1284,6 +1284,44 @@ class NetPlan:
                     flush_reduce()
                     bwd.marks[o.name] = len(bwd.calls)
                     continue
+                if (nd.op == "dw" and nd.k == 5 and nd.stride == 2 and os.environ.get("MNY_NO_DWFUSE5S2") != "1" and o.C % 2 == 0
+                        and o.act != _lib.ACT_HSIGMOID and nd.ins[0].act != _lib.ACT_HSIGMOID):
+                    # 5x5 stride-2 depthwise unit (MobileNetV3's two down-sampling 5x5 blocks): mny_dw_bnbwd_s2k5 — one launch instead of
+                    # bn_bwd_apply + dw5_wgrad + dw_bwd_data_s2k5, and the producer's BN-backward sums with it where the unit is its only consumer
+                    i = nd.ins[0]
+                    ish = shape(i)
+                    xv = view(i)
+                    red_buf, red_parts = self.fused_red.get(o.id, (None, 0))
+                    if red_buf is None:
+                        red_buf, red_parts = self.red_ws, parts
+                        bwd.add(K("mny_bn_bwd_reduce"), G, u.Y, u.scale, u.shift, o.act, u.mean, u.invstd, self.red_ws, M, o.C, self.stream,
+                                meta=dict(flops=0, bytes=2 * eb * M * o.C, shape="M%d C%d" % (M, o.C)))
+                    bwd.add(fin_name, red_buf, red_parts, M, gam, u.mean, u.invstd, gv(nd.bn + ".weight"), gv(nd.bn + ".bias"),
+                            self.coef_ws, o.C, self.stream)
+                    dwv = gv(nd.conv + ".weight")
+                    wt = P[nd.conv + ".weight"]
+                    dparts = _lib.query("mny_dw_bnbwd_s2k5_parts", N, ish[1], ish[2], o.C)
+                    dwv_k, ws_k = dwv, self.ws
+                    if self.defer and single(nd):
+                        dwv_k, ws_k = None, defer_job(dparts * o.C * 25, dwv, dparts, o.C * 25)
+                    prod = i.node
+                    with_red = (os.environ.get("MNY_NO_DWRED") != "1" and i.kind == "unit" and prod is not None and prod.op in ("pw", "stem")
+                                and gs[i.id].buf is None and n_consumers[i.id] == 1 and not takes_own_sums(prod) and xv[1] is not None
+                                and i.act not in (_lib.ACT_HSIGMOID,))
+                    pu, rbuf = None, None
+                    if with_red:
+                        pu = self.units[i.id]
+                        rbuf = torch.empty(dparts * 2 * i.C, **f32)
+                        self.fused_red[i.id] = (rbuf, dparts)
+                    contribute_kernel(i, lambda out, addend, G=G, u=u, xv=xv, wt=wt, dwv=dwv_k, wsl=ws_k, ish=ish, C=o.C, act=o.act, M=M, pu=pu, rbuf=rbuf: bwd.add(
+                        self.K("mny_dw_bnbwd_s2k5"), G, u.Y, u.scale, u.shift, act, self.coef_ws, xv[0], xv[1], xv[2], xv[3],
+                        pu.mean if pu is not None else None, pu.invstd if pu is not None else None, wt, addend, out, dwv, wsl, rbuf,
+                        N, ish[1], ish[2], C, self.stream,
+                        meta=dict(flops=4 * M * C * 25, bytes=self.eb * (2 * M * C + 2 * N * ish[1] * ish[2] * C), shape="C%d H%d s2 k5%s" % (C, ish[1], " +red" if rbuf is not None else ""))))
+                    flush_shared()
+                    flush_reduce()
+                    bwd.marks[o.name] = len(bwd.calls)
+                    continue
                 dY = G if not s.shared else alloc(o)
                 red_buf, red_parts = self.fused_red.get(o.id, (None, 0))
                 if red_buf is None:

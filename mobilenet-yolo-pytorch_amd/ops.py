@@ -136,6 +136,22 @@ def dw_bnbwd_s2(g, y, scale, shift, act, coef, xview, w, addend=None):
     return dx, dw
 
 
+def dw_bnbwd_s2k5(g, y, scale, shift, act, coef, xview, w, addend=None, in_stats=None):
+    """Fused BN-backward-apply + weight / data gradient of a 5x5 STRIDE-2 depthwise unit -> (dx, dw) or, with in_stats = (mean, invstd) of the
+    unit that produced x, (dx, dw, red[parts, 2, C]): that unit's BN-backward sums as partial rows."""
+    x, xs, xh, xact = xview
+    N, H, W, C = x.shape
+    parts = query("mny_dw_bnbwd_s2k5_parts", N, H, W, C)
+    ws = _new(parts, C * 25, like=w)
+    dx = torch.empty_like(x)
+    dw = _new(C, 1, 5, 5, like=w)
+    red = _new(parts, 2, C, like=w) if in_stats is not None else None
+    mu, istd = in_stats if in_stats is not None else (None, None)
+    call(_k("mny_dw_bnbwd_s2k5", x), _p(g), _p(y), _p(scale), _p(shift), act, _p(coef), _p(x), _p(xs), _p(xh), xact, _p(mu), _p(istd), _p(w), _p(addend),
+         _p(dx), _p(dw), _p(ws), _p(red), N, H, W, C, _st())
+    return (dx, dw) if red is None else (dx, dw, red)
+
+
 # ---- pointwise --------------------------------------------------------------------------------------
 def pw_fwd(view, w2d, bias=None, addend=None, want_stats=True, out=None):
     """bf16 activations take bf16 weights (mny_pw_fwd_bf16)."""

@@ -322,6 +322,81 @@ def test_fused_bn_backward_expand_unit_is_run_to_run_deterministic(ops, M, K, Nc
         assert err <= 2 ** -7 * ref.abs().max().item(), err
 
 
+@pytest.mark.parametrize("N,H,W,C,act,xact,dtype", [(2, 16, 16, 32, 1, 1, "f32"), (3, 22, 19, 96, 2, 3, "f32"), (2, 37, 9, 144, 3, 3, "f32"),
+                                                    (1, 5, 5, 672, 4, 4, "f32"), (2, 20, 21, 120, 4, 4, "bf16"), (2, 33, 17, 72, 3, 3, "bf16"),
+                                                    (2, 1, 7, 16, 1, 0, "f32"), (2, 32, 32, 672, 4, 4, "bf16"), (3, 128, 128, 72, 3, 3, "bf16"),
+                                                    (40, 64, 64, 72, 3, 3, "bf16"), (2, 12, 12, 136, 0, 1, "f32")])
+def test_fused_dw5_stride2_unit_backward(ops, N, H, W, C, act, xact, dtype):
+    """mny_dw_bnbwd_s2k5 == mny_bn_bwd_apply -> mny_dw_bwd_weight + mny_dw_bwd_data (the three launches it replaces) on the same inputs — fp32
+    2e-4 relative; bf16 storage: dX within one rounding of the unfused path (which rounds dY to bf16 in between) — and, with the producer's
+    statistics, the same dX / dW plus partial rows that sum to mny_bn_bwd_reduce(dX, x).  Odd sizes, one-row images, several strips per
+    workgroup (40 x 64 x 64: 2 560 strips of 16 quad rows over 768 workgroups), 68 channel pairs (two channel chunks)."""
+    import ctypes
+    from mobilenet_yolo_pytorch_amd import _lib
+    bf = dtype == "bf16"
+    q = (lambda t: t.to(torch.bfloat16).float()) if bf else (lambda t: t)
+    dev = (lambda t: nhwc(t).to(torch.bfloat16)) if bf else nhwc
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    x, add = dev(q(rnd(N, C, H, W, seed=1))), dev(q(rnd(N, C, H, W, seed=4)))
+    y, g = dev(q(rnd(N, C, Ho, Wo, seed=2))), dev(q(rnd(N, C, Ho, Wo, seed=3)))
+    w = rnd(C, 1, 5, 5, seed=5, scale=0.25).cuda().contiguous()
+    mk = lambda seed, a, b: (a + b * rnd(C, seed=seed)).cuda()          # noqa: E731
+    scale, shift, coef = mk(6, 1.0, 0.2), mk(7, 0.0, 0.3), torch.stack((mk(8, 1.0, 0.2), mk(9, 0.0, 0.05), mk(10, 0.0, 0.05))).contiguous()
+    xs, xh = (mk(11, 1.0, 0.2), mk(12, 0.0, 0.3)) if xact else (None, None)
+    dx, dw = ops.dw_bnbwd_s2k5(g, y, scale, shift, act, coef, (x, xs, xh, xact), w, addend=add)
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    dy = torch.empty_like(g)
+    _lib.call("mny_bn_bwd_apply" + ("_bf16" if bf else ""), p(g), p(y), p(scale), p(shift), act, p(coef), p(dy), N * Ho * Wo, C, st)
+    dx_ref = ops.dw_bwd_data(dy, w, (H, W), 2, addend=add)
+    dw_ref = ops.dw_bwd_weight((x, xs, xh, xact), dy, 5, 2)
+    rt, at = (2.0 ** -6, 2e-2) if bf else (2e-4, 2e-5)
+    check(dx.float(), dx_ref.float(), rt, at * max(1.0, dx_ref.float().abs().max().item()), "fused 5x5 s2 dw: dX")
+    tw = 5e-3 if bf else 3e-4
+    check(dw, dw_ref, tw, tw * dw_ref.abs().max().item(), "fused 5x5 s2 dw: dW")
+    if xact:                                             # the producer-sums form: same gradients, + the sums of mny_bn_bwd_reduce over (dX, x)
+        xmean, xinv = mk(13, 0.0, 0.2), mk(14, 1.0, 0.1).abs()
+        dx1, dw1, red = ops.dw_bnbwd_s2k5(g, y, scale, shift, act, coef, (x, xs, xh, xact), w, addend=add, in_stats=(xmean, xinv))
+        assert torch.equal(dx1, dx) and torch.equal(dw1, dw)
+        M = N * H * W
+        parts = _lib.query("mny_bn_bwd_parts", M, C)
+        ref = torch.empty(parts, 2, C, device="cuda")
+        _lib.call("mny_bn_bwd_reduce" + ("_bf16" if bf else ""), p(dx1), p(x), p(xs), p(xh), xact, p(xmean), p(xinv), p(ref), M, C, st)
+        got, want = red.double().sum(0).cpu(), ref.double().sum(0).cpu()
+        for j in range(2):
+            tol = 2e-5 * want[j].abs().max().item() + 1e-4 + 1e-6 * M
+            assert (got[j] - want[j]).abs().max().item() <= tol, (j, (got[j] - want[j]).abs().max().item(), tol)
+
+
+def test_fused_dw5_stride2_unit_backward_against_autograd(ops):
+    """The same kernel against torch autograd in fp64 (an independent statement of the unit: BatchNorm backward in coefficient form, h-swish, a
+    ReLU view of the input, 5x5 stride-2 pad-2 depthwise conv): dX, dW 1e-4."""
+    N, H, W, C = 3, 18, 22, 48
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    x = rnd(N, C, H, W, seed=1).double()
+    xs, xh = (1.0 + 0.2 * rnd(C, seed=11)).double(), (0.3 * rnd(C, seed=12)).double()
+    w = rnd(C, 1, 5, 5, seed=5, scale=0.25).double().requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    a = torch.relu(xr * xs.view(1, -1, 1, 1) + xh.view(1, -1, 1, 1))
+    yraw = F.conv2d(a, w, None, 2, 2, 1, C)
+    scale, shift = (1.0 + 0.2 * rnd(C, seed=6)).double(), (0.3 * rnd(C, seed=7)).double()
+    coef = torch.stack((1.0 + 0.2 * rnd(C, seed=8), 0.05 * rnd(C, seed=9), 0.05 * rnd(C, seed=10))).double()
+    gout = rnd(N, C, Ho, Wo, seed=3).double()
+    yd = yraw.detach()
+    z = yd * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    d = torch.where(z <= -3, torch.zeros_like(z), torch.where(z >= 3, torch.ones_like(z), (2 * z + 3) / 6))
+    dY = coef[0].view(1, -1, 1, 1) * gout * d + coef[1].view(1, -1, 1, 1) * yd + coef[2].view(1, -1, 1, 1)
+    yraw.backward(dY)
+    # dL/dx through the view: the kernel returns the gradient w.r.t. the RAW input's activated value a (the producer applies its own act')
+    a2 = a.detach().clone().requires_grad_(True)
+    F.conv2d(a2, w.detach(), None, 2, 2, 1, C).backward(dY)
+    f = lambda t: nhwc(t.float())                          # noqa: E731
+    dx, dw = ops.dw_bnbwd_s2k5(f(gout), f(yd), scale.float().cuda(), shift.float().cuda(), 4, coef.float().cuda().contiguous(),
+                               (f(x), xs.float().cuda(), xh.float().cuda(), 3), w.detach().float().cuda().contiguous())
+    check(nchw(dx), a2.grad.float(), 1e-4, 1e-4 * a2.grad.abs().max().item(), "dX vs autograd")
+    check(dw, w.grad.float(), 1e-4, 1e-4 * w.grad.abs().max().item(), "dW vs autograd")
+
+
 @pytest.mark.parametrize("N,H,W,C,act,xact,dtype,k", [(2, 11, 11, 32, 1, 1, "f32", 3), (3, 22, 19, 96, 2, 2, "f32", 3), (2, 37, 8, 144, 1, 0, "f32", 3),
                                                       (1, 5, 5, 960, 0, 1, "f32", 3), (2, 16, 16, 72, 3, 3, "f32", 3), (2, 20, 20, 120, 4, 4, "f32", 3),
                                                       (2, 33, 17, 64, 1, 1, "bf16", 3), (2, 9, 9, 240, 4, 4, "bf16", 3),
