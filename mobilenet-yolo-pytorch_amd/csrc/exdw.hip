@@ -928,10 +928,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
         int lo = q;
         asm volatile("" : "+v"(lo));
         const float4* my = cst + lo;
+        // (G_z, Z) of output row ho at columns j, j + 1: per-item 64-bit bases, per-row 32-bit offsets (an image plane stays below 2^31 elements) — the
+        // full 64-bit index arithmetic per row was 13 v_mad_u64_u32 per thread and row pair in a loop bound by instruction issue
+        const float* gz0 = p.gz + ((int64_t)n * Ho * Wo + jc0) * C + c;
+        const float* zz0 = p.z + ((int64_t)n * Ho * Wo + jc0) * C + c;
+        const int dj = (jc1 - jc0) * C;
         auto dz_fetch = [&](int ho, float4 (&r)[4]) {
-            const int64_t ro = ((int64_t)n * Ho + min(ho, Ho - 1)) * Wo;
-            r[0] = ld4(p.gz + (ro + jc0) * C + c); r[1] = ld4(p.z + (ro + jc0) * C + c);
-            r[2] = ld4(p.gz + (ro + jc1) * C + c); r[3] = ld4(p.z + (ro + jc1) * C + c);
+            const int ro = min(ho, Ho - 1) * Wo * C;
+            r[0] = ld4(gz0 + ro); r[1] = ld4(zz0 + ro);
+            r[2] = ld4(gz0 + ro + dj); r[3] = ld4(zz0 + ro + dj);
         };
         auto dz2 = [&](v2f gv, v2f zv, v2f s, v2f h, v2f a, v2f b, v2f cterm) {
             const v2f t = __builtin_elementwise_fma(zv, s, h);
