@@ -594,22 +594,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
             const int hs = (int)((strip / Wo) % gm.nHS);
             const int n = (int)(strip / ((int64_t)Wo * gm.nHS));
             const int i0 = hs * gm.TH, i1 = min(i0 + gm.TH, Ho);
-            const T* xn = x + (int64_t)n * gm.H * pitch + c;
-            const int64_t on = (int64_t)n * Ho * opitch + c;
+            // 64-bit image bases once per strip; inside an image 32-bit element offsets, advanced by addition (an image plane stays below 2^31 elements:
+            // checked by the launcher) — the row loop is bound by instruction issue, 64-bit multiplies per row were 24 of its 226 vector instructions
+            const int64_t ximg = (int64_t)n * gm.H * pitch + c;
+            const T* xn = x + ximg;
+            const T* an = addend ? addend + ximg : nullptr;
+            T* dn = dx + ximg;
+            const T* gn = g + (int64_t)n * Ho * opitch + c;
+            const T* yn = y + (int64_t)n * Ho * opitch + c;
+            const int pitch32 = (int)pitch, opitch32 = (int)opitch;
             int goff[3];
             float cm[3];
 #pragma unroll
             for (int q = 0; q < 3; ++q) { const int wo = j - 1 + q; cm[q] = (wo >= 0 && wo < Wo) ? 1.f : 0.f; goff[q] = min(max(wo, 0), Wo - 1) * gm.C; }
             const bool wv2 = 2 * j + 1 < gm.W;
             const int xoff0 = 2 * j * gm.C, xoff1 = min(2 * j + 1, gm.W - 1) * gm.C;
+            const int olast = (Ho - 1) * opitch32, xlast = (gm.H - 1) * pitch32;
 
-            // dY of output row `ho` at columns j-1, j, j+1 (zero outside the output)
-            auto dy_row = [&](int ho, const v2f* my, v2f (&d)[3]) {
+            // dY of output row `ho` (element offset `ro` of its clamped row) at columns j-1, j, j+1 (zero outside the output)
+            auto dy_row = [&](int ho, int ro, const v2f* my, v2f (&d)[3]) {
                 const float rm = (ho >= 0 && ho < Ho) ? 1.f : 0.f;
-                const int64_t ro = on + (int64_t)min(max(ho, 0), Ho - 1) * opitch;
                 v2f gv[3], yv[3];
 #pragma unroll
-                for (int q = 0; q < 3; ++q) { gv[q] = ld2<T>(g + ro + goff[q]); yv[q] = ld2<T>(y + ro + goff[q]); }
+                for (int q = 0; q < 3; ++q) { gv[q] = ld2<T>(gn + ro + goff[q]); yv[q] = ld2<T>(yn + ro + goff[q]); }
                 const v2f sc = my[25 * gm.cgb], sh = my[26 * gm.cgb], ca = my[27 * gm.cgb], cb = my[28 * gm.cgb], cc = my[29 * gm.cgb];
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
@@ -624,22 +631,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                 int lo = cgl;
                 asm volatile("" : "+v"(lo));
                 const v2f* my = cst2 + lo;
-                dy_row(i0 - 1, my, D[0]);
-                dy_row(i0, my, D[1]);
+                dy_row(i0 - 1, max(i0 - 1, 0) * opitch32, my, D[0]);
+                dy_row(i0, i0 * opitch32, my, D[1]);
             }
+            int ro_next = min((i0 + 1) * opitch32, olast);       // row i + 1 of the step
+            int xo0 = 2 * i0 * pitch32;                          // input row 2 i
             for (int i = i0; i < i1; ++i) {
                 int lo = cgl;
                 asm volatile("" : "+v"(lo));                       // keeps the LDS constant reads inside the loop
                 const v2f* my = cst2 + lo;
-                dy_row(i + 1, my, D[2]);
+                dy_row(i + 1, ro_next, my, D[2]);
+                ro_next = min(ro_next + opitch32, olast);
                 // the thread's own input quad, raw and activated (zero outside the image)
                 v2f raw[2][2], A[2][2];
                 const bool hv = 2 * i + 1 < gm.H;
+                const int xo1 = min(xo0 + pitch32, xlast);
                 {
-                    const T* p0 = xn + (int64_t)(2 * i) * pitch;
-                    const T* p1 = xn + (int64_t)min(2 * i + 1, gm.H - 1) * pitch;
-                    raw[0][0] = ld2<T>(p0 + xoff0); raw[0][1] = ld2<T>(p0 + xoff1);
-                    raw[1][0] = ld2<T>(p1 + xoff0); raw[1][1] = ld2<T>(p1 + xoff1);
+                    raw[0][0] = ld2<T>(xn + xo0 + xoff0); raw[0][1] = ld2<T>(xn + xo0 + xoff1);
+                    raw[1][0] = ld2<T>(xn + xo1 + xoff0); raw[1][1] = ld2<T>(xn + xo1 + xoff1);
                     const v2f xsc = my[30 * gm.cgb], xsh = my[31 * gm.cgb];
                     const float m01 = wv2 ? 1.f : 0.f, m10 = hv ? 1.f : 0.f, m11 = (hv && wv2) ? 1.f : 0.f;
                     A[0][0] = xf2(raw[0][0], xsc, xsh);
@@ -667,17 +676,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) voi
                                 o[a][b] = __builtin_elementwise_fma(d, my[u * gm.cgb], o[a][b]);
                                 wacc[u] = __builtin_elementwise_fma(A[a][b], d, wacc[u]);
                             }
-                const int64_t base = (int64_t)n * gm.H * pitch + (int64_t)(2 * i) * pitch + (int64_t)(2 * j) * gm.C + c;
-                if (addend) {
-                    o[0][0] += ld2<T>(addend + base);
-                    if (wv2) o[0][1] += ld2<T>(addend + base + gm.C);
-                    if (hv) o[1][0] += ld2<T>(addend + base + pitch);
-                    if (hv && wv2) o[1][1] += ld2<T>(addend + base + pitch + gm.C);
+                const int base = xo0 + xoff0;                     // element offset of the quad's first pixel inside the image
+                if (an) {
+                    o[0][0] += ld2<T>(an + base);
+                    if (wv2) o[0][1] += ld2<T>(an + base + gm.C);
+                    if (hv) o[1][0] += ld2<T>(an + base + pitch32);
+                    if (hv && wv2) o[1][1] += ld2<T>(an + base + pitch32 + gm.C);
                 }
-                st2_stream(dx + base, o[0][0]);
-                if (wv2) st2_stream(dx + base + gm.C, o[0][1]);
-                if (hv) st2_stream(dx + base + pitch, o[1][0]);
-                if (hv && wv2) st2_stream(dx + base + pitch + gm.C, o[1][1]);
+                st2_stream(dn + base, o[0][0]);
+                if (wv2) st2_stream(dn + base + gm.C, o[0][1]);
+                if (hv) st2_stream(dn + base + pitch32, o[1][0]);
+                if (hv && wv2) st2_stream(dn + base + pitch32 + gm.C, o[1][1]);
+                xo0 += 2 * pitch32;
                 if constexpr (RED) {
                     const v2f xsc = my[30 * gm.cgb], xsh = my[31 * gm.cgb], mu = my[32 * gm.cgb], is = my[33 * gm.cgb];
                     auto one = [&](v2f ov, v2f rv, float ok) {
@@ -758,6 +768,7 @@ static int dw_bnbwd_s2k5_impl(const T* g, const T* y, const float* scale, const 
     MNY_REQUIRE(g && y && scale && shift && coef && x && w && dx && ws, "dw_bnbwd_s2k5: null pointer");
     MNY_REQUIRE(act != MNY_ACT_HSIGMOID && in_act != MNY_ACT_HSIGMOID, "dw_bnbwd_s2k5: h-sigmoid views are not supported");
     MNY_REQUIRE(!in_red || (in_mean && in_invstd && in_scale && in_shift), "dw_bnbwd_s2k5: the producer's sums need its mean / invstd and view");
+    MNY_REQUIRE((int64_t)H * W * C < ((int64_t)1 << 31), "dw_bnbwd_s2k5: an image plane of %d x %d x %d elements exceeds 32-bit offsets", H, W, C);
     DwbGeom gm; int chunks, threads, gx;
     int rc = dwb5_geom(gm, chunks, threads, gx, N, H, W, C);
     if (rc) return rc;
