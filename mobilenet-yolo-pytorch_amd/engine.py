@@ -13,6 +13,7 @@ Residual adds alias G to both operands; a second contribution to a value is fuse
 kernel's `addend` epilogue, so no separate accumulation pass exists.
 """
 import ctypes
+import itertools
 import os
 import warnings
 
@@ -20,6 +21,8 @@ import torch
 
 from . import _lib
 from ._lib import ACT_NONE, MnyError, YoloHead
+
+_FWD_TICK = itertools.count()            # process-wide order of training forwards (NetPlan.last_fwd_tick)
 
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
@@ -214,6 +217,8 @@ class NetPlan:
         self.bn_batch = bn_batch
         self.frozen = bool(training and not bn_batch and frozen_bwd)
         self.fwd_gen = 0
+        self.inflight_gen = None                # model._InFlight: forward generation whose backward is still owed
+        self.last_fwd_tick = -1                 # process-wide order of training forwards (model._grad_plan picks the oldest when every slot is busy)
         self.resident_bytes = 0
         dev = net.device
         self.dev = dev
@@ -1633,6 +1638,7 @@ class NetPlan:
         self._replay("fwd", self.fwd)
         self.saved_x = x
         self.fwd_gen += 1
+        self.last_fwd_tick = next(_FWD_TICK)
         return self.out14
 
     def backward(self, g_losses):

@@ -54,6 +54,24 @@ class HeadState:
         self.iou_weighting = iou_weighting
 
 
+class _InFlight:
+    """Marks a plan whose forward has run and whose backward is still owed.  A further differentiable forward of the same shape then runs on a
+    SECOND plan (own activations, own gradient arena) instead of overwriting what the pending backward needs — `a = model(x, t); b = model(x, t);
+    a_loss.backward(); b_loss.backward()` works like it does under autograd.  Released by backward() or when the autograd graph is dropped."""
+
+    def __init__(self, plan):
+        self.plan, self.gen = plan, plan.fwd_gen
+        plan.inflight_gen = plan.fwd_gen
+
+    def release(self):
+        if self.plan is not None and getattr(self.plan, "inflight_gen", None) == self.gen:
+            self.plan.inflight_gen = None
+        self.plan = None
+
+    def __del__(self):
+        self.release()
+
+
 class _TrainStep(torch.autograd.Function):
     """One autograd node for the whole network + both losses.  Parameter gradients are written
     straight into the model's flat gradient arena (and exposed as `p.grad` views) instead of being
@@ -64,6 +82,7 @@ class _TrainStep(torch.autograd.Function):
         out14 = plan.forward_train(x, targets, seg_maps)
         res = out14.clone()
         ctx.model, ctx.plan, ctx.gen = model, plan, plan.fwd_gen
+        ctx.token = _InFlight(plan)               # the plan's saved activations are spoken for until backward() ran or this graph is dropped
         losses, metrics = res[:, 0].contiguous(), res[:, 1:].contiguous()
         if plan.seg_head is not None:             # third loss: SegLoss (mbv2_yolo.py:167-170); its two means ride along
             seg3 = plan.seg_out3.clone()
@@ -78,6 +97,7 @@ class _TrainStep(torch.autograd.Function):
             raise RuntimeError("backward() of a step whose plan has run another forward since (static plans keep ONE set of saved "
                                "activations per (batch, height, width)): call backward before the next forward of the same shape")
         ctx.model._run_backward(ctx.plan, g_losses.contiguous())
+        ctx.token.release()
         return None, None, None, None, None, None
 
 
@@ -188,12 +208,14 @@ class yolo(nn.Module):
     # ---- plans --------------------------------------------------------------------------------
     PLAN_BUDGET_FRAC = 0.6        # share of the device's HBM the cached plans may keep resident
 
-    def _plan(self, N, H, W, training):
+    def _plan(self, N, H, W, training, slot=0):
         """`training`: True (loss + backward, batch statistics), False (decode + NMS, running statistics), "traindet" (decode + NMS on BATCH
         statistics with the running-statistics update: `model.train()(images)`, mbv2_yolo.py:158-166 in training mode), "evalloss" (loss on running
         statistics, no statistics update, forward only: `model.eval()(images, targets)` under no_grad) or "evalgrad" (the same with the
         backward list of frozen BatchNorm: `model.eval()(images, targets)` with gradients, mbv2_yolo.py:157)."""
         key = (N, H, W, training) if self.act_dtype == torch.float32 else (N, H, W, training, "bf16")
+        if slot:
+            key = key + ("slot%d" % slot,)
         p = self._plans.get(key)
         if p is None or p.stale():
             if not torch.cuda.is_available() or self.device.type != "cuda":
@@ -220,6 +242,19 @@ class yolo(nn.Module):
             self._plans[key] = self._plans.pop(key)                             # most recently used last
         return p
 
+    MAX_INFLIGHT = 2                               # differentiable forwards of one shape that may await their backward at the same time
+
+    def _grad_plan(self, N, H, W, mode):
+        """The plan a differentiable forward runs on: the first one of the shape whose previous step is settled (backward ran, or its graph was
+        dropped); all MAX_INFLIGHT busy: the one whose forward is oldest (its pending backward then raises, as a stale step always did)."""
+        plans = []
+        for slot in range(self.MAX_INFLIGHT):
+            p = self._plan(N, H, W, mode, slot)
+            if getattr(p, "inflight_gen", None) is None:
+                return p
+            plans.append(p)
+        return min(plans, key=lambda q: q.last_fwd_tick)
+
     def _check_input(self, x):
         if not isinstance(x, torch.Tensor) or not x.is_cuda:
             raise _lib.MnyError("input must be a CUDA(HIP) tensor — the HIP path has no CPU fallback")
@@ -238,7 +273,7 @@ class yolo(nn.Module):
         if self.has_seg and seg_maps is not None:
             seg_maps = seg_maps.to(device=x.device, dtype=torch.float32)
         if self.training:
-            plan = self._plan(N, H, W, True)
+            plan = self._grad_plan(N, H, W, True)
             if self._anchor is None or self._anchor.device != x.device:
                 self._anchor = torch.zeros((), device=x.device, requires_grad=True)
             nbt = [b for k, b in self.named_buffers() if k.endswith("num_batches_tracked")]
@@ -247,7 +282,7 @@ class yolo(nn.Module):
         elif torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             # model.eval()(images, targets) with gradients — frozen-BatchNorm fine-tuning (mbv2_yolo.py:157 returns differentiable losses in
             # eval mode): running statistics in the forward, untouched buffers, and a backward in which they are constants
-            plan = self._plan(N, H, W, "evalgrad")
+            plan = self._grad_plan(N, H, W, "evalgrad")
             if self._anchor is None or self._anchor.device != x.device:
                 self._anchor = torch.zeros((), device=x.device, requires_grad=True)
             losses, metrics = _TrainStep.apply(x, self._anchor, self, plan, targets, seg_maps if self.has_seg else None)

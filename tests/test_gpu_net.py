@@ -302,15 +302,51 @@ def test_train_mode_without_targets_decodes_on_batch_statistics_like_the_referen
     assert len(m(x.cuda())) == 4
 
 
-def test_backward_after_a_second_forward_of_the_same_plan_is_refused():
+def test_two_forwards_of_one_shape_may_await_their_backward_like_under_autograd():
+    """`a = model(x, t); b = model(x, t); a.backward(); b.backward()`: the second differentiable forward of a shape whose first step still owes
+    its backward runs on a second plan (own activations and gradient arena), so both backwards work and their gradients ACCUMULATE in p.grad like
+    autograd's do; a graph that is dropped without backward frees its plan again (no third plan, no growth)."""
+    m = _model(train=True)
+    x = procedural.images(2, 96, 96, seed=33).cuda()
+    tg = procedural.targets(2, seed=34, empty_every=0)
+    one = m(x, tg)
+    (one[0][0] + one[1][0]).backward()
+    g1 = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    m.zero_grad(set_to_none=True)
+    n_plans = len(m._plans)
+    a = m(x, tg)
+    b = m(x, tg)                                             # a's backward is still owed: b runs on the second plan
+    assert len(m._plans) == n_plans + 1
+    for i in range(2):
+        assert float(a[i][0]) == float(b[i][0])              # same batch, batch statistics: same losses
+    (a[0][0] + a[1][0]).backward()
+    (b[0][0] + b[1][0]).backward()
+    torch.cuda.synchronize()
+    for k, p in m.named_parameters():
+        if k in g1:
+            d = (p.grad - 2 * g1[k]).abs().max().item()
+            assert d <= 1e-5 * (2 * g1[k]).abs().max().item() + 1e-7, (k, d)
+    # dropped graphs release their plans: many forwards without backward reuse the two plans
+    m.zero_grad(set_to_none=True)
+    del a, b, one
+    for _ in range(4):
+        m(x, tg)
+    assert len(m._plans) == n_plans + 1
+
+
+def test_backward_of_a_step_whose_plan_was_reused_is_refused():
+    """With every plan slot of a shape awaiting a backward, a further forward reuses the OLDEST plan; that step's late backward raises instead of
+    differentiating through another step's activations."""
     m = _model(train=True)
     x = procedural.images(2, 96, 96, seed=33).cuda()
     tg = procedural.targets(2, seed=34, empty_every=0)
     a = m(x, tg)
-    b = m(x, tg)                                             # overwrites the plan's saved activations
+    b = m(x, tg)
+    c = m(x, tg)                                             # both slots busy: overwrites a's saved activations
     with pytest.raises(RuntimeError, match="another forward"):
         (a[0][0] + a[1][0]).backward()
-    (b[0][0] + b[1][0]).backward()                           # the latest one is fine
+    (b[0][0] + b[1][0]).backward()
+    (c[0][0] + c[1][0]).backward()
 
 
 def test_training_step_is_bit_deterministic_at_a_size_that_uses_every_kernel_family():
