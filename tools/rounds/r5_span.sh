@@ -1,4 +1,4 @@
-# usage: bash tools/r5_span.sh TAG "ENV=.. ENV=.." [c1|c3]: kernel-trace of the un-bracketed, single-stream bench -> span / sum of durations / gaps per step
+# usage: bash tools/rounds/r5_span.sh TAG "ENV=.. ENV=.." [c1|c3]: kernel-trace of the un-bracketed, single-stream bench -> span / sum of durations / gaps per step
 TAG=$1; ENVS="$2"; WHICH=${3:-c3}
 REPO=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
