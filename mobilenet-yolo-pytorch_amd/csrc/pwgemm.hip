@@ -1347,7 +1347,7 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(WgradArgs p) {
 // Requires N % 4 == 0 and K % 4 == 0 (16-B aligned rows) and a non-hswish view.
 // ------------------------------------------------------------------------------------------------
 template <int MODE, int TI, int TJ, int X6 = 0>
-__global__ __launch_bounds__(256) void pw_wgrad_dma_kernel(WgradArgs p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TI * TJ >= 8 ? 2 : 1, 8))) void pw_wgrad_dma_kernel(WgradArgs p) {
     constexpr int KC = 16, S = 3;
     constexpr int BI = (MODE == 0 ? 64 : 32) * TI;
     constexpr int BJ = (MODE == 0 ? 64 : 32) * TJ;
@@ -1750,6 +1750,7 @@ static WgKernel wg_dma_kernel(int mode, int TI, int TJ, int x6 = 0) {
     if (x6 && mode == 0) switch (TI * 10 + TJ) {
         case 11: return (WgKernel)pw_wgrad_dma_kernel<0, 1, 1, 1>; case 12: return (WgKernel)pw_wgrad_dma_kernel<0, 1, 2, 1>;
         case 21: return (WgKernel)pw_wgrad_dma_kernel<0, 2, 1, 1>; case 22: return (WgKernel)pw_wgrad_dma_kernel<0, 2, 2, 1>;
+        case 24: return (WgKernel)pw_wgrad_dma_kernel<0, 2, 4, 1>;
     }
     switch (mode * 100 + TI * 10 + TJ) {
 #define MNY_W(MD, I, J) case MD * 100 + I * 10 + J: return (WgKernel)pw_wgrad_dma_kernel<MD, I, J>;
@@ -1768,7 +1769,17 @@ static int pick_block(int c) {      // 64 or 128: minimise the padded extent, ti
     return p128 <= p64 ? 128 : 64;
 }
 
-static WgPlan wg_plan(int64_t M, int K, int N, bool bf16 = false) {
+// wide (round 6): the six-product fp32 form with a 128 x 256 tile per workgroup (a wave = 2 x 4 blocks of 32: three operand cuts per 24 MFMAs instead
+// of four — both operands of a weight gradient are activations, cut in the kernel —, and a 512 x 512 problem re-reads dY twice and X four times
+// instead of four + four); 254 VGPRs at two waves per SIMD, 72 KB of LDS ring (two workgroups per CU).  The split count is the 128 x 128 plan's
+// either way, so the partial-row count does not depend on which of the two a launch takes.  Measured (bracketed steps, same box): 512 x 512 @
+// M 123 904 0.423 -> 0.399 ms, 1280 -> 512 @ 30 976 0.262 -> 0.248, the 33 weight gradients of the headline step 4.30 -> 4.20 ms
+static bool wg_wide_shape(int64_t M, int K, int N) {
+    static const int env = getenv("MNY_WG_TJ4") ? atoi(getenv("MNY_WG_TJ4")) : 1;     // (=0: the 128 x 128 tile, for A/B runs)
+    return env != 0 && nt_x6(M, K, N) && K % 256 == 0 && N % 128 == 0;
+}
+
+static WgPlan wg_plan(int64_t M, int K, int N, bool bf16 = false, bool wide_ok = false) {
     WgPlan pl;
     const int nco = (int)cdiv(N, 32), nci = (int)cdiv(K, 32);
     int BI, BJ, KC;
@@ -1797,6 +1808,7 @@ static WgPlan wg_plan(int64_t M, int K, int N, bool bf16 = false) {
     const int64_t rpb = cdiv(cdiv(M, splits), KC) * KC;
     pl.rows_per_block = rpb;
     pl.splits = (int)cdiv(M, rpb);
+    if (wide_ok && !bf16 && pl.mode == 0 && BI == 128 && wg_wide_shape(M, K, N)) { BJ = 256; pl.TJ = 4; pl.gy = K / 256; }
     size_t stage = (size_t)2 * (bf16 ? 32 : KC) * (BI + BJ) * sizeof(float);    // register-staged kernel: fp32 image, its own KC
     if (pl.mode == 0) stage = (size_t)2 * 16 * (BI + BJ) * sizeof(float);
     if (stage < 3 * 16 * 64 * sizeof(float)) stage = 3 * 16 * 64 * sizeof(float);
@@ -3224,7 +3236,9 @@ static int pw_wgrad_impl(const T* x, const float* in_scale, const float* in_shif
         hipLaunchKernelGGL(reduce_parts_kernel, dim3((unsigned)cdiv(n, 32)), dim3(256), 0, (hipStream_t)stream, ws, pw_wgs_splits(M, K, Nc), n, dw);
         return check_launch("reduce_parts_kernel");
     }
-    WgPlan pl = wg_plan(M, K, Nc, !is_f32);
+    static const bool force_v1 = getenv("MNY_WGRAD_V1") != nullptr;
+    const bool dma_f32 = is_f32 && (Nc & 3) == 0 && (K & 3) == 0 && in_act != MNY_ACT_HSWISH && !force_v1;
+    WgPlan pl = wg_plan(M, K, Nc, !is_f32, dma_f32);
     WgradArgs a{x, in_scale, in_shift, in_act, dy, ws, M, K, Nc, pl.rows_per_block, 0, pl.gy, pl.splits};
     dim3 grid(pl.gx, pl.gy, pl.splits), block(256);
     static const bool xcd_order = getenv("MNY_WGRAD_NO_XCD") == nullptr;      // (same-box A/B switch)
@@ -3234,10 +3248,10 @@ static int pw_wgrad_impl(const T* x, const float* in_scale, const float* in_shif
     if (use_xcd) a_dma.gx = pl.gx;
     const dim3 grid_dma = use_xcd ? dim3((unsigned)(cdiv(pl.splits, 8) * 8 * pl.gx * pl.gy)) : grid;
     hipStream_t st = (hipStream_t)stream;
-    static const bool force_v1 = getenv("MNY_WGRAD_V1") != nullptr;
     WgKernel dk = nullptr;                       // LDS-DMA kernels read raw 16-B chunks: aligned rows only
     if (is_f32) {
-        if ((Nc & 3) == 0 && (K & 3) == 0 && in_act != MNY_ACT_HSWISH && !force_v1) dk = wg_dma_kernel(pl.mode, pl.TI, pl.TJ, nt_x6(M, K, Nc));
+        if (dma_f32) dk = wg_dma_kernel(pl.mode, pl.TI, pl.TJ, nt_x6(M, K, Nc));
+        if (dk && pl.lds_dma > 64 * 1024 && !allow_lds((const void*)dk, 160 * 1024)) { set_error("pw_wgrad: hipFuncSetAttribute failed"); return MNY_EHIP; }
     } else if ((Nc & 7) == 0 && (K & 7) == 0 && !force_v1) {
         const int XF = (in_scale == nullptr && in_act == MNY_ACT_NONE) ? 0 : (in_act == MNY_ACT_HSWISH ? 2 : 1);
         dk = wg_bf16_kernel(pl.mode, pl.TI, pl.TJ, XF);
