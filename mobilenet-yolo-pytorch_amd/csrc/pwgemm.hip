@@ -1799,7 +1799,7 @@ static WgPlan wg_plan(int64_t M, int K, int N, bool bf16 = false, bool wide_ok =
         pl.TI = BI / 64; pl.TJ = BJ / 64;
         pl.gx = (int)cdiv(N, BI); pl.gy = (int)cdiv(K, BJ);
     }
-    static const int wg_blocks = getenv("MNY_WG_BLOCKS") ? atoi(getenv("MNY_WG_BLOCKS")) : 1536;
+    static const int wg_blocks = getenv("MNY_WG_BLOCKS") ? atoi(getenv("MNY_WG_BLOCKS")) : 1024;     // (round 6, next to the 128 x 256 tile: 1536 -> 1024: weight gradients 4.00 -> 3.99 ms, their combines 0.34 -> 0.31 ms, 0.4 GB fewer partial rows per step; 768: 4.32 ms)
     int64_t splits = wg_blocks / ((int64_t)pl.gx * pl.gy);
     if (splits < 1) splits = 1;
     const int64_t max_splits = cdiv(M, 4 * KC);
