@@ -647,6 +647,33 @@ def test_stem_weight_gradient_on_the_matrix_cores_against_fp64(N, H, W, Co, act,
     assert err <= 2e-6 * ref.abs().max().item() + 1e-6 * (dY.abs().mean().item() * x.abs().mean().item() * N * Ho * Wo) ** 0.5, err
 
 
+@pytest.mark.parametrize("M,K,N", [(30976, 512, 512), (7757, 1280, 512), (20011, 256, 128)])
+def test_wide_tile_weight_gradient_is_deterministic_and_exact(M, K, N):
+    """The 128 x 256 workgroup tile of the six-product weight gradients (pw_wgrad_dma_kernel<0,2,4,1>: K % 256 == 0, N % 128 == 0; 254 VGPRs): against an
+    fp64 product of the same operands (2e-6 relative: the six-product form is fp32-equivalent) and bit-identical over repeated launches on a
+    NaN-filled workspace (ragged M, every partial row written)."""
+    import ctypes
+    from mobilenet_yolo_pytorch_amd import _lib
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None   # noqa: E731
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    x, dy = rnd(M, K, seed=1).cuda(), (0.1 * rnd(M, N, seed=2)).cuda()
+    sc, sh = (0.5 + torch.rand(K, generator=torch.Generator().manual_seed(3))).cuda(), (0.2 * rnd(K, seed=4)).cuda()
+    ws = torch.empty(int(_lib.query("mny_pw_wgrad_ws_floats", M, K, N)), device="cuda")
+    dw = torch.empty(N, K, device="cuda")
+    first = None
+    for _ in range(6):
+        ws.fill_(float("nan"))
+        _lib.call("mny_pw_wgrad", p(x), p(sc), p(sh), 1, p(dy), p(dw), None, p(ws), M, K, N, st)
+        torch.cuda.synchronize()
+        if first is None:
+            first = dw.clone()
+            ref = dy.double().t() @ torch.clamp(x.double() * sc.double() + sh.double(), 0, 6)
+            assert torch.isfinite(first).all()
+            assert ((first.double() - ref).abs().max() / ref.abs().max()).item() <= 2e-6
+        else:
+            assert torch.equal(first, dw)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_batched_weight_transposes(dtype):
     """mny_transpose_batch: every W^T of a backward pass in one launch (ragged shapes, padded rows for the heads)."""
