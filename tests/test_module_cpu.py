@@ -113,3 +113,42 @@ def test_pretrained_backbone_loader_follows_reference_remap():
     with tempfile.NamedTemporaryFile(suffix=".pth") as f:
         torch.save(ckpt, f.name)
         assert _mk().load_pretrained_backbone(f.name) == loaded
+
+
+def test_plan_slots_for_steps_that_await_their_backward(monkeypatch):
+    """Host logic of `yolo._grad_plan` / `_InFlight` (no GPU): a differentiable forward takes the first plan of its shape whose previous step is
+    settled; with every slot busy it takes the plan whose forward is oldest; a token releases its plan only if no later forward re-claimed it."""
+    import types
+    from mobilenet_yolo_pytorch_amd import model as M
+    m = _mk()
+    made = {}
+
+    def fake_plan(self, N, H, W, mode, slot=0):
+        return made.setdefault((N, H, W, mode, slot), types.SimpleNamespace(fwd_gen=0, inflight_gen=None, last_fwd_tick=-1, slot=slot))
+
+    monkeypatch.setattr(M.yolo, "_plan", fake_plan)
+    tick = [0]
+
+    def forward_on(p):                      # what NetPlan.forward_train + _TrainStep.forward do to the bookkeeping
+        p.fwd_gen += 1
+        p.last_fwd_tick = tick[0]
+        tick[0] += 1
+        return M._InFlight(p)
+
+    p0 = m._grad_plan(2, 96, 96, True)
+    t0 = forward_on(p0)
+    p1 = m._grad_plan(2, 96, 96, True)
+    assert p1 is not p0 and p1.slot == 1                       # the first step still owes its backward
+    t1 = forward_on(p1)
+    assert m._grad_plan(2, 96, 96, True) is p0                 # both busy: the oldest forward's plan is reused ...
+    t2 = forward_on(p0)
+    t0.release()                                               # ... and the superseded step's token must not free it
+    assert p0.inflight_gen == p0.fwd_gen
+    t1.release()
+    assert m._grad_plan(2, 96, 96, True) is p1                 # slot 1 settled: it is the free one now
+    t2.release()
+    assert m._grad_plan(2, 96, 96, True) is p0
+    t3 = forward_on(p0)
+    del t3                                                     # a dropped autograd graph releases its plan
+    assert p0.inflight_gen is None
+    assert m._grad_plan(4, 96, 96, True) is not p0             # other shapes have their own slots
